@@ -1,7 +1,467 @@
+// =============================================================================
+// ORACLE (test infrastructure only — see nlp_model.hpp).
+//
+// CPU restatement of the interior-point solve that the reference delegates to
+// ifopt::IpoptSolver / IPOPT (phys_optim.cpp:567-580): a primal-dual log-barrier
+// method on the slack formulation  c_E(x)=0, c_I(x)-s=0, l<=s<=u  [Waechter &
+// Biegler 2006, the published IPOPT algorithm]:
+//   * gradient-based NLP scaling (nlp_scaling_max_gradient = 100),
+//   * bound relaxation 1e-8, slack push kappa_1 = kappa_2 = 1e-2,
+//   * monotone Fiacco-McCormick barrier update (kappa_mu 0.2, theta_mu 1.5,
+//     kappa_eps 10), fraction-to-boundary tau = max(0.99, 1-mu),
+//   * termination on IPOPT's scaled optimality error E_0 <= tol (tol = 1e-3 is
+//     the reference's option, phys_optim.cpp:578),
+//   * symmetric indefinite (quasi-definite) KKT solve  [H+dw*Dw  J^T; J  -D].
+// Deliberate differences from IPOPT (the reference binary cannot be run here, so
+// its iterates are not reproducible anyway; SURVEY.md §7 "Hard parts"):
+//   * Hessian: Gauss-Newton Hessian of the sum-of-squares objective plus an adaptive
+//     Levenberg damping dw*Dw, instead of L-BFGS(6);
+//   * globalisation: l1 merit function with backtracking instead of the filter +
+//     restoration phase;
+//   * mu_init = 1e-3 and mu-based bound multipliers for the warm-started stages;
+//   * linear algebra: bordered banded LDL^T without pivoting in a time ordering
+//     (stance positions / durations in the border) instead of MA57.
+// The HIP solver (contact-human-dynamics_amd/csrc) implements the same algorithm
+// with the same constants; parity tests compare the two.
+// =============================================================================
 #pragma once
 #include "nlp_model.hpp"
+
 namespace orc {
-struct IpmOptions { int max_iter = 500; double ref_tol = 1e-3; };
-struct IpmResult { int status = -2; int iters = 0; double kkt_error = 0, constr_viol = 0, objective = 0, mu = 0; int n_factor = 0, N = 0, bandwidth = 0; };
-inline IpmResult ipm_solve(Problem&, const IpmOptions&) { return IpmResult(); }
+
+struct IpmOptions {
+  int max_iter = 500;
+  double ref_tol = 1e-3;        // IPOPT tol (phys_optim.cpp:578)
+  double mu_init_cold = 0.1;    // IPOPT default mu_init (first stage)
+  double mu_init_warm = 1e-3;   // warm-started stages
+  double delta_w0 = 1e-4, delta_w_min = 1e-9, delta_c = 1e-9, delta_w_max = 1e8;
+  double constr_viol_tol = 1e-4;   // IPOPT default (unscaled)
+  int max_backtrack = 3;
+  bool use_soc = true;
+  int max_attempts = 12;
+  bool verbose = false;
+};
+
+struct IpmResult {
+  int status = -2;
+  int iters = 0;
+  double kkt_error = 0, constr_viol = 0, objective = 0, mu = 0;
+  int n_factor = 0, N = 0, bandwidth = 0;
+};
+
+// -----------------------------------------------------------------------------
+// Bordered banded LDL^T (no pivoting).  K = [A B; B^T C], A banded (Nb, half-bandwidth w).
+// -----------------------------------------------------------------------------
+struct BorderedBandLDL {
+  int Nb = 0, b = 0, w = 0;
+  std::vector<double> A;     // Nb x (w+1), row i holds columns i-w..i
+  std::vector<double> B;     // Nb x b
+  std::vector<double> C;     // b x b (lower used)
+  std::vector<double> A0, B0, C0;   // unfactored copies for residuals
+  std::vector<double> Y;     // A^{-1} B
+  std::vector<double> S;     // Schur complement factor
+  std::vector<char> sign;    // expected pivot sign per position (+1 primal, -1 dual), size Nb+b
+  int n_bad_pivots = 0;
+
+  double& a(int i, int j) { return A[(size_t)i * (w + 1) + (j - i + w)]; }
+  void resize(int Nb_, int b_, int w_) {
+    Nb = Nb_; b = b_; w = w_;
+    A.assign((size_t)Nb * (w + 1), 0.0); B.assign((size_t)Nb * b, 0.0); C.assign((size_t)b * b, 0.0);
+  }
+  void add(int i, int j, double v) {          // symmetric entry, positions in [0, Nb+b)
+    if (i < j) std::swap(i, j);
+    if (i < Nb) a(i, j) += v;
+    else if (j < Nb) B[(size_t)j * b + (i - Nb)] += v;
+    else C[(size_t)(i - Nb) * b + (j - Nb)] += v;
+  }
+  void band_solve(double* r) const {          // in-place A^{-1} r using the factor in A
+    const int W = w + 1;
+    for (int i = 0; i < Nb; ++i) {
+      int k0 = std::max(0, i - w);
+      const double* Li = &A[(size_t)i * W + (k0 - i + w)];
+      double sum = r[i];
+      for (int k = k0; k < i; ++k) sum -= Li[k - k0] * r[k];
+      r[i] = sum;
+    }
+    for (int i = 0; i < Nb; ++i) r[i] /= A[(size_t)i * W + w];
+    for (int i = Nb - 1; i >= 0; --i) {
+      int k0 = std::max(0, i - w);
+      const double* Li = &A[(size_t)i * W + (k0 - i + w)];
+      double xi = r[i];
+      for (int k = k0; k < i; ++k) r[k] -= Li[k - k0] * xi;
+    }
+  }
+  bool fix_pivot(double& d, int pos) {
+    double sg = sign[pos];
+    if (!(d * sg > 1e-14)) { d = sg * 1e-10; ++n_bad_pivots; return false; }
+    return true;
+  }
+  void factor() {
+    A0 = A; B0 = B; C0 = C;
+    n_bad_pivots = 0;
+    const int W = w + 1;
+    std::vector<double> v(w + 1);
+    for (int i = 0; i < Nb; ++i) {
+      int k0 = std::max(0, i - w);
+      double* Ai = &A[(size_t)i * W + (k0 - i + w)];     // Ai[k-k0] = A(i,k)
+      for (int j = k0; j < i; ++j) {
+        int j0 = std::max(0, j - w);
+        int s0 = std::max(k0, j0);
+        const double* Lj = &A[(size_t)j * W + (j0 - j + w)];
+        double sum = Ai[j - k0];
+        for (int k = s0; k < j; ++k) sum -= v[k - k0] * Lj[k - j0];
+        v[j - k0] = sum;                                  // = L(i,j) * D(j)
+      }
+      double d = Ai[i - k0];
+      for (int j = k0; j < i; ++j) {
+        double dj = A[(size_t)j * W + w];
+        double l = v[j - k0] / dj;
+        d -= l * v[j - k0];
+        Ai[j - k0] = l;
+      }
+      fix_pivot(d, i);
+      Ai[i - k0] = d;
+    }
+    // Y = A^{-1} B, S = C - B^T Y
+    Y = B;
+    if (b > 0) {
+      std::vector<double> col(Nb);
+      for (int c = 0; c < b; ++c) {
+        for (int i = 0; i < Nb; ++i) col[i] = B[(size_t)i * b + c];
+        band_solve(col.data());
+        for (int i = 0; i < Nb; ++i) Y[(size_t)i * b + c] = col[i];
+      }
+      S.assign((size_t)b * b, 0.0);
+      for (int r = 0; r < b; ++r)
+        for (int c = 0; c <= r; ++c) {
+          double sum = C[(size_t)r * b + c];
+          for (int i = 0; i < Nb; ++i) sum -= B0[(size_t)i * b + r] * Y[(size_t)i * b + c];
+          S[(size_t)r * b + c] = sum;
+        }
+      // dense LDL^T of S (lower), in place
+      for (int i = 0; i < b; ++i) {
+        for (int j = 0; j < i; ++j) {
+          double sum = S[(size_t)i * b + j];
+          for (int k = 0; k < j; ++k) sum -= S[(size_t)i * b + k] * S[(size_t)k * b + k] * S[(size_t)j * b + k];
+          S[(size_t)i * b + j] = sum / S[(size_t)j * b + j];
+        }
+        double d = S[(size_t)i * b + i];
+        for (int k = 0; k < i; ++k) d -= S[(size_t)i * b + k] * S[(size_t)i * b + k] * S[(size_t)k * b + k];
+        fix_pivot(d, Nb + i);
+        S[(size_t)i * b + i] = d;
+      }
+    }
+  }
+  void solve_once(const double* rhs, double* x) const {
+    std::vector<double> y(rhs, rhs + Nb);
+    band_solve(y.data());
+    std::vector<double> x2(b);
+    for (int c = 0; c < b; ++c) {
+      double sum = rhs[Nb + c];
+      for (int i = 0; i < Nb; ++i) sum -= B0[(size_t)i * b + c] * y[i];
+      x2[c] = sum;
+    }
+    for (int i = 0; i < b; ++i) { double sum = x2[i]; for (int k = 0; k < i; ++k) sum -= S[(size_t)i * b + k] * x2[k]; x2[i] = sum; }
+    for (int i = 0; i < b; ++i) x2[i] /= S[(size_t)i * b + i];
+    for (int i = b - 1; i >= 0; --i) { double xi = x2[i]; for (int k = 0; k < i; ++k) x2[k] -= S[(size_t)i * b + k] * xi; }
+    for (int i = 0; i < Nb; ++i) {
+      double sum = y[i];
+      for (int c = 0; c < b; ++c) sum -= Y[(size_t)i * b + c] * x2[c];
+      x[i] = sum;
+    }
+    for (int c = 0; c < b; ++c) x[Nb + c] = x2[c];
+  }
+  void matvec0(const double* x, double* y) const {   // y = K0 x (unfactored)
+    const int W = w + 1;
+    for (int i = 0; i < Nb + b; ++i) y[i] = 0.0;
+    for (int i = 0; i < Nb; ++i) {
+      int k0 = std::max(0, i - w);
+      for (int k = k0; k < i; ++k) { double v = A0[(size_t)i * W + (k - i + w)]; y[i] += v * x[k]; y[k] += v * x[i]; }
+      y[i] += A0[(size_t)i * W + w] * x[i];
+      for (int c = 0; c < b; ++c) { double v = B0[(size_t)i * b + c]; y[i] += v * x[Nb + c]; y[Nb + c] += v * x[i]; }
+    }
+    for (int r = 0; r < b; ++r) {
+      for (int c = 0; c < r; ++c) { double v = C0[(size_t)r * b + c]; y[Nb + r] += v * x[Nb + c]; y[Nb + c] += v * x[Nb + r]; }
+      y[Nb + r] += C0[(size_t)r * b + r] * x[Nb + r];
+    }
+  }
+  void solve(const double* rhs, double* x, int refine = 2) const {
+    const int N = Nb + b;
+    solve_once(rhs, x);
+    std::vector<double> r(N), dx(N);
+    for (int it = 0; it < refine; ++it) {
+      matvec0(x, r.data());
+      for (int i = 0; i < N; ++i) r[i] = rhs[i] - r[i];
+      solve_once(r.data(), dx.data());
+      for (int i = 0; i < N; ++i) x[i] += dx[i];
+    }
+  }
+};
+
+// -----------------------------------------------------------------------------
+inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
+  IpmResult res;
+  const int n = P.n, m = P.m;
+  const double INF = 1e19;
+  std::vector<double> x(n), g(n), c(m), J((size_t)m * n), H((size_t)n * n), graw(n), craw(m);
+  P.get_x(x.data());
+  double fraw = 0;
+
+  // ---- variable descriptors, damping metric --------------------------------
+  std::vector<double> vtime; std::vector<char> vborder, vkind;
+  P.var_descriptors(vtime, vborder, vkind);
+  std::vector<double> Dw(n, 1.0);
+  const double fscale = P.in.mass * kGravity / 4.0;
+  for (int j = 0; j < n; ++j) if (vkind[j] == 1) Dw[j] = 1.0 / (fscale * fscale);
+
+  // ---- first evaluation, scaling ------------------------------------------
+  P.eval(x.data(), &fraw, graw.data(), craw.data(), J.data(), H.data());
+  double gmax = 0; for (int j = 0; j < n; ++j) gmax = std::max(gmax, std::fabs(graw[j]));
+  const double sf = gmax > 100.0 ? 100.0 / gmax : 1.0;
+  std::vector<double> sc(m, 1.0);
+  for (int i = 0; i < m; ++i) {
+    double rm = 0; for (int j = 0; j < n; ++j) rm = std::max(rm, std::fabs(J[(size_t)i * n + j]));
+    if (rm > 100.0) sc[i] = std::max(100.0 / rm, 1e-8);
+  }
+  std::vector<char> eq(m), hasL(m), hasU(m);
+  std::vector<double> l(m), u(m);
+  for (int i = 0; i < m; ++i) {
+    eq[i] = (P.cu[i] - P.cl[i]) <= 0.0;
+    hasL[i] = !eq[i] && P.cl[i] > -INF; hasU[i] = !eq[i] && P.cu[i] < INF;
+    l[i] = P.cl[i] > -INF ? P.cl[i] * sc[i] : -HUGE_VAL;
+    u[i] = P.cu[i] < INF ? P.cu[i] * sc[i] : HUGE_VAL;
+    if (hasL[i]) l[i] -= 1e-8 * std::max(1.0, std::fabs(l[i]));
+    if (hasU[i]) u[i] += 1e-8 * std::max(1.0, std::fabs(u[i]));
+  }
+  auto apply_scaling = [&](bool with_jac) {
+    for (int i = 0; i < m; ++i) c[i] = sc[i] * craw[i];
+    if (with_jac) {
+      for (int j = 0; j < n; ++j) g[j] = sf * graw[j];
+      for (int i = 0; i < m; ++i) { double s_ = sc[i]; if (s_ != 1.0) { double* r = &J[(size_t)i * n]; for (int j = 0; j < n; ++j) r[j] *= s_; } }
+      if (sf != 1.0) for (size_t k = 0; k < H.size(); ++k) H[k] *= sf;
+    }
+  };
+  apply_scaling(true);
+  double f = sf * fraw;
+
+  // ---- KKT ordering (time-banded, border = long-range variables) ------------
+  // structural pattern: union of |J| at x0 and at a deterministic perturbation
+  std::vector<char> pat((size_t)m * n, 0);
+  for (size_t k = 0; k < pat.size(); ++k) pat[k] = J[k] != 0.0;
+  {
+    std::vector<double> xp(x), cp(m), Jp((size_t)m * n);
+    unsigned s_ = 12345u;
+    for (int j = 0; j < n; ++j) { s_ = s_ * 1664525u + 1013904223u; double r = ((s_ >> 8) & 0xFFFF) / 65535.0 - 0.5; xp[j] += (vkind[j] == 1 ? 10.0 : vkind[j] == 2 ? 0.0 : 1e-2) * r; }
+    P.eval(xp.data(), nullptr, nullptr, cp.data(), Jp.data(), nullptr);
+    for (size_t k = 0; k < pat.size(); ++k) pat[k] |= (Jp[k] != 0.0);
+    P.set_x(x.data());
+  }
+  std::vector<int> band_vars;
+  for (int j = 0; j < n; ++j) if (!vborder[j]) band_vars.push_back(j);
+  std::stable_sort(band_vars.begin(), band_vars.end(), [&](int a, int b2) { return vtime[a] < vtime[b2]; });
+  std::vector<int> rank(n, -1);
+  for (size_t r = 0; r < band_vars.size(); ++r) rank[band_vars[r]] = (int)r;
+  std::vector<int> row_last(m, -1);
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j < n; ++j) if (pat[(size_t)i * n + j] && rank[j] >= 0) row_last[i] = std::max(row_last[i], rank[j]);
+  std::vector<std::vector<int>> rows_after(band_vars.size());
+  std::vector<int> border_rows;
+  for (int i = 0; i < m; ++i) { if (row_last[i] >= 0) rows_after[row_last[i]].push_back(i); else border_rows.push_back(i); }
+  std::vector<int> pos_var(n, -1), pos_row(m, -1);
+  int Nb = 0;
+  for (size_t r = 0; r < band_vars.size(); ++r) { pos_var[band_vars[r]] = Nb++; for (int i : rows_after[r]) pos_row[i] = Nb++; }
+  int bcount = 0;
+  for (int j = 0; j < n; ++j) if (vborder[j]) pos_var[j] = Nb + bcount++;
+  for (int i : border_rows) pos_row[i] = Nb + bcount++;
+  const int N = Nb + bcount;
+  BorderedBandLDL K;
+  K.sign.assign(N, 1);
+  for (int i = 0; i < m; ++i) K.sign[pos_row[i]] = -1;
+  res.N = N;
+
+  // ---- slack / multiplier initialisation ------------------------------------
+  double mu = (P.stage == 0) ? opt.mu_init_cold : opt.mu_init_warm;
+  std::vector<double> s(m, 0.0), zL(m, 0.0), zU(m, 0.0), lam(m, 0.0);
+  for (int i = 0; i < m; ++i) {
+    if (eq[i]) continue;
+    double si = c[i];
+    const double k1 = 1e-2, k2 = 1e-2;
+    if (hasL[i]) { double pl = k1 * std::max(1.0, std::fabs(l[i])); if (hasU[i]) pl = std::min(pl, k2 * (u[i] - l[i])); si = std::max(si, l[i] + pl); }
+    if (hasU[i]) { double pu = k1 * std::max(1.0, std::fabs(u[i])); if (hasL[i]) pu = std::min(pu, k2 * (u[i] - l[i])); si = std::min(si, u[i] - pu); }
+    s[i] = si;
+    if (hasL[i]) zL[i] = mu / (si - l[i]);
+    if (hasU[i]) zU[i] = mu / (u[i] - si);
+    lam[i] = zU[i] - zL[i];
+  }
+  double nu = 1.0, dw = opt.delta_w0;
+  const double kappa_eps = 10.0, kappa_mu = 0.2, theta_mu = 1.5, smax = 100.0, tol = opt.ref_tol;
+
+  auto resid = [&](const std::vector<double>& cc, const std::vector<double>& ss, std::vector<double>& r) {
+    for (int i = 0; i < m; ++i) r[i] = eq[i] ? cc[i] - l[i] : cc[i] - ss[i];
+  };
+  auto barrier = [&](const std::vector<double>& ss, double mu_) {
+    double b = 0;
+    for (int i = 0; i < m; ++i) { if (hasL[i]) b -= mu_ * std::log(ss[i] - l[i]); if (hasU[i]) b -= mu_ * std::log(u[i] - ss[i]); }
+    return b;
+  };
+  std::vector<double> r(m), dualx(n);
+  double e_d = 0, e_p = 0, e_c = 0, e_p_unscaled = 0;
+  auto errors = [&](double mu_) {
+    for (int j = 0; j < n; ++j) dualx[j] = g[j];
+    for (int i = 0; i < m; ++i) { double li = lam[i]; if (li == 0.0) continue; const double* Jr = &J[(size_t)i * n]; for (int j = 0; j < n; ++j) dualx[j] += Jr[j] * li; }
+    double d1 = 0; for (int j = 0; j < n; ++j) d1 = std::max(d1, std::fabs(dualx[j]));
+    double sumlam = 0, sumz = 0; int nz = 0;
+    e_c = 0;
+    for (int i = 0; i < m; ++i) {
+      sumlam += std::fabs(lam[i]);
+      if (!eq[i]) d1 = std::max(d1, std::fabs(-lam[i] - zL[i] + zU[i]));
+      if (hasL[i]) { sumz += std::fabs(zL[i]); ++nz; e_c = std::max(e_c, std::fabs((s[i] - l[i]) * zL[i] - mu_)); }
+      if (hasU[i]) { sumz += std::fabs(zU[i]); ++nz; e_c = std::max(e_c, std::fabs((u[i] - s[i]) * zU[i] - mu_)); }
+    }
+    resid(c, s, r);
+    e_p = 0; e_p_unscaled = 0;
+    for (int i = 0; i < m; ++i) { e_p = std::max(e_p, std::fabs(r[i])); e_p_unscaled = std::max(e_p_unscaled, std::fabs(r[i]) / sc[i]); }
+    double sd = std::max(smax, (sumlam + sumz) / std::max(1, m + nz)) / smax;
+    double scmp = std::max(smax, sumz / std::max(1, nz)) / smax;
+    e_d = d1 / sd; e_c = e_c / scmp;
+    return std::max(e_d, std::max(e_p, e_c));
+  };
+
+  std::vector<double> Sigma(m), rs(m), D(m), rhs(N), sol(N), dx(n), dlam(m), ds(m), dzL(m), dzU(m);
+  std::vector<double> xt(n), st(m), ct(m), rt(m), Hdx(n), rhs2(N), sol2(N), xs(n), ss2(m);
+  int status = -1, it = 0;
+  double last_alpha = 0; int last_nls = 0, last_att = 0; bool last_soc = false;
+  for (it = 0; it < opt.max_iter; ++it) {
+    double E0 = errors(0.0);
+    if (opt.verbose) std::printf("%4d f=%.6e E0=%.2e (d %.1e p %.1e pu %.1e c %.1e) mu=%.1e nu=%.1e dw=%.1e | last a=%.2e nls=%d att=%d soc=%d\n", it, f / sf, E0, e_d, e_p, e_p_unscaled, e_c, mu, nu, dw, last_alpha, last_nls, last_att, (int)last_soc);
+    if (E0 <= tol && e_p_unscaled <= opt.constr_viol_tol) { status = 0; break; }
+    while (true) {
+      double Emu = errors(mu);
+      if (Emu <= kappa_eps * mu && mu > tol / 10) mu = std::max(tol / 10, std::min(kappa_mu * mu, std::pow(mu, theta_mu)));
+      else break;
+    }
+    const double tau = std::max(0.99, 1 - mu);
+    resid(c, s, r);
+    for (int i = 0; i < m; ++i) {
+      if (eq[i]) { Sigma[i] = 0; rs[i] = 0; D[i] = opt.delta_c; continue; }
+      double sig = 0, q = -lam[i];
+      if (hasL[i]) { sig += zL[i] / (s[i] - l[i]); q -= mu / (s[i] - l[i]); }
+      if (hasU[i]) { sig += zU[i] / (u[i] - s[i]); q += mu / (u[i] - s[i]); }
+      Sigma[i] = std::max(sig, 1e-300); rs[i] = q; D[i] = 1.0 / Sigma[i];
+    }
+    // rhs
+    for (int j = 0; j < n; ++j) dualx[j] = g[j];
+    for (int i = 0; i < m; ++i) { double li = lam[i]; if (li == 0.0) continue; const double* Jr = &J[(size_t)i * n]; for (int j = 0; j < n; ++j) dualx[j] += Jr[j] * li; }
+    for (int j = 0; j < n; ++j) rhs[pos_var[j]] = -dualx[j];
+    for (int i = 0; i < m; ++i) rhs[pos_row[i]] = eq[i] ? -r[i] : -(r[i] + rs[i] / Sigma[i]);
+    // bandwidth of the current pattern
+    int w = 0;
+    for (int a = 0; a < n; ++a) { if (pos_var[a] >= Nb) continue; const double* Hr = &H[(size_t)a * n]; for (int b2 = 0; b2 < a; ++b2) if (Hr[b2] != 0.0 && pos_var[b2] < Nb) w = std::max(w, std::abs(pos_var[a] - pos_var[b2])); }
+    for (int i = 0; i < m; ++i) { if (pos_row[i] >= Nb) continue; const double* Jr = &J[(size_t)i * n]; for (int j = 0; j < n; ++j) if (Jr[j] != 0.0 && pos_var[j] < Nb) w = std::max(w, std::abs(pos_row[i] - pos_var[j])); }
+    res.bandwidth = std::max(res.bandwidth, w);
+
+    bool ok = false, used_soc = false; double alpha = 0, a_du = 1.0; int nls = 0, attempt = 0;
+    for (attempt = 0; attempt < opt.max_attempts; ++attempt) {
+      K.resize(Nb, bcount, w);
+      for (int a = 0; a < n; ++a) {
+        const double* Hr = &H[(size_t)a * n];
+        for (int b2 = 0; b2 < a; ++b2) if (Hr[b2] != 0.0) K.add(pos_var[a], pos_var[b2], Hr[b2]);
+        K.add(pos_var[a], pos_var[a], Hr[a] + dw * Dw[a]);
+      }
+      for (int i = 0; i < m; ++i) {
+        const double* Jr = &J[(size_t)i * n];
+        for (int j = 0; j < n; ++j) if (Jr[j] != 0.0) K.add(pos_row[i], pos_var[j], Jr[j]);
+        K.add(pos_row[i], pos_row[i], -D[i]);
+      }
+      K.factor(); ++res.n_factor;
+      K.solve(rhs.data(), sol.data(), 2);
+      for (int j = 0; j < n; ++j) dx[j] = sol[pos_var[j]];
+      for (int i = 0; i < m; ++i) dlam[i] = sol[pos_row[i]];
+      double a_pr = 1.0; a_du = 1.0;
+      double dbar = 0, sSds = 0;
+      for (int i = 0; i < m; ++i) {
+        ds[i] = 0; dzL[i] = 0; dzU[i] = 0;
+        if (eq[i]) continue;
+        ds[i] = (dlam[i] - rs[i]) / Sigma[i];
+        if (hasL[i]) { double sl = s[i] - l[i]; dzL[i] = mu / sl - zL[i] - zL[i] / sl * ds[i]; if (ds[i] < 0) a_pr = std::min(a_pr, -tau * sl / ds[i]); if (dzL[i] < 0) a_du = std::min(a_du, -tau * zL[i] / dzL[i]); dbar -= mu / sl * ds[i]; }
+        if (hasU[i]) { double su = u[i] - s[i]; dzU[i] = mu / su - zU[i] + zU[i] / su * ds[i]; if (ds[i] > 0) a_pr = std::min(a_pr, tau * su / ds[i]); if (dzU[i] < 0) a_du = std::min(a_du, -tau * zU[i] / dzU[i]); dbar += mu / su * ds[i]; }
+        sSds += Sigma[i] * ds[i] * ds[i];
+      }
+      double cn = 0; for (int i = 0; i < m; ++i) cn += std::fabs(r[i]);
+      double gdx = 0; for (int j = 0; j < n; ++j) gdx += g[j] * dx[j];
+      double dHd = 0;
+      for (int a = 0; a < n; ++a) { const double* Hr = &H[(size_t)a * n]; double sum = 0; for (int b2 = 0; b2 < n; ++b2) sum += Hr[b2] * dx[b2]; dHd += dx[a] * sum + dw * Dw[a] * dx[a] * dx[a]; }
+      dHd += sSds;
+      double dphi_bar = gdx + dbar;
+      if (cn > 1e-14) { double nut = (dphi_bar + 0.5 * std::max(dHd, 0.0)) / ((1 - 0.1) * cn); if (nut > nu) nu = nut * 1.1 + 1e-8; }
+      double Dphi = dphi_bar - nu * cn;
+      double phi0 = f + barrier(s, mu) + nu * cn;
+      alpha = a_pr; ok = false; nls = 0; used_soc = false;
+      const double cn_floor = 1e-12;
+      while (nls <= opt.max_backtrack) {
+        for (int j = 0; j < n; ++j) xt[j] = x[j] + alpha * dx[j];
+        for (int i = 0; i < m; ++i) st[i] = s[i] + alpha * ds[i];
+        double ft = 0;
+        P.eval(xt.data(), &ft, nullptr, ct.data(), nullptr, nullptr);
+        ft *= sf; for (int i = 0; i < m; ++i) ct[i] *= sc[i];
+        resid(ct, st, rt);
+        double cnt = 0; for (int i = 0; i < m; ++i) cnt += std::fabs(rt[i]);
+        double phit = ft + barrier(st, mu) + nu * cnt;
+        if (phit <= phi0 + 1e-4 * alpha * Dphi + 1e-12 * std::fabs(phi0)) { ok = true; break; }
+        if (nls == 0 && opt.use_soc && cnt > cn_floor) {
+          // second-order correction (IPOPT sec. 2.4): same factorisation, rhs = constraint
+          // residual at the trial point; avoids the Maratos effect of the l1 merit function.
+          for (int j = 0; j < n; ++j) rhs2[pos_var[j]] = 0.0;
+          for (int i = 0; i < m; ++i) rhs2[pos_row[i]] = -rt[i];
+          K.solve(rhs2.data(), sol2.data(), 1);
+          bool inside = true;
+          for (int j = 0; j < n; ++j) xs[j] = xt[j] + sol2[pos_var[j]];
+          for (int i = 0; i < m; ++i) {
+            ss2[i] = st[i];
+            if (eq[i]) continue;
+            ss2[i] = st[i] + sol2[pos_row[i]] / Sigma[i];
+            if (hasL[i] && ss2[i] - l[i] < (1 - tau) * (s[i] - l[i])) inside = false;
+            if (hasU[i] && u[i] - ss2[i] < (1 - tau) * (u[i] - s[i])) inside = false;
+          }
+          if (inside) {
+            double fs = 0;
+            P.eval(xs.data(), &fs, nullptr, ct.data(), nullptr, nullptr);
+            fs *= sf; for (int i = 0; i < m; ++i) ct[i] *= sc[i];
+            resid(ct, ss2, rt);
+            double cns = 0; for (int i = 0; i < m; ++i) cns += std::fabs(rt[i]);
+            double phis = fs + barrier(ss2, mu) + nu * cns;
+            if (phis <= phi0 + 1e-4 * alpha * Dphi + 1e-12 * std::fabs(phi0)) { ok = true; used_soc = true; break; }
+          }
+        }
+        alpha *= 0.5; ++nls;
+      }
+      if (ok) break;
+      dw *= 10.0;
+      if (dw > opt.delta_w_max) break;
+    }
+    if (!ok) { status = -2; P.set_x(x.data()); break; }
+    if (attempt == 0 && nls == 0) dw = std::max(opt.delta_w_min, dw / 3.0);
+    else if (nls >= 2) dw *= 4.0;
+    last_alpha = alpha; last_nls = nls; last_att = attempt; last_soc = used_soc;
+    if (used_soc) { for (int j = 0; j < n; ++j) x[j] = xs[j]; } else { for (int j = 0; j < n; ++j) x[j] += alpha * dx[j]; }
+    for (int i = 0; i < m; ++i) {
+      if (used_soc) s[i] = ss2[i]; else s[i] += alpha * ds[i];
+      lam[i] += alpha * dlam[i];
+      zL[i] += a_du * dzL[i]; zU[i] += a_du * dzU[i];
+      const double ks = 1e10;
+      if (hasL[i]) { double sl = s[i] - l[i]; zL[i] = std::min(std::max(zL[i], mu / (ks * sl)), ks * mu / sl); }
+      if (hasU[i]) { double su = u[i] - s[i]; zU[i] = std::min(std::max(zU[i], mu / (ks * su)), ks * mu / su); }
+    }
+    P.eval(x.data(), &fraw, graw.data(), craw.data(), J.data(), H.data());
+    apply_scaling(true);
+    f = sf * fraw;
+  }
+  P.set_x(x.data());
+  res.status = status; res.iters = it; res.kkt_error = errors(0.0); res.objective = f / sf; res.mu = mu;
+  double cv = 0;
+  for (int i = 0; i < m; ++i) { double v = craw[i]; cv = std::max(cv, std::max(P.cl[i] - v, v - P.cu[i])); }
+  res.constr_viol = std::max(cv, 0.0);
+  return res;
 }
+
+}  // namespace orc

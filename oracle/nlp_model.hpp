@@ -273,6 +273,7 @@ class Problem {
 
   // sample-time tables [UPSTREAM] TimeDiscretizationConstraint ctor
   std::vector<double> t_dyn, t_rom, t_height;
+  std::vector<double> t_height_kept[4];   // per ee, see height_row_kept()
 
   explicit Problem(const SeqInput& input, const Config& c = Config()) : in(input), cfg(c) { build(); }
 
@@ -533,9 +534,31 @@ class Problem {
     n_dur = 0;
     if (sd.opt_durations)
       for (int e = 0; e < 4; ++e) { dur_off[e] = n; n += (int)phase_dur[e].size() - 1; n_dur += (int)phase_dur[e].size() - 1; }
-    if (st == 4)  // DurationCost keeps durations near the INPUT durations (phys_optim.cpp:696-703)
-      ;
     count_rows();
+  }
+
+  // Per-variable descriptors used by the solver to order the KKT system: the time of the
+  // node a variable belongs to, whether the variable couples over a long time span
+  // (stance positions, phase durations -> "border"), and the damping scale class.
+  // kind: 0 base/ee-motion node value, 1 force node value, 2 duration.
+  void var_descriptors(std::vector<double>& time, std::vector<char>& border, std::vector<char>& kind) const {
+    time.assign(n, 0.0); border.assign(n, 0); kind.assign(n, 0);
+    for (int i = 0; i < 10; ++i) {
+      const Spline& s = sp[i];
+      std::vector<double> tn(s.n_nodes, 0.0);
+      for (int k = 1; k < s.n_nodes; ++k) tn[k] = tn[k - 1] + s.poly_dur[k - 1];
+      for (int nd = 0; nd < s.n_nodes; ++nd)
+        for (int q = 0; q < 6; ++q) {
+          int v = s.var_of[nd * 6 + q];
+          if (v < 0) continue;
+          int g = s.var_off + v;
+          bool stance_shared = s.phase_based && i < 6 && s.is_const_node(nd);
+          if (stance_shared) { border[g] = 1; if (nd + 1 < s.n_nodes && s.pinfo[std::min(nd, s.n_polys() - 1)].is_const) time[g] = tn[nd]; }
+          else time[g] = tn[nd];
+          kind[g] = (i >= 6) ? 1 : 0;
+        }
+    }
+    for (int g = n_nodesvars; g < n; ++g) { border[g] = 1; kind[g] = 2; time[g] = 0.0; }
   }
 
   // Constraint-row layout (order is irrelevant to the NLP; chosen once here).
@@ -549,6 +572,22 @@ class Problem {
     // (identical feasible set, avoids a structurally rank-deficient Jacobian).
     if (node == 0) return false;
     if (node < s.n_polys() && s.pinfo[node].is_const) return false;
+    return true;
+  }
+
+  // HeightConstraint rows (height_constraint.cpp:24-36) whose sample evaluates to a stance
+  // (constant) node are identically zero once the TerrainConstraint equality of that stance
+  // holds: n.(p-p0) = n_z (z - h(x,y)).  They are always-active degenerate inequalities with
+  // an empty interior; the oracle drops them (same feasible set).  The mask is taken with the
+  // phase durations in force when the stage is set up.
+  bool height_row_kept(int e, double t) const {
+    const Spline& s = sp[2 + e];
+    int id = segment_id(t, s.poly_dur);
+    if (s.pinfo[id].is_const) return false;
+    double tl = t;
+    for (int i = 0; i < id; ++i) tl -= s.poly_dur[i];
+    if (tl >= s.poly_dur[id] - 1e-9 && id + 1 < s.n_polys() && s.pinfo[id + 1].is_const) return false;
+    if (tl <= 1e-9 && id > 0 && s.pinfo[id - 1].is_const) return false;
     return true;
   }
 
@@ -575,7 +614,12 @@ class Problem {
         for (int nd = 0; nd < sp[6 + e].n_nodes; ++nd) c += !sp[6 + e].is_const_node(nd);
         push(FAM_FORCE, e, 5 * c);
       }
-    if (sd.families & FAM_HEIGHT) for (int e = 0; e < 4; ++e) push(FAM_HEIGHT, e, (int)t_height.size());
+    if (sd.families & FAM_HEIGHT)
+      for (int e = 0; e < 4; ++e) {
+        t_height_kept[e].clear();
+        for (double t : t_height) if (height_row_kept(e, t)) t_height_kept[e].push_back(t);
+        push(FAM_HEIGHT, e, (int)t_height_kept[e].size());
+      }
     if (sd.families & FAM_TOTALTIME)
       for (int e = 0; e < 4; ++e) {
         push(FAM_TOTALTIME, e, 1);
@@ -868,8 +912,8 @@ class Problem {
         } break;
         case FAM_HEIGHT: {    // height_constraint.cpp:24-58 (un-normalised file normal)
           const Spline& s = sp[2 + b.ee];
-          for (size_t k = 0; k < t_height.size(); ++k) {
-            double t = t_height[k];
+          for (size_t k = 0; k < t_height_kept[b.ee].size(); ++k) {
+            double t = t_height_kept[b.ee][k];
             int row = b.row0 + (int)k;
             s.eval(t, pe);
             c[row] = in.normal[0] * (pe.p[0] - in.point[0]) + in.normal[1] * (pe.p[1] - in.point[1]) + in.normal[2] * (pe.p[2] - in.point[2]);
