@@ -1,0 +1,104 @@
+// chd_device.hpp — plain-old-data descriptors shared by the host-side table builder
+// (chd_model.hpp) and the solver kernel (chd_kernels.hpp).
+//
+// One sequence = one NLP (phys_optim.cpp:375-762).  Everything a workgroup needs is reachable
+// from a SeqDesc: four base pointers (constant doubles / ints, workspace doubles / ints) plus
+// 32-bit offsets.  All arithmetic data is fp64.
+#pragma once
+#include <stdint.h>
+
+namespace chd {
+
+enum { N_SPLINES = 10, N_EE = 4, N_STAGES = 6 };
+// spline ids: 0 base-lin, 1 base-ang, 2..5 ee-motion (NLP ee order), 6..9 ee-force
+
+// constraint families (bit flags) — names follow Parameters::ConstraintName (parameters.h)
+enum {
+  FAM_BASEACC = 1, FAM_TERRAIN = 2, FAM_ROM = 4, FAM_HEELDIST = 8,
+  FAM_DYNAMIC = 16, FAM_FORCE = 32, FAM_HEIGHT = 64, FAM_TOTALTIME = 128
+};
+
+// row tasks: one task = the rows one thread evaluates together
+enum {
+  T_BASEACC = 0,   // a = spline (0/1), b = junction j       -> 3 rows
+  T_TERRAIN = 1,   // a = ee, b = node                        -> 1 row
+  T_ROM = 2,       // a = ee, b = sample index in t_rom       -> 1 row
+  T_HEELDIST = 3,  // a = pair (0/1), b = sample index        -> 1 row
+  T_DYN = 4,       // b = sample index in t_dyn               -> 6 rows
+  T_FORCE = 5,     // a = ee, b = node                        -> 5 rows
+  T_HEIGHT = 6,    // a = ee, t = sample time                 -> 1 row
+  T_TOTALTIME = 7, // a = ee                                  -> 1 row
+  T_DURBOUND = 8   // a = ee, b = duration index              -> 1 row
+};
+
+struct SplineDesc {
+  int n_nodes, n_polys, n_var, var_off;
+  int node_off;     // first entry of this spline in the node-entry arrays (6 entries per node: [deriv][dim])
+  int poly_off;     // first polynomial of this spline in the polynomial arrays
+  int phase_based;  // 0 for the two base splines
+  int ee;           // end-effector of a phase-based spline, -1 otherwise
+};
+
+struct StageDesc {
+  int stage, families, opt_dur, max_iter;
+  int n, m, n_dur, dur_off[N_EE];
+  int Nb, bc, w;            // KKT layout: banded part, border, half-bandwidth
+  int n_tasks;
+  int nnz_jac;
+  int valid;
+  double w_data[3], w_vel[3], w_acc[3], w_dur;
+  // offsets into ci
+  int o_pos_var, o_pos_row, o_task;     // task: 4 ints (type, a, b, row0)
+  // offsets into cd
+  int o_cl, o_cu, o_Dw, o_task_t;
+};
+
+// cached spline sample used by the cost terms (one per cost spline per data frame)
+enum { SC_WP = 0, SC_WV = 4, SC_P = 8, SC_V = 11, SC_DXDT = 14, SC_POLY = 17, SC_PHASE = 18, SC_LAST = 19, SC_STRIDE = 20 };
+
+struct SeqDesc {
+  const double* cd;   // constant doubles
+  const int* ci;      // constant ints
+  double* wd;         // workspace doubles (state + solver vectors + KKT storage)
+  int* wi;            // workspace ints
+  double* out_d;      // results: snapshots + per-stage statistics
+  int* out_i;
+
+  int F, cap;         // data frames, snapshot capacity
+  double dt, T, mass, leg_len, heel_len, heel_dist;
+  double normal[3], point[3], gdir[3], hx, hy, bn[3], bt1[3], bt2[3];
+  SplineDesc sp[N_SPLINES];
+  int n_phase[N_EE], phase_off[N_EE], start_contact[N_EE];
+  int n_nodesvars, tot_entries, tot_polys, tot_phases, max_polys;
+  int n_tdyn, n_trom;
+  // cd offsets
+  int o_data[6];      // com, euler, ee-motion targets (NLP ee order); F x 3 each
+  int o_hip[2], o_inertia, o_tcost, o_tdyn, o_trom, o_phase_dur0, o_node0, o_phase_dur_in;
+  // ci offsets
+  int o_varof;        // tot_entries: local optimisation index or -1
+  int o_pinfo;        // tot_polys x 4: phase, k_in_phase, n_in_phase, is_const
+  int o_varnode;      // n_nodesvars: first node entry (spline-local entry index) of each node variable
+  int o_varspl;       // n_nodesvars: spline of each node variable
+  // wd offsets — state
+  int o_node, o_poly_dur, o_pend, o_phase_dur, o_phend, o_ttot;
+  // wd offsets — solver vectors (n-, m- and N-sized), see chd_kernels.hpp
+  int o_vec_n, o_vec_m, o_vec_N, o_scache;
+  int max_n, max_m, max_N;
+  // wd offsets — KKT storage
+  int o_K0b, o_K0x, o_Kfb, o_Kfx;      // full band, border rows (unfactored); lower band, border rows (factor)
+  long long sz_K0b, sz_K0x, sz_Kfb, sz_Kfx;
+  // wi offsets
+  int o_flags, o_first, o_sign;
+  // run control
+  int stage_first, stage_last;
+  StageDesc st[N_STAGES];
+};
+
+// per-stage statistics written to out_d (8 doubles per stage)
+enum { RS_STATUS = 0, RS_ITERS = 1, RS_KKT = 2, RS_VIOL = 3, RS_OBJ = 4, RS_MU = 5, RS_NFACT = 6, RS_AUX = 7, RS_STRIDE = 8 };
+// out_d layout: [N_STAGES x RS_STRIDE] then 3 snapshots x 10 blocks (base_lin, base_ang_deg, 4 ee_pos, 4 ee_force) x cap x 3
+// out_i layout: [3 x (n_samples, header)] then 3 x 4 x cap contact flags
+inline long long out_d_size(int cap) { return (long long)N_STAGES * RS_STRIDE + 3LL * 10 * cap * 3; }
+inline long long out_i_size(int cap) { return 8 + 3LL * 4 * cap; }
+
+}  // namespace chd

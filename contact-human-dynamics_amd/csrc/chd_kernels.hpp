@@ -1,0 +1,1535 @@
+// chd_kernels.hpp — the physics hot path: one workgroup solves one sequence's staged NLP.
+//
+// What this replaces in the reference (all of it runs per IPOPT iteration on one CPU thread):
+//   spline evaluation / Jacobians        TOWR NodeSpline, PhaseSpline, CubicHermitePolynomial (absent fork)
+//   dynamics residual + Jacobians        humanoid_dynamic_constraint.cpp:63-143, humanoid_rigid_body_dynamics.cpp:89-206
+//   leg length / heel distance / height  leg_length_constraint.cpp:36-111, ee_dist_constraint.cpp:29-94, height_constraint.cpp:24-58
+//   terrain / force / base-acc rows      TOWR TerrainConstraint, ForceConstraint, SplineAccConstraint
+//   duration rows                        total_duration_constraint.cpp:60-82
+//   costs                                data_cost.cpp:40-96, vel_smooth_cost.cpp:37-100, duration_cost.cpp:25-50
+//   the NLP solve                        ifopt::IpoptSolver / IPOPT (phys_optim.cpp:567-580)
+//   SaveSolution                         phys_optim.cpp:63-143
+//
+// Execution model: the code is written as workgroup-wide phases — PAR_FOR loops separated by
+// CHD_SYNC() — over data that lives in the sequence's HBM workspace, with the KKT panel, the
+// substitution vector and the border Schur complement staged in LDS.  Every accumulation is
+// owner-computes (one thread owns a KKT entry / gradient entry), so results are bitwise
+// reproducible for a given workgroup size and independent of where the workgroup runs.
+//
+// The same source compiles for gfx950 (hipcc) and, with CHD_HOST_EMU, as a single-"thread"
+// host function that tests use to debug phases without a GPU.  The emulation build is test
+// infrastructure; libchd_phys.so contains only the HIP build.
+#pragma once
+#include <math.h>
+
+#include "chd_device.hpp"
+
+#ifdef CHD_HOST_EMU
+#define CHD_DEV static inline
+#define CHD_TID 0
+#define CHD_NT 1
+#define CHD_SYNC() ((void)0)
+#define CHD_GL 1
+#else
+#define CHD_DEV __device__ inline
+#define CHD_TID ((int)threadIdx.x)
+#define CHD_NT ((int)blockDim.x)
+#define CHD_SYNC() __syncthreads()
+#define CHD_GL 16
+#endif
+#define PAR_FOR(i, n) for (int i = CHD_TID; i < (n); i += CHD_NT)
+// one group of CHD_GL consecutive lanes per item; `lane_` is the lane inside the group
+#define GROUP_FOR(i, n) for (int i = CHD_TID / CHD_GL, lane_ = CHD_TID % CHD_GL; i < (n); i += CHD_NT / CHD_GL)
+
+namespace chd {
+
+// ---- solver constants (IPOPT defaults unless noted) ----------------------
+#define CHD_MU_INIT_COLD 0.1
+#define CHD_MU_INIT_WARM 1e-3
+#define CHD_DELTA_W0 1e-4
+#define CHD_DELTA_W_MIN 1e-9
+#define CHD_DELTA_W_MAX 1e8
+#define CHD_DELTA_C 1e-9
+#define CHD_CONSTR_VIOL_TOL 1e-4
+#define CHD_MAX_BACKTRACK 3
+#define CHD_MAX_ATTEMPTS 12
+#define CHD_G 9.80665
+#define CHD_MU_FRICTION 0.5
+#define CHD_INF 1e19
+
+enum { EV_VALUES = 0, EV_FULL = 1 };
+// n-sized vectors
+enum { VN_X = 0, VN_G, VN_DUALX, VN_DX, VN_XT, VN_XS, VN_COUNT };
+// m-sized vectors
+enum { VM_C = 0, VM_S, VM_ZL, VM_ZU, VM_LAM, VM_L, VM_U, VM_SC, VM_SIGMA, VM_RS, VM_D, VM_R, VM_DLAM, VM_DS, VM_DZL, VM_DZU,
+       VM_ST, VM_CT, VM_RT, VM_SS2, VM_COUNT };
+// N-sized vectors
+enum { VK_RHS = 0, VK_SOL, VK_RHS2, VK_SOL2, VK_T1, VK_T2, VK_DIAG, VK_Y, VK_COUNT };
+// row flags
+enum { RF_EQ = 1, RF_L = 2, RF_U = 4 };
+
+struct Ctx {
+  const SeqDesc* q;
+  const StageDesc* S;
+  double* lds;          // workgroup scratch (LDS on the device)
+  int lds_cap;          // doubles available in lds
+  int n, m, N, Nb, bc, w, W2, LD;
+  double* K0b; double* K0x; double* Kfb; double* Kfx;
+  const int* pos_var; const int* pos_row;
+  double sf;            // objective scaling
+  double tol;           // IPOPT tol of the stage (phys_optim.cpp:578)
+  int err;              // sticky error flag (band overflow), uniform across the workgroup after a sync
+  int n_bad_pivots;
+};
+
+#define VN(c, k) ((c).q->wd + (c).q->o_vec_n + (long long)(k) * (c).q->max_n)
+#define VM(c, k) ((c).q->wd + (c).q->o_vec_m + (long long)(k) * (c).q->max_m)
+#define VK(c, k) ((c).q->wd + (c).q->o_vec_N + (long long)(k) * (c).q->max_N)
+
+// ------------------------------------------------------------------------------------------
+// workgroup reductions (deterministic: fixed tree, every thread combines the per-wave partials
+// in the same order)
+// ------------------------------------------------------------------------------------------
+#ifdef CHD_HOST_EMU
+CHD_DEV double block_sum(Ctx&, double v) { return v; }
+CHD_DEV double block_max(Ctx&, double v) { return v; }
+CHD_DEV double block_min(Ctx&, double v) { return v; }
+CHD_DEV double group_sum(double v) { return v; }
+#else
+CHD_DEV double block_sum(Ctx& c, double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) c.lds[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0; const int nw = (blockDim.x + 63) >> 6;
+  for (int k = 0; k < nw; ++k) t += c.lds[k];
+  return t;
+}
+CHD_DEV double block_max(Ctx& c, double v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) c.lds[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = c.lds[0]; const int nw = (blockDim.x + 63) >> 6;
+  for (int k = 1; k < nw; ++k) t = fmax(t, c.lds[k]);
+  return t;
+}
+CHD_DEV double block_min(Ctx& c, double v) { return -block_max(c, -v); }
+CHD_DEV double group_sum(double v) {
+  v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+  return v;
+}
+#endif
+#define LDS_RED 64     // doubles reserved at the start of lds for the reductions
+
+// ------------------------------------------------------------------------------------------
+// Cubic Hermite splines (TOWR CubicHermitePolynomial / NodeSpline)
+// ------------------------------------------------------------------------------------------
+struct PE {
+  int poly;
+  double tl, T;
+  double p[3], v[3], a[3];
+  double w[3][4];     // d{pos,vel,acc}/d(p0, v0, p1, v1) of the active polynomial
+};
+
+CHD_DEV int seg_lookup(const double* cum_end, int n, double t) {    // first i with cum_end[i] >= t - 1e-10, clamped
+  int lo = 0, hi = n - 1;
+  const double tt = t - 1e-10;
+  while (lo < hi) { int mid = (lo + hi) >> 1; if (cum_end[mid] >= tt) hi = mid; else lo = mid + 1; }
+  return lo;
+}
+
+CHD_DEV void hermite_eval(const SeqDesc* q, int s, int id, double tl, PE& e) {
+  const SplineDesc& sp = q->sp[s];
+  const double T = q->wd[q->o_poly_dur + sp.poly_off + id];
+  e.poly = id; e.tl = tl; e.T = T;
+  const double t = tl, t2 = t * t, t3 = t2 * t, iT = 1.0 / T, iT2 = iT * iT, iT3 = iT2 * iT;
+  e.w[0][0] = 2 * t3 * iT3 - 3 * t2 * iT2 + 1;   e.w[0][1] = t - 2 * t2 * iT + t3 * iT2;
+  e.w[0][2] = 3 * t2 * iT2 - 2 * t3 * iT3;       e.w[0][3] = t3 * iT2 - t2 * iT;
+  e.w[1][0] = 6 * t2 * iT3 - 6 * t * iT2;        e.w[1][1] = 3 * t2 * iT2 - 4 * t * iT + 1;
+  e.w[1][2] = 6 * t * iT2 - 6 * t2 * iT3;        e.w[1][3] = 3 * t2 * iT2 - 2 * t * iT;
+  e.w[2][0] = 12 * t * iT3 - 6 * iT2;            e.w[2][1] = 6 * t * iT2 - 4 * iT;
+  e.w[2][2] = 6 * iT2 - 12 * t * iT3;            e.w[2][3] = 6 * t * iT2 - 2 * iT;
+  const double* nv = q->wd + q->o_node + sp.node_off + id * 6;   // [node id: p xyz, v xyz][node id+1: ...]
+  for (int k = 0; k < 3; ++k) {
+    const double p0 = nv[k], v0 = nv[3 + k], p1 = nv[6 + k], v1 = nv[9 + k];
+    e.p[k] = e.w[0][0] * p0 + e.w[0][1] * v0 + e.w[0][2] * p1 + e.w[0][3] * v1;
+    e.v[k] = e.w[1][0] * p0 + e.w[1][1] * v0 + e.w[1][2] * p1 + e.w[1][3] * v1;
+    e.a[k] = e.w[2][0] * p0 + e.w[2][1] * v0 + e.w[2][2] * p1 + e.w[2][3] * v1;
+  }
+}
+
+CHD_DEV void spline_eval(const SeqDesc* q, int s, double tg, PE& e) {
+  const SplineDesc& sp = q->sp[s];
+  const double* pend = q->wd + q->o_pend + sp.poly_off;
+  const int id = seg_lookup(pend, sp.n_polys, tg);
+  hermite_eval(q, s, id, tg - (id > 0 ? pend[id - 1] : 0.0), e);
+}
+
+// d p(t) / d T_poly for the active polynomial (CubicHermitePolynomial::GetDerivativeOfPosWrtDuration)
+CHD_DEV void dpos_dT(const SeqDesc* q, int s, const PE& e, double* out) {
+  const SplineDesc& sp = q->sp[s];
+  const double* nv = q->wd + q->o_node + sp.node_off + e.poly * 6;
+  const double t = e.tl, t2 = t * t, t3 = t2 * t, T = e.T, iT = 1.0 / T, iT2 = iT * iT, iT3 = iT2 * iT, iT4 = iT2 * iT2;
+  for (int k = 0; k < 3; ++k) {
+    const double x0 = nv[k], v0 = nv[3 + k], x1 = nv[6 + k], v1 = nv[9 + k];
+    out[k] = t3 * (v0 + v1) * iT3 - t2 * (2 * v0 + v1) * iT2 - 3 * t3 * (2 * x0 - 2 * x1 + T * v0 + T * v1) * iT4 +
+             2 * t2 * (3 * x0 - 3 * x1 + 2 * T * v0 + T * v1) * iT3;
+  }
+}
+
+// phase of end-effector e at time t, and whether it is the last one
+CHD_DEV int phase_lookup(const SeqDesc* q, int e, double t) {
+  return seg_lookup(q->wd + q->o_phend + q->phase_off[e], q->n_phase[e], t);
+}
+
+// d p(t) / d(phase durations) for a phase-based spline (PhaseSpline::GetJacobianOfPosWrtDurations,
+// PhaseDurations::GetJacobianOfPos).  Returns cur phase; dj_k[d] for k < cur is `early[d]`,
+// for k == cur (when not last) is `own[d]`; zero beyond.
+struct DurJac { int cur, last, nvar; double own[3], early[3]; };
+CHD_DEV void dur_jac(const SeqDesc* q, int s, double t, const PE& e, DurJac& dj) {
+  const SplineDesc& sp = q->sp[s];
+  const int ee = sp.ee;
+  const int* pi = q->ci + q->o_pinfo + (sp.poly_off + e.poly) * 4;
+  double dT[3];
+  dpos_dT(q, s, e, dT);
+  const double inv = 1.0 / pi[2];
+  dj.cur = phase_lookup(q, ee, t);
+  dj.last = dj.cur == q->n_phase[ee] - 1;
+  dj.nvar = q->n_phase[ee] - 1;
+  for (int k = 0; k < 3; ++k) {
+    const double dx = inv * (dT[k] - pi[1] * e.v[k]);
+    dj.own[k] = dj.last ? 0.0 : dx;
+    dj.early[k] = -e.v[k] - (dj.last ? dx : 0.0);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Euler angles (TOWR EulerConverter, ZYX), hand-derived derivatives
+// ------------------------------------------------------------------------------------------
+CHD_DEV void mat3_mul(const double A[3][3], const double B[3][3], double C[3][3]) {
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) C[i][j] = A[i][0] * B[0][j] + A[i][1] * B[1][j] + A[i][2] * B[2][j];
+}
+// R = Rz(z) Ry(y) Rx(x) and dR[k] = dR/d e_k
+CHD_DEV void rot_and_derivs(const double e[3], double R[3][3], double dR[3][3][3]) {
+  const double cx = cos(e[0]), sx = sin(e[0]), cy = cos(e[1]), sy = sin(e[1]), cz = cos(e[2]), sz = sin(e[2]);
+  const double Rx[3][3] = {{1, 0, 0}, {0, cx, -sx}, {0, sx, cx}}, dRx[3][3] = {{0, 0, 0}, {0, -sx, -cx}, {0, cx, -sx}};
+  const double Ry[3][3] = {{cy, 0, sy}, {0, 1, 0}, {-sy, 0, cy}}, dRy[3][3] = {{-sy, 0, cy}, {0, 0, 0}, {-cy, 0, -sy}};
+  const double Rz[3][3] = {{cz, -sz, 0}, {sz, cz, 0}, {0, 0, 1}}, dRz[3][3] = {{-sz, -cz, 0}, {cz, -sz, 0}, {0, 0, 0}};
+  double ZY[3][3], t[3][3];
+  mat3_mul(Rz, Ry, ZY); mat3_mul(ZY, Rx, R);
+  mat3_mul(ZY, dRx, dR[0]);
+  mat3_mul(Rz, dRy, t); mat3_mul(t, Rx, dR[1]);
+  mat3_mul(dRz, Ry, t); mat3_mul(t, Rx, dR[2]);
+}
+CHD_DEV void cross3(const double a[3], const double b[3], double o[3]) {
+  o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+CHD_DEV void matvec3(const double A[3][3], const double v[3], double o[3]) {
+  for (int i = 0; i < 3; ++i) o[i] = A[i][0] * v[0] + A[i][1] * v[1] + A[i][2] * v[2];
+}
+
+// Angular part of the centroidal dynamics (humanoid_rigid_body_dynamics.cpp:89-115):
+//   ang = I_w wd + w x (I_w w),  I_w = R I_b R^T,  w = M(e) e',  wd = Md(e,e') e' + M(e) e''.
+// Outputs ang[3] and its partials d0 (wrt e), d1 (wrt e'), d2 (wrt e''): dX[i][k] = d ang_i / d (.)_k.
+CHD_DEV void angular_term(const double e[3], const double ed[3], const double edd[3], const double Ib[3][3], int want_jac,
+                          double ang[3], double d0[3][3], double d1[3][3], double d2[3][3]) {
+  double R[3][3], dR[3][3][3];
+  rot_and_derivs(e, R, dR);
+  const double cy = cos(e[1]), sy = sin(e[1]), cz = cos(e[2]), sz = sin(e[2]);
+  const double M[3][3] = {{cy * cz, -sz, 0}, {cy * sz, cz, 0}, {-sy, 0, 1}};
+  // dM/dy, dM/dz (dM/dx = 0) and the second derivatives
+  const double My[3][3] = {{-sy * cz, 0, 0}, {-sy * sz, 0, 0}, {-cy, 0, 0}};
+  const double Mz[3][3] = {{-cy * sz, -cz, 0}, {cy * cz, -sz, 0}, {0, 0, 0}};
+  const double Myy[3][3] = {{-cy * cz, 0, 0}, {-cy * sz, 0, 0}, {sy, 0, 0}};
+  const double Myz[3][3] = {{sy * sz, 0, 0}, {-sy * cz, 0, 0}, {0, 0, 0}};
+  const double Mzz[3][3] = {{-cy * cz, sz, 0}, {-cy * sz, -cz, 0}, {0, 0, 0}};
+  double Md[3][3];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Md[i][j] = My[i][j] * ed[1] + Mz[i][j] * ed[2];
+  double om[3], omd[3], t1[3], t2[3];
+  matvec3(M, ed, om);
+  matvec3(Md, ed, t1); matvec3(M, edd, t2);
+  for (int i = 0; i < 3; ++i) omd[i] = t1[i] + t2[i];
+  double RI[3][3], Rt[3][3], Iw[3][3];
+  mat3_mul(R, Ib, RI);
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rt[i][j] = R[j][i];
+  mat3_mul(RI, Rt, Iw);
+  double Iw_om[3], Iw_omd[3], cr[3];
+  matvec3(Iw, om, Iw_om); matvec3(Iw, omd, Iw_omd);
+  cross3(om, Iw_om, cr);
+  for (int i = 0; i < 3; ++i) ang[i] = Iw_omd[i] + cr[i];
+  if (!want_jac) return;
+  for (int k = 0; k < 3; ++k) {
+    // ---- wrt e''_k : I_w M[:,k]
+    double mk[3] = {M[0][k], M[1][k], M[2][k]}, o[3];
+    matvec3(Iw, mk, o);
+    for (int i = 0; i < 3; ++i) d2[i][k] = o[i];
+    // ---- wrt e'_k : d om = M[:,k] ; d omd = Md[:,k] + (dM/de_k) e'
+    double domd[3], dMk_ed[3] = {0, 0, 0};
+    if (k == 1) matvec3(My, ed, dMk_ed);
+    if (k == 2) matvec3(Mz, ed, dMk_ed);
+    for (int i = 0; i < 3; ++i) domd[i] = Md[i][k] + dMk_ed[i];
+    double a1[3], a2[3], a3[3], Iw_mk[3];
+    matvec3(Iw, domd, a1);
+    cross3(mk, Iw_om, a2);
+    matvec3(Iw, mk, Iw_mk); cross3(om, Iw_mk, a3);
+    for (int i = 0; i < 3; ++i) d1[i][k] = a1[i] + a2[i] + a3[i];
+    // ---- wrt e_k
+    double dIw[3][3], A[3][3], B[3][3], dRt[3][3], IbRt[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) dRt[i][j] = dR[k][j][i];
+    mat3_mul(Ib, Rt, IbRt);
+    mat3_mul(dR[k], IbRt, A);          // dR Ib R^T
+    mat3_mul(RI, dRt, B);              // R Ib dR^T
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) dIw[i][j] = A[i][j] + B[i][j];
+    double dom[3] = {0, 0, 0}, domd_e[3] = {0, 0, 0};
+    if (k == 1) {
+      matvec3(My, ed, dom);
+      double Mdk[3][3];
+      for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Mdk[i][j] = Myy[i][j] * ed[1] + Myz[i][j] * ed[2];
+      double u1[3], u2[3]; matvec3(Mdk, ed, u1); matvec3(My, edd, u2);
+      for (int i = 0; i < 3; ++i) domd_e[i] = u1[i] + u2[i];
+    } else if (k == 2) {
+      matvec3(Mz, ed, dom);
+      double Mdk[3][3];
+      for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Mdk[i][j] = Myz[i][j] * ed[1] + Mzz[i][j] * ed[2];
+      double u1[3], u2[3]; matvec3(Mdk, ed, u1); matvec3(Mz, edd, u2);
+      for (int i = 0; i < 3; ++i) domd_e[i] = u1[i] + u2[i];
+    }
+    double b1[3], b2[3], b3[3], b4[3], b5[3], tmp[3];
+    matvec3(dIw, omd, b1);
+    matvec3(Iw, domd_e, b2);
+    cross3(dom, Iw_om, b3);
+    matvec3(dIw, om, tmp); cross3(om, tmp, b4);
+    matvec3(Iw, dom, tmp); cross3(om, tmp, b5);
+    for (int i = 0; i < 3; ++i) d0[i][k] = b1[i] + b2[i] + b3[i] + b4[i] + b5[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// KKT storage.  K = [H + dw Dw, J^T; J, -D] in a time ordering: positions < Nb form a band of
+// half-width w, the last bc positions (shared stance positions, durations, rows touching only
+// those) form a dense border.  K0 (unfactored, both triangles): band rows Nb x (2w+1), border
+// rows bc x N.  Kf (factor, lower): band rows Nb x (w+1), border rows bc x N.
+// ------------------------------------------------------------------------------------------
+CHD_DEV void kadd(Ctx& c, int p, int qq, double val) {
+  if (p < c.Nb && qq < c.Nb) {
+    int dlt = qq - p;
+    if (dlt > c.w || dlt < -c.w) { c.err = 1; return; }
+    c.K0b[(long long)p * c.W2 + (dlt + c.w)] += val;
+    if (dlt != 0) c.K0b[(long long)qq * c.W2 + (c.w - dlt)] += val;
+  } else {
+    const int hi = p > qq ? p : qq, lo = p > qq ? qq : p;
+    c.K0x[(long long)(hi - c.Nb) * c.LD + lo] += val;
+    if (lo >= c.Nb && lo != hi) c.K0x[(long long)(lo - c.Nb) * c.LD + hi] += val;
+  }
+}
+CHD_DEV double kget(const Ctx& c, int p, int qq) {
+  if (p < c.Nb && qq < c.Nb) {
+    int dlt = qq - p;
+    if (dlt > c.w || dlt < -c.w) return 0.0;
+    return c.K0b[(long long)p * c.W2 + (dlt + c.w)];
+  }
+  const int hi = p > qq ? p : qq, lo = p > qq ? qq : p;
+  return c.K0x[(long long)(hi - c.Nb) * c.LD + lo];
+}
+
+CHD_DEV void kzero(Ctx& c) {
+  const long long nb_ = (long long)c.Nb * c.W2, nx_ = (long long)c.bc * c.LD;
+  for (long long i = CHD_TID; i < nb_; i += CHD_NT) c.K0b[i] = 0.0;
+  for (long long i = CHD_TID; i < nx_; i += CHD_NT) c.K0x[i] = 0.0;
+}
+
+// y = K0 x (+ diag .* x)
+CHD_DEV void kmatvec(Ctx& c, const double* x, double* y, const double* diag) {
+  const int Nb = c.Nb, w = c.w, W2 = c.W2, LD = c.LD, bc = c.bc;
+  GROUP_FOR(i, Nb) {
+    const int lo = i - w < 0 ? 0 : i - w, hi = i + w >= Nb ? Nb - 1 : i + w;
+    const double* row = c.K0b + (long long)i * W2 + (w - i);
+    double acc = 0;
+    for (int k = lo + lane_; k <= hi; k += CHD_GL) acc += row[k] * x[k];
+    acc = group_sum(acc);
+    if (lane_ == 0) y[i] = acc + (diag ? diag[i] * x[i] : 0.0);
+  }
+  GROUP_FOR(r, bc) {
+    const double* row = c.K0x + (long long)r * LD;
+    double acc = 0;
+    for (int k = lane_; k < LD; k += CHD_GL) acc += row[k] * x[k];
+    acc = group_sum(acc);
+    if (lane_ == 0) y[Nb + r] = acc + (diag ? diag[Nb + r] * x[Nb + r] : 0.0);
+  }
+  CHD_SYNC();
+  PAR_FOR(i, Nb) {
+    double acc = 0;
+    for (int r = 0; r < bc; ++r) acc += c.K0x[(long long)r * LD + i] * x[Nb + r];
+    y[i] += acc;
+  }
+  CHD_SYNC();
+}
+
+// ---- factorisation: K0 + diag -> L D L^T in Kf (no pivoting; expected pivot sign from `sign`) ----
+CHD_DEV double pivot_fix(Ctx& c, double d, int sg) {
+  if (!(d * sg > 1e-14)) { d = sg * 1e-10; if (CHD_TID == 0) c.n_bad_pivots++; }
+  return d;
+}
+
+CHD_DEV void kfactor(Ctx& c, const double* diag, const int* sign) {
+  const int Nb = c.Nb, w = c.w, W2 = c.W2, W1 = c.w + 1, LD = c.LD, bc = c.bc;
+  if (CHD_TID == 0) c.n_bad_pivots = 0;
+  // copy the lower triangle (+ diagonal shift) into the factor storage
+  for (long long idx = CHD_TID; idx < (long long)Nb * W1; idx += CHD_NT) {
+    const int i = (int)(idx / W1), cc = (int)(idx % W1);
+    double v = c.K0b[(long long)i * W2 + cc];
+    if (cc == w) v += diag[i];
+    c.Kfb[idx] = v;
+  }
+  for (long long idx = CHD_TID; idx < (long long)bc * LD; idx += CHD_NT) {
+    const int r = (int)(idx / LD), k = (int)(idx % LD);
+    double v = c.K0x[idx];
+    if (k == Nb + r) v += diag[Nb + r];
+    c.Kfx[idx] = v;
+  }
+  CHD_SYNC();
+  // panel width from the LDS budget
+  double* dv = c.lds + LDS_RED;          // pivots of the current panel (<= 32)
+  double* PT = dv + 32;                  // panel, column-major: PT[j * ldp + a]
+  const int avail = c.lds_cap - LDS_RED - 32;
+  int nb = 32;
+  while (nb > 4 && (long long)(nb + w + bc + 8) * nb > avail) nb >>= 1;
+  const int ldp = nb + w + bc + 8;
+  for (int c0 = 0; c0 < Nb; c0 += nb) {
+    const int jb = Nb - c0 < nb ? Nb - c0 : nb;
+    const int nbr = (Nb - c0 < jb + w) ? Nb - c0 : jb + w;     // band rows in the panel
+    const int pr = nbr + bc;
+    // ---- load panel (zero padded)
+    PAR_FOR(idx, ldp * jb) {
+      const int a = idx / jb, j = idx % jb;
+      double v = 0.0;
+      if (a < nbr) {
+        const int i = c0 + a, k = c0 + j;
+        if (k <= i && i - k <= w) v = c.Kfb[(long long)i * W1 + (k - i + w)];
+      } else if (a < pr) {
+        v = c.Kfx[(long long)(a - nbr) * LD + c0 + j];
+      }
+      PT[j * ldp + a] = v;
+    }
+    CHD_SYNC();
+    // ---- factor the panel column by column
+    for (int j = 0; j < jb; ++j) {
+      const double d = pivot_fix(c, PT[j * ldp + j], sign[c0 + j]);
+      const double id = 1.0 / d;
+      CHD_SYNC();
+      for (int a = j + 1 + CHD_TID; a < pr; a += CHD_NT) PT[j * ldp + a] *= id;
+      if (CHD_TID == 0) dv[j] = d;
+      CHD_SYNC();
+      const int nr = pr - j - 1, nc = jb - j - 1;
+      PAR_FOR(idx, nr * nc) {
+        const int a = j + 1 + idx % nr, jj = j + 1 + idx / nr;
+        if (a >= jj) PT[jj * ldp + a] -= PT[j * ldp + a] * d * PT[j * ldp + jj];
+      }
+      CHD_SYNC();
+    }
+    // ---- write the panel back
+    PAR_FOR(idx, pr * jb) {
+      const int a = idx / jb, j = idx % jb;
+      if (a < nbr) {
+        const int i = c0 + a, k = c0 + j;
+        if (k < i && i - k <= w) c.Kfb[(long long)i * W1 + (k - i + w)] = PT[j * ldp + a];
+        else if (k == i) c.Kfb[(long long)i * W1 + w] = dv[j];
+      } else {
+        c.Kfx[(long long)(a - nbr) * LD + c0 + j] = PT[j * ldp + a];
+      }
+    }
+    // ---- trailing update of the window (4x4 register tiles)
+    const int wr = pr - jb;
+    const int nt = (wr + 3) >> 2;
+    PAR_FOR(tix, nt * nt) {
+      const int tr = tix / nt, tc = tix % nt;
+      if (tc > tr) continue;
+      double acc[4][4];
+      for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+      const double* pa = PT + jb + 4 * tr;
+      const double* pb = PT + jb + 4 * tc;
+      for (int j = 0; j < jb; ++j) {
+        const double dj = dv[j];
+        const double la0 = pa[j * ldp], la1 = pa[j * ldp + 1], la2 = pa[j * ldp + 2], la3 = pa[j * ldp + 3];
+        const double lb0 = pb[j * ldp] * dj, lb1 = pb[j * ldp + 1] * dj, lb2 = pb[j * ldp + 2] * dj, lb3 = pb[j * ldp + 3] * dj;
+        acc[0][0] += la0 * lb0; acc[0][1] += la0 * lb1; acc[0][2] += la0 * lb2; acc[0][3] += la0 * lb3;
+        acc[1][0] += la1 * lb0; acc[1][1] += la1 * lb1; acc[1][2] += la1 * lb2; acc[1][3] += la1 * lb3;
+        acc[2][0] += la2 * lb0; acc[2][1] += la2 * lb1; acc[2][2] += la2 * lb2; acc[2][3] += la2 * lb3;
+        acc[3][0] += la3 * lb0; acc[3][1] += la3 * lb1; acc[3][2] += la3 * lb2; acc[3][3] += la3 * lb3;
+      }
+      for (int a = 0; a < 4; ++a) {
+        const int ar = jb + 4 * tr + a;
+        if (ar >= pr) break;
+        for (int b = 0; b < 4; ++b) {
+          const int ac = jb + 4 * tc + b;
+          if (ac > ar) break;
+          const double v = acc[a][b];
+          if (v == 0.0) continue;
+          if (ar < nbr) {
+            const int i = c0 + ar, k = c0 + ac;
+            c.Kfb[(long long)i * W1 + (k - i + w)] -= v;
+          } else {
+            const int r = ar - nbr;
+            if (ac < nbr) c.Kfx[(long long)r * LD + c0 + ac] -= v;
+            else c.Kfx[(long long)r * LD + Nb + (ac - nbr)] -= v;
+          }
+        }
+      }
+    }
+    CHD_SYNC();
+  }
+  // ---- dense L D L^T of the border Schur complement (rows/cols Nb..N-1)
+  if (bc > 0) {
+    double* SL = c.lds + LDS_RED;
+    const bool in_lds = (long long)bc * bc <= c.lds_cap - LDS_RED;
+    const int lds_ = in_lds ? bc : LD;
+    double* Sp = in_lds ? SL : c.Kfx + Nb;
+    if (in_lds) {
+      PAR_FOR(idx, bc * bc) { const int r = idx / bc, k = idx % bc; SL[idx] = k <= r ? c.Kfx[(long long)r * LD + Nb + k] : 0.0; }
+      CHD_SYNC();
+    }
+    for (int j = 0; j < bc; ++j) {
+      const double d = pivot_fix(c, Sp[(long long)j * lds_ + j], sign[Nb + j]);
+      const double id = 1.0 / d;
+      CHD_SYNC();
+      for (int r = j + 1 + CHD_TID; r < bc; r += CHD_NT) Sp[(long long)r * lds_ + j] *= id;
+      if (CHD_TID == 0) Sp[(long long)j * lds_ + j] = d;
+      CHD_SYNC();
+      const int nr = bc - j - 1;
+      PAR_FOR(idx, nr * nr) {
+        const int r = j + 1 + idx / nr, k = j + 1 + idx % nr;
+        if (k <= r) Sp[(long long)r * lds_ + k] -= Sp[(long long)r * lds_ + j] * d * Sp[(long long)k * lds_ + j];
+      }
+      CHD_SYNC();
+    }
+    if (in_lds) {
+      PAR_FOR(idx, bc * bc) { const int r = idx / bc, k = idx % bc; if (k <= r) c.Kfx[(long long)r * LD + Nb + k] = SL[idx]; }
+      CHD_SYNC();
+    }
+  }
+}
+
+// in-block triangular solves for the substitution (wave-cooperative on the device)
+#ifdef CHD_HOST_EMU
+CHD_DEV void tri_forward(Ctx& c, double* y, int c0, int jb) {
+  const int W1 = c.w + 1, w = c.w;
+  for (int i = 1; i < jb; ++i) {
+    double s = y[c0 + i];
+    for (int j = 0; j < i; ++j) s -= c.Kfb[(long long)(c0 + i) * W1 + (j - i + w)] * y[c0 + j];
+    y[c0 + i] = s;
+  }
+}
+CHD_DEV void tri_backward(Ctx& c, double* y, int c0, int jb) {
+  const int W1 = c.w + 1, w = c.w;
+  for (int i = jb - 2; i >= 0; --i) {
+    double s = y[c0 + i];
+    for (int j = i + 1; j < jb; ++j) s -= c.Kfb[(long long)(c0 + j) * W1 + (i - j + w)] * y[c0 + j];
+    y[c0 + i] = s;
+  }
+}
+#else
+CHD_DEV void tri_forward(Ctx& c, double* y, int c0, int jb) {
+  if (threadIdx.x < 64) {
+    const int W1 = c.w + 1, w = c.w, i = threadIdx.x;
+    const bool act = i < jb;
+    double yi = act ? y[c0 + i] : 0.0;
+    const double* row = c.Kfb + (long long)(c0 + (act ? i : 0)) * W1 + (w - (act ? i : 0));
+    for (int j = 0; j < jb - 1; ++j) {
+      const double yj = __shfl(yi, j);
+      if (act && i > j) yi -= row[j] * yj;
+    }
+    if (act) y[c0 + i] = yi;
+  }
+}
+CHD_DEV void tri_backward(Ctx& c, double* y, int c0, int jb) {
+  if (threadIdx.x < 64) {
+    const int W1 = c.w + 1, w = c.w, i = threadIdx.x;
+    const bool act = i < jb;
+    double yi = act ? y[c0 + i] : 0.0;
+    for (int j = jb - 1; j > 0; --j) {
+      const double yj = __shfl(yi, j);
+      if (act && i < j) yi -= c.Kfb[(long long)(c0 + j) * W1 + (i - j + w)] * yj;
+    }
+    if (act) y[c0 + i] = yi;
+  }
+}
+#endif
+
+// x = K^{-1} rhs using the factor.  y: work vector of N doubles (LDS when it fits).
+CHD_DEV void ksolve_once(Ctx& c, const double* rhs, double* x) {
+  const int Nb = c.Nb, w = c.w, W1 = c.w + 1, LD = c.LD, bc = c.bc, N = c.N;
+  double* y = (c.lds_cap - LDS_RED >= N) ? c.lds + LDS_RED : VK(c, VK_Y);
+  PAR_FOR(i, N) y[i] = rhs[i];
+  CHD_SYNC();
+  const int nb = 32;
+  // forward, band
+  for (int c0 = 0; c0 < Nb; c0 += nb) {
+    const int jb = Nb - c0 < nb ? Nb - c0 : nb;
+    GROUP_FOR(a, jb) {
+      const int i = c0 + a;
+      const int lo = i - w < 0 ? 0 : i - w;
+      const double* row = c.Kfb + (long long)i * W1 + (w - i);
+      double acc = 0;
+      for (int k = lo + lane_; k < c0; k += CHD_GL) acc += row[k] * y[k];
+      acc = group_sum(acc);
+      if (lane_ == 0) y[i] -= acc;
+    }
+    CHD_SYNC();
+    tri_forward(c, y, c0, jb);
+    CHD_SYNC();
+  }
+  // forward, border rows: band part of L_border
+  GROUP_FOR(r, bc) {
+    const double* row = c.Kfx + (long long)r * LD;
+    double acc = 0;
+    for (int k = lane_; k < Nb; k += CHD_GL) acc += row[k] * y[k];
+    acc = group_sum(acc);
+    if (lane_ == 0) y[Nb + r] -= acc;
+  }
+  CHD_SYNC();
+  for (int j = 0; j + 1 < bc; ++j) {     // dense unit-lower part
+    const double yj = y[Nb + j];
+    for (int r = j + 1 + CHD_TID; r < bc; r += CHD_NT) y[Nb + r] -= c.Kfx[(long long)r * LD + Nb + j] * yj;
+    CHD_SYNC();
+  }
+  // diagonal
+  PAR_FOR(i, N) y[i] /= (i < Nb ? c.Kfb[(long long)i * W1 + w] : c.Kfx[(long long)(i - Nb) * LD + i]);
+  CHD_SYNC();
+  // backward, border
+  for (int j = bc - 1; j > 0; --j) {
+    const double yj = y[Nb + j];
+    const double* row = c.Kfx + (long long)j * LD + Nb;
+    for (int r = CHD_TID; r < j; r += CHD_NT) y[Nb + r] -= row[r] * yj;
+    CHD_SYNC();
+  }
+  PAR_FOR(k, Nb) {
+    double acc = 0;
+    for (int r = 0; r < bc; ++r) acc += c.Kfx[(long long)r * LD + k] * y[Nb + r];
+    y[k] -= acc;
+  }
+  CHD_SYNC();
+  // backward, band
+  const int nblk = (Nb + nb - 1) / nb;
+  for (int bk = nblk - 1; bk >= 0; --bk) {
+    const int c0 = bk * nb;
+    const int jb = Nb - c0 < nb ? Nb - c0 : nb;
+    tri_backward(c, y, c0, jb);
+    CHD_SYNC();
+    const int k0 = c0 - w < 0 ? 0 : c0 - w;
+    for (int k = k0 + CHD_TID; k < c0; k += CHD_NT) {
+      double acc = 0;
+      for (int a = 0; a < jb; ++a) {
+        const int i = c0 + a;
+        if (i - k <= w) acc += c.Kfb[(long long)i * W1 + (k - i + w)] * y[i];
+      }
+      y[k] -= acc;
+    }
+    CHD_SYNC();
+  }
+  PAR_FOR(i, N) x[i] = y[i];
+  CHD_SYNC();
+}
+
+CHD_DEV void ksolve(Ctx& c, const double* rhs, double* x, const double* diag, int refine) {
+  ksolve_once(c, rhs, x);
+  double* t1 = VK(c, VK_T1); double* t2 = VK(c, VK_T2);
+  for (int it = 0; it < refine; ++it) {
+    kmatvec(c, x, t1, diag);
+    PAR_FOR(i, c.N) t1[i] = rhs[i] - t1[i];
+    CHD_SYNC();
+    ksolve_once(c, t1, t2);
+    PAR_FOR(i, c.N) x[i] += t2[i];
+    CHD_SYNC();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// NLP state <-> x
+// ------------------------------------------------------------------------------------------
+CHD_DEV void refresh_durations(const SeqDesc* q) {     // polynomial durations + cumulative times from the phase durations
+  double* wd = q->wd;
+  PAR_FOR(idx, q->tot_polys) {
+    int s = 0;
+    while (s + 1 < N_SPLINES && idx >= q->sp[s + 1].poly_off) ++s;
+    const SplineDesc& sp = q->sp[s];
+    if (sp.phase_based) {
+      const int* pi = q->ci + q->o_pinfo + idx * 4;
+      wd[q->o_poly_dur + idx] = wd[q->o_phase_dur + q->phase_off[sp.ee] + pi[0]] / pi[2];
+    }
+  }
+  CHD_SYNC();
+  PAR_FOR(s, N_SPLINES + N_EE) {
+    if (s < N_SPLINES) {
+      const SplineDesc& sp = q->sp[s];
+      double t = 0;
+      for (int p = 0; p < sp.n_polys; ++p) { t += wd[q->o_poly_dur + sp.poly_off + p]; wd[q->o_pend + sp.poly_off + p] = t; }
+      wd[q->o_ttot + s] = t;
+    } else {
+      const int e = s - N_SPLINES;
+      double t = 0;
+      for (int p = 0; p < q->n_phase[e]; ++p) { t += wd[q->o_phase_dur + q->phase_off[e] + p]; wd[q->o_phend + q->phase_off[e] + p] = t; }
+    }
+  }
+  CHD_SYNC();
+}
+
+CHD_DEV void state_from_x(Ctx& c, const double* x) {
+  const SeqDesc* q = c.q;
+  PAR_FOR(k, q->tot_entries) {
+    const int v = q->ci[q->o_varof + k];
+    if (v >= 0) {
+      int s = 0;
+      while (s + 1 < N_SPLINES && k >= q->sp[s + 1].node_off) ++s;
+      q->wd[q->o_node + k] = x[q->sp[s].var_off + v];
+    }
+  }
+  if (c.S->opt_dur) {
+    PAR_FOR(e, N_EE) {      // TOWR PhaseDurations::SetVariables: last duration = T - sum
+      double sum = 0;
+      const int np = q->n_phase[e];
+      double* ph = q->wd + q->o_phase_dur + q->phase_off[e];
+      for (int k = 0; k + 1 < np; ++k) { ph[k] = x[c.S->dur_off[e] + k]; sum += ph[k]; }
+      ph[np - 1] = q->T - sum;
+    }
+  }
+  CHD_SYNC();
+  if (c.S->opt_dur) refresh_durations(q);
+}
+
+CHD_DEV void x_from_state(Ctx& c, double* x) {
+  const SeqDesc* q = c.q;
+  PAR_FOR(k, q->tot_entries) {
+    const int v = q->ci[q->o_varof + k];
+    if (v >= 0) {
+      int s = 0;
+      while (s + 1 < N_SPLINES && k >= q->sp[s + 1].node_off) ++s;
+      x[q->sp[s].var_off + v] = q->wd[q->o_node + k];
+    }
+  }
+  if (c.S->opt_dur)
+    PAR_FOR(e, N_EE)
+      for (int k = 0; k + 1 < q->n_phase[e]; ++k) x[c.S->dur_off[e] + k] = q->wd[q->o_phase_dur + q->phase_off[e] + k];
+  CHD_SYNC();
+}
+
+// ------------------------------------------------------------------------------------------
+// Constraint rows
+// ------------------------------------------------------------------------------------------
+struct RowW {           // where one row's Jacobian entries go
+  Ctx* c; int pr; double sc; bool on;
+};
+CHD_DEV void row_nodes(const RowW& r, int s, const PE& e, int which, const double coef[3], int dimmask) {
+  if (!r.on) return;
+  const SeqDesc* q = r.c->q;
+  const SplineDesc& sp = q->sp[s];
+  const int* vo = q->ci + q->o_varof + sp.node_off + e.poly * 6;
+  for (int side = 0; side < 2; ++side)
+    for (int dq = 0; dq < 2; ++dq) {
+      const double wgt = e.w[which][side * 2 + dq];
+      for (int k = 0; k < 3; ++k) {
+        if (!((dimmask >> k) & 1)) continue;
+        const int v = vo[side * 6 + dq * 3 + k];
+        if (v >= 0) kadd(*r.c, r.pr, r.c->pos_var[sp.var_off + v], r.sc * coef[k] * wgt);
+      }
+    }
+}
+CHD_DEV void row_durs(const RowW& r, int s, double t, const PE& e, const double coef[3]) {
+  if (!r.on || !r.c->S->opt_dur) return;
+  const SeqDesc* q = r.c->q;
+  DurJac dj;
+  dur_jac(q, s, t, e, dj);
+  const int ee = q->sp[s].ee;
+  const int base = r.c->S->dur_off[ee];
+  const double ve = coef[0] * dj.early[0] + coef[1] * dj.early[1] + coef[2] * dj.early[2];
+  for (int k = 0; k < dj.cur && k < dj.nvar; ++k) kadd(*r.c, r.pr, r.c->pos_var[base + k], r.sc * ve);
+  if (!dj.last) {
+    const double vo = coef[0] * dj.own[0] + coef[1] * dj.own[1] + coef[2] * dj.own[2];
+    kadd(*r.c, r.pr, r.c->pos_var[base + dj.cur], r.sc * vo);
+  }
+}
+
+CHD_DEV int frame_index(const SeqDesc* q, double t) {       // humanoid_rigid_body_dynamics.cpp:81-87, leg_length_constraint.cpp:40-42
+  int idx = (int)((t / q->T) * q->F);
+  if (idx >= q->F) idx = q->F - 1;
+  if (idx < 0) idx = 0;
+  return idx;
+}
+
+CHD_DEV void eval_rows(Ctx& c, int mode, double* cout_) {
+  const SeqDesc* q = c.q; const StageDesc* S = c.S;
+  const double* sc = VM(c, VM_SC);
+  const bool J = mode == EV_FULL;
+  PAR_FOR(ti, S->n_tasks) {
+    const int* tk = q->ci + S->o_task + 4 * ti;
+    const int type = tk[0], A = tk[1], B = tk[2], row0 = tk[3];
+    const double t = q->cd[S->o_task_t + ti];
+    switch (type) {
+      case T_BASEACC: {      // TOWR SplineAccConstraint: a_j(T_j) - a_{j+1}(0) = 0
+        PE e1, e2;
+        hermite_eval(q, A, B, q->wd[q->o_poly_dur + q->sp[A].poly_off + B], e1);
+        hermite_eval(q, A, B + 1, 0.0, e2);
+        for (int k = 0; k < 3; ++k) {
+          const int row = row0 + k;
+          cout_[row] = sc[row] * (e1.a[k] - e2.a[k]);
+          RowW r{&c, c.pos_row[row], sc[row], J};
+          double cf[3] = {0, 0, 0};
+          cf[k] = 1.0; row_nodes(r, A, e1, 2, cf, 1 << k);
+          cf[k] = -1.0; row_nodes(r, A, e2, 2, cf, 1 << k);
+        }
+      } break;
+      case T_TERRAIN: {      // TOWR TerrainConstraint: z - h(x, y)
+        const SplineDesc& sp = q->sp[2 + A];
+        const double* nv = q->wd + q->o_node + sp.node_off + B * 6;
+        const double h = (-q->normal[1] * (nv[1] - q->point[1]) - q->normal[0] * (nv[0] - q->point[0])) / q->normal[2] + q->point[2];   // ground_plane.cpp:18-27
+        cout_[row0] = sc[row0] * (nv[2] - h);
+        if (J) {
+          const int* vo = q->ci + q->o_varof + sp.node_off + B * 6;
+          const int pr = c.pos_row[row0];
+          if (vo[2] >= 0) kadd(c, pr, c.pos_var[sp.var_off + vo[2]], sc[row0]);
+          if (vo[0] >= 0 && q->hx != 0.0) kadd(c, pr, c.pos_var[sp.var_off + vo[0]], -sc[row0] * q->hx);
+          if (vo[1] >= 0 && q->hy != 0.0) kadd(c, pr, c.pos_var[sp.var_off + vo[1]], -sc[row0] * q->hy);
+        }
+      } break;
+      case T_ROM: {          // leg_length_constraint.cpp:36-111: 1/2 |p_ee - (R hip + c)|^2
+        const int e = A;
+        PE pl, pa, pm;
+        spline_eval(q, 0, t, pl); spline_eval(q, 1, t, pa); spline_eval(q, 2 + e, t, pm);
+        const double* hip = q->cd + q->o_hip[(e == 0 || e == 2) ? 0 : 1] + frame_index(q, t) * 3;   // humanoid.h:45-48
+        double R[3][3], dR[3][3][3], Rh[3], dvec[3];
+        rot_and_derivs(pa.p, R, dR);
+        matvec3(R, hip, Rh);
+        for (int k = 0; k < 3; ++k) dvec[k] = pm.p[k] - (Rh[k] + pl.p[k]);
+        cout_[row0] = sc[row0] * 0.5 * (dvec[0] * dvec[0] + dvec[1] * dvec[1] + dvec[2] * dvec[2]);
+        if (J) {
+          RowW r{&c, c.pos_row[row0], sc[row0], true};
+          double cf[3] = {-dvec[0], -dvec[1], -dvec[2]}, ca[3];
+          row_nodes(r, 0, pl, 0, cf, 7);
+          for (int k = 0; k < 3; ++k) { double dRh[3]; matvec3(dR[k], hip, dRh); ca[k] = -(dvec[0] * dRh[0] + dvec[1] * dRh[1] + dvec[2] * dRh[2]); }
+          row_nodes(r, 1, pa, 0, ca, 7);
+          row_nodes(r, 2 + e, pm, 0, dvec, 7);
+          row_durs(r, 2 + e, t, pm, dvec);
+        }
+      } break;
+      case T_HEELDIST: {     // ee_dist_constraint.cpp:29-94: 1/2 |p_toe - p_heel|^2
+        PE p1, p2;
+        spline_eval(q, 2 + A, t, p1); spline_eval(q, 4 + A, t, p2);
+        double dvec[3], md[3];
+        for (int k = 0; k < 3; ++k) { dvec[k] = p1.p[k] - p2.p[k]; md[k] = -dvec[k]; }
+        cout_[row0] = sc[row0] * 0.5 * (dvec[0] * dvec[0] + dvec[1] * dvec[1] + dvec[2] * dvec[2]);
+        if (J) {
+          RowW r{&c, c.pos_row[row0], sc[row0], true};
+          row_nodes(r, 2 + A, p1, 0, dvec, 7); row_nodes(r, 4 + A, p2, 0, md, 7);
+          row_durs(r, 2 + A, t, p1, dvec); row_durs(r, 4 + A, t, p2, md);
+        }
+      } break;
+      case T_DYN: {          // humanoid_dynamic_constraint.cpp:63-143, humanoid_rigid_body_dynamics.cpp:89-206
+        PE pl, pa, pm[4], pf[4];
+        spline_eval(q, 0, t, pl); spline_eval(q, 1, t, pa);
+        for (int e = 0; e < 4; ++e) { spline_eval(q, 2 + e, t, pm[e]); spline_eval(q, 6 + e, t, pf[e]); }
+        const double* I6 = q->cd + q->o_inertia + frame_index(q, t) * 6;
+        const double Ib[3][3] = {{I6[0], I6[3], I6[4]}, {I6[3], I6[1], I6[5]}, {I6[4], I6[5], I6[2]}};   // humanoid_rigid_body_dynamics.cpp:47-56
+        double ang[3], d0[3][3], d1[3][3], d2[3][3];
+        angular_term(pa.p, pa.v, pa.a, Ib, J, ang, d0, d1, d2);
+        double tau[3] = {0, 0, 0}, fsum[3] = {0, 0, 0};
+        for (int e = 0; e < 4; ++e) {
+          double rr[3] = {pl.p[0] - pm[e].p[0], pl.p[1] - pm[e].p[1], pl.p[2] - pm[e].p[2]}, tq[3];
+          cross3(pf[e].p, rr, tq);
+          for (int k = 0; k < 3; ++k) { tau[k] += tq[k]; fsum[k] += pf[e].p[k]; }
+        }
+        for (int k = 0; k < 3; ++k) {
+          cout_[row0 + k] = sc[row0 + k] * (ang[k] - tau[k]);
+          cout_[row0 + 3 + k] = sc[row0 + 3 + k] * (q->mass * pl.a[k] - fsum[k] - q->mass * CHD_G * q->gdir[k]);
+        }
+        if (J) {
+          for (int i = 0; i < 3; ++i) {
+            RowW ra{&c, c.pos_row[row0 + i], sc[row0 + i], true};
+            RowW rl{&c, c.pos_row[row0 + 3 + i], sc[row0 + 3 + i], true};
+            const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+            // (v x u)_i = v_{i1} u_{i2} - v_{i2} u_{i1}  ->  coefficients on u: [i2] = v_{i1}, [i1] = -v_{i2}
+            double cf[3] = {0, 0, 0};
+            for (int e = 0; e < 4; ++e) { cf[i2] -= pf[e].p[i1]; cf[i1] += pf[e].p[i2]; }     // -sum_e (f_e x dc)_i
+            row_nodes(ra, 0, pl, 0, cf, 7 & ~(1 << i));
+            double cm[3] = {0, 0, 0}; cm[i] = q->mass;
+            row_nodes(rl, 0, pl, 2, cm, 1 << i);
+            row_nodes(ra, 1, pa, 0, d0[i], 7);
+            row_nodes(ra, 1, pa, 1, d1[i], 7);
+            row_nodes(ra, 1, pa, 2, d2[i], 7);
+            for (int e = 0; e < 4; ++e) {
+              const double rr[3] = {pl.p[0] - pm[e].p[0], pl.p[1] - pm[e].p[1], pl.p[2] - pm[e].p[2]};
+              double xr[3] = {0, 0, 0}, xf[3] = {0, 0, 0}, ml[3] = {0, 0, 0};
+              xr[i2] = rr[i1]; xr[i1] = -rr[i2];              // +(r x df)_i
+              xf[i2] = pf[e].p[i1]; xf[i1] = -pf[e].p[i2];    // +(f x dp)_i
+              ml[i] = -1.0;
+              row_nodes(ra, 6 + e, pf[e], 0, xr, 7 & ~(1 << i));
+              row_nodes(rl, 6 + e, pf[e], 0, ml, 1 << i);
+              row_nodes(ra, 2 + e, pm[e], 0, xf, 7 & ~(1 << i));
+              row_durs(ra, 6 + e, t, pf[e], xr);              // humanoid_dynamic_constraint.cpp:112-118
+              row_durs(rl, 6 + e, t, pf[e], ml);
+              row_durs(ra, 2 + e, t, pm[e], xf);
+            }
+          }
+        }
+      } break;
+      case T_FORCE: {        // TOWR ForceConstraint: normal force range + friction pyramid
+        const SplineDesc& sp = q->sp[6 + A];
+        const double* nv = q->wd + q->o_node + sp.node_off + B * 6;
+        const int* vo = q->ci + q->o_varof + sp.node_off + B * 6;
+        for (int r5 = 0; r5 < 5; ++r5) {
+          double dir[3];
+          for (int k = 0; k < 3; ++k) {
+            const double tk_ = (r5 == 1 || r5 == 2) ? q->bt1[k] : q->bt2[k];
+            dir[k] = r5 == 0 ? q->bn[k] : ((r5 & 1) ? tk_ - CHD_MU_FRICTION * q->bn[k] : tk_ + CHD_MU_FRICTION * q->bn[k]);
+          }
+          const int row = row0 + r5;
+          cout_[row] = sc[row] * (nv[0] * dir[0] + nv[1] * dir[1] + nv[2] * dir[2]);
+          if (J) for (int k = 0; k < 3; ++k) if (vo[k] >= 0 && dir[k] != 0.0) kadd(c, c.pos_row[row], c.pos_var[sp.var_off + vo[k]], sc[row] * dir[k]);
+        }
+      } break;
+      case T_HEIGHT: {       // height_constraint.cpp:24-58: n . (p - p0) >= 0 with the file normal
+        PE pm;
+        spline_eval(q, 2 + A, t, pm);
+        cout_[row0] = sc[row0] * (q->normal[0] * (pm.p[0] - q->point[0]) + q->normal[1] * (pm.p[1] - q->point[1]) + q->normal[2] * (pm.p[2] - q->point[2]));
+        if (J) {
+          RowW r{&c, c.pos_row[row0], sc[row0], true};
+          const int mask = (q->normal[0] != 0.0 ? 1 : 0) | (q->normal[1] != 0.0 ? 2 : 0) | (q->normal[2] != 0.0 ? 4 : 0);
+          row_nodes(r, 2 + A, pm, 0, q->normal, mask);
+          row_durs(r, 2 + A, t, pm, q->normal);
+        }
+      } break;
+      case T_TOTALTIME: {    // total_duration_constraint.cpp:60-82
+        const int nv = q->n_phase[A] - 1;
+        double sum = 0;
+        for (int k = 0; k < nv; ++k) sum += q->wd[q->o_phase_dur + q->phase_off[A] + k];
+        cout_[row0] = sc[row0] * sum;
+        if (J) for (int k = 0; k < nv; ++k) kadd(c, c.pos_row[row0], c.pos_var[S->dur_off[A] + k], sc[row0]);
+      } break;
+      case T_DURBOUND: {     // TOWR PhaseDurations::GetBounds
+        cout_[row0] = sc[row0] * q->wd[q->o_phase_dur + q->phase_off[A] + B];
+        if (J) kadd(c, c.pos_row[row0], c.pos_var[S->dur_off[A] + B], sc[row0]);
+      } break;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Cost terms: sum 1/2 w r^2 with gradient and Gauss-Newton Hessian
+// ------------------------------------------------------------------------------------------
+CHD_DEV const double* scache(const SeqDesc* q, int s, int i) { return q->wd + q->o_scache + ((long long)s * (q->F + 2) + i) * SC_STRIDE; }
+
+CHD_DEV void fill_sample_cache(Ctx& c) {
+  const SeqDesc* q = c.q;
+  const int F1 = q->F + 1;
+  PAR_FOR(idx, 6 * F1) {
+    const int s = idx / F1, i = idx % F1;
+    const double t = q->cd[q->o_tcost + i];
+    PE e;
+    spline_eval(q, s, t, e);
+    double* sc_ = q->wd + q->o_scache + ((long long)s * (q->F + 2) + i) * SC_STRIDE;
+    for (int k = 0; k < 4; ++k) { sc_[SC_WP + k] = e.w[0][k]; sc_[SC_WV + k] = e.w[1][k]; }
+    for (int k = 0; k < 3; ++k) { sc_[SC_P + k] = e.p[k]; sc_[SC_V + k] = e.v[k]; sc_[SC_DXDT + k] = 0.0; }
+    sc_[SC_POLY] = e.poly; sc_[SC_PHASE] = 0; sc_[SC_LAST] = 0;
+    if (c.S->opt_dur && s >= 2) {
+      DurJac dj;
+      dur_jac(q, s, t, e, dj);
+      // store own / early in a form usable per k: own[] (k == cur, not last) and early[] (k < cur)
+      for (int k = 0; k < 3; ++k) sc_[SC_DXDT + k] = dj.last ? -(dj.early[k] + e.v[k]) : dj.own[k];   // = dx_dT
+      sc_[SC_PHASE] = dj.cur; sc_[SC_LAST] = dj.last;
+    }
+  }
+  CHD_SYNC();
+}
+// d p_i[dim] / d T_k from the cache
+CHD_DEV double cache_djac(const double* sc_, int dim, int k) {
+  const int cur = (int)sc_[SC_PHASE], last = (int)sc_[SC_LAST];
+  if (k > cur) return 0.0;
+  if (k == cur) return last ? 0.0 : sc_[SC_DXDT + dim];
+  return -sc_[SC_V + dim] - (last ? sc_[SC_DXDT + dim] : 0.0);
+}
+
+// number of smoothing residuals of spline s: loop `for (t = 0; t < T_s - dt; t += dt)` (vel_smooth_cost.cpp:41)
+CHD_DEV int n_smooth(const SeqDesc* q, int s) {
+  const double lim = q->wd[q->o_ttot + s] - q->dt;
+  int n = q->F;
+  while (n > 0 && !(q->cd[q->o_tcost + n - 1] < lim)) --n;
+  return n;
+}
+
+CHD_DEV double eval_cost_value(Ctx& c) {
+  const SeqDesc* q = c.q; const StageDesc* S = c.S;
+  const int F = q->F;
+  double part = 0.0;
+  PAR_FOR(idx, 6 * F) {
+    const int s = idx / F, i = idx % F;
+    const double wdat = S->w_data[s < 2 ? s : 2], wvel = S->w_vel[s < 2 ? s : 2], wacc = S->w_acc[s < 2 ? s : 2];
+    const double* a = scache(q, s, i);
+    const double* dat = q->cd + q->o_data[s] + i * 3;
+    double acc = 0;
+    for (int k = 0; k < 3; ++k) { const double r = dat[k] - a[SC_P + k]; acc += 0.5 * wdat * r * r; }
+    if (i < n_smooth(q, s)) {
+      const double* b = scache(q, s, i + 1);
+      if (wvel >= 0) for (int k = 0; k < 3; ++k) { const double r = b[SC_P + k] - a[SC_P + k]; acc += 0.5 * wvel * r * r; }
+      if (wacc >= 0) for (int k = 0; k < 3; ++k) { const double r = b[SC_V + k] - a[SC_V + k]; acc += 0.5 * wacc * r * r; }
+    }
+    part += acc;
+  }
+  if (S->opt_dur && S->w_dur >= 0) {
+    PAR_FOR(idx, q->tot_phases) {
+      int e = 0; while (e + 1 < N_EE && idx >= q->phase_off[e + 1]) ++e;
+      const int k = idx - q->phase_off[e];
+      if (k + 1 < q->n_phase[e]) { const double r = q->cd[q->o_phase_dur0 + idx] - q->wd[q->o_phase_dur + idx]; part += 0.5 * S->w_dur * r * r; }
+    }
+  }
+  return block_sum(c, part);
+}
+
+// one residual's node support: up to 8 (node, deriv, weight) entries
+struct Supp { int n; int node[8]; int dq[8]; double g[8]; };
+CHD_DEV void supp_add_sample(Supp& sp, const double* sc_, int which, double sign) {
+  const int poly = (int)sc_[SC_POLY];
+  const double* wv = sc_ + (which == 0 ? SC_WP : SC_WV);
+  for (int side = 0; side < 2; ++side)
+    for (int dq = 0; dq < 2; ++dq) { sp.node[sp.n] = poly + side; sp.dq[sp.n] = dq; sp.g[sp.n] = sign * wv[side * 2 + dq]; ++sp.n; }
+}
+
+CHD_DEV void eval_cost_grad_hess(Ctx& c, double* g) {
+  const SeqDesc* q = c.q; const StageDesc* S = c.S;
+  const int F = q->F;
+  int* first = q->wi + q->o_first;
+  const int fstride = q->max_polys + 2;
+  // first data sample of every polynomial
+  PAR_FOR(idx, 6 * fstride) first[idx] = F;
+  PAR_FOR(j, c.n) g[j] = 0.0;
+  CHD_SYNC();
+  PAR_FOR(idx, 6 * F) {
+    const int s = idx / F, i = idx % F;
+    const int pi = (int)scache(q, s, i)[SC_POLY];
+    const int pp = i > 0 ? (int)scache(q, s, i - 1)[SC_POLY] : -1;
+    for (int p = pp + 1; p <= pi; ++p) first[s * fstride + p] = i;
+  }
+  CHD_SYNC();
+  // ---- node variables: one thread per (spline, node group, dimension)
+  int tot_nodes = 0;
+  for (int s = 0; s < 6; ++s) tot_nodes += q->sp[s].n_nodes;
+  PAR_FOR(idx, tot_nodes * 3) {
+    const int dim = idx % 3;
+    int nd = idx / 3, s = 0;
+    while (nd >= q->sp[s].n_nodes) { nd -= q->sp[s].n_nodes; ++s; }
+    const SplineDesc& sp = q->sp[s];
+    const int* pinfo = q->ci + q->o_pinfo + sp.poly_off * 4;
+    const int* vo = q->ci + q->o_varof + sp.node_off;
+    if (sp.phase_based && nd > 0 && pinfo[(nd - 1) * 4 + 3]) continue;       // second node of a stance pair: owned by the first
+    const int nd_hi = (sp.phase_based && nd < sp.n_polys && pinfo[nd * 4 + 3]) ? nd + 1 : nd;
+    bool any = false;
+    for (int n2 = nd; n2 <= nd_hi; ++n2) for (int dq = 0; dq < 2; ++dq) any = any || vo[n2 * 6 + dq * 3 + dim] >= 0;
+    if (!any) continue;
+    const int pa = nd - 1 < 0 ? 0 : nd - 1, pb = nd_hi > sp.n_polys - 1 ? sp.n_polys - 1 : nd_hi;
+    const int i_lo = first[s * fstride + pa], i_hi = first[s * fstride + pb + 1] - 1;
+    const int nsm = n_smooth(q, s);
+    const int ti = s < 2 ? s : 2;
+    const double wdat = S->w_data[ti], wvel = S->w_vel[ti], wacc = S->w_acc[ti];
+    const double* dat = q->cd + q->o_data[s];
+    // residual kinds: 0 data(i), 1 position difference (i, i+1), 2 velocity difference (i, i+1)
+    for (int kind = 0; kind < 3; ++kind) {
+      const double wt = kind == 0 ? wdat : kind == 1 ? wvel : wacc;
+      if (wt < 0) continue;
+      int r_lo = i_lo, r_hi = i_hi;
+      if (kind > 0) { r_lo = i_lo - 1 < 0 ? 0 : i_lo - 1; if (r_hi > nsm - 1) r_hi = nsm - 1; }
+      else if (r_hi > F - 1) r_hi = F - 1;
+      for (int i = r_lo; i <= r_hi; ++i) {
+        const double* a = scache(q, s, i);
+        Supp su; su.n = 0;
+        double r;
+        if (kind == 0) { supp_add_sample(su, a, 0, -1.0); r = dat[i * 3 + dim] - a[SC_P + dim]; }
+        else {
+          const double* b = scache(q, s, i + 1);
+          supp_add_sample(su, b, kind - 1, 1.0); supp_add_sample(su, a, kind - 1, -1.0);
+          r = kind == 1 ? b[SC_P + dim] - a[SC_P + dim] : b[SC_V + dim] - a[SC_V + dim];
+        }
+        for (int x1 = 0; x1 < su.n; ++x1) {
+          if (su.node[x1] < nd || su.node[x1] > nd_hi) continue;
+          const int v = vo[su.node[x1] * 6 + su.dq[x1] * 3 + dim];
+          if (v < 0) continue;
+          const int gv = sp.var_off + v, P = c.pos_var[gv];
+          g[gv] += c.sf * wt * r * su.g[x1];
+          for (int x2 = 0; x2 < su.n; ++x2) {
+            const int v2 = vo[su.node[x2] * 6 + su.dq[x2] * 3 + dim];
+            if (v2 < 0) continue;
+            const int Q = c.pos_var[sp.var_off + v2];
+            if (Q <= P) kadd(c, P, Q, c.sf * wt * su.g[x1] * su.g[x2]);
+          }
+        }
+      }
+    }
+  }
+  // ---- duration variables (stage 3 only): one thread per KKT entry (T_k, target)
+  if (S->opt_dur) {
+    int tot = 0;
+    for (int e = 0; e < 4; ++e) tot += (q->n_phase[e] - 1) * (q->sp[2 + e].n_var + q->n_phase[e] - 1);
+    PAR_FOR(idx0, tot) {
+      int idx = idx0, e = 0;
+      while (idx >= (q->n_phase[e] - 1) * (q->sp[2 + e].n_var + q->n_phase[e] - 1)) { idx -= (q->n_phase[e] - 1) * (q->sp[2 + e].n_var + q->n_phase[e] - 1); ++e; }
+      const int s = 2 + e;
+      const SplineDesc& sp = q->sp[s];
+      const int ntar = sp.n_var + q->n_phase[e] - 1;
+      const int k = idx / ntar, tar = idx % ntar;
+      const int Pk = c.pos_var[S->dur_off[e] + k];
+      const double wdat = S->w_data[2], wvel = S->w_vel[2];
+      const int nsm = n_smooth(q, s);
+      const double* dat = q->cd + q->o_data[s];
+      if (tar >= sp.n_var) {
+        // ---- (T_k, T_k2), k2 <= k : all residuals of this end-effector
+        const int k2 = tar - sp.n_var;
+        if (k2 > k) continue;
+        double hacc = 0, gacc = 0;
+        for (int i = 0; i < F; ++i) {
+          const double* a = scache(q, s, i);
+          for (int dm = 0; dm < 3; ++dm) {
+            const double gk = -cache_djac(a, dm, k), gk2 = -cache_djac(a, dm, k2);
+            hacc += wdat * gk * gk2;
+            if (k2 == k) gacc += wdat * (dat[i * 3 + dm] - a[SC_P + dm]) * gk;
+          }
+          if (i < nsm && wvel >= 0) {
+            const double* b = scache(q, s, i + 1);
+            for (int dm = 0; dm < 3; ++dm) {
+              const double gk = cache_djac(b, dm, k) - cache_djac(a, dm, k), gk2 = cache_djac(b, dm, k2) - cache_djac(a, dm, k2);
+              hacc += wvel * gk * gk2;
+              if (k2 == k) gacc += wvel * (b[SC_P + dm] - a[SC_P + dm]) * gk;
+            }
+          }
+        }
+        if (k2 == k && S->w_dur >= 0) {     // DurationCost (duration_cost.cpp:25-50): 1/2 w (T0 - T)^2
+          hacc += S->w_dur;
+          gacc += S->w_dur * (q->wd[q->o_phase_dur + q->phase_off[e] + k] - q->cd[q->o_phase_dur0 + q->phase_off[e] + k]);
+        }
+        kadd(c, Pk, c.pos_var[S->dur_off[e] + k2], c.sf * hacc);
+        if (k2 == k) g[S->dur_off[e] + k] = c.sf * gacc;
+      } else {
+        // ---- (T_k, node variable): residuals whose polynomial touches the variable's node(s)
+        const int ent = q->ci[q->o_varnode + sp.var_off + tar];
+        const int nd = ent / 6, dq0 = (ent % 6) / 3, dm = ent % 3;
+        const int* pinfo = q->ci + q->o_pinfo + sp.poly_off * 4;
+        const int nd_hi = (dq0 == 0 && nd < sp.n_polys && pinfo[nd * 4 + 3]) ? nd + 1 : nd;
+        const int pa = nd - 1 < 0 ? 0 : nd - 1, pb = nd_hi > sp.n_polys - 1 ? sp.n_polys - 1 : nd_hi;
+        const int i_lo = first[s * fstride + pa];
+        int i_hi = first[s * fstride + pb + 1] - 1;
+        double hacc = 0;
+        for (int kind = 0; kind < 2; ++kind) {
+          const double wt = kind == 0 ? wdat : wvel;
+          if (wt < 0) continue;
+          int r_lo = i_lo, r_hi = i_hi;
+          if (kind > 0) { r_lo = i_lo - 1 < 0 ? 0 : i_lo - 1; if (r_hi > nsm - 1) r_hi = nsm - 1; }
+          else if (r_hi > F - 1) r_hi = F - 1;
+          for (int i = r_lo; i <= r_hi; ++i) {
+            const double* a = scache(q, s, i);
+            Supp su; su.n = 0;
+            double gk;
+            if (kind == 0) { supp_add_sample(su, a, 0, -1.0); gk = -cache_djac(a, dm, k); }
+            else { const double* b = scache(q, s, i + 1); supp_add_sample(su, b, 0, 1.0); supp_add_sample(su, a, 0, -1.0); gk = cache_djac(b, dm, k) - cache_djac(a, dm, k); }
+            double gt = 0;
+            for (int x1 = 0; x1 < su.n; ++x1) if (su.node[x1] >= nd && su.node[x1] <= nd_hi && su.dq[x1] == dq0) gt += su.g[x1];
+            hacc += wt * gk * gt;
+          }
+        }
+        if (hacc != 0.0) kadd(c, Pk, c.pos_var[sp.var_off + tar], c.sf * hacc);
+      }
+    }
+  }
+  CHD_SYNC();
+}
+
+// Full evaluation at x.  Returns the (scaled) objective; fills c_out (scaled rows), and in
+// EV_FULL mode the scaled gradient g and the unfactored KKT matrix K0 = [sf H, (sc J)^T; sc J, 0].
+CHD_DEV double eval_nlp(Ctx& c, const double* x, int mode, double* c_out, double* g) {
+  state_from_x(c, x);
+  if (mode == EV_FULL) kzero(c);
+  fill_sample_cache(c);      // ends with a sync (also orders kzero before the kadd's below)
+  eval_rows(c, mode, c_out);
+  const double f = c.sf * eval_cost_value(c);
+  if (mode == EV_FULL) {
+    eval_cost_grad_hess(c, g);
+    c.err = block_max(c, (double)c.err) > 0.5 ? 1 : 0;     // a band overflow seen by any thread
+  }
+  CHD_SYNC();
+  return f;
+}
+
+// ------------------------------------------------------------------------------------------
+// Interior-point solve of one stage (restates ifopt::IpoptSolver::Solve, phys_optim.cpp:567-580;
+// algorithm: primal-dual log-barrier on the slack formulation, Gauss-Newton Hessian with
+// Levenberg damping, l1 merit line search with second-order correction).
+// ------------------------------------------------------------------------------------------
+struct StageResult { int status, iters, n_factor; double kkt, viol, obj, mu; };
+
+CHD_DEV double compl_error(Ctx& c, double mu) {
+  const int* fl = c.q->wi + c.q->o_flags;
+  const double *s = VM(c, VM_S), *l = VM(c, VM_L), *u = VM(c, VM_U), *zL = VM(c, VM_ZL), *zU = VM(c, VM_ZU);
+  double e = 0;
+  PAR_FOR(i, c.m) {
+    if (fl[i] & RF_L) e = fmax(e, fabs((s[i] - l[i]) * zL[i] - mu));
+    if (fl[i] & RF_U) e = fmax(e, fabs((u[i] - s[i]) * zU[i] - mu));
+  }
+  return block_max(c, e);
+}
+
+CHD_DEV double barrier_val(Ctx& c, const double* ss, double mu) {
+  const int* fl = c.q->wi + c.q->o_flags;
+  const double *l = VM(c, VM_L), *u = VM(c, VM_U);
+  double b = 0;
+  PAR_FOR(i, c.m) {
+    if (fl[i] & RF_L) b -= mu * log(ss[i] - l[i]);
+    if (fl[i] & RF_U) b -= mu * log(u[i] - ss[i]);
+  }
+  return block_sum(c, b);
+}
+
+CHD_DEV void residual(Ctx& c, const double* cc, const double* ss, double* r) {
+  const int* fl = c.q->wi + c.q->o_flags;
+  const double* l = VM(c, VM_L);
+  PAR_FOR(i, c.m) r[i] = (fl[i] & RF_EQ) ? cc[i] - l[i] : cc[i] - ss[i];
+  CHD_SYNC();
+}
+
+CHD_DEV void solve_stage(Ctx& c, StageResult& res) {
+  const SeqDesc* q = c.q; const StageDesc* S = c.S;
+  const int n = c.n, m = c.m, N = c.N;
+  double *x = VN(c, VN_X), *g = VN(c, VN_G), *dualx = VN(c, VN_DUALX), *dx = VN(c, VN_DX), *xt = VN(c, VN_XT), *xs = VN(c, VN_XS);
+  double *cc = VM(c, VM_C), *s = VM(c, VM_S), *zL = VM(c, VM_ZL), *zU = VM(c, VM_ZU), *lam = VM(c, VM_LAM), *l = VM(c, VM_L), *u = VM(c, VM_U),
+         *sc = VM(c, VM_SC), *Sig = VM(c, VM_SIGMA), *rs = VM(c, VM_RS), *D = VM(c, VM_D), *r = VM(c, VM_R), *dlam = VM(c, VM_DLAM),
+         *ds = VM(c, VM_DS), *dzL = VM(c, VM_DZL), *dzU = VM(c, VM_DZU), *st = VM(c, VM_ST), *ct = VM(c, VM_CT), *rt = VM(c, VM_RT), *ss2 = VM(c, VM_SS2);
+  double *rhs = VK(c, VK_RHS), *sol = VK(c, VK_SOL), *rhs2 = VK(c, VK_RHS2), *sol2 = VK(c, VK_SOL2), *diag = VK(c, VK_DIAG), *t1 = VK(c, VK_T1);
+  int* fl = q->wi + q->o_flags; int* sign = q->wi + q->o_sign;
+  const double* Dw = q->cd + S->o_Dw; const double* cl = q->cd + S->o_cl; const double* cu = q->cd + S->o_cu;
+  const int* pos_var = c.pos_var; const int* pos_row = c.pos_row;
+
+  x_from_state(c, x);
+  // ---- unscaled evaluation -> gradient-based scaling (nlp_scaling_max_gradient = 100)
+  c.sf = 1.0;
+  PAR_FOR(i, m) sc[i] = 1.0;
+  PAR_FOR(i, N) sign[i] = 1;
+  CHD_SYNC();
+  PAR_FOR(i, m) sign[pos_row[i]] = -1;
+  CHD_SYNC();
+  eval_nlp(c, x, EV_FULL, cc, g);
+  double gm = 0;
+  PAR_FOR(j, n) gm = fmax(gm, fabs(g[j]));
+  gm = block_max(c, gm);
+  const double sf = gm > 100.0 ? 100.0 / gm : 1.0;
+  PAR_FOR(i, m) {          // largest |J_ij| of the row = largest entry of row/column pos_row[i] of K0
+    const int p = pos_row[i];
+    double rm = 0;
+    if (p < c.Nb) {
+      const int lo = p - c.w < 0 ? 0 : p - c.w, hi = p + c.w >= c.Nb ? c.Nb - 1 : p + c.w;
+      const double* row = c.K0b + (long long)p * c.W2 + (c.w - p);
+      for (int k = lo; k <= hi; ++k) rm = fmax(rm, fabs(row[k]));
+      for (int rr = 0; rr < c.bc; ++rr) rm = fmax(rm, fabs(c.K0x[(long long)rr * c.LD + p]));
+    } else {
+      const double* row = c.K0x + (long long)(p - c.Nb) * c.LD;
+      for (int k = 0; k < c.LD; ++k) rm = fmax(rm, fabs(row[k]));
+    }
+    t1[i] = rm > 100.0 ? fmax(100.0 / rm, 1e-8) : 1.0;
+  }
+  CHD_SYNC();
+  PAR_FOR(i, m) {
+    sc[i] = t1[i];
+    const bool eq = (cu[i] - cl[i]) <= 0.0;
+    const bool hl = !eq && cl[i] > -CHD_INF, hu = !eq && cu[i] < CHD_INF;
+    fl[i] = (eq ? RF_EQ : 0) | (hl ? RF_L : 0) | (hu ? RF_U : 0);
+    double li = cl[i] > -CHD_INF ? cl[i] * sc[i] : -HUGE_VAL;
+    double ui = cu[i] < CHD_INF ? cu[i] * sc[i] : HUGE_VAL;
+    if (hl) li -= 1e-8 * fmax(1.0, fabs(li));      // bound_relax_factor
+    if (hu) ui += 1e-8 * fmax(1.0, fabs(ui));
+    l[i] = li; u[i] = ui;
+  }
+  CHD_SYNC();
+  c.sf = sf;
+  double f = eval_nlp(c, x, EV_FULL, cc, g);
+
+  // ---- slack / multiplier initialisation
+  double mu = (S->stage == 0) ? CHD_MU_INIT_COLD : CHD_MU_INIT_WARM;
+  PAR_FOR(i, m) {
+    double si = 0, zl = 0, zu = 0;
+    if (!(fl[i] & RF_EQ)) {
+      si = cc[i];
+      const bool hl = fl[i] & RF_L, hu = fl[i] & RF_U;
+      if (hl) { double pl = 1e-2 * fmax(1.0, fabs(l[i])); if (hu) pl = fmin(pl, 1e-2 * (u[i] - l[i])); si = fmax(si, l[i] + pl); }
+      if (hu) { double pu = 1e-2 * fmax(1.0, fabs(u[i])); if (hl) pu = fmin(pu, 1e-2 * (u[i] - l[i])); si = fmin(si, u[i] - pu); }
+      if (hl) zl = mu / (si - l[i]);
+      if (hu) zu = mu / (u[i] - si);
+    }
+    s[i] = si; zL[i] = zl; zU[i] = zu; lam[i] = zu - zl;
+  }
+  CHD_SYNC();
+  double nu = 1.0, dw = CHD_DELTA_W0;
+  const double kappa_eps = 10.0, kappa_mu = 0.2, theta_mu = 1.5, smax = 100.0;
+  const double tol_ = c.tol;
+
+  int status = -1, it = 0, n_factor = 0;
+  double E0 = 0, e_d = 0, e_p = 0, e_pu = 0;
+  for (it = 0; it < S->max_iter; ++it) {
+    // ---- optimality error (IPOPT eq. (5)/(6))
+    PAR_FOR(i, N) t1[i] = 0.0;
+    CHD_SYNC();
+    PAR_FOR(i, m) t1[pos_row[i]] = lam[i];
+    CHD_SYNC();
+    kmatvec(c, t1, sol2, nullptr);                 // J^T lam at the variable positions
+    double d1 = 0, sumlam = 0, sumz = 0, cnt = 0, ep = 0, epu = 0;
+    PAR_FOR(j, n) { const double v = g[j] + sol2[pos_var[j]]; dualx[j] = v; d1 = fmax(d1, fabs(v)); }
+    residual(c, cc, s, r);
+    PAR_FOR(i, m) {
+      sumlam += fabs(lam[i]);
+      if (!(fl[i] & RF_EQ)) d1 = fmax(d1, fabs(-lam[i] - zL[i] + zU[i]));
+      if (fl[i] & RF_L) { sumz += fabs(zL[i]); cnt += 1; }
+      if (fl[i] & RF_U) { sumz += fabs(zU[i]); cnt += 1; }
+      ep = fmax(ep, fabs(r[i])); epu = fmax(epu, fabs(r[i]) / sc[i]);
+    }
+    d1 = block_max(c, d1); sumlam = block_sum(c, sumlam); sumz = block_sum(c, sumz); cnt = block_sum(c, cnt);
+    e_p = block_max(c, ep); e_pu = block_max(c, epu);
+    const double s_d = fmax(smax, (sumlam + sumz) / fmax(1.0, m + cnt)) / smax;
+    const double s_c = fmax(smax, sumz / fmax(1.0, cnt)) / smax;
+    e_d = d1 / s_d;
+    E0 = fmax(e_d, fmax(e_p, compl_error(c, 0.0) / s_c));
+    if (E0 <= tol_ && e_pu <= CHD_CONSTR_VIOL_TOL) { status = 0; break; }
+    // ---- monotone barrier update
+    while (true) {
+      const double Emu = fmax(e_d, fmax(e_p, compl_error(c, mu) / s_c));
+      if (Emu <= kappa_eps * mu && mu > tol_ / 10) mu = fmax(tol_ / 10, fmin(kappa_mu * mu, pow(mu, theta_mu)));
+      else break;
+    }
+    const double tau = fmax(0.99, 1 - mu);
+    PAR_FOR(i, m) {
+      if (fl[i] & RF_EQ) { Sig[i] = 0; rs[i] = 0; D[i] = CHD_DELTA_C; continue; }
+      double sg = 0, qq = -lam[i];
+      if (fl[i] & RF_L) { sg += zL[i] / (s[i] - l[i]); qq -= mu / (s[i] - l[i]); }
+      if (fl[i] & RF_U) { sg += zU[i] / (u[i] - s[i]); qq += mu / (u[i] - s[i]); }
+      Sig[i] = fmax(sg, 1e-300); rs[i] = qq; D[i] = 1.0 / Sig[i];
+    }
+    PAR_FOR(j, n) rhs[pos_var[j]] = -dualx[j];
+    CHD_SYNC();
+    PAR_FOR(i, m) rhs[pos_row[i]] = (fl[i] & RF_EQ) ? -r[i] : -(r[i] + rs[i] / Sig[i]);
+    double cn = 0, gdx;
+    PAR_FOR(i, m) cn += fabs(r[i]);
+    cn = block_sum(c, cn);
+
+    bool ok = false, used_soc = false;
+    double alpha = 0, a_du = 1.0;
+    int nls = 0, attempt = 0;
+    for (attempt = 0; attempt < CHD_MAX_ATTEMPTS; ++attempt) {
+      PAR_FOR(j, n) diag[pos_var[j]] = dw * Dw[j];
+      PAR_FOR(i, m) diag[pos_row[i]] = -D[i];
+      CHD_SYNC();
+      kfactor(c, diag, sign); ++n_factor;
+      ksolve(c, rhs, sol, diag, 2);
+      PAR_FOR(j, n) dx[j] = sol[pos_var[j]];
+      PAR_FOR(i, m) dlam[i] = sol[pos_row[i]];
+      CHD_SYNC();
+      double a_pr = 1.0, adu = 1.0, dbar = 0, sSds = 0;
+      PAR_FOR(i, m) {
+        double dsi = 0, dl = 0, du = 0;
+        if (!(fl[i] & RF_EQ)) {
+          dsi = (dlam[i] - rs[i]) / Sig[i];
+          if (fl[i] & RF_L) {
+            const double sl = s[i] - l[i];
+            dl = mu / sl - zL[i] - zL[i] / sl * dsi;
+            if (dsi < 0) a_pr = fmin(a_pr, -tau * sl / dsi);
+            if (dl < 0) adu = fmin(adu, -tau * zL[i] / dl);
+            dbar -= mu / sl * dsi;
+          }
+          if (fl[i] & RF_U) {
+            const double su = u[i] - s[i];
+            du = mu / su - zU[i] + zU[i] / su * dsi;
+            if (dsi > 0) a_pr = fmin(a_pr, tau * su / dsi);
+            if (du < 0) adu = fmin(adu, -tau * zU[i] / du);
+            dbar += mu / su * dsi;
+          }
+          sSds += Sig[i] * dsi * dsi;
+        }
+        ds[i] = dsi; dzL[i] = dl; dzU[i] = du;
+      }
+      a_pr = block_min(c, a_pr); a_du = block_min(c, adu); dbar = block_sum(c, dbar); sSds = block_sum(c, sSds);
+      // dx^T (H + dw Dw) dx through K0 [dx; 0]
+      PAR_FOR(i, N) t1[i] = 0.0;
+      CHD_SYNC();
+      PAR_FOR(j, n) t1[pos_var[j]] = dx[j];
+      CHD_SYNC();
+      kmatvec(c, t1, sol2, nullptr);
+      double dHd = 0; gdx = 0;
+      PAR_FOR(j, n) { dHd += dx[j] * (sol2[pos_var[j]] + dw * Dw[j] * dx[j]); gdx += g[j] * dx[j]; }
+      dHd = block_sum(c, dHd) + sSds; gdx = block_sum(c, gdx);
+      const double dphi_bar = gdx + dbar;
+      if (cn > 1e-14) { const double nut = (dphi_bar + 0.5 * fmax(dHd, 0.0)) / ((1 - 0.1) * cn); if (nut > nu) nu = nut * 1.1 + 1e-8; }
+      const double Dphi = dphi_bar - nu * cn;
+      const double phi0 = f + barrier_val(c, s, mu) + nu * cn;
+      alpha = a_pr; ok = false; nls = 0; used_soc = false;
+      while (nls <= CHD_MAX_BACKTRACK) {
+        PAR_FOR(j, n) xt[j] = x[j] + alpha * dx[j];
+        PAR_FOR(i, m) st[i] = s[i] + alpha * ds[i];
+        CHD_SYNC();
+        const double ft = eval_nlp(c, xt, EV_VALUES, ct, nullptr);
+        residual(c, ct, st, rt);
+        double cnt_ = 0;
+        PAR_FOR(i, m) cnt_ += fabs(rt[i]);
+        cnt_ = block_sum(c, cnt_);
+        const double phit = ft + barrier_val(c, st, mu) + nu * cnt_;
+        if (phit <= phi0 + 1e-4 * alpha * Dphi + 1e-12 * fabs(phi0)) { ok = true; break; }
+        if (nls == 0 && cnt_ > 1e-12) {
+          // second-order correction: same factorisation, constraint residual of the trial point
+          PAR_FOR(j, n) rhs2[pos_var[j]] = 0.0;
+          CHD_SYNC();
+          PAR_FOR(i, m) rhs2[pos_row[i]] = -rt[i];
+          CHD_SYNC();
+          ksolve(c, rhs2, sol2, diag, 1);
+          double inside = 1.0;
+          PAR_FOR(j, n) xs[j] = xt[j] + sol2[pos_var[j]];
+          PAR_FOR(i, m) {
+            double v = st[i];
+            if (!(fl[i] & RF_EQ)) {
+              v = st[i] + sol2[pos_row[i]] / Sig[i];
+              if ((fl[i] & RF_L) && v - l[i] < (1 - tau) * (s[i] - l[i])) inside = 0.0;
+              if ((fl[i] & RF_U) && u[i] - v < (1 - tau) * (u[i] - s[i])) inside = 0.0;
+            }
+            ss2[i] = v;
+          }
+          inside = block_min(c, inside);
+          if (inside > 0.5) {
+            const double fs = eval_nlp(c, xs, EV_VALUES, ct, nullptr);
+            residual(c, ct, ss2, rt);
+            double cns = 0;
+            PAR_FOR(i, m) cns += fabs(rt[i]);
+            cns = block_sum(c, cns);
+            const double phis = fs + barrier_val(c, ss2, mu) + nu * cns;
+            if (phis <= phi0 + 1e-4 * alpha * Dphi + 1e-12 * fabs(phi0)) { ok = true; used_soc = true; break; }
+          }
+        }
+        alpha *= 0.5; ++nls;
+      }
+      if (ok) break;
+      dw *= 10.0;
+      if (dw > CHD_DELTA_W_MAX) break;
+    }
+    if (!ok) { status = -2; break; }
+    if (attempt == 0 && nls == 0) dw = fmax(CHD_DELTA_W_MIN, dw / 3.0);
+    else if (nls >= 2) dw *= 4.0;
+    PAR_FOR(j, n) x[j] = used_soc ? xs[j] : x[j] + alpha * dx[j];
+    PAR_FOR(i, m) {
+      s[i] = used_soc ? ss2[i] : s[i] + alpha * ds[i];
+      lam[i] += alpha * dlam[i];
+      double zl = zL[i] + a_du * dzL[i], zu = zU[i] + a_du * dzU[i];
+      const double ks = 1e10;
+      if (fl[i] & RF_L) { const double sl = s[i] - l[i]; zl = fmin(fmax(zl, mu / (ks * sl)), ks * mu / sl); }
+      if (fl[i] & RF_U) { const double su = u[i] - s[i]; zu = fmin(fmax(zu, mu / (ks * su)), ks * mu / su); }
+      zL[i] = zl; zU[i] = zu;
+    }
+    CHD_SYNC();
+    f = eval_nlp(c, x, EV_FULL, cc, g);
+    if (c.err) { status = -3; ++it; break; }
+  }
+  state_from_x(c, x);
+  double cv = 0;
+  PAR_FOR(i, m) { const double v = cc[i] / sc[i]; cv = fmax(cv, fmax(cl[i] - v, v - cu[i])); }
+  cv = block_max(c, cv);
+  res.status = c.err ? -3 : status; res.iters = it; res.n_factor = n_factor; res.kkt = E0; res.viol = fmax(cv, 0.0); res.obj = f / c.sf; res.mu = mu;
+}
+
+// ------------------------------------------------------------------------------------------
+// SaveSolution (phys_optim.cpp:63-143): resample the splines at the data rate
+// ------------------------------------------------------------------------------------------
+CHD_DEV void sample_solution(const SeqDesc* q, int snap) {
+  const int cap = q->cap;
+  double* od = q->out_d + N_STAGES * RS_STRIDE + (long long)snap * 10 * cap * 3;
+  int* oi = q->out_i;
+  const double tot = q->wd[q->o_ttot + 0];                 // solution.base_linear_->GetTotalTime() (:69)
+  // number of samples of `while (t <= tot + 1e-5)` with t accumulated by += dt
+  int ns = 0;
+  { double t = 0; while (t <= tot + 1e-5 && ns < cap) { ++ns; t += q->dt; } }
+  if (CHD_TID == 0) { oi[snap * 2] = ns; oi[snap * 2 + 1] = (int)((tot + 1e-5) / q->dt) + 1; }
+  const double* tc = q->cd + q->o_tcost;
+  PAR_FOR(idx, ns * 10) {
+    const int i = idx / 10, b = idx % 10;
+    double t = 0;
+    if (i <= q->F + 1) t = tc[i]; else { for (int k = 0; k < i; ++k) t += q->dt; }
+    PE e;
+    const int s = b < 2 ? b : (b < 6 ? b : b);          // blocks: 0 base_lin, 1 base_ang, 2..5 ee_pos, 6..9 ee_force
+    spline_eval(q, s, t, e);
+    double* o = od + ((long long)b * cap + i) * 3;
+    if (b == 1) for (int k = 0; k < 3; ++k) o[k] = e.p[k] / M_PI * 180;     // :97
+    else for (int k = 0; k < 3; ++k) o[k] = e.p[k];
+    if (b >= 2 && b < 6) {
+      const int ee = b - 2;
+      const int ph = phase_lookup(q, ee, t);                                  // TOWR PhaseDurations::IsContactPhase
+      const int cflag = (ph % 2 == 0) ? q->start_contact[ee] : !q->start_contact[ee];
+      oi[8 + ((long long)snap * 4 + ee) * cap + i] = cflag ? 1 : 0;
+    }
+  }
+  CHD_SYNC();
+}
+
+// ------------------------------------------------------------------------------------------
+// One sequence, stages stage_first..stage_last (the whole of main() after the readers)
+// ------------------------------------------------------------------------------------------
+CHD_DEV void bind_stage(Ctx& c, const SeqDesc* q, int stage) {
+  c.q = q; c.S = &q->st[stage];
+  c.n = c.S->n; c.m = c.S->m; c.N = c.n + c.m; c.Nb = c.S->Nb; c.bc = c.S->bc; c.w = c.S->w;
+  c.W2 = 2 * c.w + 1; c.LD = c.N;
+  c.K0b = q->wd + q->o_K0b; c.K0x = q->wd + q->o_K0x; c.Kfb = q->wd + q->o_Kfb; c.Kfx = q->wd + q->o_Kfx;
+  c.pos_var = q->ci + c.S->o_pos_var; c.pos_row = q->ci + c.S->o_pos_row;
+  c.sf = 1.0; c.err = 0; c.n_bad_pivots = 0;
+}
+
+CHD_DEV void init_state(const SeqDesc* q) {
+  PAR_FOR(k, q->tot_entries) q->wd[q->o_node + k] = q->cd[q->o_node0 + k];
+  PAR_FOR(k, q->tot_phases) q->wd[q->o_phase_dur + k] = q->cd[q->o_phase_dur_in + k];
+  // base splines: fixed 0.1 s polynomials (parameters.cpp:109-125)
+  for (int b = 0; b < 2; ++b) {
+    const SplineDesc& sp = q->sp[b];
+    PAR_FOR(p, sp.n_polys) {
+      double left = q->T;
+      for (int k = 0; k < p; ++k) left -= 0.1;
+      q->wd[q->o_poly_dur + sp.poly_off + p] = left > 0.1 ? 0.1 : left;
+    }
+  }
+  CHD_SYNC();
+  refresh_durations(q);
+}
+
+CHD_DEV void run_sequence(const SeqDesc* q, double* lds, int lds_cap, double tol) {
+  Ctx c;
+  c.lds = lds; c.lds_cap = lds_cap;
+  if (q->stage_first == 0) init_state(q);
+  else refresh_durations(q);
+  for (int stage = q->stage_first; stage <= q->stage_last; ++stage) {
+    double* rs = q->out_d + stage * RS_STRIDE;
+    if (!q->st[stage].valid) { if (CHD_TID == 0) { rs[RS_STATUS] = -3; rs[RS_ITERS] = 0; } continue; }
+    bind_stage(c, q, stage);
+    c.tol = tol;
+    StageResult r;
+    solve_stage(c, r);
+    if (CHD_TID == 0) {
+      rs[RS_STATUS] = r.status; rs[RS_ITERS] = r.iters; rs[RS_KKT] = r.kkt; rs[RS_VIOL] = r.viol; rs[RS_OBJ] = r.obj;
+      rs[RS_MU] = r.mu; rs[RS_NFACT] = r.n_factor; rs[RS_AUX] = c.n_bad_pivots;
+    }
+    if (stage == 1) sample_solution(q, 0);       // sol_out_no_dynamics.txt  (phys_optim.cpp:603)
+    if (stage == 3) sample_solution(q, 1);       // sol_out_dynamics.txt     (:661)
+    if (stage == 4 || stage == 5) sample_solution(q, 2);   // sol_out_durations.txt (:757)
+    CHD_SYNC();
+  }
+}
+
+// Debug entry: evaluate stage `stage` at the state currently in the workspace (or at x if given in VN_XT).
+CHD_DEV void debug_eval(const SeqDesc* q, int stage, int use_x, double* lds, int lds_cap, double* f_out) {
+  Ctx c;
+  c.lds = lds; c.lds_cap = lds_cap;
+  init_state(q);
+  bind_stage(c, q, stage);
+  c.tol = 1e-3;
+  double* x = VN(c, VN_X);
+  if (use_x) { PAR_FOR(j, c.n) x[j] = VN(c, VN_XT)[j]; CHD_SYNC(); state_from_x(c, x); }
+  x_from_state(c, x);
+  PAR_FOR(i, c.m) VM(c, VM_SC)[i] = 1.0;
+  CHD_SYNC();
+  const double f = eval_nlp(c, x, EV_FULL, VM(c, VM_C), VN(c, VN_G));
+  if (CHD_TID == 0) { f_out[0] = f; f_out[1] = c.err; }
+  CHD_SYNC();
+}
+
+}  // namespace chd

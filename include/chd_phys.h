@@ -1,0 +1,151 @@
+/*
+ * chd_phys.h — C ABI of the MI355X-native physics stage (libchd_phys.so).
+ *
+ * This library replaces the child process that the reference launches per video,
+ *     subprocess.run(['./phys_optim', '--in_dir', ..., '--nframes', F, '--out_dir', ...,
+ *                     '--w_com_lin', ..., '--w_com_ang', ..., '--w_ee', ..., '--w_smooth', ..., '--w_dur', ...])
+ * (reference: scripts/run_phys_mocap.py:159-174; flags: towr_phys_optim/phys_optim.cpp:23-31),
+ * by an in-process, batched call: many independent sequences are solved by one
+ * persistent HIP kernel launch (one workgroup per sequence) on one gfx950 device.
+ *
+ * Conventions: plain C, every function returns 0 on success and <0 on error (the
+ * message is available through chd_phys_last_error), no exception crosses the boundary,
+ * the library never retains caller pointers after a call returns, a handle is bound to
+ * one HIP device and is not thread-safe (distinct handles may run concurrently, one
+ * per GPU).  There is NO CPU fallback: chd_phys_create fails when no gfx950 device
+ * can be opened.
+ */
+#ifndef CHD_PHYS_H
+#define CHD_PHYS_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CHD_PHYS_ABI_VERSION 1
+#define CHD_N_EE 4          /* NLP end-effector order: 0 L-toe, 1 R-toe, 2 L-heel, 3 R-heel (phys_optim.cpp:505-513) */
+#define CHD_N_STAGES 6      /* 1.1, 1.2, 2.1, 2.2, 3, 4   (phys_optim.cpp:544-749) */
+#define CHD_N_SNAPSHOTS 3   /* sol_out_no_dynamics / sol_out_dynamics / sol_out_durations (run_phys_mocap.py:182) */
+
+/* Replaces the gflags of phys_optim (phys_optim.cpp:23-31) and the IPOPT options set at
+ * phys_optim.cpp:567-578, 640, 652, 706, 743. */
+typedef struct chd_config {
+  double w_com_lin;        /* --w_com_lin  default 0.4  */
+  double w_com_ang;        /* --w_com_ang  default 1.7  */
+  double w_ee;             /* --w_ee       default 0.3  */
+  double w_smooth;         /* --w_smooth   default 0.1  */
+  double w_dur;            /* --w_dur      default 0.1  */
+  int max_iter[CHD_N_STAGES];   /* 7000, 7000, 7000, 2500, 2000, 7000 */
+  double tol;              /* IPOPT "tol", 1e-3 (phys_optim.cpp:578) */
+  int threads_per_sequence;     /* workgroup size of the solver kernel; 0 = default (512) */
+  int reserved[7];
+} chd_config;
+
+/* One sequence = the content of phys_optim_in_<char>/{skel,motion,terrain,contact}_info.txt
+ * (reader being replaced: phys_optim.cpp:155-267).  All arrays are caller-owned, contiguous
+ * fp64, row-major F x 3 (inertia: F x 6 = Ixx Iyy Izz Ixy Ixz Iyz). */
+typedef struct chd_seq_in {
+  int F;                       /* --nframes */
+  double dt;                   /* motion_info.txt first token */
+  const double* hip_l;         /* skel_info.txt  (phys_optim.cpp:176) */
+  const double* hip_r;         /*                (:177) */
+  double leg_len, heel_len, heel_dist, mass;   /* (:179-182) */
+  const double* inertia;       /* (:183-187) */
+  const double* com;           /* motion_info.txt (:199) */
+  const double* euler;         /* (:200) extrinsic-xyz Euler, radians */
+  const double* ltoe;          /* (:201) file order L-toe, L-heel, R-toe, R-heel */
+  const double* lheel;         /* (:202) */
+  const double* rtoe;          /* (:203) */
+  const double* rheel;         /* (:204) */
+  double normal[3];            /* terrain_info.txt (:216-218) */
+  double point[3];             /* (:219-221) */
+  int start_contact[4];        /* contact_info.txt, file order L-toe, L-heel, R-toe, R-heel (:236-264) */
+  int n_phases[4];
+  const double* durations[4];
+} chd_seq_in;
+
+/* One output snapshot = one sol_out_*.txt (writer being replaced: phys_optim.cpp:63-143).
+ * Arrays are caller-allocated with room for `capacity` samples (>= F + 2 is always enough);
+ * n_samples is the number the reference's `while (t <= T + 1e-5)` loop produces. */
+typedef struct chd_snapshot {
+  int capacity;
+  int n_samples;               /* out */
+  int num_frames_header;       /* out: int((T+1e-5)/dt)+1 (phys_optim.cpp:71) */
+  double* base_lin;            /* capacity x 3 */
+  double* base_ang_deg;        /* capacity x 3, degrees (phys_optim.cpp:97) */
+  double* ee_pos;              /* 4 x capacity x 3, NLP ee order */
+  double* ee_force;            /* 4 x capacity x 3 */
+  unsigned char* contact;      /* 4 x capacity, 0/1 */
+} chd_snapshot;
+
+typedef struct chd_seq_out {
+  chd_snapshot snap[CHD_N_SNAPSHOTS];
+  int stage_status[CHD_N_STAGES];   /* 0 solved, 1 acceptable, -1 max-iter, -2 numerical failure, -3 internal (band overflow), 9 not run */
+  int stage_iters[CHD_N_STAGES];
+  double stage_kkt_error[CHD_N_STAGES];
+  double stage_constr_viol[CHD_N_STAGES];
+  double stage_objective[CHD_N_STAGES];
+  int dynamics_succeed;        /* success_log.txt line 1 (phys_optim.cpp:655) */
+  int durations_succeed;       /* success_log.txt line 2 (phys_optim.cpp:709, :747) */
+  /* problem sizes of the largest stage, for the roofline accounting */
+  int n_vars, n_rows, kkt_dim, kkt_halfband, kkt_border;
+  long long nnz_jac;           /* structural non-zeros of the constraint Jacobian, stage 2.2 */
+} chd_seq_out;
+
+typedef struct chd_handle chd_handle;   /* bound to one HIP device */
+typedef struct chd_batch chd_batch;     /* device-resident problem data + results of one batch */
+
+int chd_phys_version(void);
+void chd_config_default(chd_config* cfg);
+
+int chd_phys_create(const chd_config* cfg, int device_id, chd_handle** out);
+void chd_phys_destroy(chd_handle* h);
+const char* chd_phys_last_error(const chd_handle* h);   /* owned by the handle; "" if none */
+
+/* Split interface (what the benchmark times is chd_batch_solve alone: inputs are resident
+ * in HBM when it starts).
+ *   upload : builds the per-sequence NLP structure tables on the host and copies inputs +
+ *            tables to the device;
+ *   solve  : runs stages 1.1 .. 3 (+4 where stage 3 failed) for every sequence on the device;
+ *   fetch  : copies the three snapshots and the per-stage statistics back. */
+int chd_batch_upload(chd_handle* h, int B, const chd_seq_in* in, chd_batch** out);
+int chd_batch_solve(chd_handle* h, chd_batch* b);
+int chd_batch_fetch(chd_handle* h, chd_batch* b, chd_seq_out* out /* B entries */);
+void chd_batch_free(chd_handle* h, chd_batch* b);
+/* Timing / accounting of the last chd_batch_solve on this batch (HIP events on the library's
+ * stream): kernel_ms[0] = stages 1.1..3 launch, kernel_ms[1] = stage-4 fallback launch (0 if
+ * not needed), host_ms = host work between the two launches; total_iters = sum of interior-
+ * point iterations, alg_bytes = SURVEY 8(d) algorithmic bytes summed over all iterations. */
+typedef struct chd_batch_stats {
+  double kernel_ms[2];
+  double host_ms;
+  long long total_iters;
+  long long total_factorizations;
+  double alg_bytes;
+  int n_fallback;              /* sequences that needed stage 4 */
+} chd_batch_stats;
+int chd_batch_get_stats(chd_handle* h, chd_batch* b, chd_batch_stats* out);
+
+/* Convenience: upload + solve + fetch. */
+int chd_phys_solve_batch(chd_handle* h, int B, const chd_seq_in* in, chd_seq_out* out);
+
+/* Drop-in for B invocations of ./phys_optim: reads the four input files of every in_dirs[i],
+ * solves the batch, writes sol_out_no_dynamics.txt, sol_out_dynamics.txt, sol_out_durations.txt
+ * and success_log.txt into out_dirs[i] (which must exist, as for the reference,
+ * phys_optim.cpp:23).  status[i] (optional) = 0 ok, <0 I/O error for that directory. */
+int chd_phys_solve_dirs(chd_handle* h, int B, const char* const* in_dirs, const char* const* out_dirs,
+                        const int* nframes, int* status);
+
+/* Test / profiling hooks (used by tests/ to compare single pieces of the hot path with the
+ * oracle; not needed by a drop-in user).
+ *   chd_debug_eval: evaluates f, grad, c and the dense Jacobian J (m x n row-major) and the
+ *   Gauss-Newton objective Hessian H (n x n) of `stage` at x (NULL = initial guess) for
+ *   sequence `seq` of an uploaded batch, on the device.  Any output pointer may be NULL. */
+int chd_debug_sizes(chd_handle* h, chd_batch* b, int seq, int stage, int* n, int* m, int* kkt_dim, int* halfband, int* border);
+int chd_debug_eval(chd_handle* h, chd_batch* b, int seq, int stage, const double* x,
+                   double* x_out, double* f, double* grad, double* c, double* J, double* H);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHD_PHYS_H */

@@ -1,0 +1,108 @@
+// Host emulation of the solver kernel — TEST INFRASTRUCTURE ONLY.
+// Compiles contact-human-dynamics_amd/csrc/chd_kernels.hpp with CHD_HOST_EMU (one "thread",
+// barriers are no-ops) so that the phases of the HIP kernel can be compared with the oracle
+// in the CPU-only container.  Never loaded by the product; libchd_phys.so has no CPU path.
+#define CHD_HOST_EMU 1
+#include <cstdio>
+#include <memory>
+#include "../../contact-human-dynamics_amd/csrc/chd_model.hpp"
+#include "../../contact-human-dynamics_amd/csrc/chd_kernels.hpp"
+
+using namespace chd;
+
+struct Emu {
+  SeqModel M;
+  chd_config cfg;
+  std::vector<double> wd, out_d, lds;
+  std::vector<int> wi, out_i;
+  void bind() {
+    M.d.cd = M.cd.data(); M.d.ci = M.ci.data(); M.d.wd = wd.data(); M.d.wi = wi.data();
+    M.d.out_d = out_d.data(); M.d.out_i = out_i.data();
+  }
+};
+
+extern "C" {
+void* emu_create(const chd_seq_in* in, const chd_config* cfg) {
+  try {
+    auto e = std::make_unique<Emu>();
+    e->cfg = *cfg;
+    e->M.build(*in, *cfg);
+    e->wd.assign(e->M.wd_size, 0.0); e->wi.assign(e->M.wi_size, 0);
+    e->out_d.assign(out_d_size(e->M.d.cap), 0.0); e->out_i.assign(out_i_size(e->M.d.cap), 0);
+    e->lds.assign(1 << 20, 0.0);
+    e->bind();
+    return e.release();
+  } catch (const std::exception& ex) { std::fprintf(stderr, "emu_create: %s\n", ex.what()); return nullptr; }
+}
+void emu_destroy(void* h) { delete (Emu*)h; }
+void emu_sizes(void* h, int stage, int* out) {
+  Emu* e = (Emu*)h; const StageDesc& S = e->M.d.st[stage];
+  out[0] = S.n; out[1] = S.m; out[2] = S.Nb; out[3] = S.bc; out[4] = S.w; out[5] = S.nnz_jac; out[6] = S.valid; out[7] = e->M.d.cap;
+}
+// dense J (m x n) and H (n x n) from the unfactored KKT storage
+static void dense_from_K(Emu* e, int stage, double* J, double* H) {
+  Ctx c; c.lds = e->lds.data(); c.lds_cap = (int)e->lds.size();
+  bind_stage(c, &e->M.d, stage);
+  const int n = c.n, m = c.m;
+  if (J) for (int i = 0; i < m; ++i) for (int j = 0; j < n; ++j) J[(size_t)i * n + j] = kget(c, c.pos_row[i], c.pos_var[j]);
+  if (H) for (int a = 0; a < n; ++a) for (int b = 0; b < n; ++b) H[(size_t)a * n + b] = kget(c, c.pos_var[a], c.pos_var[b]);
+}
+int emu_eval(void* h, int stage, const double* x, double* x_out, double* f, double* grad, double* cvals, double* J, double* H) {
+  Emu* e = (Emu*)h; e->bind();
+  const StageDesc& S = e->M.d.st[stage];
+  Ctx c; c.q = &e->M.d;
+  if (x) for (int j = 0; j < S.n; ++j) VN(c, VN_XT)[j] = x[j];
+  double fo[2];
+  debug_eval(&e->M.d, stage, x != nullptr, e->lds.data(), (int)e->lds.size(), fo);
+  if (f) *f = fo[0];
+  if (x_out) for (int j = 0; j < S.n; ++j) x_out[j] = VN(c, VN_X)[j];
+  if (grad) for (int j = 0; j < S.n; ++j) grad[j] = VN(c, VN_G)[j];
+  if (cvals) for (int i = 0; i < S.m; ++i) cvals[i] = VM(c, VM_C)[i];
+  dense_from_K(e, stage, J, H);
+  return (int)fo[1];
+}
+// factor/solve self test: builds K0 at the initial point of `stage`, adds diag, solves K x = b
+int emu_linsolve(void* h, int stage, double dw, double dval, const double* b, double* x, int refine) {
+  Emu* e = (Emu*)h; e->bind();
+  double fo[2];
+  debug_eval(&e->M.d, stage, 0, e->lds.data(), (int)e->lds.size(), fo);
+  Ctx c; c.lds = e->lds.data(); c.lds_cap = 18432;
+  bind_stage(c, &e->M.d, stage);
+  double* diag = VK(c, VK_DIAG); int* sign = e->M.d.wi + e->M.d.o_sign;
+  const double* Dw = e->M.d.cd + c.S->o_Dw;
+  for (int j = 0; j < c.n; ++j) { diag[c.pos_var[j]] = dw * Dw[j]; sign[c.pos_var[j]] = 1; }
+  for (int i = 0; i < c.m; ++i) { diag[c.pos_row[i]] = -dval; sign[c.pos_row[i]] = -1; }
+  kfactor(c, diag, sign);
+  double* rhs = VK(c, VK_RHS); double* sol = VK(c, VK_SOL);
+  for (int i = 0; i < c.N; ++i) rhs[i] = b[i];
+  ksolve(c, rhs, sol, diag, refine);
+  for (int i = 0; i < c.N; ++i) x[i] = sol[i];
+  // residual check: K x - b
+  kmatvec(c, sol, VK(c, VK_T1), diag);
+  double worst = 0;
+  for (int i = 0; i < c.N; ++i) worst = std::max(worst, std::fabs(VK(c, VK_T1)[i] - b[i]));
+  std::fprintf(stderr, "emu_linsolve: N=%d Nb=%d bc=%d w=%d bad_pivots=%d residual=%.3e\n", c.N, c.Nb, c.bc, c.w, c.n_bad_pivots, worst);
+  return c.n_bad_pivots;
+}
+int emu_solve(void* h, int stage_first, int stage_last, int lds_doubles) {
+  Emu* e = (Emu*)h; e->bind();
+  e->M.d.stage_first = stage_first; e->M.d.stage_last = stage_last;
+  run_sequence(&e->M.d, e->lds.data(), lds_doubles > 0 ? lds_doubles : 18432, e->cfg.tol);
+  return 0;
+}
+// stage-4 fallback: rebuild the tables of stage index 5 with the durations stage 3 left
+int emu_rebuild_fallback(void* h) {
+  Emu* e = (Emu*)h; e->bind();
+  std::vector<double> cur[4];
+  for (int k = 0; k < 4; ++k) cur[k].assign(e->wd.data() + e->M.d.o_phase_dur + e->M.d.phase_off[k],
+                                            e->wd.data() + e->M.d.o_phase_dur + e->M.d.phase_off[k] + e->M.d.n_phase[k]);
+  e->M.build_stage(5, e->cfg, cur, false);
+  e->bind();
+  return e->M.d.st[5].valid;
+}
+void emu_get_out(void* h, double* od, int* oi) {
+  Emu* e = (Emu*)h;
+  std::copy(e->out_d.begin(), e->out_d.end(), od);
+  std::copy(e->out_i.begin(), e->out_i.end(), oi);
+}
+}
