@@ -89,8 +89,6 @@ struct SeqDesc {
   long long sz_K0b, sz_K0x, sz_Kfb, sz_Kfx;
   // wi offsets
   int o_flags, o_first, o_sign;
-  // run control
-  int stage_first, stage_last;
   StageDesc st[N_STAGES];
 };
 

@@ -1492,12 +1492,12 @@ CHD_DEV void init_state(const SeqDesc* q) {
   refresh_durations(q);
 }
 
-CHD_DEV void run_sequence(const SeqDesc* q, double* lds, int lds_cap, double tol) {
+CHD_DEV void run_sequence(const SeqDesc* q, double* lds, int lds_cap, double tol, int stage_first, int stage_last) {
   Ctx c;
   c.lds = lds; c.lds_cap = lds_cap;
-  if (q->stage_first == 0) init_state(q);
+  if (stage_first == 0) init_state(q);
   else refresh_durations(q);
-  for (int stage = q->stage_first; stage <= q->stage_last; ++stage) {
+  for (int stage = stage_first; stage <= stage_last; ++stage) {
     double* rs = q->out_d + stage * RS_STRIDE;
     if (!q->st[stage].valid) { if (CHD_TID == 0) { rs[RS_STATUS] = -3; rs[RS_ITERS] = 0; } continue; }
     bind_stage(c, q, stage);

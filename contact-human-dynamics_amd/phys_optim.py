@@ -1,0 +1,221 @@
+"""Python host side of the physics stage: a thin ``ctypes`` layer over ``libchd_phys.so``.
+
+This is the in-process replacement for the child process the reference starts per video
+(``subprocess.run(['./phys_optim', '--in_dir', ..., '--nframes', ..., '--out_dir', ...,
+'--w_com_lin', ...])``, ``scripts/run_phys_mocap.py:159-174``).  All arithmetic happens in the
+HIP library; nothing here falls back to a CPU solve — if the extension or a GPU is missing
+the constructor raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from .io_formats import Solution
+from .phys_capi import (ChdBatchStats, ChdConfig, ChdSeqIn, ChdSeqOut, N_SNAPSHOTS, N_STAGES, PD, default_config,
+                        seq_to_c)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, 'csrc')
+LIB_PATH = os.path.join(_CSRC, 'libchd_phys.so')
+SOURCES = ['chd_phys.hip', 'chd_kernels.hpp', 'chd_model.hpp', 'chd_device.hpp', 'chd_io.hpp']
+SNAPSHOT_FILES = ('sol_out_no_dynamics.txt', 'sol_out_dynamics.txt', 'sol_out_durations.txt')
+
+EXPORTS = ['chd_phys_version', 'chd_config_default', 'chd_phys_create', 'chd_phys_destroy', 'chd_phys_last_error',
+           'chd_batch_upload', 'chd_batch_solve', 'chd_batch_fetch', 'chd_batch_free', 'chd_batch_get_stats',
+           'chd_phys_solve_batch', 'chd_phys_solve_dirs', 'chd_debug_sizes', 'chd_debug_eval']
+
+
+def build_library(force=False, verbose=False):
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, s) for s in SOURCES] + [os.path.join(os.path.dirname(_HERE), 'include', 'chd_phys.h')]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
+        return LIB_PATH
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wno-unused-value',
+           os.path.join(_CSRC, 'chd_phys.hip'), '-o', LIB_PATH]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_LIB = None
+
+
+def load_library():
+    """dlopen ``libchd_phys.so`` and declare the prototypes of ``include/chd_phys.h``."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError('libchd_phys.so is not built (%s); run __graft_entry__.build() — there is no CPU fallback' % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.chd_phys_version.restype = C.c_int
+    L.chd_config_default.argtypes = [C.POINTER(ChdConfig)]
+    L.chd_phys_create.argtypes = [C.POINTER(ChdConfig), C.c_int, C.POINTER(vp)]
+    L.chd_phys_destroy.argtypes = [vp]
+    L.chd_phys_last_error.argtypes = [vp]; L.chd_phys_last_error.restype = C.c_char_p
+    L.chd_batch_upload.argtypes = [vp, C.c_int, C.POINTER(ChdSeqIn), C.POINTER(vp)]
+    L.chd_batch_solve.argtypes = [vp, vp]
+    L.chd_batch_fetch.argtypes = [vp, vp, C.POINTER(ChdSeqOut)]
+    L.chd_batch_free.argtypes = [vp, vp]
+    L.chd_batch_get_stats.argtypes = [vp, vp, C.POINTER(ChdBatchStats)]
+    L.chd_phys_solve_batch.argtypes = [vp, C.c_int, C.POINTER(ChdSeqIn), C.POINTER(ChdSeqOut)]
+    L.chd_phys_solve_dirs.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.chd_debug_sizes.argtypes = [vp, vp, C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 5
+    L.chd_debug_eval.argtypes = [vp, vp, C.c_int, C.c_int, PD, PD, PD, PD, PD, PD, PD]
+    _LIB = L
+    return L
+
+
+class PhysError(RuntimeError):
+    pass
+
+
+class SeqResult:
+    """Per-sequence output: three snapshots (:class:`io_formats.Solution`) + solver statistics."""
+
+    def __init__(self, dt, out, bufs):
+        self.snapshots = []
+        for s in range(N_SNAPSHOTS):
+            sn = out.snap[s]
+            ns = min(sn.n_samples, sn.capacity)
+            bl, ba, ep, ef, ct = bufs[s]
+            self.snapshots.append(Solution(dt=dt, num_frames=sn.num_frames_header, base_lin=bl[:ns].copy(), base_ang_deg=ba[:ns].copy(),
+                                           ee_pos=ep[:, :ns].copy(), ee_force=ef[:, :ns].copy(), contact=ct[:, :ns].astype(np.int64)))
+        self.stage_status = [out.stage_status[i] for i in range(N_STAGES)]
+        self.stage_iters = [out.stage_iters[i] for i in range(N_STAGES)]
+        self.stage_kkt_error = [out.stage_kkt_error[i] for i in range(N_STAGES)]
+        self.stage_constr_viol = [out.stage_constr_viol[i] for i in range(N_STAGES)]
+        self.stage_objective = [out.stage_objective[i] for i in range(N_STAGES)]
+        self.dynamics_succeed = bool(out.dynamics_succeed)
+        self.durations_succeed = bool(out.durations_succeed)
+        self.sizes = dict(n=out.n_vars, m=out.n_rows, kkt_dim=out.kkt_dim, halfband=out.kkt_halfband, border=out.kkt_border,
+                          nnz_jac=out.nnz_jac)
+
+    @property
+    def total_iters(self):
+        return sum(self.stage_iters)
+
+
+class Batch:
+    """Device-resident batch (``chd_batch``): upload once, solve (the timed part), fetch."""
+
+    def __init__(self, solver, seqs):
+        self.solver = solver
+        self.seqs = list(seqs)
+        self._keep = []
+        B = len(self.seqs)
+        self._in = (ChdSeqIn * B)(*[seq_to_c(s, self._keep) for s in self.seqs])
+        self.h = C.c_void_p()
+        solver._check(solver.L.chd_batch_upload(solver.h, B, self._in, C.byref(self.h)), 'chd_batch_upload')
+
+    def solve(self):
+        self.solver._check(self.solver.L.chd_batch_solve(self.solver.h, self.h), 'chd_batch_solve')
+        st = ChdBatchStats()
+        self.solver._check(self.solver.L.chd_batch_get_stats(self.solver.h, self.h, C.byref(st)), 'chd_batch_get_stats')
+        return dict(kernel_ms=[st.kernel_ms[0], st.kernel_ms[1]], host_ms=st.host_ms, total_iters=st.total_iters,
+                    total_factorizations=st.total_factorizations, alg_bytes=st.alg_bytes, n_fallback=st.n_fallback)
+
+    def fetch(self):
+        B = len(self.seqs)
+        outs = (ChdSeqOut * B)()
+        bufs = []
+        for i, s in enumerate(self.seqs):
+            cap = s.F + 4
+            per = []
+            for k in range(N_SNAPSHOTS):
+                bl = np.zeros((cap, 3)); ba = np.zeros((cap, 3)); ep = np.zeros((4, cap, 3)); ef = np.zeros((4, cap, 3))
+                ct = np.zeros((4, cap), dtype=np.uint8)
+                sn = outs[i].snap[k]
+                sn.capacity = cap
+                sn.base_lin = bl.ctypes.data_as(PD); sn.base_ang_deg = ba.ctypes.data_as(PD)
+                sn.ee_pos = ep.ctypes.data_as(PD); sn.ee_force = ef.ctypes.data_as(PD)
+                sn.contact = ct.ctypes.data_as(C.POINTER(C.c_ubyte))
+                per.append((bl, ba, ep, ef, ct))
+            bufs.append(per)
+        self.solver._check(self.solver.L.chd_batch_fetch(self.solver.h, self.h, outs), 'chd_batch_fetch')
+        return [SeqResult(self.seqs[i].dt, outs[i], bufs[i]) for i in range(B)]
+
+    def sizes(self, seq, stage):
+        v = [C.c_int() for _ in range(5)]
+        self.solver._check(self.solver.L.chd_debug_sizes(self.solver.h, self.h, seq, stage, *[C.byref(x) for x in v]), 'chd_debug_sizes')
+        return dict(n=v[0].value, m=v[1].value, kkt_dim=v[2].value, halfband=v[3].value, border=v[4].value)
+
+    def debug_eval(self, seq, stage, x=None, jac=True, hess=True):
+        sz = self.sizes(seq, stage); n, m = sz['n'], sz['m']
+        xo = np.zeros(n); g = np.zeros(n); c = np.zeros(m); f = C.c_double(0)
+        J = np.zeros((m, n)) if jac else None
+        H = np.zeros((n, n)) if hess else None
+        xx = np.ascontiguousarray(x, dtype=np.float64) if x is not None else None
+        p = lambda a: a.ctypes.data_as(PD) if a is not None else None   # noqa: E731
+        rc = self.solver.L.chd_debug_eval(self.solver.h, self.h, seq, stage, p(xx), p(xo), C.byref(f), p(g), p(c), p(J), p(H))
+        if rc < 0:
+            raise PhysError('chd_debug_eval: ' + self.solver.last_error())
+        return dict(x=xo, f=f.value, g=g, c=c, J=J, H=H, err=rc)
+
+    def free(self):
+        if self.h:
+            self.solver.L.chd_batch_free(self.solver.h, self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class PhysOptim:
+    """One solver handle bound to one GPU (``chd_handle``)."""
+
+    def __init__(self, device=0, config=None, **cfg_kw):
+        self.L = load_library()
+        self.cfg = config if config is not None else default_config(**cfg_kw)
+        self.h = C.c_void_p()
+        rc = self.L.chd_phys_create(C.byref(self.cfg), int(device), C.byref(self.h))
+        if rc != 0:
+            raise PhysError('chd_phys_create failed (rc=%d): no usable HIP device %d — the physics stage has no CPU path' % (rc, device))
+
+    def last_error(self):
+        return (self.L.chd_phys_last_error(self.h) or b'').decode()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise PhysError('%s failed: %s' % (what, self.last_error()))
+
+    def upload(self, seqs):
+        return Batch(self, seqs)
+
+    def solve(self, seqs):
+        """Upload + solve + fetch.  Returns (results, stats)."""
+        b = self.upload(seqs)
+        try:
+            st = b.solve()
+            return b.fetch(), st
+        finally:
+            b.free()
+
+    def solve_dirs(self, in_dirs, out_dirs, nframes):
+        """Batched drop-in for ``./phys_optim --in_dir D_in --nframes F --out_dir D_out`` run once per directory."""
+        B = len(in_dirs)
+        a = (C.c_char_p * B)(*[os.fsencode(d) for d in in_dirs])
+        o = (C.c_char_p * B)(*[os.fsencode(d) for d in out_dirs])
+        nf = (C.c_int * B)(*[int(x) for x in nframes])
+        st = (C.c_int * B)()
+        self._check(self.L.chd_phys_solve_dirs(self.h, B, a, o, nf, st), 'chd_phys_solve_dirs')
+        return [st[i] for i in range(B)]
+
+    def close(self):
+        if self.h:
+            self.L.chd_phys_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

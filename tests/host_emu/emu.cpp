@@ -86,8 +86,7 @@ int emu_linsolve(void* h, int stage, double dw, double dval, const double* b, do
 }
 int emu_solve(void* h, int stage_first, int stage_last, int lds_doubles) {
   Emu* e = (Emu*)h; e->bind();
-  e->M.d.stage_first = stage_first; e->M.d.stage_last = stage_last;
-  run_sequence(&e->M.d, e->lds.data(), lds_doubles > 0 ? lds_doubles : 18432, e->cfg.tol);
+  run_sequence(&e->M.d, e->lds.data(), lds_doubles > 0 ? lds_doubles : 18432, e->cfg.tol, stage_first, stage_last);
   return 0;
 }
 // stage-4 fallback: rebuild the tables of stage index 5 with the durations stage 3 left
