@@ -949,7 +949,7 @@ CHD_DEV double cache_djac(const double* sc_, int dim, int k) {
 
 // number of smoothing residuals of spline s: loop `for (t = 0; t < T_s - dt; t += dt)` (vel_smooth_cost.cpp:41)
 CHD_DEV int n_smooth(const SeqDesc* q, int s) {
-  const double lim = q->wd[q->o_ttot + s] - q->dt;
+  const double lim = q->wd[q->o_ttot + s] - q->dt - 1e-9;   // the last sample sits exactly on the limit: tolerance, not rounding, decides
   int n = q->F;
   while (n > 0 && !(q->cd[q->o_tcost + n - 1] < lim)) --n;
   return n;
@@ -1409,7 +1409,7 @@ CHD_DEV void solve_stage(Ctx& c, StageResult& res) {
     }
     if (!ok) { status = -2; break; }
     if (attempt == 0 && nls == 0) dw = fmax(CHD_DELTA_W_MIN, dw / 3.0);
-    else if (nls >= 2) dw *= 4.0;
+    else if (nls >= 1) dw *= 4.0;
     PAR_FOR(j, n) x[j] = used_soc ? xs[j] : x[j] + alpha * dx[j];
     PAR_FOR(i, m) {
       s[i] = used_soc ? ss2[i] : s[i] + alpha * ds[i];

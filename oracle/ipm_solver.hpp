@@ -333,6 +333,7 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
   double last_alpha = 0; int last_nls = 0, last_att = 0; bool last_soc = false;
   for (it = 0; it < opt.max_iter; ++it) {
     double E0 = errors(0.0);
+    if (opt.verbose) { int wi = 0; double wv = 0; for (int i = 0; i < m; ++i) { double v = std::fabs(eq[i] ? c[i] - l[i] : c[i] - s[i]); if (v > wv) { wv = v; wi = i; } } std::printf("[worst row %d fam %d eq %d c=%.4e s=%.4e l=%.3e u=%.3e lam=%.3e] ", wi, P.row_family[wi], (int)eq[wi], c[wi], s[wi], l[wi], u[wi], lam[wi]); }
     if (opt.verbose) std::printf("%4d f=%.6e E0=%.2e (d %.1e p %.1e pu %.1e c %.1e) mu=%.1e nu=%.1e dw=%.1e | last a=%.2e nls=%d att=%d soc=%d\n", it, f / sf, E0, e_d, e_p, e_p_unscaled, e_c, mu, nu, dw, last_alpha, last_nls, last_att, (int)last_soc);
     if (E0 <= tol && e_p_unscaled <= opt.constr_viol_tol) { status = 0; break; }
     while (true) {
@@ -407,6 +408,7 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
         resid(ct, st, rt);
         double cnt = 0; for (int i = 0; i < m; ++i) cnt += std::fabs(rt[i]);
         double phit = ft + barrier(st, mu) + nu * cnt;
+        if (opt.verbose) std::printf("   ls a=%.3e f %.6e->%.6e bar %.6e->%.6e cn %.6e->%.6e Dphi %.3e gdx %.3e dbar %.3e dHd %.3e a_pr %.3e\n", alpha, f, ft, barrier(s, mu), barrier(st, mu), cn, cnt, Dphi, gdx, dbar, dHd, a_pr);
         if (phit <= phi0 + 1e-4 * alpha * Dphi + 1e-12 * std::fabs(phi0)) { ok = true; break; }
         if (nls == 0 && opt.use_soc && cnt > cn_floor) {
           // second-order correction (IPOPT sec. 2.4): same factorisation, rhs = constraint
@@ -441,7 +443,7 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
     }
     if (!ok) { status = -2; P.set_x(x.data()); break; }
     if (attempt == 0 && nls == 0) dw = std::max(opt.delta_w_min, dw / 3.0);
-    else if (nls >= 2) dw *= 4.0;
+    else if (nls >= 1) dw *= 4.0;
     last_alpha = alpha; last_nls = nls; last_att = attempt; last_soc = used_soc;
     if (used_soc) { for (int j = 0; j < n; ++j) x[j] = xs[j]; } else { for (int j = 0; j < n; ++j) x[j] += alpha * dx[j]; }
     for (int i = 0; i < m; ++i) {

@@ -990,7 +990,7 @@ class Problem {
         const Spline& s = sp[term];
         double w = term == 0 ? ww[0] : term == 1 ? ww[1] : ww[2];
         double Ttot = s.total_time();
-        for (double t = 0.0; t < (Ttot - in.dt); t += in.dt) {        // :41
+        for (double t = 0.0; t < (Ttot - in.dt) - 1e-9; t += in.dt) {   // :41; the last sample sits exactly on the limit — decided with a tolerance instead of by rounding
           s.eval(t + in.dt, pe2); s.eval(t, pe);
           for (int d = 0; d < 3; ++d) {
             double r = (which == kPos ? pe2.p[d] - pe.p[d] : pe2.v[d] - pe.v[d]);
