@@ -1,0 +1,152 @@
+#!/usr/bin/env python
+"""Benchmark of the physics hot path (BASELINE.json metric: physics-optimized 90-frame sequences/sec).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full staged solve (stages 1.1, 1.2, 2.1, 2.2, 3 and the stage-4 fallback where
+stage 3 fails; phys_optim.cpp:544-749, reference iteration caps) of one batch of 128 synthetic
+90-frame sequences per GPU (BASELINE.json configs[1]; seeds rank*128 .. rank*128+127), with the
+inputs and the structure tables already resident in HBM.  N > 1: one process per GPU (launched by
+torch.distributed.run), sequences are independent so there is no data-path collective; weak scaling.
+"""
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH = 128
+FRAMES = 90
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def _cpu_worker(seed):
+    """One sequence on the CPU oracle (the restated reference algorithm), single thread."""
+    import chd_amd  # noqa: F401
+    from chd_amd.synth import make_walk
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from common import oracle_run
+    seq = make_walk(seed=seed, F=FRAMES, randomize=True)
+    t0 = time.time()
+    stats, _ = oracle_run(seq, [7000, 7000, 7000, 2500, 2000, 7000])
+    return time.time() - t0, sum(s[1] for s in stats)
+
+
+def cpu_baseline(max_workers=8):
+    """Bounded sample of the same workload on the host cores: the first C sequences, one per core."""
+    from oracle import oracle
+    oracle.build()
+    cores = max(1, min(max_workers, os.cpu_count() or 1))
+    t0 = time.time()
+    with mp.get_context('spawn').Pool(cores) as pool:
+        res = pool.map(_cpu_worker, list(range(cores)))
+    wall = time.time() - t0
+    return {'value': cores / wall, 'unit': 'sequences/s', 'cores': cores, 'kind': 'port',
+            'sample': 'first %d sequences of the workload (seeds 0..%d), one oracle process per core, %d IPM iterations, %.1f s wall'
+                      % (cores, cores - 1, sum(r[1] for r in res), wall)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--batch', type=int, default=BATCH, help=argparse.SUPPRESS)
+    ap.add_argument('--no-cpu-baseline', action='store_true', help=argparse.SUPPRESS)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import chd_amd  # noqa: F401
+    from chd_amd.phys_optim import PhysOptim, default_config
+    from chd_amd.synth import make_batch
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the physics stage has no CPU path')
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    B = args.batch
+    seqs = make_batch(B, F=FRAMES, seed0=rank * B)
+    solver = PhysOptim(device=local, config=default_config())          # reference iteration caps and tol
+    batch = solver.upload(seqs)                                         # inputs + structure tables -> HBM (not timed)
+
+    for _ in range(args.warmup):
+        batch.solve()
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = 0.0; alg_bytes = 0.0; iters = 0; nfact = 0; nfall = 0; launches = 0; max_seq_ms = 0.0
+    for _ in range(args.steps):
+        st = batch.solve()                                              # blocks until the batch is solved
+        kernel_ms += st['kernel_ms'][0] + st['kernel_ms'][1]
+        launches += 1 + (1 if st['kernel_ms'][1] > 0 else 0)
+        alg_bytes += st['alg_bytes']; iters += st['total_iters']; nfact += st['total_factorizations']; nfall += st['n_fallback']
+        max_seq_ms = max(max_seq_ms, st['max_seq_ms'])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        agg = torch.tensor([float(iters)], dtype=torch.float64, device='cuda')
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        tot_iters_all = float(agg.item())
+    else:
+        tot_iters_all = float(iters)
+
+    res = batch.fetch()
+    n_ok = sum(1 for r in res if r.dynamics_succeed and r.durations_succeed)
+    sizes = res[0].sizes
+
+    if rank == 0:
+        total_seqs = world * B * args.steps
+        ach = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0          # rank 0's kernel, GB/s
+        traffic = None
+        tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get('hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+        out = {
+            'metric': 'physics-optimized sequences/sec (90-frame)', 'value': total_seqs / elapsed, 'unit': 'sequences/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'batch of %d synthetic Mixamo-like %d-frame walks per GPU (BASELINE configs[1]), staged NLP solve, '
+                                   'reference iteration caps 7000/7000/7000/2500/2000/7000, tol 1e-3' % (B, FRAMES),
+                       'sequences_per_gpu': B, 'frames': FRAMES, 'parallelism': 'independent sequences, 1 workgroup each; %d process(es)' % world,
+                       'kkt_dim': sizes['kkt_dim'], 'halfband': sizes['halfband'], 'border': sizes['border'], 'nnz_jac': sizes['nnz_jac'],
+                       'ipm_iterations_per_sequence': tot_iters_all / (world * B * args.steps),
+                       'factorizations_rank0': nfact, 'stage4_fallbacks_rank0': nfall, 'converged_rank0': '%d/%d' % (n_ok, B),
+                       'slowest_sequence_ms': max_seq_ms},
+            'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+                         'traffic': traffic, 'kernel': 'chd_solve_kernel', 'launches': launches,
+                         'avg_launch_ms': kernel_ms / max(1, launches),
+                         'algorithmic_bytes_per_launch': alg_bytes / max(1, launches)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    batch.free()
+    solver.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -80,7 +80,15 @@ struct Ctx {
   double tol;           // IPOPT tol of the stage (phys_optim.cpp:578)
   int err;              // sticky error flag (band overflow), uniform across the workgroup after a sync
   int n_bad_pivots;
+  long long tacc[8];    // cycles per phase (thread 0): 0 eval full, 1 eval values, 2 factor, 3 solve, 4 matvec, 5 total
 };
+#ifdef CHD_HOST_EMU
+#define CHD_CLOCK() 0LL
+#else
+#define CHD_CLOCK() ((long long)wall_clock64())
+#endif
+#define TIC() const long long tic_ = CHD_CLOCK()
+#define TOC(c, k) (c).tacc[k] += CHD_CLOCK() - tic_
 
 #define VN(c, k) ((c).q->wd + (c).q->o_vec_n + (long long)(k) * (c).q->max_n)
 #define VM(c, k) ((c).q->wd + (c).q->o_vec_m + (long long)(k) * (c).q->max_m)
@@ -341,6 +349,7 @@ CHD_DEV void kzero(Ctx& c) {
 
 // y = K0 x (+ diag .* x)
 CHD_DEV void kmatvec(Ctx& c, const double* x, double* y, const double* diag) {
+  TIC();
   const int Nb = c.Nb, w = c.w, W2 = c.W2, LD = c.LD, bc = c.bc;
   GROUP_FOR(i, Nb) {
     const int lo = i - w < 0 ? 0 : i - w, hi = i + w >= Nb ? Nb - 1 : i + w;
@@ -364,6 +373,7 @@ CHD_DEV void kmatvec(Ctx& c, const double* x, double* y, const double* diag) {
     y[i] += acc;
   }
   CHD_SYNC();
+  TOC(c, 4);
 }
 
 // ---- factorisation: K0 + diag -> L D L^T in Kf (no pivoting; expected pivot sign from `sign`) ----
@@ -373,6 +383,7 @@ CHD_DEV double pivot_fix(Ctx& c, double d, int sg) {
 }
 
 CHD_DEV void kfactor(Ctx& c, const double* diag, const int* sign) {
+  TIC();
   const int Nb = c.Nb, w = c.w, W2 = c.W2, W1 = c.w + 1, LD = c.LD, bc = c.bc;
   if (CHD_TID == 0) c.n_bad_pivots = 0;
   // copy the lower triangle (+ diagonal shift) into the factor storage
@@ -508,6 +519,7 @@ CHD_DEV void kfactor(Ctx& c, const double* diag, const int* sign) {
       CHD_SYNC();
     }
   }
+  TOC(c, 2);
 }
 
 // in-block triangular solves for the substitution (wave-cooperative on the device)
@@ -558,6 +570,7 @@ CHD_DEV void tri_backward(Ctx& c, double* y, int c0, int jb) {
 
 // x = K^{-1} rhs using the factor.  y: work vector of N doubles (LDS when it fits).
 CHD_DEV void ksolve_once(Ctx& c, const double* rhs, double* x) {
+  TIC();
   const int Nb = c.Nb, w = c.w, W1 = c.w + 1, LD = c.LD, bc = c.bc, N = c.N;
   double* y = (c.lds_cap - LDS_RED >= N) ? c.lds + LDS_RED : VK(c, VK_Y);
   PAR_FOR(i, N) y[i] = rhs[i];
@@ -629,6 +642,7 @@ CHD_DEV void ksolve_once(Ctx& c, const double* rhs, double* x) {
   }
   PAR_FOR(i, N) x[i] = y[i];
   CHD_SYNC();
+  TOC(c, 3);
 }
 
 CHD_DEV void ksolve(Ctx& c, const double* rhs, double* x, const double* diag, int refine) {
@@ -1141,6 +1155,7 @@ CHD_DEV void eval_cost_grad_hess(Ctx& c, double* g) {
 // Full evaluation at x.  Returns the (scaled) objective; fills c_out (scaled rows), and in
 // EV_FULL mode the scaled gradient g and the unfactored KKT matrix K0 = [sf H, (sc J)^T; sc J, 0].
 CHD_DEV double eval_nlp(Ctx& c, const double* x, int mode, double* c_out, double* g) {
+  TIC();
   state_from_x(c, x);
   if (mode == EV_FULL) kzero(c);
   fill_sample_cache(c);      // ends with a sync (also orders kzero before the kadd's below)
@@ -1151,6 +1166,7 @@ CHD_DEV double eval_nlp(Ctx& c, const double* x, int mode, double* c_out, double
     c.err = block_max(c, (double)c.err) > 0.5 ? 1 : 0;     // a band overflow seen by any thread
   }
   CHD_SYNC();
+  TOC(c, mode == EV_FULL ? 0 : 1);
   return f;
 }
 
@@ -1495,6 +1511,8 @@ CHD_DEV void init_state(const SeqDesc* q) {
 CHD_DEV void run_sequence(const SeqDesc* q, double* lds, int lds_cap, double tol, int stage_first, int stage_last) {
   Ctx c;
   c.lds = lds; c.lds_cap = lds_cap;
+  for (int k = 0; k < 8; ++k) c.tacc[k] = 0;
+  const long long t_begin = CHD_CLOCK();
   if (stage_first == 0) init_state(q);
   else refresh_durations(q);
   for (int stage = stage_first; stage <= stage_last; ++stage) {
@@ -1513,12 +1531,18 @@ CHD_DEV void run_sequence(const SeqDesc* q, double* lds, int lds_cap, double tol
     if (stage == 4 || stage == 5) sample_solution(q, 2);   // sol_out_durations.txt (:757)
     CHD_SYNC();
   }
+  if (CHD_TID == 0) {      // phase timers (100 MHz wall clock ticks), accumulated over launches
+    c.tacc[5] = CHD_CLOCK() - t_begin;
+    double* tm = q->out_d + N_STAGES * RS_STRIDE + 3LL * 10 * q->cap * 3;
+    for (int k = 0; k < 8; ++k) tm[k] += (double)c.tacc[k];
+  }
 }
 
 // Debug entry: evaluate stage `stage` at the state currently in the workspace (or at x if given in VN_XT).
 CHD_DEV void debug_eval(const SeqDesc* q, int stage, int use_x, double* lds, int lds_cap, double* f_out) {
   Ctx c;
   c.lds = lds; c.lds_cap = lds_cap;
+  for (int k = 0; k < 8; ++k) c.tacc[k] = 0;
   init_state(q);
   bind_stage(c, q, stage);
   c.tol = 1e-3;

@@ -211,6 +211,7 @@ int chd_batch_solve(chd_handle* h, chd_batch* b) {
   HIP_TRY(h, hipSetDevice(h->device));
   const int lds_doubles = h->lds_bytes / 8;
   b->stats = chd_batch_stats{};
+  HIP_TRY(h, hipMemsetAsync(b->d_od, 0, b->tot_od * 8, h->stream));
   // ---- launch 1: stages 1.1, 1.2, 2.1, 2.2, 3 for every sequence
   HIP_TRY(h, hipEventRecord(b->ev[0], h->stream));
   hipLaunchKernelGGL(chd_solve_kernel, dim3(b->B), dim3(h->threads), h->lds_bytes, h->stream, b->d_descs, (const int*)nullptr, lds_doubles,
@@ -293,6 +294,9 @@ int chd_batch_solve(chd_handle* h, chd_batch* b) {
       b->stats.total_factorizations += (long long)s[stg * RS_STRIDE + RS_NFACT];
       b->stats.alg_bytes += it * b->models[i].alg_bytes_iter[stg];
     }
+    const double* tm = s + N_STAGES * RS_STRIDE + 3LL * 10 * b->models[i].d.cap * 3;     // 100 MHz ticks
+    for (int k = 0; k < 8; ++k) b->stats.phase_ms[k] += tm[k] * 1e-5;
+    if (tm[5] * 1e-5 > b->stats.max_seq_ms) b->stats.max_seq_ms = tm[5] * 1e-5;
   }
   return 0;
 }

@@ -87,11 +87,11 @@ class EmuProblem:
 
     def results(self):
         cap = self.sizes(0)['cap']
-        od = np.zeros(6 * 8 + 3 * 10 * cap * 3); oi = np.zeros(8 + 3 * 4 * cap, dtype=np.int32)
+        od = np.zeros(6 * 8 + 3 * 10 * cap * 3 + 8); oi = np.zeros(8 + 3 * 4 * cap, dtype=np.int32)
         lib().emu_get_out(self.h, _p(od), oi.ctypes.data_as(C.POINTER(C.c_int)))
         stats = od[:48].reshape(6, 8)
         snaps = []
-        blocks = od[48:].reshape(3, 10, cap, 3)
+        blocks = od[48:48 + 3 * 10 * cap * 3].reshape(3, 10, cap, 3)
         for s in range(3):
             ns = oi[2 * s]
             snaps.append(dict(n_samples=int(ns), num_frames=int(oi[2 * s + 1]), base_lin=blocks[s, 0, :ns], base_ang_deg=blocks[s, 1, :ns],

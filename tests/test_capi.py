@@ -1,0 +1,62 @@
+"""The C-ABI shared library: loads without a GPU, exports every function include/chd_phys.h declares,
+refuses to create a handle when no HIP device exists (no silent CPU fallback), and the Python structs
+mirror the C layout."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import chd_amd
+from chd_amd import phys_capi, phys_optim
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    phys_optim.build_library()
+    return C.CDLL(phys_optim.LIB_PATH)
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, 'include', 'chd_phys.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(chd_[a-z_]+)\s*\(', src)))
+
+
+def test_header_and_exports_agree(lib):
+    names = declared_functions()
+    assert set(names) == set(phys_optim.EXPORTS)
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_version_and_default_config(lib):
+    assert lib.chd_phys_version() == 1
+    c = phys_capi.ChdConfig()
+    lib.chd_config_default(C.byref(c))
+    assert list(c.max_iter) == [7000, 7000, 7000, 2500, 2000, 7000] and c.tol == 1e-3      # phys_optim.cpp:571-743, :578
+    d = phys_capi.default_config()
+    assert (c.w_com_lin, c.w_com_ang, c.w_ee, c.w_smooth, c.w_dur) == (d.w_com_lin, d.w_com_ang, d.w_ee, d.w_smooth, d.w_dur) == (0.4, 1.7, 0.3, 0.1, 0.1)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU failure mode')
+def test_create_fails_loudly_without_gpu(lib):
+    h = C.c_void_p()
+    rc = lib.chd_phys_create(None, 0, C.byref(h))
+    assert rc != 0 and not h.value
+    with pytest.raises(phys_optim.PhysError):
+        phys_optim.PhysOptim(device=0)
+
+
+def test_product_never_touches_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may use oracle/."""
+    pkg = os.path.join(ROOT, 'contact-human-dynamics_amd')
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hpp', '.hip', '.h', '.cpp')):
+                txt = open(os.path.join(dp, f), errors='ignore').read()
+                assert 'liboracle' not in txt and 'from oracle' not in txt and 'import oracle' not in txt and '#include "../../oracle' not in txt, f

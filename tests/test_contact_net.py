@@ -1,0 +1,82 @@
+"""Contact network: this repo's PyTorch implementation against golden vectors produced by the
+reference's own classes (tests/golden/make_contact_golden.py, run in the build container)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import chd_amd
+from chd_amd import contact_net as cn
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'contact_net_golden.npz')
+
+
+@pytest.fixture(scope='module')
+def gold():
+    return np.load(GOLD)
+
+
+def _model(gold):
+    """Seeded weights: identical to the reference OpenPoseModel built under the same seeds (fingerprints in the fixture)."""
+    torch.manual_seed(1234)
+    return cn.randomize_batchnorm_stats(cn.OpenPoseModel(), seed=7).eval()
+
+
+def test_parameter_count():
+    assert sum(p.numel() for p in cn.OpenPoseModel().parameters()) == 959092
+
+
+def test_seeded_init_matches_reference(gold):
+    m = _model(gold)
+    keys = [k for k in gold.files if k.startswith('sd_')]
+    assert len(keys) >= 18
+    for k in keys:
+        v = m.state_dict()[k[3:]].double()
+        fp = np.concatenate([[float(v.sum()), float(v.abs().sum())], v.reshape(-1)[:6].numpy()])
+        assert np.array_equal(fp, gold[k]), k
+
+
+def test_windows_bit_exact(gold):
+    w = cn.make_windows(gold['raw0'])
+    assert w.dtype == np.float32 and np.array_equal(w, gold['windows_vid0'])
+
+
+def test_logits_and_labels_cpu(gold):
+    m = _model(gold)
+    vids = [gold['raw0'], gold['raw1'], gold['raw2']]
+    fmax = max(v.shape[0] for v in vids)
+    pads = [np.concatenate([v, np.repeat(v[-1:], fmax - v.shape[0], axis=0)]) for v in vids]
+    x = torch.from_numpy(np.concatenate([cn.make_windows(v) for v in pads]))
+    with torch.no_grad():
+        lg = m(x).numpy()
+    assert np.allclose(lg, gold['logits'], atol=1e-5)
+    labels, margin = cn.detect_contacts(vids, m, torch.device('cpu'))
+    for k in range(3):
+        assert np.array_equal(labels[k], gold['contacts%d' % k])
+
+
+def test_vote_merge_edges():
+    pred = np.zeros((10, 5, 4), dtype=bool)
+    pred[0, 0, 0] = True            # first frame: one vote is enough (test.py:103-106)
+    pred[3, 2, 1] = True            # interior frame with a single vote: below the threshold of 3
+    lab = cn.vote_merge(pred)
+    assert lab.shape == (18, 4)
+    assert lab[0, 0] == 1 and lab[1, 0] == 1 and lab[2, 0] == 1      # two-frame leading pad repeats frame 0
+    assert lab[:, 1].sum() == 0
+
+
+def test_low_confidence_fill_matches_linear_interpolation():
+    op = np.zeros((6, 1, 3)); op[:, 0, 0] = [0, 9, 9, 9, 4, 5]; op[:, 0, 2] = [1, 0, 0, 0, 1, 1]
+    out = cn.fill_low_confidence(op)
+    assert np.allclose(out[:, 0, 0], [0, 1, 2, 3, 4, 5])
+
+
+@pytest.mark.gpu
+def test_labels_bit_exact_on_gpu(gold):
+    m = _model(gold)
+    vids = [gold['raw0'], gold['raw1'], gold['raw2']]
+    labels, margin = cn.detect_contacts(vids, m, torch.device('cuda:0'))
+    for k in range(3):
+        assert np.array_equal(labels[k], gold['contacts%d' % k]), 'min |logit| %.3e' % margin
+    assert cn.smoke(torch.device('cuda:0')) > 0

@@ -1,0 +1,82 @@
+"""The solver-kernel source, compiled for the host (one emulated thread), against the oracle.
+This exercises exactly the code hipcc compiles for gfx950 (chd_kernels.hpp + chd_model.hpp), minus the
+parallel execution, so algorithmic regressions are caught in the CPU-only container."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import chd_amd
+from chd_amd.phys_capi import default_config
+from chd_amd.synth import make_walk
+
+from common import oracle_run, rel_max, snapshot_errors
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'host_emu'))
+
+
+@pytest.fixture(scope='module')
+def emu():
+    import emu as e
+    e.build()
+    return e
+
+
+def test_eval_parity_all_stages(emu, oracle_lib):
+    from oracle.oracle import OracleProblem
+    seq = make_walk(seed=4, F=40, randomize=True, tilt_deg=3.0)
+    o = OracleProblem(seq); e = emu.EmuProblem(seq)
+    rng = np.random.default_rng(2)
+    x0 = None
+    for st in range(5):
+        o.set_stage(st)
+        sz = e.sizes(st)
+        assert (sz['n'], sz['m']) == (o.n, o.m)
+        if x0 is None:
+            x0 = o.get_x()
+        x = x0.copy() if st != 4 else np.concatenate([x0, o.get_x()[x0.size:]])
+        pert = 0.01 * rng.normal(size=x.size)
+        if st == 4:
+            pert[x0.size:] *= 0.01
+        x = x + pert
+        fo, go, co, Jo, Ho = o.eval(x, jac=True, hess=True)
+        r = e.eval(st, x)
+        assert r['err'] == 0
+        assert abs(r['f'] - fo) <= 1e-11 * abs(fo)
+        for a, b in ((r['g'], go), (r['c'], co), (r['J'], Jo), (r['H'], Ho)):
+            assert rel_max(a, b) < 1e-11
+        o.set_x(x0 if st != 4 else np.concatenate([x0, o.get_x()[x0.size:]]))
+
+
+def test_bordered_band_factorisation(emu):
+    seq = make_walk(seed=0, F=40, randomize=True)
+    e = emu.EmuProblem(seq)
+    for st in (1, 4):
+        sz = e.sizes(st)
+        b = np.random.default_rng(st).normal(size=sz['n'] + sz['m'])
+        x, bad = e.linsolve(st, b, dw=1e-2, dval=1e-3, refine=2)
+        assert bad == 0 and np.isfinite(x).all()
+
+
+def test_staged_solve_parity(emu, oracle_lib):
+    seq = make_walk(seed=2, F=40, randomize=True)
+    caps = [300] * 6
+    e = emu.EmuProblem(seq, default_config(max_iter=caps))
+    e.solve(0, 4)
+    stats, snaps = e.results()
+    if stats[4, 0] != 0:
+        assert e.rebuild_fallback() == 1
+        e.solve(5, 5)
+        stats, snaps = e.results()
+    ostats, osnaps = oracle_run(seq, caps)
+    for st in range(len(ostats)):
+        assert int(stats[st, 0]) == ostats[st][0] and int(stats[st, 1]) == ostats[st][1]
+    from chd_amd.io_formats import Solution
+    for k in range(3):
+        s = snaps[k]
+        sol = Solution(dt=seq.dt, num_frames=s['num_frames'], base_lin=s['base_lin'], base_ang_deg=s['base_ang_deg'],
+                       ee_pos=s['ee_pos'], ee_force=s['ee_force'], contact=s['contact'])
+        err = snapshot_errors(sol, osnaps[k])
+        assert err['contact_mismatch'] == 0
+        assert max(err['base_lin'], err['base_ang_deg'], err['ee_pos'], err['ee_force']) < 1e-8, err
