@@ -96,7 +96,7 @@ struct SeqDesc {
 enum { RS_STATUS = 0, RS_ITERS = 1, RS_KKT = 2, RS_VIOL = 3, RS_OBJ = 4, RS_MU = 5, RS_NFACT = 6, RS_AUX = 7, RS_STRIDE = 8 };
 // out_d layout: [N_STAGES x RS_STRIDE] then 3 snapshots x 10 blocks (base_lin, base_ang_deg, 4 ee_pos, 4 ee_force) x cap x 3
 // out_i layout: [3 x (n_samples, header)] then 3 x 4 x cap contact flags
-inline long long out_d_size(int cap) { return (long long)N_STAGES * RS_STRIDE + 3LL * 10 * cap * 3 + 8; }   // + 8 phase timers
+inline long long out_d_size(int cap) { return (long long)N_STAGES * RS_STRIDE + 3LL * 10 * cap * 3 + 16; }   // + 16 phase timers
 inline long long out_i_size(int cap) { return 8 + 3LL * 4 * cap; }
 
 }  // namespace chd

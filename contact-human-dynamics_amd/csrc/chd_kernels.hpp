@@ -30,12 +30,32 @@
 #define CHD_NT 1
 #define CHD_SYNC() ((void)0)
 #define CHD_GL 1
+#define CHD_NOINLINE
 #else
 #define CHD_DEV __device__ inline
 #define CHD_TID ((int)threadIdx.x)
 #define CHD_NT ((int)blockDim.x)
 #define CHD_SYNC() __syncthreads()
 #define CHD_GL 16
+#define CHD_NOINLINE __attribute__((noinline))
+#endif
+// LDS data is addressed through an explicit local-address-space pointer: a generic `double*` would make
+// hipcc emit flat_load/flat_store for every access instead of ds_read/ds_write
+#ifdef CHD_HOST_EMU
+typedef double LdsD;
+#else
+typedef __attribute__((address_space(3))) double LdsD;
+#endif
+#ifdef CHD_HOST_EMU
+#define CHD_WAVE_ID 0
+#define CHD_NWAVES 1
+#define CHD_LANE 0
+#define CHD_WAVE_SZ 1
+#else
+#define CHD_WAVE_ID ((int)(threadIdx.x >> 6))
+#define CHD_NWAVES ((int)(blockDim.x >> 6))
+#define CHD_LANE ((int)(threadIdx.x & 63))
+#define CHD_WAVE_SZ 64
 #endif
 #define PAR_FOR(i, n) for (int i = CHD_TID; i < (n); i += CHD_NT)
 // one group of CHD_GL consecutive lanes per item; `lane_` is the lane inside the group
@@ -71,7 +91,7 @@ enum { RF_EQ = 1, RF_L = 2, RF_U = 4 };
 struct Ctx {
   const SeqDesc* q;
   const StageDesc* S;
-  double* lds;          // workgroup scratch (LDS on the device)
+  LdsD* lds;            // workgroup scratch (LDS on the device)
   int lds_cap;          // doubles available in lds
   int n, m, N, Nb, bc, w, W2, LD;
   double* K0b; double* K0x; double* Kfb; double* Kfx;
@@ -80,7 +100,7 @@ struct Ctx {
   double tol;           // IPOPT tol of the stage (phys_optim.cpp:578)
   int err;              // sticky error flag (band overflow), uniform across the workgroup after a sync
   int n_bad_pivots;
-  long long tacc[8];    // cycles per phase (thread 0): 0 eval full, 1 eval values, 2 factor, 3 solve, 4 matvec, 5 total
+  long long tacc[16];    // cycles per phase (thread 0): 0 eval full, 1 eval values, 2 factor, 3 solve, 4 matvec, 5 total
 };
 #ifdef CHD_HOST_EMU
 #define CHD_CLOCK() 0LL
@@ -240,7 +260,7 @@ CHD_DEV void matvec3(const double A[3][3], const double v[3], double o[3]) {
 // Angular part of the centroidal dynamics (humanoid_rigid_body_dynamics.cpp:89-115):
 //   ang = I_w wd + w x (I_w w),  I_w = R I_b R^T,  w = M(e) e',  wd = Md(e,e') e' + M(e) e''.
 // Outputs ang[3] and its partials d0 (wrt e), d1 (wrt e'), d2 (wrt e''): dX[i][k] = d ang_i / d (.)_k.
-CHD_DEV void angular_term(const double e[3], const double ed[3], const double edd[3], const double Ib[3][3], int want_jac,
+CHD_NOINLINE CHD_DEV void angular_term(const double e[3], const double ed[3], const double edd[3], const double Ib[3][3], int want_jac,
                           double ang[3], double d0[3][3], double d1[3][3], double d2[3][3]) {
   double R[3][3], dR[3][3][3];
   rot_and_derivs(e, R, dR);
@@ -348,15 +368,20 @@ CHD_DEV void kzero(Ctx& c) {
 }
 
 // y = K0 x (+ diag .* x)
-CHD_DEV void kmatvec(Ctx& c, const double* x, double* y, const double* diag) {
+CHD_NOINLINE CHD_DEV void kmatvec(Ctx& c, const double* x, double* y, const double* diag) {
   TIC();
   const int Nb = c.Nb, w = c.w, W2 = c.W2, LD = c.LD, bc = c.bc;
   GROUP_FOR(i, Nb) {
     const int lo = i - w < 0 ? 0 : i - w, hi = i + w >= Nb ? Nb - 1 : i + w;
     const double* row = c.K0b + (long long)i * W2 + (w - i);
-    double acc = 0;
-    for (int k = lo + lane_; k <= hi; k += CHD_GL) acc += row[k] * x[k];
-    acc = group_sum(acc);
+    double acc = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+    int k = lo + lane_;
+    for (; k + 3 * CHD_GL <= hi; k += 4 * CHD_GL) {
+      acc += row[k] * x[k]; acc1 += row[k + CHD_GL] * x[k + CHD_GL];
+      acc2 += row[k + 2 * CHD_GL] * x[k + 2 * CHD_GL]; acc3 += row[k + 3 * CHD_GL] * x[k + 3 * CHD_GL];
+    }
+    for (; k <= hi; k += CHD_GL) acc += row[k] * x[k];
+    acc = group_sum((acc + acc1) + (acc2 + acc3));
     if (lane_ == 0) y[i] = acc + (diag ? diag[i] * x[i] : 0.0);
   }
   GROUP_FOR(r, bc) {
@@ -382,149 +407,289 @@ CHD_DEV double pivot_fix(Ctx& c, double d, int sg) {
   return d;
 }
 
-CHD_DEV void kfactor(Ctx& c, const double* diag, const int* sign) {
+// wave-0-only sections: one wavefront works through a short dependent chain in LDS while the
+// other waves wait at the next workgroup barrier
+#ifdef CHD_HOST_EMU
+#define CHD_WAVE0 true
+#define CHD_WLANE 0
+#define CHD_WSTEP 1
+#define CHD_WSYNC() ((void)0)
+#else
+#define CHD_WAVE0 (threadIdx.x < 64)
+#define CHD_WLANE ((int)threadIdx.x)
+#define CHD_WSTEP 64
+#define CHD_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#endif
+
+
+// ---- diagonal block of a panel (NB x NB, in LDS column-major PT[j * ldp + a]) -------------------
+#ifdef CHD_HOST_EMU
+template <int NB>
+CHD_DEV void diag_block(Ctx& c, const int* sign, LdsD* dv, LdsD* PT, const int ldp, const int c0, const int jb) {
+  for (int j = 0; j < NB; ++j) {
+    double d = PT[j * ldp + j];
+    if (j < jb) d = pivot_fix(c, d, sign[c0 + j]);
+    for (int a = j + 1; a < NB; ++a) PT[j * ldp + a] /= d;
+    dv[j] = d;
+    for (int jj = j + 1; jj < NB; ++jj)
+      for (int a = jj; a < NB; ++a) PT[jj * ldp + a] -= PT[j * ldp + a] * d * PT[j * ldp + jj];
+  }
+}
+#else
+CHD_DEV double readlane_f64(double v, int l) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, l); hi = __builtin_amdgcn_readlane(hi, l);
+  return __hiloint2double(hi, lo);
+}
+// one wavefront: lane a keeps row a of the block in registers; column j's pivot and multipliers are
+// broadcast with v_readlane, so the whole right-looking elimination runs without touching LDS
+template <int NB>
+CHD_DEV void diag_block(Ctx& c, const int* sign, LdsD* dv, LdsD* PT, const int ldp, const int c0, const int jb) {
+  if (threadIdx.x < 64) {
+    const int a = threadIdx.x;
+    const bool act = a < NB;
+    double r[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) r[j] = (act && j <= a) ? PT[j * ldp + a] : 0.0;
+    int bad = 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      double d = readlane_f64(r[j], j);
+      if (j < jb) { const int sg = sign[c0 + j]; if (!(d * sg > 1e-14)) { d = sg * 1e-10; ++bad; } }
+      const double lj = r[j] / d;            // L(a, j) for a > j
+      if (act && a > j) PT[j * ldp + a] = lj;
+      if (a == j) dv[j] = d;
+      CHD_WSYNC();
+#pragma unroll
+      for (int jj = j + 1; jj < NB; ++jj) {
+        const double ljj = PT[j * ldp + jj];          // L(jj, j), same address for every lane
+        if (a >= jj) r[jj] -= lj * d * ljj;
+      }
+    }
+    if (threadIdx.x == 0) c.n_bad_pivots += bad;
+  }
+}
+#endif
+
+// ---- trailing update: window -= L_below D L_below^T (lower triangle) ------------------------------
+// window rows/cols u = 0..wr-1 live at PT rows NB+u; u < nbelow are band rows i0+u, the rest border rows
+#ifdef CHD_HOST_EMU
+template <int NB>
+CHD_DEV void trailing_update(Ctx& c, const LdsD* dv, const LdsD* PT, const int ldp, const int wr, const int nbelow, const int i0) {
+  const int W1 = c.w + 1, w = c.w, LD = c.LD, Nb = c.Nb;
+  for (int ur = 0; ur < wr; ++ur)
+    for (int uc = 0; uc <= ur; ++uc) {
+      double v = 0;
+      for (int j = 0; j < NB; ++j) v += PT[j * ldp + NB + ur] * (PT[j * ldp + NB + uc] * dv[j]);
+      if (ur < nbelow) { const int i = i0 + ur, k = i0 + uc; c.Kfb[(long long)i * W1 + (k - i + w)] -= v; }
+      else if (uc < nbelow) c.Kfx[(long long)(ur - nbelow) * LD + i0 + uc] -= v;
+      else c.Kfx[(long long)(ur - nbelow) * LD + Nb + (uc - nbelow)] -= v;
+    }
+}
+#else
+typedef double chd_f64x4 __attribute__((ext_vector_type(4)));
+// one 16x16 output tile per wavefront pass, K = NB in steps of 4 on the fp64 matrix core
+// (v_mfma_f64_16x16x4_f64: A[row = lane & 15][k = lane >> 4], B[k = lane >> 4][col = lane & 15],
+//  D[row = (lane >> 4) + 4 * reg][col = lane & 15])
+template <int NB>
+CHD_DEV void trailing_update(Ctx& c, const LdsD* dv, const LdsD* PT, const int ldp, const int wr, const int nbelow, const int i0) {
+  const int W1 = c.w + 1, w = c.w, LD = c.LD, Nb = c.Nb;
+  const int wave = threadIdx.x >> 6, nwv = blockDim.x >> 6, lane = threadIdx.x & 63;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int nt = (wr + 15) >> 4;
+  const int ntri = nt * (nt + 1) / 2;
+  auto tile_of = [](int t, int& tr, int& tc) {
+    tr = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
+    while (tr * (tr + 1) / 2 > t) --tr;
+    tc = t - tr * (tr + 1) / 2;
+  };
+  auto dest = [&](int ur, int uc) -> double* {
+    if (ur < nbelow) { const int i = i0 + ur, k = i0 + uc; return c.Kfb + (long long)i * W1 + (k - i + w); }
+    if (uc < nbelow) return c.Kfx + (long long)(ur - nbelow) * LD + i0 + uc;
+    return c.Kfx + (long long)(ur - nbelow) * LD + Nb + (uc - nbelow);
+  };
+  // two independent tiles per pass: their MFMA chains interleave, and the old window values are
+  // fetched before the chain starts
+  for (int t0 = wave; t0 < ntri; t0 += 2 * nwv) {
+    const int t1 = t0 + nwv;
+    const bool two = t1 < ntri;
+    int trA, tcA, trB, tcB;
+    tile_of(t0, trA, tcA);
+    tile_of(two ? t1 : t0, trB, tcB);
+    double* pdA[4]; double* pdB[4]; double oA[4], oB[4]; bool okA[4], okB[4];
+    const int ucA = 16 * tcA + lr, ucB = 16 * tcB + lr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int urA = 16 * trA + lk + 4 * r, urB = 16 * trB + lk + 4 * r;
+      okA[r] = urA < wr && ucA <= urA; okB[r] = two && urB < wr && ucB <= urB;
+      pdA[r] = dest(okA[r] ? urA : 0, okA[r] ? ucA : 0); pdB[r] = dest(okB[r] ? urB : 0, okB[r] ? ucB : 0);
+      oA[r] = okA[r] ? *pdA[r] : 0.0; oB[r] = okB[r] ? *pdB[r] : 0.0;
+    }
+    chd_f64x4 accA = {0.0, 0.0, 0.0, 0.0}, accB = {0.0, 0.0, 0.0, 0.0};
+    const LdsD* paA = PT + NB + 16 * trA + lr; const LdsD* pbA = PT + NB + 16 * tcA + lr;
+    const LdsD* paB = PT + NB + 16 * trB + lr; const LdsD* pbB = PT + NB + 16 * tcB + lr;
+#pragma unroll
+    for (int kk = 0; kk < NB / 4; ++kk) {
+      const int j = kk * 4 + lk;
+      const double dj = dv[j];
+      accA = __builtin_amdgcn_mfma_f64_16x16x4f64(paA[j * ldp], pbA[j * ldp] * dj, accA, 0, 0, 0);
+      accB = __builtin_amdgcn_mfma_f64_16x16x4f64(paB[j * ldp], pbB[j * ldp] * dj, accB, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (okA[r]) *pdA[r] = oA[r] - accA[r];
+      if (okB[r]) *pdB[r] = oB[r] - accB[r];
+    }
+  }
+}
+#endif
+
+// Banded part of the factorisation, NB columns per panel.  Panel in LDS, column-major PT[j * ldp + a];
+// local rows: [0, NB) diagonal block (rows >= jb of a short last block are identity padding),
+// [NB, NB + nbelow) band rows below it, then the bc border rows.
+template <int NB>
+CHD_NOINLINE CHD_DEV void kfactor_band(Ctx& c, const int* sign, LdsD* dv, LdsD* PT, const int ldp) {
+  const int Nb = c.Nb, w = c.w, W1 = c.w + 1, LD = c.LD, bc = c.bc;
+  for (int c0 = 0; c0 < Nb; c0 += NB) {
+    const int jb = Nb - c0 < NB ? Nb - c0 : NB;
+    const int nbr = (Nb - c0 < jb + w) ? Nb - c0 : jb + w;     // band rows touched by this panel
+    const int nbelow = nbr - jb;
+    const int pr = NB + nbelow + bc;
+    long long tp_ = CHD_CLOCK();
+    // ---- load (zero padded; identity in the padding columns); one task = 8 consecutive columns of one row
+    PAR_FOR(idx, ldp * (NB / 8)) {
+      const int a = idx / (NB / 8), j0 = (idx % (NB / 8)) * 8;
+      double v[8];
+      const bool band = a < jb || (a >= NB && a < NB + nbelow), bord = a >= NB + nbelow && a < pr;
+      const int i = c0 + (a < jb ? a : jb + a - NB);
+      const double* src = band ? c.Kfb + (long long)i * W1 + (c0 + j0 - i + w) : c.Kfx + (long long)(bord ? a - NB - nbelow : 0) * LD + c0 + j0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int j = j0 + q, k = c0 + j;
+        const bool ok = j < jb && ((band && k <= i && i - k <= w) || bord);
+        v[q] = ok ? src[q] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) PT[(j0 + q) * ldp + a] = (j0 + q >= jb && a == j0 + q) ? 1.0 : v[q];
+    }
+    CHD_SYNC();
+    c.tacc[7] += CHD_CLOCK() - tp_; tp_ = CHD_CLOCK();
+    // ---- (A) NB x NB diagonal block: unit-lower L in place, pivots to dv
+    diag_block<NB>(c, sign, dv, PT, ldp, c0, jb);
+    CHD_SYNC();
+    c.tacc[8] += CHD_CLOCK() - tp_; tp_ = CHD_CLOCK();
+    // ---- (B) rows below: y_j = A(a,j) - sum_{k<j} y_k L(j,k);  L(a,j) = y_j / d_j   (one thread per row)
+    PAR_FOR(a2, pr - NB) {
+      const int a = NB + a2;
+      double y[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) y[j] = PT[j * ldp + a];
+#pragma unroll
+      for (int k = 0; k < NB - 1; ++k) {       // y_j -= y_k L(j,k) for all j > k: independent FMAs, L(.,k) contiguous in LDS
+#pragma unroll
+        for (int j = k + 1; j < NB; ++j) y[j] -= y[k] * PT[k * ldp + j];
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) PT[j * ldp + a] = y[j] / dv[j];
+    }
+    CHD_SYNC();
+    c.tacc[9] += CHD_CLOCK() - tp_; tp_ = CHD_CLOCK();
+    // ---- write the panel back (8 consecutive columns of one row per task)
+    PAR_FOR(idx, pr * (NB / 8)) {
+      const int a = idx / (NB / 8), j0 = (idx % (NB / 8)) * 8;
+      if (a >= jb && a < NB) continue;
+      const bool band = a < jb || a < NB + nbelow;
+      const int i = c0 + (a < jb ? a : jb + a - NB);
+      double* dst = band ? c.Kfb + (long long)i * W1 + (c0 + j0 - i + w) : c.Kfx + (long long)(a - NB - nbelow) * LD + c0 + j0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int j = j0 + q, k = c0 + j;
+        if (j >= jb) break;
+        if (band) {
+          if (k < i && i - k <= w) dst[q] = PT[j * ldp + a];
+          else if (k == i) dst[q] = dv[j];
+        } else dst[q] = PT[j * ldp + a];
+      }
+    }
+    CHD_SYNC();
+    c.tacc[10] += CHD_CLOCK() - tp_; tp_ = CHD_CLOCK();
+    // ---- trailing update of the window
+    trailing_update<NB>(c, dv, PT, ldp, pr - NB, nbelow, c0 + jb);
+    CHD_SYNC();
+    c.tacc[11] += CHD_CLOCK() - tp_;
+  }
+}
+
+// in-place L D L^T of a dense symmetric n x n matrix (lower triangle, leading dimension ld)
+template <class P>
+CHD_DEV void dense_ldlt(Ctx& c, P Sp, const int ld, const int n, const int* sign) {
+  for (int j = 0; j < n; ++j) {
+    const double d = pivot_fix(c, Sp[(long long)j * ld + j], sign[j]);
+    const double id = 1.0 / d;
+    CHD_SYNC();
+    for (int r = j + 1 + CHD_TID; r < n; r += CHD_NT) Sp[(long long)r * ld + j] *= id;
+    if (CHD_TID == 0) Sp[(long long)j * ld + j] = d;
+    CHD_SYNC();
+    const int nr = n - j - 1;
+    PAR_FOR(idx, nr * nr) {
+      const int r = j + 1 + idx / nr, k = j + 1 + idx % nr;
+      if (k <= r) Sp[(long long)r * ld + k] -= Sp[(long long)r * ld + j] * d * Sp[(long long)k * ld + j];
+    }
+    CHD_SYNC();
+  }
+}
+
+CHD_NOINLINE CHD_DEV void kfactor(Ctx& c, const double* diag, const int* sign) {
   TIC();
   const int Nb = c.Nb, w = c.w, W2 = c.W2, W1 = c.w + 1, LD = c.LD, bc = c.bc;
   if (CHD_TID == 0) c.n_bad_pivots = 0;
-  // copy the lower triangle (+ diagonal shift) into the factor storage
-  for (long long idx = CHD_TID; idx < (long long)Nb * W1; idx += CHD_NT) {
-    const int i = (int)(idx / W1), cc = (int)(idx % W1);
-    double v = c.K0b[(long long)i * W2 + cc];
-    if (cc == w) v += diag[i];
-    c.Kfb[idx] = v;
+  // copy the lower triangle (+ diagonal shift) into the factor storage: one wavefront per row
+  for (int i = CHD_WAVE_ID; i < Nb; i += CHD_NWAVES) {
+    const double* src = c.K0b + (long long)i * W2;
+    double* dst = c.Kfb + (long long)i * W1;
+    for (int cc = CHD_LANE; cc < W1; cc += CHD_WAVE_SZ) dst[cc] = src[cc] + (cc == w ? diag[i] : 0.0);
   }
-  for (long long idx = CHD_TID; idx < (long long)bc * LD; idx += CHD_NT) {
-    const int r = (int)(idx / LD), k = (int)(idx % LD);
-    double v = c.K0x[idx];
-    if (k == Nb + r) v += diag[Nb + r];
-    c.Kfx[idx] = v;
+  for (int r = CHD_WAVE_ID; r < bc; r += CHD_NWAVES) {
+    const double* src = c.K0x + (long long)r * LD;
+    double* dst = c.Kfx + (long long)r * LD;
+    for (int k = CHD_LANE; k < LD; k += CHD_WAVE_SZ) dst[k] = src[k] + (k == Nb + r ? diag[Nb + r] : 0.0);
   }
   CHD_SYNC();
+  c.tacc[6] += CHD_CLOCK() - tic_;
   // panel width from the LDS budget
-  double* dv = c.lds + LDS_RED;          // pivots of the current panel (<= 32)
-  double* PT = dv + 32;                  // panel, column-major: PT[j * ldp + a]
+  LdsD* dv = c.lds + LDS_RED;            // pivots of the current panel (<= 32)
+  LdsD* PT = dv + 32;                    // panel
   const int avail = c.lds_cap - LDS_RED - 32;
   int nb = 32;
-  while (nb > 4 && (long long)(nb + w + bc + 8) * nb > avail) nb >>= 1;
-  const int ldp = nb + w + bc + 8;
-  for (int c0 = 0; c0 < Nb; c0 += nb) {
-    const int jb = Nb - c0 < nb ? Nb - c0 : nb;
-    const int nbr = (Nb - c0 < jb + w) ? Nb - c0 : jb + w;     // band rows in the panel
-    const int pr = nbr + bc;
-    // ---- load panel (zero padded)
-    PAR_FOR(idx, ldp * jb) {
-      const int a = idx / jb, j = idx % jb;
-      double v = 0.0;
-      if (a < nbr) {
-        const int i = c0 + a, k = c0 + j;
-        if (k <= i && i - k <= w) v = c.Kfb[(long long)i * W1 + (k - i + w)];
-      } else if (a < pr) {
-        v = c.Kfx[(long long)(a - nbr) * LD + c0 + j];
-      }
-      PT[j * ldp + a] = v;
-    }
-    CHD_SYNC();
-    // ---- factor the panel column by column
-    for (int j = 0; j < jb; ++j) {
-      const double d = pivot_fix(c, PT[j * ldp + j], sign[c0 + j]);
-      const double id = 1.0 / d;
-      CHD_SYNC();
-      for (int a = j + 1 + CHD_TID; a < pr; a += CHD_NT) PT[j * ldp + a] *= id;
-      if (CHD_TID == 0) dv[j] = d;
-      CHD_SYNC();
-      const int nr = pr - j - 1, nc = jb - j - 1;
-      PAR_FOR(idx, nr * nc) {
-        const int a = j + 1 + idx % nr, jj = j + 1 + idx / nr;
-        if (a >= jj) PT[jj * ldp + a] -= PT[j * ldp + a] * d * PT[j * ldp + jj];
-      }
-      CHD_SYNC();
-    }
-    // ---- write the panel back
-    PAR_FOR(idx, pr * jb) {
-      const int a = idx / jb, j = idx % jb;
-      if (a < nbr) {
-        const int i = c0 + a, k = c0 + j;
-        if (k < i && i - k <= w) c.Kfb[(long long)i * W1 + (k - i + w)] = PT[j * ldp + a];
-        else if (k == i) c.Kfb[(long long)i * W1 + w] = dv[j];
-      } else {
-        c.Kfx[(long long)(a - nbr) * LD + c0 + j] = PT[j * ldp + a];
-      }
-    }
-    // ---- trailing update of the window (4x4 register tiles)
-    const int wr = pr - jb;
-    const int nt = (wr + 3) >> 2;
-    PAR_FOR(tix, nt * nt) {
-      const int tr = tix / nt, tc = tix % nt;
-      if (tc > tr) continue;
-      double acc[4][4];
-      for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-      const double* pa = PT + jb + 4 * tr;
-      const double* pb = PT + jb + 4 * tc;
-      for (int j = 0; j < jb; ++j) {
-        const double dj = dv[j];
-        const double la0 = pa[j * ldp], la1 = pa[j * ldp + 1], la2 = pa[j * ldp + 2], la3 = pa[j * ldp + 3];
-        const double lb0 = pb[j * ldp] * dj, lb1 = pb[j * ldp + 1] * dj, lb2 = pb[j * ldp + 2] * dj, lb3 = pb[j * ldp + 3] * dj;
-        acc[0][0] += la0 * lb0; acc[0][1] += la0 * lb1; acc[0][2] += la0 * lb2; acc[0][3] += la0 * lb3;
-        acc[1][0] += la1 * lb0; acc[1][1] += la1 * lb1; acc[1][2] += la1 * lb2; acc[1][3] += la1 * lb3;
-        acc[2][0] += la2 * lb0; acc[2][1] += la2 * lb1; acc[2][2] += la2 * lb2; acc[2][3] += la2 * lb3;
-        acc[3][0] += la3 * lb0; acc[3][1] += la3 * lb1; acc[3][2] += la3 * lb2; acc[3][3] += la3 * lb3;
-      }
-      for (int a = 0; a < 4; ++a) {
-        const int ar = jb + 4 * tr + a;
-        if (ar >= pr) break;
-        for (int b = 0; b < 4; ++b) {
-          const int ac = jb + 4 * tc + b;
-          if (ac > ar) break;
-          const double v = acc[a][b];
-          if (v == 0.0) continue;
-          if (ar < nbr) {
-            const int i = c0 + ar, k = c0 + ac;
-            c.Kfb[(long long)i * W1 + (k - i + w)] -= v;
-          } else {
-            const int r = ar - nbr;
-            if (ac < nbr) c.Kfx[(long long)r * LD + c0 + ac] -= v;
-            else c.Kfx[(long long)r * LD + Nb + (ac - nbr)] -= v;
-          }
-        }
-      }
-    }
-    CHD_SYNC();
-  }
+  while (nb > 8 && (long long)(nb + w + bc + 18) * nb > avail) nb >>= 1;
+  const int ldp = (nb + w + bc + 17) | 1;  // odd leading dimension (conflict-free column walks), >= 16 rows of zero padding
+  if (nb == 32) kfactor_band<32>(c, sign, dv, PT, ldp);
+  else if (nb == 16) kfactor_band<16>(c, sign, dv, PT, ldp);
+  else kfactor_band<8>(c, sign, dv, PT, ldp);
   // ---- dense L D L^T of the border Schur complement (rows/cols Nb..N-1)
+  const long long td_ = CHD_CLOCK();
   if (bc > 0) {
-    double* SL = c.lds + LDS_RED;
+    LdsD* SL = c.lds + LDS_RED;
     const bool in_lds = (long long)bc * bc <= c.lds_cap - LDS_RED;
-    const int lds_ = in_lds ? bc : LD;
-    double* Sp = in_lds ? SL : c.Kfx + Nb;
     if (in_lds) {
       PAR_FOR(idx, bc * bc) { const int r = idx / bc, k = idx % bc; SL[idx] = k <= r ? c.Kfx[(long long)r * LD + Nb + k] : 0.0; }
       CHD_SYNC();
-    }
-    for (int j = 0; j < bc; ++j) {
-      const double d = pivot_fix(c, Sp[(long long)j * lds_ + j], sign[Nb + j]);
-      const double id = 1.0 / d;
-      CHD_SYNC();
-      for (int r = j + 1 + CHD_TID; r < bc; r += CHD_NT) Sp[(long long)r * lds_ + j] *= id;
-      if (CHD_TID == 0) Sp[(long long)j * lds_ + j] = d;
-      CHD_SYNC();
-      const int nr = bc - j - 1;
-      PAR_FOR(idx, nr * nr) {
-        const int r = j + 1 + idx / nr, k = j + 1 + idx % nr;
-        if (k <= r) Sp[(long long)r * lds_ + k] -= Sp[(long long)r * lds_ + j] * d * Sp[(long long)k * lds_ + j];
-      }
-      CHD_SYNC();
-    }
-    if (in_lds) {
+      dense_ldlt(c, SL, bc, bc, sign + Nb);
       PAR_FOR(idx, bc * bc) { const int r = idx / bc, k = idx % bc; if (k <= r) c.Kfx[(long long)r * LD + Nb + k] = SL[idx]; }
       CHD_SYNC();
+    } else {
+      dense_ldlt(c, c.Kfx + Nb, LD, bc, sign + Nb);
     }
   }
+  c.tacc[12] += CHD_CLOCK() - td_;
   TOC(c, 2);
 }
 
 // in-block triangular solves for the substitution (wave-cooperative on the device)
 #ifdef CHD_HOST_EMU
-CHD_DEV void tri_forward(Ctx& c, double* y, int c0, int jb) {
+template <class YP>
+CHD_DEV void tri_forward(Ctx& c, YP y, int c0, int jb) {
   const int W1 = c.w + 1, w = c.w;
   for (int i = 1; i < jb; ++i) {
     double s = y[c0 + i];
@@ -532,7 +697,8 @@ CHD_DEV void tri_forward(Ctx& c, double* y, int c0, int jb) {
     y[c0 + i] = s;
   }
 }
-CHD_DEV void tri_backward(Ctx& c, double* y, int c0, int jb) {
+template <class YP>
+CHD_DEV void tri_backward(Ctx& c, YP y, int c0, int jb) {
   const int W1 = c.w + 1, w = c.w;
   for (int i = jb - 2; i >= 0; --i) {
     double s = y[c0 + i];
@@ -541,39 +707,51 @@ CHD_DEV void tri_backward(Ctx& c, double* y, int c0, int jb) {
   }
 }
 #else
-CHD_DEV void tri_forward(Ctx& c, double* y, int c0, int jb) {
+// lane i owns row c0+i of the 32x32 diagonal block; its entries are fetched up front (32 independent
+// loads) so that the dependent chain below runs out of registers
+template <class YP>
+CHD_DEV void tri_forward(Ctx& c, YP y, int c0, int jb) {
   if (threadIdx.x < 64) {
     const int W1 = c.w + 1, w = c.w, i = threadIdx.x;
     const bool act = i < jb;
     double yi = act ? y[c0 + i] : 0.0;
     const double* row = c.Kfb + (long long)(c0 + (act ? i : 0)) * W1 + (w - (act ? i : 0));
-    for (int j = 0; j < jb - 1; ++j) {
+    double l[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) l[j] = (act && j < i) ? row[j] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 31; ++j) {
       const double yj = __shfl(yi, j);
-      if (act && i > j) yi -= row[j] * yj;
+      yi -= l[j] * yj;
     }
     if (act) y[c0 + i] = yi;
   }
 }
-CHD_DEV void tri_backward(Ctx& c, double* y, int c0, int jb) {
+template <class YP>
+CHD_DEV void tri_backward(Ctx& c, YP y, int c0, int jb) {
   if (threadIdx.x < 64) {
     const int W1 = c.w + 1, w = c.w, i = threadIdx.x;
     const bool act = i < jb;
     double yi = act ? y[c0 + i] : 0.0;
-    for (int j = jb - 1; j > 0; --j) {
+    double l[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) l[j] = (act && j > i && j < jb) ? c.Kfb[(long long)(c0 + j) * W1 + (i - j + w)] : 0.0;
+#pragma unroll
+    for (int j = 31; j > 0; --j) {
       const double yj = __shfl(yi, j);
-      if (act && i < j) yi -= c.Kfb[(long long)(c0 + j) * W1 + (i - j + w)] * yj;
+      yi -= l[j] * yj;
     }
     if (act) y[c0 + i] = yi;
   }
 }
 #endif
 
-// x = K^{-1} rhs using the factor.  y: work vector of N doubles (LDS when it fits).
-CHD_DEV void ksolve_once(Ctx& c, const double* rhs, double* x) {
-  TIC();
+// x = K^{-1} rhs using the factor.  y: work vector of N doubles, S: the dense border factor (both in LDS when they fit).
+template <class YP, class SP>
+CHD_DEV void ksolve_impl(Ctx& c, const double* rhs, double* x, YP y, SP Sp, const int lds_, const bool stage_s) {
   const int Nb = c.Nb, w = c.w, W1 = c.w + 1, LD = c.LD, bc = c.bc, N = c.N;
-  double* y = (c.lds_cap - LDS_RED >= N) ? c.lds + LDS_RED : VK(c, VK_Y);
   PAR_FOR(i, N) y[i] = rhs[i];
+  if (stage_s) PAR_FOR(idx, bc * bc) { const int r = idx / bc, k = idx % bc; Sp[idx] = c.Kfx[(long long)r * LD + Nb + k]; }
   CHD_SYNC();
   const int nb = 32;
   // forward, band
@@ -601,9 +779,9 @@ CHD_DEV void ksolve_once(Ctx& c, const double* rhs, double* x) {
     if (lane_ == 0) y[Nb + r] -= acc;
   }
   CHD_SYNC();
-  for (int j = 0; j + 1 < bc; ++j) {     // dense unit-lower part
+  for (int j = 0; j + 1 < bc; ++j) {       // dense unit-lower part of the border
     const double yj = y[Nb + j];
-    for (int r = j + 1 + CHD_TID; r < bc; r += CHD_NT) y[Nb + r] -= c.Kfx[(long long)r * LD + Nb + j] * yj;
+    for (int r = j + 1 + CHD_TID; r < bc; r += CHD_NT) y[Nb + r] -= Sp[(long long)r * lds_ + j] * yj;
     CHD_SYNC();
   }
   // diagonal
@@ -612,8 +790,7 @@ CHD_DEV void ksolve_once(Ctx& c, const double* rhs, double* x) {
   // backward, border
   for (int j = bc - 1; j > 0; --j) {
     const double yj = y[Nb + j];
-    const double* row = c.Kfx + (long long)j * LD + Nb;
-    for (int r = CHD_TID; r < j; r += CHD_NT) y[Nb + r] -= row[r] * yj;
+    for (int r = CHD_TID; r < j; r += CHD_NT) y[Nb + r] -= Sp[(long long)j * lds_ + r] * yj;
     CHD_SYNC();
   }
   PAR_FOR(k, Nb) {
@@ -642,6 +819,15 @@ CHD_DEV void ksolve_once(Ctx& c, const double* rhs, double* x) {
   }
   PAR_FOR(i, N) x[i] = y[i];
   CHD_SYNC();
+}
+
+CHD_NOINLINE CHD_DEV void ksolve_once(Ctx& c, const double* rhs, double* x) {
+  TIC();
+  const int N = c.N, bc = c.bc, Npad = (N + 1) & ~1;
+  const int room = c.lds_cap - LDS_RED;
+  if (room >= Npad + bc * bc) ksolve_impl(c, rhs, x, c.lds + LDS_RED, c.lds + LDS_RED + Npad, bc, true);
+  else if (room >= N) ksolve_impl(c, rhs, x, c.lds + LDS_RED, c.Kfx + c.Nb, c.LD, false);
+  else ksolve_impl(c, rhs, x, VK(c, VK_Y), c.Kfx + c.Nb, c.LD, false);
   TOC(c, 3);
 }
 
@@ -770,7 +956,7 @@ CHD_DEV int frame_index(const SeqDesc* q, double t) {       // humanoid_rigid_bo
   return idx;
 }
 
-CHD_DEV void eval_rows(Ctx& c, int mode, double* cout_) {
+CHD_NOINLINE CHD_DEV void eval_rows(Ctx& c, int mode, double* cout_) {
   const SeqDesc* q = c.q; const StageDesc* S = c.S;
   const double* sc = VM(c, VM_SC);
   const bool J = mode == EV_FULL;
@@ -931,7 +1117,7 @@ CHD_DEV void eval_rows(Ctx& c, int mode, double* cout_) {
 // ------------------------------------------------------------------------------------------
 CHD_DEV const double* scache(const SeqDesc* q, int s, int i) { return q->wd + q->o_scache + ((long long)s * (q->F + 2) + i) * SC_STRIDE; }
 
-CHD_DEV void fill_sample_cache(Ctx& c) {
+CHD_NOINLINE CHD_DEV void fill_sample_cache(Ctx& c) {
   const SeqDesc* q = c.q;
   const int F1 = q->F + 1;
   PAR_FOR(idx, 6 * F1) {
@@ -969,7 +1155,7 @@ CHD_DEV int n_smooth(const SeqDesc* q, int s) {
   return n;
 }
 
-CHD_DEV double eval_cost_value(Ctx& c) {
+CHD_NOINLINE CHD_DEV double eval_cost_value(Ctx& c) {
   const SeqDesc* q = c.q; const StageDesc* S = c.S;
   const int F = q->F;
   double part = 0.0;
@@ -1006,7 +1192,7 @@ CHD_DEV void supp_add_sample(Supp& sp, const double* sc_, int which, double sign
     for (int dq = 0; dq < 2; ++dq) { sp.node[sp.n] = poly + side; sp.dq[sp.n] = dq; sp.g[sp.n] = sign * wv[side * 2 + dq]; ++sp.n; }
 }
 
-CHD_DEV void eval_cost_grad_hess(Ctx& c, double* g) {
+CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, double* g) {
   const SeqDesc* q = c.q; const StageDesc* S = c.S;
   const int F = q->F;
   int* first = q->wi + q->o_first;
@@ -1206,7 +1392,7 @@ CHD_DEV void residual(Ctx& c, const double* cc, const double* ss, double* r) {
   CHD_SYNC();
 }
 
-CHD_DEV void solve_stage(Ctx& c, StageResult& res) {
+CHD_NOINLINE CHD_DEV void solve_stage(Ctx& c, StageResult& res) {
   const SeqDesc* q = c.q; const StageDesc* S = c.S;
   const int n = c.n, m = c.m, N = c.N;
   double *x = VN(c, VN_X), *g = VN(c, VN_G), *dualx = VN(c, VN_DUALX), *dx = VN(c, VN_DX), *xt = VN(c, VN_XT), *xs = VN(c, VN_XS);
@@ -1335,7 +1521,7 @@ CHD_DEV void solve_stage(Ctx& c, StageResult& res) {
       PAR_FOR(i, m) diag[pos_row[i]] = -D[i];
       CHD_SYNC();
       kfactor(c, diag, sign); ++n_factor;
-      ksolve(c, rhs, sol, diag, 2);
+      ksolve(c, rhs, sol, diag, 1);
       PAR_FOR(j, n) dx[j] = sol[pos_var[j]];
       PAR_FOR(i, m) dlam[i] = sol[pos_row[i]];
       CHD_SYNC();
@@ -1450,7 +1636,7 @@ CHD_DEV void solve_stage(Ctx& c, StageResult& res) {
 // ------------------------------------------------------------------------------------------
 // SaveSolution (phys_optim.cpp:63-143): resample the splines at the data rate
 // ------------------------------------------------------------------------------------------
-CHD_DEV void sample_solution(const SeqDesc* q, int snap) {
+CHD_NOINLINE CHD_DEV void sample_solution(const SeqDesc* q, int snap) {
   const int cap = q->cap;
   double* od = q->out_d + N_STAGES * RS_STRIDE + (long long)snap * 10 * cap * 3;
   int* oi = q->out_i;
@@ -1508,10 +1694,10 @@ CHD_DEV void init_state(const SeqDesc* q) {
   refresh_durations(q);
 }
 
-CHD_DEV void run_sequence(const SeqDesc* q, double* lds, int lds_cap, double tol, int stage_first, int stage_last) {
+CHD_DEV void run_sequence(const SeqDesc* q, LdsD* lds, int lds_cap, double tol, int stage_first, int stage_last) {
   Ctx c;
   c.lds = lds; c.lds_cap = lds_cap;
-  for (int k = 0; k < 8; ++k) c.tacc[k] = 0;
+  for (int k = 0; k < 16; ++k) c.tacc[k] = 0;
   const long long t_begin = CHD_CLOCK();
   if (stage_first == 0) init_state(q);
   else refresh_durations(q);
@@ -1534,15 +1720,15 @@ CHD_DEV void run_sequence(const SeqDesc* q, double* lds, int lds_cap, double tol
   if (CHD_TID == 0) {      // phase timers (100 MHz wall clock ticks), accumulated over launches
     c.tacc[5] = CHD_CLOCK() - t_begin;
     double* tm = q->out_d + N_STAGES * RS_STRIDE + 3LL * 10 * q->cap * 3;
-    for (int k = 0; k < 8; ++k) tm[k] += (double)c.tacc[k];
+    for (int k = 0; k < 16; ++k) tm[k] += (double)c.tacc[k];
   }
 }
 
 // Debug entry: evaluate stage `stage` at the state currently in the workspace (or at x if given in VN_XT).
-CHD_DEV void debug_eval(const SeqDesc* q, int stage, int use_x, double* lds, int lds_cap, double* f_out) {
+CHD_DEV void debug_eval(const SeqDesc* q, int stage, int use_x, LdsD* lds, int lds_cap, double* f_out) {
   Ctx c;
   c.lds = lds; c.lds_cap = lds_cap;
-  for (int k = 0; k < 8; ++k) c.tacc[k] = 0;
+  for (int k = 0; k < 16; ++k) c.tacc[k] = 0;
   init_state(q);
   bind_stage(c, q, stage);
   c.tol = 1e-3;

@@ -25,12 +25,12 @@ __global__ __launch_bounds__(CHD_MAX_THREADS) void chd_solve_kernel(const SeqDes
                                                                     int stage_first, int stage_last) {
   extern __shared__ double lds[];
   const SeqDesc* q = descs + (index ? index[blockIdx.x] : (int)blockIdx.x);
-  run_sequence(q, lds, lds_doubles, tol, stage_first, stage_last);
+  run_sequence(q, (LdsD*)lds, lds_doubles, tol, stage_first, stage_last);
 }
 
 __global__ __launch_bounds__(CHD_MAX_THREADS) void chd_debug_eval_kernel(const SeqDesc* descs, int seq, int stage, int use_x, int lds_doubles, double* f_out) {
   extern __shared__ double lds[];
-  debug_eval(descs + seq, stage, use_x, lds, lds_doubles, f_out);
+  debug_eval(descs + seq, stage, use_x, (LdsD*)lds, lds_doubles, f_out);
 }
 
 struct chd_handle {
@@ -295,7 +295,7 @@ int chd_batch_solve(chd_handle* h, chd_batch* b) {
       b->stats.alg_bytes += it * b->models[i].alg_bytes_iter[stg];
     }
     const double* tm = s + N_STAGES * RS_STRIDE + 3LL * 10 * b->models[i].d.cap * 3;     // 100 MHz ticks
-    for (int k = 0; k < 8; ++k) b->stats.phase_ms[k] += tm[k] * 1e-5;
+    for (int k = 0; k < 16; ++k) b->stats.phase_ms[k] += tm[k] * 1e-5;
     if (tm[5] * 1e-5 > b->stats.max_seq_ms) b->stats.max_seq_ms = tm[5] * 1e-5;
   }
   return 0;
