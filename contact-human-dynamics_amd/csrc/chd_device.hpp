@@ -54,7 +54,10 @@ struct StageDesc {
 };
 
 // cached spline sample used by the cost terms (one per cost spline per data frame)
-enum { SC_WP = 0, SC_WV = 4, SC_P = 8, SC_V = 11, SC_DXDT = 14, SC_POLY = 17, SC_PHASE = 18, SC_LAST = 19, SC_STRIDE = 20 };
+enum { SC_WP = 0, SC_WV = 4, SC_P = 8, SC_V = 11, SC_DXDT = 14, SC_POLY = 17, SC_PHASE = 18, SC_LAST = 19,
+       SC_QEE = 20, SC_QEC = 23, SC_QCC = 26, SC_STRIDE = 30 };
+// second-order duration tables (stage 3): per end-effector one slot per row sample; 4 doubles = (cur phase, S_ee, S_ec, S_cc)
+enum { D2_STRIDE = 4, X2_STRIDE = 6 };
 
 struct SeqDesc {
   const double* cd;   // constant doubles
@@ -82,7 +85,7 @@ struct SeqDesc {
   // wd offsets — state
   int o_node, o_poly_dur, o_pend, o_phase_dur, o_phend, o_ttot;
   // wd offsets — solver vectors (n-, m- and N-sized), see chd_kernels.hpp
-  int o_vec_n, o_vec_m, o_vec_N, o_scache;
+  int o_vec_n, o_vec_m, o_vec_N, o_scache, o_d2tab, o_x2tab, d2_slots;
   int max_n, max_m, max_N;
   // wd offsets — KKT storage
   int o_K0b, o_K0x, o_Kfb, o_Kfx;      // full band, border rows (unfactored); lower band, border rows (factor)

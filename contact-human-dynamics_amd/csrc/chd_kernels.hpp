@@ -232,6 +232,55 @@ CHD_DEV void dur_jac(const SeqDesc* q, int s, double t, const PE& e, DurJac& dj)
   }
 }
 
+// First AND second derivatives of p(t) with respect to the phase durations of a phase-based spline.
+// With tau = local time in the active polynomial and Tp its duration, both are affine in the duration
+// variables T_k:  d tau/dT_k = u_k, d Tp/dT_k = v_k, where (u, v) only depends on whether k is an
+// earlier phase ("e") or the current one ("c"):
+//     current phase not the last:  e: (-1, 0)            c: (-k_in/n, 1/n)
+//     current phase is the last :  e: (-1 + k_in/n, -1/n)   (the last duration is T - sum of the variables)
+//   dp/dT_k       = G_x     = h_tau u_x + h_T v_x
+//   d2p/dT_k dT_l = Q_xy    = h_tautau u_x u_y + h_tauT (u_x v_y + v_x u_y) + h_TT v_x v_y
+// (the reference only needs first derivatives because IPOPT runs with an L-BFGS Hessian, phys_optim.cpp:572;
+//  this solver uses the exact duration block of the Lagrangian Hessian instead — DESIGN.md)
+struct DurJac2 { int cur, last, nvar; double Ge[3], Gc[3], Qee[3], Qec[3], Qcc[3]; };
+CHD_DEV void dur_jac2(const SeqDesc* q, int s, double t, const PE& e, DurJac2& dj) {
+  const SplineDesc& sp = q->sp[s];
+  const int ee = sp.ee;
+  const int* pi = q->ci + q->o_pinfo + (sp.poly_off + e.poly) * 4;
+  const double* nv = q->wd + q->o_node + sp.node_off + e.poly * 6;
+  const double kin = pi[1], inv = 1.0 / pi[2];
+  dj.cur = phase_lookup(q, ee, t);
+  dj.last = dj.cur == q->n_phase[ee] - 1;
+  dj.nvar = q->n_phase[ee] - 1;
+  const double ue = dj.last ? -1.0 + kin * inv : -1.0, ve = dj.last ? -inv : 0.0;
+  const double uc = -kin * inv, vc = inv;
+  const double tau = e.tl, tau2 = tau * tau, tau3 = tau2 * tau, T = e.T, iT = 1.0 / T, iT2 = iT * iT, iT3 = iT2 * iT, iT4 = iT2 * iT2, iT5 = iT4 * iT;
+  for (int k = 0; k < 3; ++k) {
+    const double dl = nv[k] - nv[6 + k], s2 = 2 * nv[3 + k] + nv[9 + k], s1 = nv[3 + k] + nv[9 + k];
+    const double cT = 6 * dl * iT3 + s2 * iT2, dT = -6 * dl * iT4 - 2 * s1 * iT3;
+    const double cTT = -18 * dl * iT4 - 2 * s2 * iT3, dTT = 24 * dl * iT5 + 6 * s1 * iT4;
+    const double hT = cT * tau2 + dT * tau3, htT = 2 * cT * tau + 3 * dT * tau2, hTT = cTT * tau2 + dTT * tau3;
+    const double ht = e.v[k], htt = e.a[k];
+    dj.Ge[k] = ht * ue + hT * ve;
+    dj.Gc[k] = dj.last ? 0.0 : ht * uc + hT * vc;
+    dj.Qee[k] = htt * ue * ue + 2 * htT * ue * ve + hTT * ve * ve;
+    dj.Qec[k] = dj.last ? 0.0 : htt * ue * uc + htT * (ue * vc + ve * uc) + hTT * ve * vc;
+    dj.Qcc[k] = dj.last ? 0.0 : htt * uc * uc + 2 * htT * uc * vc + hTT * vc * vc;
+  }
+}
+CHD_DEV double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+CHD_DEV void d2_store(const SeqDesc* q, int ee, int slot, int cur, double see, double sec, double scc) {
+  double* t = q->wd + q->o_d2tab + ((long long)ee * q->d2_slots + slot) * D2_STRIDE;
+  t[0] = cur; t[1] = see; t[2] = sec; t[3] = scc;
+}
+// class of the pair (k, l), l <= k, for a sample whose current phase is cur: 1 = S_ee, 2 = S_ec, 3 = S_cc, 0 = none
+CHD_DEV double d2_select(const double* t, int k, int l) {
+  const int cur = (int)t[0];
+  if (k < cur) return t[1];
+  if (k == cur) return l < cur ? t[2] : t[3];
+  return 0.0;
+}
+
 // ------------------------------------------------------------------------------------------
 // Euler angles (TOWR EulerConverter, ZYX), hand-derived derivatives
 // ------------------------------------------------------------------------------------------
@@ -956,10 +1005,12 @@ CHD_DEV int frame_index(const SeqDesc* q, double t) {       // humanoid_rigid_bo
   return idx;
 }
 
-CHD_NOINLINE CHD_DEV void eval_rows(Ctx& c, int mode, double* cout_) {
+CHD_NOINLINE CHD_DEV void eval_rows(Ctx& c, int mode, double* cout_, const double* lam) {
   const SeqDesc* q = c.q; const StageDesc* S = c.S;
   const double* sc = VM(c, VM_SC);
   const bool J = mode == EV_FULL;
+  const bool D2 = J && S->opt_dur && lam != nullptr;      // exact duration block of the Lagrangian Hessian
+  const int slot_height = q->n_tdyn, slot_rom = 2 * q->n_tdyn, slot_heel = 2 * q->n_tdyn + q->n_trom;
   PAR_FOR(ti, S->n_tasks) {
     const int* tk = q->ci + S->o_task + 4 * ti;
     const int type = tk[0], A = tk[1], B = tk[2], row0 = tk[3];
@@ -1009,6 +1060,12 @@ CHD_NOINLINE CHD_DEV void eval_rows(Ctx& c, int mode, double* cout_) {
           row_nodes(r, 1, pa, 0, ca, 7);
           row_nodes(r, 2 + e, pm, 0, dvec, 7);
           row_durs(r, 2 + e, t, pm, dvec);
+          if (D2) {      // d2/dT2 of 1/2 |d|^2 = G_k . G_l + d . Q_kl
+            DurJac2 dj; dur_jac2(q, 2 + e, t, pm, dj);
+            const double ls = lam[row0] * sc[row0];
+            d2_store(q, e, slot_rom + B, dj.cur, ls * (dot3(dj.Ge, dj.Ge) + dot3(dvec, dj.Qee)), ls * (dot3(dj.Ge, dj.Gc) + dot3(dvec, dj.Qec)),
+                     ls * (dot3(dj.Gc, dj.Gc) + dot3(dvec, dj.Qcc)));
+          }
         }
       } break;
       case T_HEELDIST: {     // ee_dist_constraint.cpp:29-94: 1/2 |p_toe - p_heel|^2
@@ -1021,6 +1078,17 @@ CHD_NOINLINE CHD_DEV void eval_rows(Ctx& c, int mode, double* cout_) {
           RowW r{&c, c.pos_row[row0], sc[row0], true};
           row_nodes(r, 2 + A, p1, 0, dvec, 7); row_nodes(r, 4 + A, p2, 0, md, 7);
           row_durs(r, 2 + A, t, p1, dvec); row_durs(r, 4 + A, t, p2, md);
+          if (D2) {      // toe block, heel block and the toe x heel cross block
+            DurJac2 da, db; dur_jac2(q, 2 + A, t, p1, da); dur_jac2(q, 4 + A, t, p2, db);
+            const double ls = lam[row0] * sc[row0];
+            d2_store(q, A, slot_heel + B, da.cur, ls * (dot3(da.Ge, da.Ge) + dot3(dvec, da.Qee)), ls * (dot3(da.Ge, da.Gc) + dot3(dvec, da.Qec)),
+                     ls * (dot3(da.Gc, da.Gc) + dot3(dvec, da.Qcc)));
+            d2_store(q, A + 2, slot_heel + B, db.cur, ls * (dot3(db.Ge, db.Ge) - dot3(dvec, db.Qee)), ls * (dot3(db.Ge, db.Gc) - dot3(dvec, db.Qec)),
+                     ls * (dot3(db.Gc, db.Gc) - dot3(dvec, db.Qcc)));
+            double* x2 = q->wd + q->o_x2tab + ((long long)A * q->n_trom + B) * X2_STRIDE;
+            x2[0] = da.cur; x2[1] = db.cur;
+            x2[2] = -ls * dot3(da.Ge, db.Ge); x2[3] = -ls * dot3(da.Ge, db.Gc); x2[4] = -ls * dot3(da.Gc, db.Ge); x2[5] = -ls * dot3(da.Gc, db.Gc);
+          }
         }
       } break;
       case T_DYN: {          // humanoid_dynamic_constraint.cpp:63-143, humanoid_rigid_body_dynamics.cpp:89-206
@@ -1069,6 +1137,29 @@ CHD_NOINLINE CHD_DEV void eval_rows(Ctx& c, int mode, double* cout_) {
               row_durs(ra, 2 + e, t, pm[e], xf);
             }
           }
+          if (D2) {
+            // rows: ang_i - sum_e (F_e x r_e)_i with r_e = c - p_e, and m a_i - sum_e F_e,i.  With La / Ll the multipliers of the
+            // angular / linear rows:  d2L = -La . [Q^F x r - (G^F_k x G^p_l + G^F_l x G^p_k) - F x Q^p] - Ll . Q^F
+            double La[3], Ll[3];
+            for (int k = 0; k < 3; ++k) { La[k] = lam[row0 + k] * sc[row0 + k]; Ll[k] = lam[row0 + 3 + k] * sc[row0 + 3 + k]; }
+            for (int e = 0; e < 4; ++e) {
+              DurJac2 dF, dP; dur_jac2(q, 6 + e, t, pf[e], dF); dur_jac2(q, 2 + e, t, pm[e], dP);
+              const double rr[3] = {pl.p[0] - pm[e].p[0], pl.p[1] - pm[e].p[1], pl.p[2] - pm[e].p[2]};
+              double S3[3];
+              for (int cls = 0; cls < 3; ++cls) {
+                const double* QF = cls == 0 ? dF.Qee : cls == 1 ? dF.Qec : dF.Qcc;
+                const double* QP = cls == 0 ? dP.Qee : cls == 1 ? dP.Qec : dP.Qcc;
+                const double* GFx = cls == 2 ? dF.Gc : dF.Ge; const double* GFy = cls == 0 ? dF.Ge : dF.Gc;
+                const double* GPx = cls == 2 ? dP.Gc : dP.Ge; const double* GPy = cls == 0 ? dP.Ge : dP.Gc;
+                double a1[3], a2[3], a3[3], a4[3];
+                cross3(QF, rr, a1); cross3(GFx, GPy, a2); cross3(GFy, GPx, a3); cross3(pf[e].p, QP, a4);
+                double v = 0;
+                for (int k = 0; k < 3; ++k) v += -La[k] * (a1[k] - a2[k] - a3[k] - a4[k]) - Ll[k] * QF[k];
+                S3[cls] = v;
+              }
+              d2_store(q, e, B, dF.cur, S3[0], S3[1], S3[2]);
+            }
+          }
         }
       } break;
       case T_FORCE: {        // TOWR ForceConstraint: normal force range + friction pyramid
@@ -1095,6 +1186,11 @@ CHD_NOINLINE CHD_DEV void eval_rows(Ctx& c, int mode, double* cout_) {
           const int mask = (q->normal[0] != 0.0 ? 1 : 0) | (q->normal[1] != 0.0 ? 2 : 0) | (q->normal[2] != 0.0 ? 4 : 0);
           row_nodes(r, 2 + A, pm, 0, q->normal, mask);
           row_durs(r, 2 + A, t, pm, q->normal);
+          if (D2) {
+            DurJac2 dj; dur_jac2(q, 2 + A, t, pm, dj);
+            const double ls = lam[row0] * sc[row0];
+            d2_store(q, A, slot_height + B, dj.cur, ls * dot3(q->normal, dj.Qee), ls * dot3(q->normal, dj.Qec), ls * dot3(q->normal, dj.Qcc));
+          }
         }
       } break;
       case T_TOTALTIME: {    // total_duration_constraint.cpp:60-82
@@ -1135,6 +1231,9 @@ CHD_NOINLINE CHD_DEV void fill_sample_cache(Ctx& c) {
       // store own / early in a form usable per k: own[] (k == cur, not last) and early[] (k < cur)
       for (int k = 0; k < 3; ++k) sc_[SC_DXDT + k] = dj.last ? -(dj.early[k] + e.v[k]) : dj.own[k];   // = dx_dT
       sc_[SC_PHASE] = dj.cur; sc_[SC_LAST] = dj.last;
+      DurJac2 d2;
+      dur_jac2(q, s, t, e, d2);
+      for (int k = 0; k < 3; ++k) { sc_[SC_QEE + k] = d2.Qee[k]; sc_[SC_QEC + k] = d2.Qec[k]; sc_[SC_QCC + k] = d2.Qcc[k]; }
     }
   }
   CHD_SYNC();
@@ -1192,7 +1291,7 @@ CHD_DEV void supp_add_sample(Supp& sp, const double* sc_, int which, double sign
     for (int dq = 0; dq < 2; ++dq) { sp.node[sp.n] = poly + side; sp.dq[sp.n] = dq; sp.g[sp.n] = sign * wv[side * 2 + dq]; ++sp.n; }
 }
 
-CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, double* g) {
+CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, double* g, const double* lam) {
   const SeqDesc* q = c.q; const StageDesc* S = c.S;
   const int F = q->F;
   int* first = q->wi + q->o_first;
@@ -1262,7 +1361,48 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, double* g) {
       }
     }
   }
-  // ---- duration variables (stage 3 only): one thread per KKT entry (T_k, target)
+  // ---- duration variables (stage 3 only)
+  if (S->opt_dur && lam) {
+    // residual-weighted curvature of the cost terms, one table slot per data sample:
+    //   data  1/2 w |data_i - p_i|^2            -> -w r_i . Q(i)
+    //   smooth 1/2 w |p_{i+1} - p_i|^2          -> +w r_i . Q(i+1)  and  -w r_i . Q(i)
+    const int slot_cost = 2 * q->n_tdyn + 2 * q->n_trom;
+    PAR_FOR(idx, 4 * F) {
+      const int e = idx / F, i = idx % F, s = 2 + e;
+      const double* a = scache(q, s, i);
+      const double* dat = q->cd + q->o_data[s] + i * 3;
+      const int nsm = n_smooth(q, s);
+      double cf[3];
+      for (int k = 0; k < 3; ++k) {
+        double v = -S->w_data[2] * (dat[k] - a[SC_P + k]);
+        if (S->w_vel[2] >= 0) {
+          if (i < nsm) v -= S->w_vel[2] * (scache(q, s, i + 1)[SC_P + k] - a[SC_P + k]);
+          if (i > 0 && i - 1 < nsm) v += S->w_vel[2] * (a[SC_P + k] - scache(q, s, i - 1)[SC_P + k]);
+        }
+        cf[k] = c.sf * v;
+      }
+      d2_store(q, e, slot_cost + i, (int)a[SC_PHASE], dot3(cf, a + SC_QEE), dot3(cf, a + SC_QEC), dot3(cf, a + SC_QCC));
+    }
+    CHD_SYNC();
+    // toe x heel cross blocks of the heel-distance rows: one thread per (pair, k, l)
+    if (S->families & FAM_HEELDIST) {
+      const int na0 = q->n_phase[0] - 1, nb0 = q->n_phase[2] - 1, na1 = q->n_phase[1] - 1, nb1 = q->n_phase[3] - 1;
+      PAR_FOR(idx0, na0 * nb0 + na1 * nb1) {
+        const int pr_ = idx0 < na0 * nb0 ? 0 : 1;
+        const int idx = pr_ ? idx0 - na0 * nb0 : idx0;
+        const int nb_ = pr_ ? nb1 : nb0;
+        const int k = idx / nb_, l = idx % nb_;
+        double acc = 0;
+        for (int smp = 0; smp < q->n_trom; ++smp) {
+          const double* x2 = q->wd + q->o_x2tab + ((long long)pr_ * q->n_trom + smp) * X2_STRIDE;
+          const int ca = (int)x2[0], cb = (int)x2[1];
+          if (k > ca || l > cb) continue;
+          acc += x2[2 + (k == ca ? 2 : 0) + (l == cb ? 1 : 0)];
+        }
+        if (acc != 0.0) kadd(c, c.pos_var[S->dur_off[pr_] + k], c.pos_var[S->dur_off[pr_ + 2] + l], acc);
+      }
+    }
+  }
   if (S->opt_dur) {
     int tot = 0;
     for (int e = 0; e < 4; ++e) tot += (q->n_phase[e] - 1) * (q->sp[2 + e].n_var + q->n_phase[e] - 1);
@@ -1297,6 +1437,12 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, double* g) {
               if (k2 == k) gacc += wvel * (b[SC_P + dm] - a[SC_P + dm]) * gk;
             }
           }
+        }
+        if (lam) {     // exact second-order terms collected by the row tasks and the cost pass above
+          const double* tb = q->wd + q->o_d2tab + (long long)e * q->d2_slots * D2_STRIDE;
+          double h2 = 0;
+          for (int sl = 0; sl < q->d2_slots; ++sl) h2 += d2_select(tb + sl * D2_STRIDE, k, k2);
+          hacc += h2 / c.sf;
         }
         if (k2 == k && S->w_dur >= 0) {     // DurationCost (duration_cost.cpp:25-50): 1/2 w (T0 - T)^2
           hacc += S->w_dur;
@@ -1340,15 +1486,22 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, double* g) {
 
 // Full evaluation at x.  Returns the (scaled) objective; fills c_out (scaled rows), and in
 // EV_FULL mode the scaled gradient g and the unfactored KKT matrix K0 = [sf H, (sc J)^T; sc J, 0].
-CHD_DEV double eval_nlp(Ctx& c, const double* x, int mode, double* c_out, double* g) {
+CHD_DEV double eval_nlp(Ctx& c, const double* x, int mode, double* c_out, double* g, const double* lam = nullptr) {
   TIC();
   state_from_x(c, x);
-  if (mode == EV_FULL) kzero(c);
+  if (mode == EV_FULL) {
+    kzero(c);
+    if (c.S->opt_dur && lam) {
+      PAR_FOR(i, 4 * c.q->d2_slots * D2_STRIDE) c.q->wd[c.q->o_d2tab + i] = 0.0;
+      PAR_FOR(i, 2 * c.q->n_trom * X2_STRIDE) c.q->wd[c.q->o_x2tab + i] = 0.0;
+    }
+  }
   fill_sample_cache(c);      // ends with a sync (also orders kzero before the kadd's below)
-  eval_rows(c, mode, c_out);
+  eval_rows(c, mode, c_out, lam);
   const double f = c.sf * eval_cost_value(c);
   if (mode == EV_FULL) {
-    eval_cost_grad_hess(c, g);
+    CHD_SYNC();
+    eval_cost_grad_hess(c, g, lam);
     c.err = block_max(c, (double)c.err) > 0.5 ? 1 : 0;     // a band overflow seen by any thread
   }
   CHD_SYNC();
@@ -1445,7 +1598,7 @@ CHD_NOINLINE CHD_DEV void solve_stage(Ctx& c, StageResult& res) {
   }
   CHD_SYNC();
   c.sf = sf;
-  double f = eval_nlp(c, x, EV_FULL, cc, g);
+  double f = eval_nlp(c, x, EV_FULL, cc, g);     // multipliers are initialised below: the first model has no curvature terms
 
   // ---- slack / multiplier initialisation
   double mu = (S->stage == 0) ? CHD_MU_INIT_COLD : CHD_MU_INIT_WARM;
@@ -1623,7 +1776,7 @@ CHD_NOINLINE CHD_DEV void solve_stage(Ctx& c, StageResult& res) {
       zL[i] = zl; zU[i] = zu;
     }
     CHD_SYNC();
-    f = eval_nlp(c, x, EV_FULL, cc, g);
+    f = eval_nlp(c, x, EV_FULL, cc, g, lam);
     if (c.err) { status = -3; ++it; break; }
   }
   state_from_x(c, x);
@@ -1725,7 +1878,7 @@ CHD_DEV void run_sequence(const SeqDesc* q, LdsD* lds, int lds_cap, double tol, 
 }
 
 // Debug entry: evaluate stage `stage` at the state currently in the workspace (or at x if given in VN_XT).
-CHD_DEV void debug_eval(const SeqDesc* q, int stage, int use_x, LdsD* lds, int lds_cap, double* f_out) {
+CHD_DEV void debug_eval(const SeqDesc* q, int stage, int use_x, LdsD* lds, int lds_cap, double* f_out, int use_lam = 0) {
   Ctx c;
   c.lds = lds; c.lds_cap = lds_cap;
   for (int k = 0; k < 16; ++k) c.tacc[k] = 0;
@@ -1737,7 +1890,7 @@ CHD_DEV void debug_eval(const SeqDesc* q, int stage, int use_x, LdsD* lds, int l
   x_from_state(c, x);
   PAR_FOR(i, c.m) VM(c, VM_SC)[i] = 1.0;
   CHD_SYNC();
-  const double f = eval_nlp(c, x, EV_FULL, VM(c, VM_C), VN(c, VN_G));
+  const double f = eval_nlp(c, x, EV_FULL, VM(c, VM_C), VN(c, VN_G), use_lam ? VM(c, VM_LAM) : nullptr);
   if (CHD_TID == 0) { f_out[0] = f; f_out[1] = c.err; }
   CHD_SYNC();
 }

@@ -622,6 +622,9 @@ class SeqModel {
     d.o_vec_m = take((long long)NV_M * d.max_m);
     d.o_vec_N = take((long long)NV_NN * d.max_N);
     d.o_scache = take(6LL * (d.F + 2) * SC_STRIDE);
+    d.d2_slots = 2 * d.n_tdyn + 2 * d.n_trom + d.F + 2;      // DYN, HEIGHT, ROM, HEELDIST, cost samples
+    d.o_d2tab = take(4LL * d.d2_slots * D2_STRIDE);
+    d.o_x2tab = take(2LL * d.n_trom * X2_STRIDE);
     const long long Nb_cap = N_cap, W2 = 2LL * w_cap + 1, LD = N_cap;
     d.sz_K0b = Nb_cap * W2; d.sz_K0x = (long long)bc_cap * LD;
     d.sz_Kfb = Nb_cap * (w_cap + 1); d.sz_Kfx = (long long)bc_cap * LD;

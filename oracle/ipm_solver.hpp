@@ -359,7 +359,7 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
   };
 
   std::vector<double> Sigma(m), rs(m), D(m), rhs(N), sol(N), dx(n), dlam(m), ds(m), dzL(m), dzU(m);
-  std::vector<double> xt(n), st(m), ct(m), rt(m), Hdx(n), rhs2(N), sol2(N), xs(n), ss2(m);
+  std::vector<double> xt(n), st(m), ct(m), rt(m), Hdx(n), rhs2(N), sol2(N), xs(n), ss2(m), lraw(m);
   int status = -1, it = 0;
   double last_alpha = 0; int last_nls = 0, last_att = 0; bool last_soc = false;
   for (it = 0; it < opt.max_iter; ++it) {
@@ -488,9 +488,9 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
       if (hasL[i]) { double sl = s[i] - l[i]; zL[i] = std::min(std::max(zL[i], mu / (ks * sl)), ks * mu / sl); }
       if (hasU[i]) { double su = u[i] - s[i]; zU[i] = std::min(std::max(zU[i], mu / (ks * su)), ks * mu / su); }
     }
-    P.eval(x.data(), &fraw, graw.data(), craw.data(), J.data(), H.data());
-    { static const char* e_ = std::getenv("ORC_FD_DUR"); int md = e_ ? std::atoi(e_) : 0;
-      if (md) { std::vector<double> lr(m); for (int i = 0; i < m; ++i) lr[i] = lam[i] * sc[i] / sf; fd_duration_hessian(P, x, lr, graw, J, H, md); } }
+    // multipliers of the unscaled rows for the exact duration block of the Lagrangian Hessian (nlp_model.hpp)
+    for (int i = 0; i < m; ++i) lraw[i] = lam[i] * sc[i] / sf;
+    P.eval(x.data(), &fraw, graw.data(), craw.data(), J.data(), H.data(), lraw.data());
     apply_scaling(true);
     f = sf * fraw;
   }

@@ -653,6 +653,47 @@ class Problem {
       }
   }
 
+  // ------------------------------------------------- second-order duration terms
+  // Not in the reference (IPOPT runs with an L-BFGS Hessian there, phys_optim.cpp:572): the solver restated
+  // in ipm_solver.hpp uses the exact duration-duration block of the Lagrangian Hessian.  For a sample at time t
+  // in polynomial e.poly (local time tau, duration Tp) both tau and Tp are affine in the duration variables:
+  //   d tau / dT_k = u_k ,  d Tp / dT_k = v_k   (see dur_uv), hence
+  //   dp/dT_k = h_tau u_k + h_T v_k ,   d2p/dT_k dT_l = h_tautau u_k u_l + h_tauT (u_k v_l + v_k u_l) + h_TT v_k v_l.
+  void dur_uv(const Spline& s, double t, const PointEval& e, int k, double& u, double& v) const {
+    const int ee = s.ee;
+    const int cur = segment_id(t, phase_dur[ee]);
+    const bool last = cur == (int)phase_dur[ee].size() - 1;
+    const PolyInfo& pi = s.pinfo[e.poly];
+    const double n = pi.n_in_phase, kin = pi.k_in_phase;
+    u = 0; v = 0;
+    if (last) { u = -1.0 + kin / n; v = -1.0 / n; return; }      // every variable precedes the last phase; T_last = T - sum
+    if (k < cur) { u = -1.0; v = 0.0; }
+    else if (k == cur) { u = -kin / n; v = 1.0 / n; }
+  }
+  void hermite_T_derivs(const Spline& s, const PointEval& e, double hT[3], double htT[3], double hTT[3]) const {
+    const int id = e.poly;
+    const double tau = e.tl, T = e.T;
+    for (int d = 0; d < 3; ++d) {
+      const double p0 = s.nv(id, 0, d), v0 = s.nv(id, 1, d), p1 = s.nv(id + 1, 0, d), v1 = s.nv(id + 1, 1, d);
+      const double dl = p0 - p1, s2 = 2 * v0 + v1, s1 = v0 + v1;
+      const double cT = 6 * dl / std::pow(T, 3) + s2 / (T * T), dT = -6 * dl / std::pow(T, 4) - 2 * s1 / std::pow(T, 3);
+      const double cTT = -18 * dl / std::pow(T, 4) - 2 * s2 / std::pow(T, 3), dTT = 24 * dl / std::pow(T, 5) + 6 * s1 / std::pow(T, 4);
+      hT[d] = cT * tau * tau + dT * tau * tau * tau;
+      htT[d] = 2 * cT * tau + 3 * dT * tau * tau;
+      hTT[d] = cTT * tau * tau + dTT * tau * tau * tau;
+    }
+  }
+  void d1pos(const Spline& s, double t, const PointEval& e, int k, double out[3]) const {
+    double u, v, hT[3], htT[3], hTT[3];
+    dur_uv(s, t, e, k, u, v); hermite_T_derivs(s, e, hT, htT, hTT);
+    for (int d = 0; d < 3; ++d) out[d] = e.v[d] * u + hT[d] * v;
+  }
+  void d2pos(const Spline& s, double t, const PointEval& e, int k, int l, double out[3]) const {
+    double uk, vk, ul, vl, hT[3], htT[3], hTT[3];
+    dur_uv(s, t, e, k, uk, vk); dur_uv(s, t, e, l, ul, vl); hermite_T_derivs(s, e, hT, htT, hTT);
+    for (int d = 0; d < 3; ++d) out[d] = e.a[d] * uk * ul + htT[d] * (uk * vl + vk * ul) + hTT[d] * vk * vl;
+  }
+
   // [UPSTREAM] EulerConverter::GetRotationMatrixBaseToWorld (ZYX, kindr cheat-sheet)
   template <class S> static void rot_zyx(const S e[3], S R[3][3]) {
     S x = e[0], y = e[1], z = e[2];
@@ -706,12 +747,21 @@ class Problem {
   // ------------------------------------------------------------------ eval
   // J: dense m x n row-major (may be null).  grad: n (may be null).
   // H: dense n x n Gauss-Newton Hessian of the (sum-of-squares) objective (may be null).
-  void eval(const double* x, double* f_out, double* grad, double* c, double* J, double* H = nullptr) {
+  // lam (optional, m entries): multipliers of the unscaled rows; when given together with H and the durations are
+  // variables, the exact duration-duration block of sum_i lam_i grad^2 c_i + (grad^2 f - Gauss-Newton part) is added to H.
+  void eval(const double* x, double* f_out, double* grad, double* c, double* J, double* H = nullptr, const double* lam = nullptr) {
     set_x(x);
     if (J) std::fill(J, J + (size_t)m * n, 0.0);
     if (grad) std::fill(grad, grad + n, 0.0);
     if (H) std::fill(H, H + (size_t)n * n, 0.0);
     std::vector<double> djac, djac2;
+    const bool D2 = H && lam && sd.opt_durations;
+    auto hdd = [&](int ea, int k, int eb, int l, double v) {      // symmetric entry of the duration block
+      const int a = dur_off[ea] + k, b = dur_off[eb] + l;
+      H[(size_t)a * n + b] += v;
+      if (a != b) H[(size_t)b * n + a] += v;
+    };
+    auto nvar_of = [&](int e) { return (int)phase_dur[e].size() - 1; };
 
     // J[row, vars of spline s touched at e] += coef[dim] * w[which][j]
     auto add_nodes = [&](int row, const Spline& s, const PointEval& e, int which, const double coef[3]) {
@@ -801,6 +851,13 @@ class Problem {
             add_nodes(row, sp[1], pa, kPos, ca);
             add_nodes(row, sm, pe, kPos, d);
             add_durs(row, sm, t, pe, d);
+            if (D2)
+              for (int k2 = 0; k2 < nvar_of(e); ++k2)
+                for (int l2 = 0; l2 <= k2; ++l2) {
+                  double gk[3], gl[3], q2[3];
+                  d1pos(sm, t, pe, k2, gk); d1pos(sm, t, pe, l2, gl); d2pos(sm, t, pe, k2, l2, q2);
+                  hdd(e, k2, e, l2, lam[row] * (gk[0] * gl[0] + gk[1] * gl[1] + gk[2] * gl[2] + d[0] * q2[0] + d[1] * q2[1] + d[2] * q2[2]));
+                }
           }
         } break;
         case FAM_HEELDIST: {  // ee_dist_constraint.cpp:29-94 ; pairs nlp_formulation.cpp:249-257
@@ -817,6 +874,27 @@ class Problem {
             add_nodes(row, sp[2 + e2], pe2, kPos, md);
             add_durs(row, sp[2 + e1], t, pe, d);
             add_durs(row, sp[2 + e2], t, pe2, md);
+            if (D2) {
+              auto dot = [](const double* a, const double* b2) { return a[0] * b2[0] + a[1] * b2[1] + a[2] * b2[2]; };
+              for (int k2 = 0; k2 < nvar_of(e1); ++k2)
+                for (int l2 = 0; l2 <= k2; ++l2) {
+                  double gk[3], gl[3], q2[3];
+                  d1pos(sp[2 + e1], t, pe, k2, gk); d1pos(sp[2 + e1], t, pe, l2, gl); d2pos(sp[2 + e1], t, pe, k2, l2, q2);
+                  hdd(e1, k2, e1, l2, lam[row] * (dot(gk, gl) + dot(d, q2)));
+                }
+              for (int k2 = 0; k2 < nvar_of(e2); ++k2)
+                for (int l2 = 0; l2 <= k2; ++l2) {
+                  double gk[3], gl[3], q2[3];
+                  d1pos(sp[2 + e2], t, pe2, k2, gk); d1pos(sp[2 + e2], t, pe2, l2, gl); d2pos(sp[2 + e2], t, pe2, k2, l2, q2);
+                  hdd(e2, k2, e2, l2, lam[row] * (dot(gk, gl) - dot(d, q2)));
+                }
+              for (int k2 = 0; k2 < nvar_of(e1); ++k2)
+                for (int l2 = 0; l2 < nvar_of(e2); ++l2) {
+                  double ga[3], gb[3];
+                  d1pos(sp[2 + e1], t, pe, k2, ga); d1pos(sp[2 + e2], t, pe2, l2, gb);
+                  hdd(e1, k2, e2, l2, -lam[row] * dot(ga, gb));
+                }
+            }
           }
         } break;
         case FAM_DYNAMIC: {   // humanoid_dynamic_constraint.cpp:63-143 + humanoid_rigid_body_dynamics.cpp:89-206
@@ -883,6 +961,24 @@ class Problem {
                 add_durs(row0 + i, sp[2 + e], t, pm[e], Xf[i]);
               }
             }
+            if (D2) {
+              auto cross = [](const double* a, const double* b2, double* o) { o[0] = a[1] * b2[2] - a[2] * b2[1]; o[1] = a[2] * b2[0] - a[0] * b2[2]; o[2] = a[0] * b2[1] - a[1] * b2[0]; };
+              for (int e = 0; e < 4; ++e) {
+                const double r[3] = {pl.p[0] - pm[e].p[0], pl.p[1] - pm[e].p[1], pl.p[2] - pm[e].p[2]};
+                for (int k2 = 0; k2 < nvar_of(e); ++k2)
+                  for (int l2 = 0; l2 <= k2; ++l2) {
+                    double gFk[3], gFl[3], gPk[3], gPl[3], qF[3], qP[3], a1[3], a2[3], a3[3], a4[3];
+                    d1pos(sp[6 + e], t, pf[e], k2, gFk); d1pos(sp[6 + e], t, pf[e], l2, gFl);
+                    d1pos(sp[2 + e], t, pm[e], k2, gPk); d1pos(sp[2 + e], t, pm[e], l2, gPl);
+                    d2pos(sp[6 + e], t, pf[e], k2, l2, qF); d2pos(sp[2 + e], t, pm[e], k2, l2, qP);
+                    // rows: ang - sum F x (c - p) ; m a - sum F
+                    cross(qF, r, a1); cross(gFk, gPl, a2); cross(gFl, gPk, a3); cross(pf[e].p, qP, a4);
+                    double v = 0;
+                    for (int i = 0; i < 3; ++i) v += -lam[row0 + i] * (a1[i] - a2[i] - a3[i] - a4[i]) - lam[row0 + 3 + i] * qF[i];
+                    hdd(e, k2, e, l2, v);
+                  }
+              }
+            }
           }
         } break;
         case FAM_FORCE: {     // [UPSTREAM] ForceConstraint (5 rows per non-constant force node)
@@ -920,6 +1016,13 @@ class Problem {
             cl[row] = 0.0; cu[row] = kInf;
             add_nodes(row, s, pe, kPos, in.normal);
             add_durs(row, s, t, pe, in.normal);
+            if (D2)
+              for (int k2 = 0; k2 < nvar_of(b.ee); ++k2)
+                for (int l2 = 0; l2 <= k2; ++l2) {
+                  double q2[3];
+                  d2pos(s, t, pe, k2, l2, q2);
+                  hdd(b.ee, k2, b.ee, l2, lam[row] * (in.normal[0] * q2[0] + in.normal[1] * q2[1] + in.normal[2] * q2[2]));
+                }
           }
         } break;
         case FAM_TOTALTIME: { // total_duration_constraint.cpp:60-82
@@ -977,6 +1080,9 @@ class Problem {
           gi.clear(); gv.clear();
           if (need_g) { push_nodes(s, pe, kPos, d, -1.0); push_durs(s, t, pe, d, -1.0); }
           flush(w, r);
+          if (D2 && s.phase_based)
+            for (int k2 = 0; k2 < nvar_of(s.ee); ++k2)
+              for (int l2 = 0; l2 <= k2; ++l2) { double q2[3]; d2pos(s, t, pe, k2, l2, q2); hdd(s.ee, k2, s.ee, l2, -w * r * q2[d]); }
         }
         t += in.dt;                                                   // :48
       }
@@ -1000,6 +1106,13 @@ class Problem {
               if (which == kPos) { push_durs(s, t + in.dt, pe2, d, 1.0); push_durs(s, t, pe, d, -1.0); }   // :55-70
             }
             flush(w, r);
+            if (D2 && s.phase_based && which == kPos)
+              for (int k2 = 0; k2 < nvar_of(s.ee); ++k2)
+                for (int l2 = 0; l2 <= k2; ++l2) {
+                  double qa[3], qb[3];
+                  d2pos(s, t + in.dt, pe2, k2, l2, qb); d2pos(s, t, pe, k2, l2, qa);
+                  hdd(s.ee, k2, s.ee, l2, w * r * (qb[d] - qa[d]));
+                }
           }
         }
       }

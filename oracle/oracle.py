@@ -50,6 +50,7 @@ def lib():
         L.orc_total_time.argtypes = [C.c_void_p]; L.orc_total_time.restype = C.c_double
         L.orc_get_x.argtypes = [C.c_void_p, PD]; L.orc_set_x.argtypes = [C.c_void_p, PD]
         L.orc_eval.argtypes = [C.c_void_p, PD, PD, PD, PD, PD, PD]
+        L.orc_eval_lam.argtypes = [C.c_void_p, PD, PD, PD, PD, PD, PD, PD]
         L.orc_bounds.argtypes = [C.c_void_p, PD, PD]
         L.orc_row_family.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.orc_var_offsets.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
@@ -131,14 +132,18 @@ class OracleProblem:
         x = np.ascontiguousarray(x, dtype=np.float64)
         lib().orc_set_x(self.h, _p(x))
 
-    def eval(self, x, jac=True, hess=False):
+    def eval(self, x, jac=True, hess=False, lam=None):
         n, m = self.n, self.m
         x = np.ascontiguousarray(x, dtype=np.float64)
         f = C.c_double(0)
         g = np.zeros(n); c = np.zeros(m)
         J = np.zeros((m, n)) if jac else None
         H = np.zeros((n, n)) if hess else None
-        lib().orc_eval(self.h, _p(x), C.byref(f), _p(g), _p(c), _p(J) if jac else None, _p(H) if hess else None)
+        if lam is not None:
+            lam = np.ascontiguousarray(lam, dtype=np.float64)
+            lib().orc_eval_lam(self.h, _p(x), _p(lam), C.byref(f), _p(g), _p(c), _p(J) if jac else None, _p(H) if hess else None)
+        else:
+            lib().orc_eval(self.h, _p(x), C.byref(f), _p(g), _p(c), _p(J) if jac else None, _p(H) if hess else None)
         return f.value, g, c, J, H
 
     def bounds(self):

@@ -77,6 +77,9 @@ void orc_set_x(void* h, const double* x) { ((Problem*)h)->set_x(x); }
 void orc_eval(void* h, const double* x, double* f, double* grad, double* c, double* J, double* H) {
   ((Problem*)h)->eval(x, f, grad, c, J, H);
 }
+void orc_eval_lam(void* h, const double* x, const double* lam, double* f, double* grad, double* c, double* J, double* H) {
+  ((Problem*)h)->eval(x, f, grad, c, J, H, lam);
+}
 void orc_bounds(void* h, double* cl, double* cu) {
   Problem* p = (Problem*)h;
   std::vector<double> x(p->n), c(p->m);

@@ -47,13 +47,18 @@ static void dense_from_K(Emu* e, int stage, double* J, double* H) {
   if (J) for (int i = 0; i < m; ++i) for (int j = 0; j < n; ++j) J[(size_t)i * n + j] = kget(c, c.pos_row[i], c.pos_var[j]);
   if (H) for (int a = 0; a < n; ++a) for (int b = 0; b < n; ++b) H[(size_t)a * n + b] = kget(c, c.pos_var[a], c.pos_var[b]);
 }
+int emu_eval_lam(void* h, int stage, const double* x, const double* lam, double* x_out, double* f, double* grad, double* cvals, double* J, double* H);
 int emu_eval(void* h, int stage, const double* x, double* x_out, double* f, double* grad, double* cvals, double* J, double* H) {
+  return emu_eval_lam(h, stage, x, nullptr, x_out, f, grad, cvals, J, H);
+}
+int emu_eval_lam(void* h, int stage, const double* x, const double* lam, double* x_out, double* f, double* grad, double* cvals, double* J, double* H) {
   Emu* e = (Emu*)h; e->bind();
   const StageDesc& S = e->M.d.st[stage];
   Ctx c; c.q = &e->M.d;
   if (x) for (int j = 0; j < S.n; ++j) VN(c, VN_XT)[j] = x[j];
+  if (lam) for (int i = 0; i < S.m; ++i) VM(c, VM_LAM)[i] = lam[i];
   double fo[2];
-  debug_eval(&e->M.d, stage, x != nullptr, e->lds.data(), (int)e->lds.size(), fo);
+  debug_eval(&e->M.d, stage, x != nullptr, e->lds.data(), (int)e->lds.size(), fo, lam != nullptr);
   if (f) *f = fo[0];
   if (x_out) for (int j = 0; j < S.n; ++j) x_out[j] = VN(c, VN_X)[j];
   if (grad) for (int j = 0; j < S.n; ++j) grad[j] = VN(c, VN_G)[j];

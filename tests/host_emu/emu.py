@@ -34,6 +34,7 @@ def lib():
         L.emu_destroy.argtypes = [C.c_void_p]
         L.emu_sizes.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.emu_eval.argtypes = [C.c_void_p, C.c_int, PD, PD, PD, PD, PD, PD, PD]
+        L.emu_eval_lam.argtypes = [C.c_void_p, C.c_int, PD, PD, PD, PD, PD, PD, PD, PD]
         L.emu_linsolve.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, PD, PD, C.c_int]
         L.emu_solve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.emu_rebuild_fallback.argtypes = [C.c_void_p]
@@ -65,13 +66,14 @@ class EmuProblem:
         lib().emu_sizes(self.h, stage, o)
         return dict(n=o[0], m=o[1], Nb=o[2], bc=o[3], w=o[4], nnz_jac=o[5], valid=o[6], cap=o[7])
 
-    def eval(self, stage, x=None, jac=True, hess=True):
+    def eval(self, stage, x=None, jac=True, hess=True, lam=None):
         sz = self.sizes(stage); n, m = sz['n'], sz['m']
         xo = np.zeros(n); g = np.zeros(n); c = np.zeros(m); f = C.c_double(0)
         J = np.zeros((m, n)) if jac else None
         H = np.zeros((n, n)) if hess else None
         xx = np.ascontiguousarray(x, dtype=np.float64) if x is not None else None
-        err = lib().emu_eval(self.h, stage, _p(xx), _p(xo), C.byref(f), _p(g), _p(c), _p(J), _p(H))
+        ll = np.ascontiguousarray(lam, dtype=np.float64) if lam is not None else None
+        err = lib().emu_eval_lam(self.h, stage, _p(xx), _p(ll), _p(xo), C.byref(f), _p(g), _p(c), _p(J), _p(H))
         return dict(x=xo, f=f.value, g=g, c=c, J=J, H=H, err=err)
 
     def linsolve(self, stage, b, dw=1e-4, dval=1e-3, refine=2):

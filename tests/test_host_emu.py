@@ -80,3 +80,33 @@ def test_staged_solve_parity(emu, oracle_lib):
         err = snapshot_errors(sol, osnaps[k])
         assert err['contact_mismatch'] == 0
         assert max(err['base_lin'], err['base_ang_deg'], err['ee_pos'], err['ee_force']) < 1e-8, err
+
+
+def test_duration_block_of_lagrangian_hessian_vs_finite_differences(emu, oracle_lib):
+    """Stage 3 uses the exact duration-duration block of the Lagrangian Hessian (second derivatives of the
+    phase-based splines with respect to the phase durations).  Kernel source (class tables) and oracle (pairwise
+    formulas) are written independently; both must match central differences of grad f + J^T lambda."""
+    from oracle.oracle import OracleProblem
+    seq = make_walk(seed=3, F=40, randomize=True, tilt_deg=3.0)
+    e = emu.EmuProblem(seq)
+    sz = e.sizes(4); n, m = sz['n'], sz['m']
+    nd = n - sum(len(d) - 1 for d in seq.durations)
+    rng = np.random.default_rng(0)
+    x = e.eval(4)['x'].copy()
+    x[:nd] += 0.01 * rng.normal(size=nd)
+    x[nd:] *= 1 + 0.03 * rng.normal(size=n - nd)
+    lam = 0.3 * rng.normal(size=m)
+    A = e.eval(4, x, lam=lam)['H'][nd:, nd:]
+
+    def grad_lagrangian(xx):
+        r = e.eval(4, xx, hess=False)
+        return r['g'] + r['J'].T @ lam
+    h = 1e-6
+    FD = np.zeros_like(A)
+    for k in range(nd, n):
+        xp = x.copy(); xm = x.copy(); xp[k] += h; xm[k] -= h
+        FD[:, k - nd] = ((grad_lagrangian(xp) - grad_lagrangian(xm)) / (2 * h))[nd:]
+    assert np.abs(A - FD).max() <= 1e-6 * np.abs(FD).max()
+    o = OracleProblem(seq); o.set_stage(4)
+    Ho = o.eval(x, jac=True, hess=True, lam=lam)[4]
+    assert np.abs(Ho[nd:, nd:] - A).max() <= 1e-11 * np.abs(A).max()
