@@ -9,6 +9,16 @@
 
 namespace chd {
 
+// Pointers into HBM carry the global address space in device code: a pointer *loaded from memory* is otherwise
+// generic and every access through it becomes a flat_load / flat_store (which also ties up the LDS counter).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(1))) double GD;
+typedef __attribute__((address_space(1))) int GI;
+#else
+typedef double GD;
+typedef int GI;
+#endif
+
 enum { N_SPLINES = 10, N_EE = 4, N_STAGES = 6 };
 // spline ids: 0 base-lin, 1 base-ang, 2..5 ee-motion (NLP ee order), 6..9 ee-force
 
@@ -60,12 +70,12 @@ enum { SC_WP = 0, SC_WV = 4, SC_P = 8, SC_V = 11, SC_DXDT = 14, SC_POLY = 17, SC
 enum { D2_STRIDE = 4, X2_STRIDE = 6 };
 
 struct SeqDesc {
-  const double* cd;   // constant doubles
-  const int* ci;      // constant ints
-  double* wd;         // workspace doubles (state + solver vectors + KKT storage)
-  int* wi;            // workspace ints
-  double* out_d;      // results: snapshots + per-stage statistics
-  int* out_i;
+  const GD* cd;       // constant doubles
+  const GI* ci;       // constant ints
+  GD* wd;             // workspace doubles (state + solver vectors + KKT storage)
+  GI* wi;             // workspace ints
+  GD* out_d;          // results: snapshots + per-stage statistics
+  GI* out_i;
 
   int F, cap;         // data frames, snapshot capacity
   double dt, T, mass, leg_len, heel_len, heel_dist;
@@ -99,7 +109,7 @@ struct SeqDesc {
 enum { RS_STATUS = 0, RS_ITERS = 1, RS_KKT = 2, RS_VIOL = 3, RS_OBJ = 4, RS_MU = 5, RS_NFACT = 6, RS_AUX = 7, RS_STRIDE = 8 };
 // out_d layout: [N_STAGES x RS_STRIDE] then 3 snapshots x 10 blocks (base_lin, base_ang_deg, 4 ee_pos, 4 ee_force) x cap x 3
 // out_i layout: [3 x (n_samples, header)] then 3 x 4 x cap contact flags
-inline long long out_d_size(int cap) { return (long long)N_STAGES * RS_STRIDE + 3LL * 10 * cap * 3 + 16; }   // + 16 phase timers
+inline long long out_d_size(int cap) { return (long long)N_STAGES * RS_STRIDE + 3LL * 10 * cap * 3 + 24; }   // + 24 phase timers
 inline long long out_i_size(int cap) { return 8 + 3LL * 4 * cap; }
 
 }  // namespace chd

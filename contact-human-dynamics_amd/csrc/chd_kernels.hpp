@@ -94,13 +94,13 @@ struct Ctx {
   LdsD* lds;            // workgroup scratch (LDS on the device)
   int lds_cap;          // doubles available in lds
   int n, m, N, Nb, bc, w, W2, LD;
-  double* K0b; double* K0x; double* Kfb; double* Kfx;
-  const int* pos_var; const int* pos_row;
+  GD* K0b; GD* K0x; GD* Kfb; GD* Kfx;
+  const GI* pos_var; const GI* pos_row;
   double sf;            // objective scaling
   double tol;           // IPOPT tol of the stage (phys_optim.cpp:578)
   int err;              // sticky error flag (band overflow), uniform across the workgroup after a sync
   int n_bad_pivots;
-  long long tacc[16];    // cycles per phase (thread 0): 0 eval full, 1 eval values, 2 factor, 3 solve, 4 matvec, 5 total
+  long long tacc[24];    // cycles per phase (thread 0): 0 eval full, 1 eval values, 2 factor, 3 solve, 4 matvec, 5 total
 };
 #ifdef CHD_HOST_EMU
 #define CHD_CLOCK() 0LL
@@ -178,7 +178,7 @@ CHD_DEV void hermite_eval(const SeqDesc* q, int s, int id, double tl, PE& e) {
   e.w[1][2] = 6 * t * iT2 - 6 * t2 * iT3;        e.w[1][3] = 3 * t2 * iT2 - 2 * t * iT;
   e.w[2][0] = 12 * t * iT3 - 6 * iT2;            e.w[2][1] = 6 * t * iT2 - 4 * iT;
   e.w[2][2] = 6 * iT2 - 12 * t * iT3;            e.w[2][3] = 6 * t * iT2 - 2 * iT;
-  const double* nv = q->wd + q->o_node + sp.node_off + id * 6;   // [node id: p xyz, v xyz][node id+1: ...]
+  const GD* nv = q->wd + q->o_node + sp.node_off + id * 6;   // [node id: p xyz, v xyz][node id+1: ...]
   for (int k = 0; k < 3; ++k) {
     const double p0 = nv[k], v0 = nv[3 + k], p1 = nv[6 + k], v1 = nv[9 + k];
     e.p[k] = e.w[0][0] * p0 + e.w[0][1] * v0 + e.w[0][2] * p1 + e.w[0][3] * v1;
@@ -189,7 +189,7 @@ CHD_DEV void hermite_eval(const SeqDesc* q, int s, int id, double tl, PE& e) {
 
 CHD_DEV void spline_eval(const SeqDesc* q, int s, double tg, PE& e) {
   const SplineDesc& sp = q->sp[s];
-  const double* pend = q->wd + q->o_pend + sp.poly_off;
+  const GD* pend = q->wd + q->o_pend + sp.poly_off;
   const int id = seg_lookup(pend, sp.n_polys, tg);
   hermite_eval(q, s, id, tg - (id > 0 ? pend[id - 1] : 0.0), e);
 }
@@ -197,7 +197,7 @@ CHD_DEV void spline_eval(const SeqDesc* q, int s, double tg, PE& e) {
 // d p(t) / d T_poly for the active polynomial (CubicHermitePolynomial::GetDerivativeOfPosWrtDuration)
 CHD_DEV void dpos_dT(const SeqDesc* q, int s, const PE& e, double* out) {
   const SplineDesc& sp = q->sp[s];
-  const double* nv = q->wd + q->o_node + sp.node_off + e.poly * 6;
+  const GD* nv = q->wd + q->o_node + sp.node_off + e.poly * 6;
   const double t = e.tl, t2 = t * t, t3 = t2 * t, T = e.T, iT = 1.0 / T, iT2 = iT * iT, iT3 = iT2 * iT, iT4 = iT2 * iT2;
   for (int k = 0; k < 3; ++k) {
     const double x0 = nv[k], v0 = nv[3 + k], x1 = nv[6 + k], v1 = nv[9 + k];
@@ -218,7 +218,7 @@ struct DurJac { int cur, last, nvar; double own[3], early[3]; };
 CHD_DEV void dur_jac(const SeqDesc* q, int s, double t, const PE& e, DurJac& dj) {
   const SplineDesc& sp = q->sp[s];
   const int ee = sp.ee;
-  const int* pi = q->ci + q->o_pinfo + (sp.poly_off + e.poly) * 4;
+  const GI* pi = q->ci + q->o_pinfo + (sp.poly_off + e.poly) * 4;
   double dT[3];
   dpos_dT(q, s, e, dT);
   const double inv = 1.0 / pi[2];
@@ -246,8 +246,8 @@ struct DurJac2 { int cur, last, nvar; double Ge[3], Gc[3], Qee[3], Qec[3], Qcc[3
 CHD_DEV void dur_jac2(const SeqDesc* q, int s, double t, const PE& e, DurJac2& dj) {
   const SplineDesc& sp = q->sp[s];
   const int ee = sp.ee;
-  const int* pi = q->ci + q->o_pinfo + (sp.poly_off + e.poly) * 4;
-  const double* nv = q->wd + q->o_node + sp.node_off + e.poly * 6;
+  const GI* pi = q->ci + q->o_pinfo + (sp.poly_off + e.poly) * 4;
+  const GD* nv = q->wd + q->o_node + sp.node_off + e.poly * 6;
   const double kin = pi[1], inv = 1.0 / pi[2];
   dj.cur = phase_lookup(q, ee, t);
   dj.last = dj.cur == q->n_phase[ee] - 1;
@@ -270,7 +270,7 @@ CHD_DEV void dur_jac2(const SeqDesc* q, int s, double t, const PE& e, DurJac2& d
 }
 CHD_DEV double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 CHD_DEV void d2_store(const SeqDesc* q, int ee, int slot, int cur, double see, double sec, double scc) {
-  double* t = q->wd + q->o_d2tab + ((long long)ee * q->d2_slots + slot) * D2_STRIDE;
+  GD* t = q->wd + q->o_d2tab + ((long long)ee * q->d2_slots + slot) * D2_STRIDE;
   t[0] = cur; t[1] = see; t[2] = sec; t[3] = scc;
 }
 // class of the pair (k, l), l <= k, for a sample whose current phase is cur: 1 = S_ee, 2 = S_ec, 3 = S_cc, 0 = none
@@ -417,12 +417,12 @@ CHD_DEV void kzero(Ctx& c) {
 }
 
 // y = K0 x (+ diag .* x)
-CHD_NOINLINE CHD_DEV void kmatvec(Ctx& c, const double* x, double* y, const double* diag) {
+CHD_NOINLINE CHD_DEV void kmatvec(Ctx& c, const GD* x, GD* y, const GD* diag) {
   TIC();
   const int Nb = c.Nb, w = c.w, W2 = c.W2, LD = c.LD, bc = c.bc;
   GROUP_FOR(i, Nb) {
     const int lo = i - w < 0 ? 0 : i - w, hi = i + w >= Nb ? Nb - 1 : i + w;
-    const double* row = c.K0b + (long long)i * W2 + (w - i);
+    const GD* row = c.K0b + (long long)i * W2 + (w - i);
     double acc = 0, acc1 = 0, acc2 = 0, acc3 = 0;
     int k = lo + lane_;
     for (; k + 3 * CHD_GL <= hi; k += 4 * CHD_GL) {
@@ -434,17 +434,28 @@ CHD_NOINLINE CHD_DEV void kmatvec(Ctx& c, const double* x, double* y, const doub
     if (lane_ == 0) y[i] = acc + (diag ? diag[i] * x[i] : 0.0);
   }
   GROUP_FOR(r, bc) {
-    const double* row = c.K0x + (long long)r * LD;
-    double acc = 0;
-    for (int k = lane_; k < LD; k += CHD_GL) acc += row[k] * x[k];
-    acc = group_sum(acc);
+    const GD* row = c.K0x + (long long)r * LD;
+    double acc = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+    int k = lane_;
+    for (; k + 3 * CHD_GL < LD; k += 4 * CHD_GL) {
+      acc += row[k] * x[k]; acc1 += row[k + CHD_GL] * x[k + CHD_GL];
+      acc2 += row[k + 2 * CHD_GL] * x[k + 2 * CHD_GL]; acc3 += row[k + 3 * CHD_GL] * x[k + 3 * CHD_GL];
+    }
+    for (; k < LD; k += CHD_GL) acc += row[k] * x[k];
+    acc = group_sum((acc + acc1) + (acc2 + acc3));
     if (lane_ == 0) y[Nb + r] = acc + (diag ? diag[Nb + r] * x[Nb + r] : 0.0);
   }
   CHD_SYNC();
   PAR_FOR(i, Nb) {
-    double acc = 0;
-    for (int r = 0; r < bc; ++r) acc += c.K0x[(long long)r * LD + i] * x[Nb + r];
-    y[i] += acc;
+    double acc = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+    const GD* col = c.K0x + i;
+    int r = 0;
+    for (; r + 3 < bc; r += 4) {
+      acc += col[(long long)r * LD] * x[Nb + r]; acc1 += col[(long long)(r + 1) * LD] * x[Nb + r + 1];
+      acc2 += col[(long long)(r + 2) * LD] * x[Nb + r + 2]; acc3 += col[(long long)(r + 3) * LD] * x[Nb + r + 3];
+    }
+    for (; r < bc; ++r) acc += col[(long long)r * LD] * x[Nb + r];
+    y[i] += (acc + acc1) + (acc2 + acc3);
   }
   CHD_SYNC();
   TOC(c, 4);
@@ -474,7 +485,7 @@ CHD_DEV double pivot_fix(Ctx& c, double d, int sg) {
 // ---- diagonal block of a panel (NB x NB, in LDS column-major PT[j * ldp + a]) -------------------
 #ifdef CHD_HOST_EMU
 template <int NB>
-CHD_DEV void diag_block(Ctx& c, const int* sign, LdsD* dv, LdsD* PT, const int ldp, const int c0, const int jb) {
+CHD_DEV void diag_block(Ctx& c, const GI* sign, LdsD* dv, LdsD* PT, const int ldp, const int c0, const int jb) {
   for (int j = 0; j < NB; ++j) {
     double d = PT[j * ldp + j];
     if (j < jb) d = pivot_fix(c, d, sign[c0 + j]);
@@ -493,7 +504,7 @@ CHD_DEV double readlane_f64(double v, int l) {
 // one wavefront: lane a keeps row a of the block in registers; column j's pivot and multipliers are
 // broadcast with v_readlane, so the whole right-looking elimination runs without touching LDS
 template <int NB>
-CHD_DEV void diag_block(Ctx& c, const int* sign, LdsD* dv, LdsD* PT, const int ldp, const int c0, const int jb) {
+CHD_DEV void diag_block(Ctx& c, const GI* sign, LdsD* dv, LdsD* PT, const int ldp, const int c0, const int jb) {
   if (threadIdx.x < 64) {
     const int a = threadIdx.x;
     const bool act = a < NB;
@@ -553,43 +564,48 @@ CHD_DEV void trailing_update(Ctx& c, const LdsD* dv, const LdsD* PT, const int l
     while (tr * (tr + 1) / 2 > t) --tr;
     tc = t - tr * (tr + 1) / 2;
   };
-  auto dest = [&](int ur, int uc) -> double* {
+  auto dest = [&](int ur, int uc) -> GD* {
     if (ur < nbelow) { const int i = i0 + ur, k = i0 + uc; return c.Kfb + (long long)i * W1 + (k - i + w); }
     if (uc < nbelow) return c.Kfx + (long long)(ur - nbelow) * LD + i0 + uc;
     return c.Kfx + (long long)(ur - nbelow) * LD + Nb + (uc - nbelow);
   };
-  // two independent tiles per pass: their MFMA chains interleave, and the old window values are
-  // fetched before the chain starts
-  for (int t0 = wave; t0 < ntri; t0 += 2 * nwv) {
-    const int t1 = t0 + nwv;
-    const bool two = t1 < ntri;
-    int trA, tcA, trB, tcB;
-    tile_of(t0, trA, tcA);
-    tile_of(two ? t1 : t0, trB, tcB);
-    double* pdA[4]; double* pdB[4]; double oA[4], oB[4]; bool okA[4], okB[4];
-    const int ucA = 16 * tcA + lr, ucB = 16 * tcB + lr;
+  // TP independent tiles per pass: the old window values of all of them are requested before the MFMA
+  // chains start (memory-level parallelism), and the chains interleave on the matrix pipe
+  constexpr int TP = 4;
+  for (int t0 = wave; t0 < ntri; t0 += TP * nwv) {
+    GD* pd[TP][4]; double old_[TP][4]; bool ok[TP][4];
+    const LdsD* pa[TP]; const LdsD* pb[TP];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int urA = 16 * trA + lk + 4 * r, urB = 16 * trB + lk + 4 * r;
-      okA[r] = urA < wr && ucA <= urA; okB[r] = two && urB < wr && ucB <= urB;
-      pdA[r] = dest(okA[r] ? urA : 0, okA[r] ? ucA : 0); pdB[r] = dest(okB[r] ? urB : 0, okB[r] ? ucB : 0);
-      oA[r] = okA[r] ? *pdA[r] : 0.0; oB[r] = okB[r] ? *pdB[r] : 0.0;
+    for (int u = 0; u < TP; ++u) {
+      const int t = t0 + u * nwv;
+      const bool live = t < ntri;
+      int tr, tc;
+      tile_of(live ? t : t0, tr, tc);
+      const int uc = 16 * tc + lr;
+      pa[u] = PT + NB + 16 * tr + lr; pb[u] = PT + NB + 16 * tc + lr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ur = 16 * tr + lk + 4 * r;
+        ok[u][r] = live && ur < wr && uc <= ur;
+        pd[u][r] = dest(ok[u][r] ? ur : 0, ok[u][r] ? uc : 0);
+        old_[u][r] = ok[u][r] ? *pd[u][r] : 0.0;
+      }
     }
-    chd_f64x4 accA = {0.0, 0.0, 0.0, 0.0}, accB = {0.0, 0.0, 0.0, 0.0};
-    const LdsD* paA = PT + NB + 16 * trA + lr; const LdsD* pbA = PT + NB + 16 * tcA + lr;
-    const LdsD* paB = PT + NB + 16 * trB + lr; const LdsD* pbB = PT + NB + 16 * tcB + lr;
+    chd_f64x4 acc[TP];
+#pragma unroll
+    for (int u = 0; u < TP; ++u) acc[u] = chd_f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int kk = 0; kk < NB / 4; ++kk) {
       const int j = kk * 4 + lk;
       const double dj = dv[j];
-      accA = __builtin_amdgcn_mfma_f64_16x16x4f64(paA[j * ldp], pbA[j * ldp] * dj, accA, 0, 0, 0);
-      accB = __builtin_amdgcn_mfma_f64_16x16x4f64(paB[j * ldp], pbB[j * ldp] * dj, accB, 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < TP; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[u][j * ldp], pb[u][j * ldp] * dj, acc[u], 0, 0, 0);
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (okA[r]) *pdA[r] = oA[r] - accA[r];
-      if (okB[r]) *pdB[r] = oB[r] - accB[r];
-    }
+    for (int u = 0; u < TP; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (ok[u][r]) *pd[u][r] = old_[u][r] - acc[u][r];
   }
 }
 #endif
@@ -598,7 +614,7 @@ CHD_DEV void trailing_update(Ctx& c, const LdsD* dv, const LdsD* PT, const int l
 // local rows: [0, NB) diagonal block (rows >= jb of a short last block are identity padding),
 // [NB, NB + nbelow) band rows below it, then the bc border rows.
 template <int NB>
-CHD_NOINLINE CHD_DEV void kfactor_band(Ctx& c, const int* sign, LdsD* dv, LdsD* PT, const int ldp) {
+CHD_NOINLINE CHD_DEV void kfactor_band(Ctx& c, const GI* sign, LdsD* dv, LdsD* PT, const int ldp) {
   const int Nb = c.Nb, w = c.w, W1 = c.w + 1, LD = c.LD, bc = c.bc;
   for (int c0 = 0; c0 < Nb; c0 += NB) {
     const int jb = Nb - c0 < NB ? Nb - c0 : NB;
@@ -672,7 +688,7 @@ CHD_NOINLINE CHD_DEV void kfactor_band(Ctx& c, const int* sign, LdsD* dv, LdsD* 
 
 // in-place L D L^T of a dense symmetric n x n matrix (lower triangle, leading dimension ld)
 template <class P>
-CHD_DEV void dense_ldlt(Ctx& c, P Sp, const int ld, const int n, const int* sign) {
+CHD_DEV void dense_ldlt(Ctx& c, P Sp, const int ld, const int n, const GI* sign) {
   for (int j = 0; j < n; ++j) {
     const double d = pivot_fix(c, Sp[(long long)j * ld + j], sign[j]);
     const double id = 1.0 / d;
@@ -689,19 +705,19 @@ CHD_DEV void dense_ldlt(Ctx& c, P Sp, const int ld, const int n, const int* sign
   }
 }
 
-CHD_NOINLINE CHD_DEV void kfactor(Ctx& c, const double* diag, const int* sign) {
+CHD_NOINLINE CHD_DEV void kfactor(Ctx& c, const GD* diag, const GI* sign) {
   TIC();
   const int Nb = c.Nb, w = c.w, W2 = c.W2, W1 = c.w + 1, LD = c.LD, bc = c.bc;
   if (CHD_TID == 0) c.n_bad_pivots = 0;
   // copy the lower triangle (+ diagonal shift) into the factor storage: one wavefront per row
   for (int i = CHD_WAVE_ID; i < Nb; i += CHD_NWAVES) {
-    const double* src = c.K0b + (long long)i * W2;
-    double* dst = c.Kfb + (long long)i * W1;
+    const GD* src = c.K0b + (long long)i * W2;
+    GD* dst = c.Kfb + (long long)i * W1;
     for (int cc = CHD_LANE; cc < W1; cc += CHD_WAVE_SZ) dst[cc] = src[cc] + (cc == w ? diag[i] : 0.0);
   }
   for (int r = CHD_WAVE_ID; r < bc; r += CHD_NWAVES) {
-    const double* src = c.K0x + (long long)r * LD;
-    double* dst = c.Kfx + (long long)r * LD;
+    const GD* src = c.K0x + (long long)r * LD;
+    GD* dst = c.Kfx + (long long)r * LD;
     for (int k = CHD_LANE; k < LD; k += CHD_WAVE_SZ) dst[k] = src[k] + (k == Nb + r ? diag[Nb + r] : 0.0);
   }
   CHD_SYNC();
@@ -736,6 +752,7 @@ CHD_NOINLINE CHD_DEV void kfactor(Ctx& c, const double* diag, const int* sign) {
 }
 
 // in-block triangular solves for the substitution (wave-cooperative on the device)
+#define CHD_SOLVE_NB 64
 #ifdef CHD_HOST_EMU
 template <class YP>
 CHD_DEV void tri_forward(Ctx& c, YP y, int c0, int jb) {
@@ -756,20 +773,20 @@ CHD_DEV void tri_backward(Ctx& c, YP y, int c0, int jb) {
   }
 }
 #else
-// lane i owns row c0+i of the 32x32 diagonal block; its entries are fetched up front (32 independent
-// loads) so that the dependent chain below runs out of registers
+// lane i owns row c0+i of the 64x64 diagonal block; its entries are fetched up front (independent loads) so that
+// the dependent chain below runs out of registers
 template <class YP>
-CHD_DEV void tri_forward(Ctx& c, YP y, int c0, int jb) {
+CHD_NOINLINE CHD_DEV void tri_forward(Ctx& c, YP y, int c0, int jb) {
   if (threadIdx.x < 64) {
     const int W1 = c.w + 1, w = c.w, i = threadIdx.x;
     const bool act = i < jb;
     double yi = act ? y[c0 + i] : 0.0;
-    const double* row = c.Kfb + (long long)(c0 + (act ? i : 0)) * W1 + (w - (act ? i : 0));
-    double l[32];
+    const GD* row = c.Kfb + (long long)(c0 + (act ? i : 0)) * W1 + (w - (act ? i : 0));
+    double l[CHD_SOLVE_NB];
 #pragma unroll
-    for (int j = 0; j < 32; ++j) l[j] = (act && j < i) ? row[j] : 0.0;
+    for (int j = 0; j < CHD_SOLVE_NB; ++j) l[j] = (act && j < i) ? row[j] : 0.0;
 #pragma unroll
-    for (int j = 0; j < 31; ++j) {
+    for (int j = 0; j < CHD_SOLVE_NB - 1; ++j) {
       const double yj = __shfl(yi, j);
       yi -= l[j] * yj;
     }
@@ -777,16 +794,16 @@ CHD_DEV void tri_forward(Ctx& c, YP y, int c0, int jb) {
   }
 }
 template <class YP>
-CHD_DEV void tri_backward(Ctx& c, YP y, int c0, int jb) {
+CHD_NOINLINE CHD_DEV void tri_backward(Ctx& c, YP y, int c0, int jb) {
   if (threadIdx.x < 64) {
     const int W1 = c.w + 1, w = c.w, i = threadIdx.x;
     const bool act = i < jb;
     double yi = act ? y[c0 + i] : 0.0;
-    double l[32];
+    double l[CHD_SOLVE_NB];
 #pragma unroll
-    for (int j = 0; j < 32; ++j) l[j] = (act && j > i && j < jb) ? c.Kfb[(long long)(c0 + j) * W1 + (i - j + w)] : 0.0;
+    for (int j = 0; j < CHD_SOLVE_NB; ++j) l[j] = (act && j > i && j < jb) ? c.Kfb[(long long)(c0 + j) * W1 + (i - j + w)] : 0.0;
 #pragma unroll
-    for (int j = 31; j > 0; --j) {
+    for (int j = CHD_SOLVE_NB - 1; j > 0; --j) {
       const double yj = __shfl(yi, j);
       yi -= l[j] * yj;
     }
@@ -797,34 +814,49 @@ CHD_DEV void tri_backward(Ctx& c, YP y, int c0, int jb) {
 
 // x = K^{-1} rhs using the factor.  y: work vector of N doubles, S: the dense border factor (both in LDS when they fit).
 template <class YP, class SP>
-CHD_DEV void ksolve_impl(Ctx& c, const double* rhs, double* x, YP y, SP Sp, const int lds_, const bool stage_s) {
+CHD_DEV void ksolve_impl(Ctx& c, const GD* rhs, GD* x, YP y, SP Sp, const int lds_, const bool stage_s) {
   const int Nb = c.Nb, w = c.w, W1 = c.w + 1, LD = c.LD, bc = c.bc, N = c.N;
   PAR_FOR(i, N) y[i] = rhs[i];
   if (stage_s) PAR_FOR(idx, bc * bc) { const int r = idx / bc, k = idx % bc; Sp[idx] = c.Kfx[(long long)r * LD + Nb + k]; }
   CHD_SYNC();
-  const int nb = 32;
+  const int nb = CHD_SOLVE_NB;
+  long long ts_ = CHD_CLOCK();
   // forward, band
   for (int c0 = 0; c0 < Nb; c0 += nb) {
     const int jb = Nb - c0 < nb ? Nb - c0 : nb;
+    ts_ = CHD_CLOCK();
     GROUP_FOR(a, jb) {
       const int i = c0 + a;
       const int lo = i - w < 0 ? 0 : i - w;
-      const double* row = c.Kfb + (long long)i * W1 + (w - i);
-      double acc = 0;
-      for (int k = lo + lane_; k < c0; k += CHD_GL) acc += row[k] * y[k];
-      acc = group_sum(acc);
+      const GD* row = c.Kfb + (long long)i * W1 + (w - i);
+      double acc = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+      int k = lo + lane_;
+      for (; k + 3 * CHD_GL < c0; k += 4 * CHD_GL) {       // four loads in flight per lane
+        acc += row[k] * y[k]; acc1 += row[k + CHD_GL] * y[k + CHD_GL];
+        acc2 += row[k + 2 * CHD_GL] * y[k + 2 * CHD_GL]; acc3 += row[k + 3 * CHD_GL] * y[k + 3 * CHD_GL];
+      }
+      for (; k < c0; k += CHD_GL) acc += row[k] * y[k];
+      acc = group_sum((acc + acc1) + (acc2 + acc3));
       if (lane_ == 0) y[i] -= acc;
     }
     CHD_SYNC();
+    c.tacc[16] += CHD_CLOCK() - ts_; ts_ = CHD_CLOCK();
     tri_forward(c, y, c0, jb);
     CHD_SYNC();
+    c.tacc[17] += CHD_CLOCK() - ts_;
   }
+  ts_ = CHD_CLOCK();
   // forward, border rows: band part of L_border
   GROUP_FOR(r, bc) {
-    const double* row = c.Kfx + (long long)r * LD;
-    double acc = 0;
-    for (int k = lane_; k < Nb; k += CHD_GL) acc += row[k] * y[k];
-    acc = group_sum(acc);
+    const GD* row = c.Kfx + (long long)r * LD;
+    double acc = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+    int k = lane_;
+    for (; k + 3 * CHD_GL < Nb; k += 4 * CHD_GL) {
+      acc += row[k] * y[k]; acc1 += row[k + CHD_GL] * y[k + CHD_GL];
+      acc2 += row[k + 2 * CHD_GL] * y[k + 2 * CHD_GL]; acc3 += row[k + 3 * CHD_GL] * y[k + 3 * CHD_GL];
+    }
+    for (; k < Nb; k += CHD_GL) acc += row[k] * y[k];
+    acc = group_sum((acc + acc1) + (acc2 + acc3));
     if (lane_ == 0) y[Nb + r] -= acc;
   }
   CHD_SYNC();
@@ -843,34 +875,49 @@ CHD_DEV void ksolve_impl(Ctx& c, const double* rhs, double* x, YP y, SP Sp, cons
     CHD_SYNC();
   }
   PAR_FOR(k, Nb) {
-    double acc = 0;
-    for (int r = 0; r < bc; ++r) acc += c.Kfx[(long long)r * LD + k] * y[Nb + r];
-    y[k] -= acc;
+    double acc = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+    const GD* col = c.Kfx + k;
+    int r = 0;
+    for (; r + 3 < bc; r += 4) {
+      acc += col[(long long)r * LD] * y[Nb + r]; acc1 += col[(long long)(r + 1) * LD] * y[Nb + r + 1];
+      acc2 += col[(long long)(r + 2) * LD] * y[Nb + r + 2]; acc3 += col[(long long)(r + 3) * LD] * y[Nb + r + 3];
+    }
+    for (; r < bc; ++r) acc += col[(long long)r * LD] * y[Nb + r];
+    y[k] -= (acc + acc1) + (acc2 + acc3);
   }
   CHD_SYNC();
+  c.tacc[18] += CHD_CLOCK() - ts_;
   // backward, band
   const int nblk = (Nb + nb - 1) / nb;
   for (int bk = nblk - 1; bk >= 0; --bk) {
     const int c0 = bk * nb;
     const int jb = Nb - c0 < nb ? Nb - c0 : nb;
+    ts_ = CHD_CLOCK();
     tri_backward(c, y, c0, jb);
     CHD_SYNC();
+    c.tacc[19] += CHD_CLOCK() - ts_; ts_ = CHD_CLOCK();
     const int k0 = c0 - w < 0 ? 0 : c0 - w;
     for (int k = k0 + CHD_TID; k < c0; k += CHD_NT) {
-      double acc = 0;
-      for (int a = 0; a < jb; ++a) {
-        const int i = c0 + a;
-        if (i - k <= w) acc += c.Kfb[(long long)i * W1 + (k - i + w)] * y[i];
+      // rows i = c0 + a reach column k while i - k <= w
+      const int amax = (w - (c0 - k)) < jb - 1 ? (w - (c0 - k)) : jb - 1;
+      const GD* col = c.Kfb + (long long)c0 * W1 + (k - c0 + w);      // L(c0 + a, k) = col[a * (W1 - 1)]
+      double acc = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+      int a = 0;
+      for (; a + 3 <= amax; a += 4) {
+        acc += col[(long long)a * (W1 - 1)] * y[c0 + a]; acc1 += col[(long long)(a + 1) * (W1 - 1)] * y[c0 + a + 1];
+        acc2 += col[(long long)(a + 2) * (W1 - 1)] * y[c0 + a + 2]; acc3 += col[(long long)(a + 3) * (W1 - 1)] * y[c0 + a + 3];
       }
-      y[k] -= acc;
+      for (; a <= amax; ++a) acc += col[(long long)a * (W1 - 1)] * y[c0 + a];
+      y[k] -= (acc + acc1) + (acc2 + acc3);
     }
     CHD_SYNC();
+    c.tacc[20] += CHD_CLOCK() - ts_;
   }
   PAR_FOR(i, N) x[i] = y[i];
   CHD_SYNC();
 }
 
-CHD_NOINLINE CHD_DEV void ksolve_once(Ctx& c, const double* rhs, double* x) {
+CHD_NOINLINE CHD_DEV void ksolve_once(Ctx& c, const GD* rhs, GD* x) {
   TIC();
   const int N = c.N, bc = c.bc, Npad = (N + 1) & ~1;
   const int room = c.lds_cap - LDS_RED;
@@ -880,9 +927,9 @@ CHD_NOINLINE CHD_DEV void ksolve_once(Ctx& c, const double* rhs, double* x) {
   TOC(c, 3);
 }
 
-CHD_DEV void ksolve(Ctx& c, const double* rhs, double* x, const double* diag, int refine) {
+CHD_DEV void ksolve(Ctx& c, const GD* rhs, GD* x, const GD* diag, int refine) {
   ksolve_once(c, rhs, x);
-  double* t1 = VK(c, VK_T1); double* t2 = VK(c, VK_T2);
+  GD* t1 = VK(c, VK_T1); GD* t2 = VK(c, VK_T2);
   for (int it = 0; it < refine; ++it) {
     kmatvec(c, x, t1, diag);
     PAR_FOR(i, c.N) t1[i] = rhs[i] - t1[i];
@@ -897,13 +944,13 @@ CHD_DEV void ksolve(Ctx& c, const double* rhs, double* x, const double* diag, in
 // NLP state <-> x
 // ------------------------------------------------------------------------------------------
 CHD_DEV void refresh_durations(const SeqDesc* q) {     // polynomial durations + cumulative times from the phase durations
-  double* wd = q->wd;
+  GD* wd = q->wd;
   PAR_FOR(idx, q->tot_polys) {
     int s = 0;
     while (s + 1 < N_SPLINES && idx >= q->sp[s + 1].poly_off) ++s;
     const SplineDesc& sp = q->sp[s];
     if (sp.phase_based) {
-      const int* pi = q->ci + q->o_pinfo + idx * 4;
+      const GI* pi = q->ci + q->o_pinfo + idx * 4;
       wd[q->o_poly_dur + idx] = wd[q->o_phase_dur + q->phase_off[sp.ee] + pi[0]] / pi[2];
     }
   }
@@ -923,7 +970,7 @@ CHD_DEV void refresh_durations(const SeqDesc* q) {     // polynomial durations +
   CHD_SYNC();
 }
 
-CHD_DEV void state_from_x(Ctx& c, const double* x) {
+CHD_DEV void state_from_x(Ctx& c, const GD* x) {
   const SeqDesc* q = c.q;
   PAR_FOR(k, q->tot_entries) {
     const int v = q->ci[q->o_varof + k];
@@ -937,7 +984,7 @@ CHD_DEV void state_from_x(Ctx& c, const double* x) {
     PAR_FOR(e, N_EE) {      // TOWR PhaseDurations::SetVariables: last duration = T - sum
       double sum = 0;
       const int np = q->n_phase[e];
-      double* ph = q->wd + q->o_phase_dur + q->phase_off[e];
+      GD* ph = q->wd + q->o_phase_dur + q->phase_off[e];
       for (int k = 0; k + 1 < np; ++k) { ph[k] = x[c.S->dur_off[e] + k]; sum += ph[k]; }
       ph[np - 1] = q->T - sum;
     }
@@ -946,7 +993,7 @@ CHD_DEV void state_from_x(Ctx& c, const double* x) {
   if (c.S->opt_dur) refresh_durations(q);
 }
 
-CHD_DEV void x_from_state(Ctx& c, double* x) {
+CHD_DEV void x_from_state(Ctx& c, GD* x) {
   const SeqDesc* q = c.q;
   PAR_FOR(k, q->tot_entries) {
     const int v = q->ci[q->o_varof + k];
@@ -972,7 +1019,7 @@ CHD_DEV void row_nodes(const RowW& r, int s, const PE& e, int which, const doubl
   if (!r.on) return;
   const SeqDesc* q = r.c->q;
   const SplineDesc& sp = q->sp[s];
-  const int* vo = q->ci + q->o_varof + sp.node_off + e.poly * 6;
+  const GI* vo = q->ci + q->o_varof + sp.node_off + e.poly * 6;
   for (int side = 0; side < 2; ++side)
     for (int dq = 0; dq < 2; ++dq) {
       const double wgt = e.w[which][side * 2 + dq];
@@ -1005,14 +1052,14 @@ CHD_DEV int frame_index(const SeqDesc* q, double t) {       // humanoid_rigid_bo
   return idx;
 }
 
-CHD_NOINLINE CHD_DEV void eval_rows(Ctx& c, int mode, double* cout_, const double* lam) {
+CHD_NOINLINE CHD_DEV void eval_rows(Ctx& c, int mode, GD* cout_, const GD* lam) {
   const SeqDesc* q = c.q; const StageDesc* S = c.S;
-  const double* sc = VM(c, VM_SC);
+  const GD* sc = VM(c, VM_SC);
   const bool J = mode == EV_FULL;
   const bool D2 = J && S->opt_dur && lam != nullptr;      // exact duration block of the Lagrangian Hessian
   const int slot_height = q->n_tdyn, slot_rom = 2 * q->n_tdyn, slot_heel = 2 * q->n_tdyn + q->n_trom;
   PAR_FOR(ti, S->n_tasks) {
-    const int* tk = q->ci + S->o_task + 4 * ti;
+    const GI* tk = q->ci + S->o_task + 4 * ti;
     const int type = tk[0], A = tk[1], B = tk[2], row0 = tk[3];
     const double t = q->cd[S->o_task_t + ti];
     switch (type) {
@@ -1031,11 +1078,11 @@ CHD_NOINLINE CHD_DEV void eval_rows(Ctx& c, int mode, double* cout_, const doubl
       } break;
       case T_TERRAIN: {      // TOWR TerrainConstraint: z - h(x, y)
         const SplineDesc& sp = q->sp[2 + A];
-        const double* nv = q->wd + q->o_node + sp.node_off + B * 6;
+        const GD* nv = q->wd + q->o_node + sp.node_off + B * 6;
         const double h = (-q->normal[1] * (nv[1] - q->point[1]) - q->normal[0] * (nv[0] - q->point[0])) / q->normal[2] + q->point[2];   // ground_plane.cpp:18-27
         cout_[row0] = sc[row0] * (nv[2] - h);
         if (J) {
-          const int* vo = q->ci + q->o_varof + sp.node_off + B * 6;
+          const GI* vo = q->ci + q->o_varof + sp.node_off + B * 6;
           const int pr = c.pos_row[row0];
           if (vo[2] >= 0) kadd(c, pr, c.pos_var[sp.var_off + vo[2]], sc[row0]);
           if (vo[0] >= 0 && q->hx != 0.0) kadd(c, pr, c.pos_var[sp.var_off + vo[0]], -sc[row0] * q->hx);
@@ -1046,7 +1093,7 @@ CHD_NOINLINE CHD_DEV void eval_rows(Ctx& c, int mode, double* cout_, const doubl
         const int e = A;
         PE pl, pa, pm;
         spline_eval(q, 0, t, pl); spline_eval(q, 1, t, pa); spline_eval(q, 2 + e, t, pm);
-        const double* hip = q->cd + q->o_hip[(e == 0 || e == 2) ? 0 : 1] + frame_index(q, t) * 3;   // humanoid.h:45-48
+        const GD* hip = q->cd + q->o_hip[(e == 0 || e == 2) ? 0 : 1] + frame_index(q, t) * 3;   // humanoid.h:45-48
         double R[3][3], dR[3][3][3], Rh[3], dvec[3];
         rot_and_derivs(pa.p, R, dR);
         matvec3(R, hip, Rh);
@@ -1085,7 +1132,7 @@ CHD_NOINLINE CHD_DEV void eval_rows(Ctx& c, int mode, double* cout_, const doubl
                      ls * (dot3(da.Gc, da.Gc) + dot3(dvec, da.Qcc)));
             d2_store(q, A + 2, slot_heel + B, db.cur, ls * (dot3(db.Ge, db.Ge) - dot3(dvec, db.Qee)), ls * (dot3(db.Ge, db.Gc) - dot3(dvec, db.Qec)),
                      ls * (dot3(db.Gc, db.Gc) - dot3(dvec, db.Qcc)));
-            double* x2 = q->wd + q->o_x2tab + ((long long)A * q->n_trom + B) * X2_STRIDE;
+            GD* x2 = q->wd + q->o_x2tab + ((long long)A * q->n_trom + B) * X2_STRIDE;
             x2[0] = da.cur; x2[1] = db.cur;
             x2[2] = -ls * dot3(da.Ge, db.Ge); x2[3] = -ls * dot3(da.Ge, db.Gc); x2[4] = -ls * dot3(da.Gc, db.Ge); x2[5] = -ls * dot3(da.Gc, db.Gc);
           }
@@ -1095,7 +1142,7 @@ CHD_NOINLINE CHD_DEV void eval_rows(Ctx& c, int mode, double* cout_, const doubl
         PE pl, pa, pm[4], pf[4];
         spline_eval(q, 0, t, pl); spline_eval(q, 1, t, pa);
         for (int e = 0; e < 4; ++e) { spline_eval(q, 2 + e, t, pm[e]); spline_eval(q, 6 + e, t, pf[e]); }
-        const double* I6 = q->cd + q->o_inertia + frame_index(q, t) * 6;
+        const GD* I6 = q->cd + q->o_inertia + frame_index(q, t) * 6;
         const double Ib[3][3] = {{I6[0], I6[3], I6[4]}, {I6[3], I6[1], I6[5]}, {I6[4], I6[5], I6[2]}};   // humanoid_rigid_body_dynamics.cpp:47-56
         double ang[3], d0[3][3], d1[3][3], d2[3][3];
         angular_term(pa.p, pa.v, pa.a, Ib, J, ang, d0, d1, d2);
@@ -1164,8 +1211,8 @@ CHD_NOINLINE CHD_DEV void eval_rows(Ctx& c, int mode, double* cout_, const doubl
       } break;
       case T_FORCE: {        // TOWR ForceConstraint: normal force range + friction pyramid
         const SplineDesc& sp = q->sp[6 + A];
-        const double* nv = q->wd + q->o_node + sp.node_off + B * 6;
-        const int* vo = q->ci + q->o_varof + sp.node_off + B * 6;
+        const GD* nv = q->wd + q->o_node + sp.node_off + B * 6;
+        const GI* vo = q->ci + q->o_varof + sp.node_off + B * 6;
         for (int r5 = 0; r5 < 5; ++r5) {
           double dir[3];
           for (int k = 0; k < 3; ++k) {
@@ -1211,7 +1258,7 @@ CHD_NOINLINE CHD_DEV void eval_rows(Ctx& c, int mode, double* cout_, const doubl
 // ------------------------------------------------------------------------------------------
 // Cost terms: sum 1/2 w r^2 with gradient and Gauss-Newton Hessian
 // ------------------------------------------------------------------------------------------
-CHD_DEV const double* scache(const SeqDesc* q, int s, int i) { return q->wd + q->o_scache + ((long long)s * (q->F + 2) + i) * SC_STRIDE; }
+CHD_DEV const GD* scache(const SeqDesc* q, int s, int i) { return q->wd + q->o_scache + ((long long)s * (q->F + 2) + i) * SC_STRIDE; }
 
 CHD_NOINLINE CHD_DEV void fill_sample_cache(Ctx& c) {
   const SeqDesc* q = c.q;
@@ -1221,7 +1268,7 @@ CHD_NOINLINE CHD_DEV void fill_sample_cache(Ctx& c) {
     const double t = q->cd[q->o_tcost + i];
     PE e;
     spline_eval(q, s, t, e);
-    double* sc_ = q->wd + q->o_scache + ((long long)s * (q->F + 2) + i) * SC_STRIDE;
+    GD* sc_ = q->wd + q->o_scache + ((long long)s * (q->F + 2) + i) * SC_STRIDE;
     for (int k = 0; k < 4; ++k) { sc_[SC_WP + k] = e.w[0][k]; sc_[SC_WV + k] = e.w[1][k]; }
     for (int k = 0; k < 3; ++k) { sc_[SC_P + k] = e.p[k]; sc_[SC_V + k] = e.v[k]; sc_[SC_DXDT + k] = 0.0; }
     sc_[SC_POLY] = e.poly; sc_[SC_PHASE] = 0; sc_[SC_LAST] = 0;
@@ -1261,12 +1308,12 @@ CHD_NOINLINE CHD_DEV double eval_cost_value(Ctx& c) {
   PAR_FOR(idx, 6 * F) {
     const int s = idx / F, i = idx % F;
     const double wdat = S->w_data[s < 2 ? s : 2], wvel = S->w_vel[s < 2 ? s : 2], wacc = S->w_acc[s < 2 ? s : 2];
-    const double* a = scache(q, s, i);
-    const double* dat = q->cd + q->o_data[s] + i * 3;
+    const GD* a = scache(q, s, i);
+    const GD* dat = q->cd + q->o_data[s] + i * 3;
     double acc = 0;
     for (int k = 0; k < 3; ++k) { const double r = dat[k] - a[SC_P + k]; acc += 0.5 * wdat * r * r; }
     if (i < n_smooth(q, s)) {
-      const double* b = scache(q, s, i + 1);
+      const GD* b = scache(q, s, i + 1);
       if (wvel >= 0) for (int k = 0; k < 3; ++k) { const double r = b[SC_P + k] - a[SC_P + k]; acc += 0.5 * wvel * r * r; }
       if (wacc >= 0) for (int k = 0; k < 3; ++k) { const double r = b[SC_V + k] - a[SC_V + k]; acc += 0.5 * wacc * r * r; }
     }
@@ -1291,10 +1338,10 @@ CHD_DEV void supp_add_sample(Supp& sp, const double* sc_, int which, double sign
     for (int dq = 0; dq < 2; ++dq) { sp.node[sp.n] = poly + side; sp.dq[sp.n] = dq; sp.g[sp.n] = sign * wv[side * 2 + dq]; ++sp.n; }
 }
 
-CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, double* g, const double* lam) {
+CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, GD* g, const GD* lam) {
   const SeqDesc* q = c.q; const StageDesc* S = c.S;
   const int F = q->F;
-  int* first = q->wi + q->o_first;
+  GI* first = q->wi + q->o_first;
   const int fstride = q->max_polys + 2;
   // first data sample of every polynomial
   PAR_FOR(idx, 6 * fstride) first[idx] = F;
@@ -1315,8 +1362,8 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, double* g, const double* l
     int nd = idx / 3, s = 0;
     while (nd >= q->sp[s].n_nodes) { nd -= q->sp[s].n_nodes; ++s; }
     const SplineDesc& sp = q->sp[s];
-    const int* pinfo = q->ci + q->o_pinfo + sp.poly_off * 4;
-    const int* vo = q->ci + q->o_varof + sp.node_off;
+    const GI* pinfo = q->ci + q->o_pinfo + sp.poly_off * 4;
+    const GI* vo = q->ci + q->o_varof + sp.node_off;
     if (sp.phase_based && nd > 0 && pinfo[(nd - 1) * 4 + 3]) continue;       // second node of a stance pair: owned by the first
     const int nd_hi = (sp.phase_based && nd < sp.n_polys && pinfo[nd * 4 + 3]) ? nd + 1 : nd;
     bool any = false;
@@ -1327,7 +1374,7 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, double* g, const double* l
     const int nsm = n_smooth(q, s);
     const int ti = s < 2 ? s : 2;
     const double wdat = S->w_data[ti], wvel = S->w_vel[ti], wacc = S->w_acc[ti];
-    const double* dat = q->cd + q->o_data[s];
+    const GD* dat = q->cd + q->o_data[s];
     // residual kinds: 0 data(i), 1 position difference (i, i+1), 2 velocity difference (i, i+1)
     for (int kind = 0; kind < 3; ++kind) {
       const double wt = kind == 0 ? wdat : kind == 1 ? wvel : wacc;
@@ -1336,12 +1383,12 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, double* g, const double* l
       if (kind > 0) { r_lo = i_lo - 1 < 0 ? 0 : i_lo - 1; if (r_hi > nsm - 1) r_hi = nsm - 1; }
       else if (r_hi > F - 1) r_hi = F - 1;
       for (int i = r_lo; i <= r_hi; ++i) {
-        const double* a = scache(q, s, i);
+        const GD* a = scache(q, s, i);
         Supp su; su.n = 0;
         double r;
         if (kind == 0) { supp_add_sample(su, a, 0, -1.0); r = dat[i * 3 + dim] - a[SC_P + dim]; }
         else {
-          const double* b = scache(q, s, i + 1);
+          const GD* b = scache(q, s, i + 1);
           supp_add_sample(su, b, kind - 1, 1.0); supp_add_sample(su, a, kind - 1, -1.0);
           r = kind == 1 ? b[SC_P + dim] - a[SC_P + dim] : b[SC_V + dim] - a[SC_V + dim];
         }
@@ -1369,8 +1416,8 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, double* g, const double* l
     const int slot_cost = 2 * q->n_tdyn + 2 * q->n_trom;
     PAR_FOR(idx, 4 * F) {
       const int e = idx / F, i = idx % F, s = 2 + e;
-      const double* a = scache(q, s, i);
-      const double* dat = q->cd + q->o_data[s] + i * 3;
+      const GD* a = scache(q, s, i);
+      const GD* dat = q->cd + q->o_data[s] + i * 3;
       const int nsm = n_smooth(q, s);
       double cf[3];
       for (int k = 0; k < 3; ++k) {
@@ -1394,7 +1441,7 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, double* g, const double* l
         const int k = idx / nb_, l = idx % nb_;
         double acc = 0;
         for (int smp = 0; smp < q->n_trom; ++smp) {
-          const double* x2 = q->wd + q->o_x2tab + ((long long)pr_ * q->n_trom + smp) * X2_STRIDE;
+          const GD* x2 = q->wd + q->o_x2tab + ((long long)pr_ * q->n_trom + smp) * X2_STRIDE;
           const int ca = (int)x2[0], cb = (int)x2[1];
           if (k > ca || l > cb) continue;
           acc += x2[2 + (k == ca ? 2 : 0) + (l == cb ? 1 : 0)];
@@ -1416,21 +1463,21 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, double* g, const double* l
       const int Pk = c.pos_var[S->dur_off[e] + k];
       const double wdat = S->w_data[2], wvel = S->w_vel[2];
       const int nsm = n_smooth(q, s);
-      const double* dat = q->cd + q->o_data[s];
+      const GD* dat = q->cd + q->o_data[s];
       if (tar >= sp.n_var) {
         // ---- (T_k, T_k2), k2 <= k : all residuals of this end-effector
         const int k2 = tar - sp.n_var;
         if (k2 > k) continue;
         double hacc = 0, gacc = 0;
         for (int i = 0; i < F; ++i) {
-          const double* a = scache(q, s, i);
+          const GD* a = scache(q, s, i);
           for (int dm = 0; dm < 3; ++dm) {
             const double gk = -cache_djac(a, dm, k), gk2 = -cache_djac(a, dm, k2);
             hacc += wdat * gk * gk2;
             if (k2 == k) gacc += wdat * (dat[i * 3 + dm] - a[SC_P + dm]) * gk;
           }
           if (i < nsm && wvel >= 0) {
-            const double* b = scache(q, s, i + 1);
+            const GD* b = scache(q, s, i + 1);
             for (int dm = 0; dm < 3; ++dm) {
               const double gk = cache_djac(b, dm, k) - cache_djac(a, dm, k), gk2 = cache_djac(b, dm, k2) - cache_djac(a, dm, k2);
               hacc += wvel * gk * gk2;
@@ -1439,7 +1486,7 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, double* g, const double* l
           }
         }
         if (lam) {     // exact second-order terms collected by the row tasks and the cost pass above
-          const double* tb = q->wd + q->o_d2tab + (long long)e * q->d2_slots * D2_STRIDE;
+          const GD* tb = q->wd + q->o_d2tab + (long long)e * q->d2_slots * D2_STRIDE;
           double h2 = 0;
           for (int sl = 0; sl < q->d2_slots; ++sl) h2 += d2_select(tb + sl * D2_STRIDE, k, k2);
           hacc += h2 / c.sf;
@@ -1454,7 +1501,7 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, double* g, const double* l
         // ---- (T_k, node variable): residuals whose polynomial touches the variable's node(s)
         const int ent = q->ci[q->o_varnode + sp.var_off + tar];
         const int nd = ent / 6, dq0 = (ent % 6) / 3, dm = ent % 3;
-        const int* pinfo = q->ci + q->o_pinfo + sp.poly_off * 4;
+        const GI* pinfo = q->ci + q->o_pinfo + sp.poly_off * 4;
         const int nd_hi = (dq0 == 0 && nd < sp.n_polys && pinfo[nd * 4 + 3]) ? nd + 1 : nd;
         const int pa = nd - 1 < 0 ? 0 : nd - 1, pb = nd_hi > sp.n_polys - 1 ? sp.n_polys - 1 : nd_hi;
         const int i_lo = first[s * fstride + pa];
@@ -1467,11 +1514,11 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, double* g, const double* l
           if (kind > 0) { r_lo = i_lo - 1 < 0 ? 0 : i_lo - 1; if (r_hi > nsm - 1) r_hi = nsm - 1; }
           else if (r_hi > F - 1) r_hi = F - 1;
           for (int i = r_lo; i <= r_hi; ++i) {
-            const double* a = scache(q, s, i);
+            const GD* a = scache(q, s, i);
             Supp su; su.n = 0;
             double gk;
             if (kind == 0) { supp_add_sample(su, a, 0, -1.0); gk = -cache_djac(a, dm, k); }
-            else { const double* b = scache(q, s, i + 1); supp_add_sample(su, b, 0, 1.0); supp_add_sample(su, a, 0, -1.0); gk = cache_djac(b, dm, k) - cache_djac(a, dm, k); }
+            else { const GD* b = scache(q, s, i + 1); supp_add_sample(su, b, 0, 1.0); supp_add_sample(su, a, 0, -1.0); gk = cache_djac(b, dm, k) - cache_djac(a, dm, k); }
             double gt = 0;
             for (int x1 = 0; x1 < su.n; ++x1) if (su.node[x1] >= nd && su.node[x1] <= nd_hi && su.dq[x1] == dq0) gt += su.g[x1];
             hacc += wt * gk * gt;
@@ -1486,7 +1533,7 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, double* g, const double* l
 
 // Full evaluation at x.  Returns the (scaled) objective; fills c_out (scaled rows), and in
 // EV_FULL mode the scaled gradient g and the unfactored KKT matrix K0 = [sf H, (sc J)^T; sc J, 0].
-CHD_DEV double eval_nlp(Ctx& c, const double* x, int mode, double* c_out, double* g, const double* lam = nullptr) {
+CHD_DEV double eval_nlp(Ctx& c, const GD* x, int mode, GD* c_out, GD* g, const GD* lam = nullptr) {
   TIC();
   state_from_x(c, x);
   if (mode == EV_FULL) {
@@ -1517,8 +1564,8 @@ CHD_DEV double eval_nlp(Ctx& c, const double* x, int mode, double* c_out, double
 struct StageResult { int status, iters, n_factor; double kkt, viol, obj, mu; };
 
 CHD_DEV double compl_error(Ctx& c, double mu) {
-  const int* fl = c.q->wi + c.q->o_flags;
-  const double *s = VM(c, VM_S), *l = VM(c, VM_L), *u = VM(c, VM_U), *zL = VM(c, VM_ZL), *zU = VM(c, VM_ZU);
+  const GI* fl = c.q->wi + c.q->o_flags;
+  const GD* s = VM(c, VM_S), *l = VM(c, VM_L), *u = VM(c, VM_U), *zL = VM(c, VM_ZL), *zU = VM(c, VM_ZU);
   double e = 0;
   PAR_FOR(i, c.m) {
     if (fl[i] & RF_L) e = fmax(e, fabs((s[i] - l[i]) * zL[i] - mu));
@@ -1527,9 +1574,9 @@ CHD_DEV double compl_error(Ctx& c, double mu) {
   return block_max(c, e);
 }
 
-CHD_DEV double barrier_val(Ctx& c, const double* ss, double mu) {
-  const int* fl = c.q->wi + c.q->o_flags;
-  const double *l = VM(c, VM_L), *u = VM(c, VM_U);
+CHD_DEV double barrier_val(Ctx& c, const GD* ss, double mu) {
+  const GI* fl = c.q->wi + c.q->o_flags;
+  const GD* l = VM(c, VM_L), *u = VM(c, VM_U);
   double b = 0;
   PAR_FOR(i, c.m) {
     if (fl[i] & RF_L) b -= mu * log(ss[i] - l[i]);
@@ -1538,9 +1585,9 @@ CHD_DEV double barrier_val(Ctx& c, const double* ss, double mu) {
   return block_sum(c, b);
 }
 
-CHD_DEV void residual(Ctx& c, const double* cc, const double* ss, double* r) {
-  const int* fl = c.q->wi + c.q->o_flags;
-  const double* l = VM(c, VM_L);
+CHD_DEV void residual(Ctx& c, const GD* cc, const GD* ss, GD* r) {
+  const GI* fl = c.q->wi + c.q->o_flags;
+  const GD* l = VM(c, VM_L);
   PAR_FOR(i, c.m) r[i] = (fl[i] & RF_EQ) ? cc[i] - l[i] : cc[i] - ss[i];
   CHD_SYNC();
 }
@@ -1548,14 +1595,14 @@ CHD_DEV void residual(Ctx& c, const double* cc, const double* ss, double* r) {
 CHD_NOINLINE CHD_DEV void solve_stage(Ctx& c, StageResult& res) {
   const SeqDesc* q = c.q; const StageDesc* S = c.S;
   const int n = c.n, m = c.m, N = c.N;
-  double *x = VN(c, VN_X), *g = VN(c, VN_G), *dualx = VN(c, VN_DUALX), *dx = VN(c, VN_DX), *xt = VN(c, VN_XT), *xs = VN(c, VN_XS);
-  double *cc = VM(c, VM_C), *s = VM(c, VM_S), *zL = VM(c, VM_ZL), *zU = VM(c, VM_ZU), *lam = VM(c, VM_LAM), *l = VM(c, VM_L), *u = VM(c, VM_U),
+  GD* x = VN(c, VN_X), *g = VN(c, VN_G), *dualx = VN(c, VN_DUALX), *dx = VN(c, VN_DX), *xt = VN(c, VN_XT), *xs = VN(c, VN_XS);
+  GD* cc = VM(c, VM_C), *s = VM(c, VM_S), *zL = VM(c, VM_ZL), *zU = VM(c, VM_ZU), *lam = VM(c, VM_LAM), *l = VM(c, VM_L), *u = VM(c, VM_U),
          *sc = VM(c, VM_SC), *Sig = VM(c, VM_SIGMA), *rs = VM(c, VM_RS), *D = VM(c, VM_D), *r = VM(c, VM_R), *dlam = VM(c, VM_DLAM),
          *ds = VM(c, VM_DS), *dzL = VM(c, VM_DZL), *dzU = VM(c, VM_DZU), *st = VM(c, VM_ST), *ct = VM(c, VM_CT), *rt = VM(c, VM_RT), *ss2 = VM(c, VM_SS2);
-  double *rhs = VK(c, VK_RHS), *sol = VK(c, VK_SOL), *rhs2 = VK(c, VK_RHS2), *sol2 = VK(c, VK_SOL2), *diag = VK(c, VK_DIAG), *t1 = VK(c, VK_T1);
-  int* fl = q->wi + q->o_flags; int* sign = q->wi + q->o_sign;
-  const double* Dw = q->cd + S->o_Dw; const double* cl = q->cd + S->o_cl; const double* cu = q->cd + S->o_cu;
-  const int* pos_var = c.pos_var; const int* pos_row = c.pos_row;
+  GD* rhs = VK(c, VK_RHS), *sol = VK(c, VK_SOL), *rhs2 = VK(c, VK_RHS2), *sol2 = VK(c, VK_SOL2), *diag = VK(c, VK_DIAG), *t1 = VK(c, VK_T1);
+  GI* fl = q->wi + q->o_flags; GI* sign = q->wi + q->o_sign;
+  const GD* Dw = q->cd + S->o_Dw; const GD* cl = q->cd + S->o_cl; const GD* cu = q->cd + S->o_cu;
+  const GI* pos_var = c.pos_var; const GI* pos_row = c.pos_row;
 
   x_from_state(c, x);
   // ---- unscaled evaluation -> gradient-based scaling (nlp_scaling_max_gradient = 100)
@@ -1575,11 +1622,11 @@ CHD_NOINLINE CHD_DEV void solve_stage(Ctx& c, StageResult& res) {
     double rm = 0;
     if (p < c.Nb) {
       const int lo = p - c.w < 0 ? 0 : p - c.w, hi = p + c.w >= c.Nb ? c.Nb - 1 : p + c.w;
-      const double* row = c.K0b + (long long)p * c.W2 + (c.w - p);
+      const GD* row = c.K0b + (long long)p * c.W2 + (c.w - p);
       for (int k = lo; k <= hi; ++k) rm = fmax(rm, fabs(row[k]));
       for (int rr = 0; rr < c.bc; ++rr) rm = fmax(rm, fabs(c.K0x[(long long)rr * c.LD + p]));
     } else {
-      const double* row = c.K0x + (long long)(p - c.Nb) * c.LD;
+      const GD* row = c.K0x + (long long)(p - c.Nb) * c.LD;
       for (int k = 0; k < c.LD; ++k) rm = fmax(rm, fabs(row[k]));
     }
     t1[i] = rm > 100.0 ? fmax(100.0 / rm, 1e-8) : 1.0;
@@ -1791,14 +1838,14 @@ CHD_NOINLINE CHD_DEV void solve_stage(Ctx& c, StageResult& res) {
 // ------------------------------------------------------------------------------------------
 CHD_NOINLINE CHD_DEV void sample_solution(const SeqDesc* q, int snap) {
   const int cap = q->cap;
-  double* od = q->out_d + N_STAGES * RS_STRIDE + (long long)snap * 10 * cap * 3;
-  int* oi = q->out_i;
+  GD* od = q->out_d + N_STAGES * RS_STRIDE + (long long)snap * 10 * cap * 3;
+  GI* oi = q->out_i;
   const double tot = q->wd[q->o_ttot + 0];                 // solution.base_linear_->GetTotalTime() (:69)
   // number of samples of `while (t <= tot + 1e-5)` with t accumulated by += dt
   int ns = 0;
   { double t = 0; while (t <= tot + 1e-5 && ns < cap) { ++ns; t += q->dt; } }
   if (CHD_TID == 0) { oi[snap * 2] = ns; oi[snap * 2 + 1] = (int)((tot + 1e-5) / q->dt) + 1; }
-  const double* tc = q->cd + q->o_tcost;
+  const GD* tc = q->cd + q->o_tcost;
   PAR_FOR(idx, ns * 10) {
     const int i = idx / 10, b = idx % 10;
     double t = 0;
@@ -1806,7 +1853,7 @@ CHD_NOINLINE CHD_DEV void sample_solution(const SeqDesc* q, int snap) {
     PE e;
     const int s = b < 2 ? b : (b < 6 ? b : b);          // blocks: 0 base_lin, 1 base_ang, 2..5 ee_pos, 6..9 ee_force
     spline_eval(q, s, t, e);
-    double* o = od + ((long long)b * cap + i) * 3;
+    GD* o = od + ((long long)b * cap + i) * 3;
     if (b == 1) for (int k = 0; k < 3; ++k) o[k] = e.p[k] / M_PI * 180;     // :97
     else for (int k = 0; k < 3; ++k) o[k] = e.p[k];
     if (b >= 2 && b < 6) {
@@ -1850,12 +1897,12 @@ CHD_DEV void init_state(const SeqDesc* q) {
 CHD_DEV void run_sequence(const SeqDesc* q, LdsD* lds, int lds_cap, double tol, int stage_first, int stage_last) {
   Ctx c;
   c.lds = lds; c.lds_cap = lds_cap;
-  for (int k = 0; k < 16; ++k) c.tacc[k] = 0;
+  for (int k = 0; k < 24; ++k) c.tacc[k] = 0;
   const long long t_begin = CHD_CLOCK();
   if (stage_first == 0) init_state(q);
   else refresh_durations(q);
   for (int stage = stage_first; stage <= stage_last; ++stage) {
-    double* rs = q->out_d + stage * RS_STRIDE;
+    GD* rs = q->out_d + stage * RS_STRIDE;
     if (!q->st[stage].valid) { if (CHD_TID == 0) { rs[RS_STATUS] = -3; rs[RS_ITERS] = 0; } continue; }
     bind_stage(c, q, stage);
     c.tol = tol;
@@ -1872,8 +1919,8 @@ CHD_DEV void run_sequence(const SeqDesc* q, LdsD* lds, int lds_cap, double tol, 
   }
   if (CHD_TID == 0) {      // phase timers (100 MHz wall clock ticks), accumulated over launches
     c.tacc[5] = CHD_CLOCK() - t_begin;
-    double* tm = q->out_d + N_STAGES * RS_STRIDE + 3LL * 10 * q->cap * 3;
-    for (int k = 0; k < 16; ++k) tm[k] += (double)c.tacc[k];
+    GD* tm = q->out_d + N_STAGES * RS_STRIDE + 3LL * 10 * q->cap * 3;
+    for (int k = 0; k < 24; ++k) tm[k] += (double)c.tacc[k];
   }
 }
 
@@ -1881,11 +1928,11 @@ CHD_DEV void run_sequence(const SeqDesc* q, LdsD* lds, int lds_cap, double tol, 
 CHD_DEV void debug_eval(const SeqDesc* q, int stage, int use_x, LdsD* lds, int lds_cap, double* f_out, int use_lam = 0) {
   Ctx c;
   c.lds = lds; c.lds_cap = lds_cap;
-  for (int k = 0; k < 16; ++k) c.tacc[k] = 0;
+  for (int k = 0; k < 24; ++k) c.tacc[k] = 0;
   init_state(q);
   bind_stage(c, q, stage);
   c.tol = 1e-3;
-  double* x = VN(c, VN_X);
+  GD* x = VN(c, VN_X);
   if (use_x) { PAR_FOR(j, c.n) x[j] = VN(c, VN_XT)[j]; CHD_SYNC(); state_from_x(c, x); }
   x_from_state(c, x);
   PAR_FOR(i, c.m) VM(c, VM_SC)[i] = 1.0;

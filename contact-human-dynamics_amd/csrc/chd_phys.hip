@@ -187,9 +187,9 @@ int chd_batch_upload(chd_handle* h, int B, const chd_seq_in* in, chd_batch** out
   b->descs.resize(B);
   for (int i = 0; i < B; ++i) {
     SeqDesc dd = b->models[i].d;
-    dd.cd = b->d_cd + b->off_cd[i]; dd.ci = b->d_ci + b->off_ci[i];
-    dd.wd = b->d_wd + b->off_wd[i]; dd.wi = b->d_wi + b->off_wi[i];
-    dd.out_d = b->d_od + b->off_od[i]; dd.out_i = b->d_oi + b->off_oi[i];
+    dd.cd = (const GD*)(b->d_cd + b->off_cd[i]); dd.ci = (const GI*)(b->d_ci + b->off_ci[i]);
+    dd.wd = (GD*)(b->d_wd + b->off_wd[i]); dd.wi = (GI*)(b->d_wi + b->off_wi[i]);
+    dd.out_d = (GD*)(b->d_od + b->off_od[i]); dd.out_i = (GI*)(b->d_oi + b->off_oi[i]);
     b->descs[i] = dd;
   }
   if ((e = hipMemcpy(b->d_descs, b->descs.data(), sizeof(SeqDesc) * B, hipMemcpyHostToDevice)) != hipSuccess) return bail("copy descs", e);
@@ -295,7 +295,7 @@ int chd_batch_solve(chd_handle* h, chd_batch* b) {
       b->stats.alg_bytes += it * b->models[i].alg_bytes_iter[stg];
     }
     const double* tm = s + N_STAGES * RS_STRIDE + 3LL * 10 * b->models[i].d.cap * 3;     // 100 MHz ticks
-    for (int k = 0; k < 16; ++k) b->stats.phase_ms[k] += tm[k] * 1e-5;
+    for (int k = 0; k < 24; ++k) b->stats.phase_ms[k] += tm[k] * 1e-5;
     if (tm[5] * 1e-5 > b->stats.max_seq_ms) b->stats.max_seq_ms = tm[5] * 1e-5;
   }
   return 0;

@@ -40,7 +40,7 @@ class ChdSeqOut(C.Structure):
 class ChdBatchStats(C.Structure):
     _fields_ = [('kernel_ms', C.c_double * 2), ('host_ms', C.c_double), ('total_iters', C.c_longlong),
                 ('total_factorizations', C.c_longlong), ('alg_bytes', C.c_double), ('n_fallback', C.c_int),
-                ('phase_ms', C.c_double * 16), ('max_seq_ms', C.c_double)]
+                ('phase_ms', C.c_double * 24), ('max_seq_ms', C.c_double)]
 
 
 def default_config(**kw):

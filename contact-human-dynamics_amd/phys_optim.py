@@ -119,7 +119,7 @@ class Batch:
         self.solver._check(self.solver.L.chd_batch_get_stats(self.solver.h, self.h, C.byref(st)), 'chd_batch_get_stats')
         return dict(kernel_ms=[st.kernel_ms[0], st.kernel_ms[1]], host_ms=st.host_ms, total_iters=st.total_iters,
                     total_factorizations=st.total_factorizations, alg_bytes=st.alg_bytes, n_fallback=st.n_fallback,
-                    phase_ms=[st.phase_ms[i] for i in range(16)], max_seq_ms=st.max_seq_ms)
+                    phase_ms=[st.phase_ms[i] for i in range(24)], max_seq_ms=st.max_seq_ms)
 
     def fetch(self):
         B = len(self.seqs)

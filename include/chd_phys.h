@@ -123,7 +123,7 @@ typedef struct chd_batch_stats {
   long long total_factorizations;
   double alg_bytes;
   int n_fallback;              /* sequences that needed stage 4 */
-  double phase_ms[16];         /* in-kernel wall-clock per phase, summed over sequences: 0 evaluation (f, grad, c, J, H), 1 evaluation (values only),
+  double phase_ms[24];         /* in-kernel wall-clock per phase, summed over sequences: 0 evaluation (f, grad, c, J, H), 1 evaluation (values only),
                                   2 factorisation, 3 substitution, 4 KKT mat-vec, 5 whole sequence,
                                   6-12 factorisation sub-phases (copy, panel load, diagonal block, row solves, write-back, trailing update, border) */
   double max_seq_ms;           /* slowest single sequence (in-kernel wall clock) */

@@ -14,8 +14,9 @@
 //   * symmetric indefinite (quasi-definite) KKT solve  [H+dw*Dw  J^T; J  -D].
 // Deliberate differences from IPOPT (the reference binary cannot be run here, so
 // its iterates are not reproducible anyway; SURVEY.md §7 "Hard parts"):
-//   * Hessian: Gauss-Newton Hessian of the sum-of-squares objective plus an adaptive
-//     Levenberg damping dw*Dw, instead of L-BFGS(6);
+//   * Hessian: Gauss-Newton Hessian of the sum-of-squares objective, plus the exact duration-duration
+//     block of the Lagrangian Hessian when the phase durations are variables (nlp_model.hpp), plus an
+//     adaptive Levenberg damping dw*Dw, instead of L-BFGS(6);
 //   * globalisation: l1 merit function with backtracking instead of the filter +
 //     restoration phase;
 //   * mu_init = 1e-3 and mu-based bound multipliers for the warm-started stages;
@@ -200,34 +201,6 @@ struct BorderedBandLDL {
 };
 
 
-// EXPERIMENT (not part of the restated algorithm): second-order information for the duration
-// variables by finite differences of grad f + J^T lam.
-inline void fd_duration_hessian(Problem& P, const std::vector<double>& x, const std::vector<double>& lam_unscaled_by_row,
-                                const std::vector<double>& graw, const std::vector<double>& Jraw, std::vector<double>& H, int mode) {
-  const int n = P.n, m = P.m, nd0 = P.n_nodesvars;
-  if (n == nd0 || mode == 0) return;
-  std::vector<double> base(n, 0.0), xp(x), gp(n), cp(m), Jp((size_t)m * n), col(n);
-  for (int j = 0; j < n; ++j) { double v = graw[j]; for (int i = 0; i < m; ++i) v += Jraw[(size_t)i * n + j] * lam_unscaled_by_row[i]; base[j] = v; }
-  const double h = 1e-6;
-  std::vector<std::vector<double>> cols;
-  for (int k = nd0; k < n; ++k) {
-    xp = x; xp[k] += h;
-    double f2;
-    P.eval(xp.data(), &f2, gp.data(), cp.data(), Jp.data(), nullptr);
-    for (int j = 0; j < n; ++j) { double v = gp[j]; for (int i = 0; i < m; ++i) v += Jp[(size_t)i * n + j] * lam_unscaled_by_row[i]; col[j] = (v - base[j]) / h; }
-    cols.push_back(col);
-  }
-  for (int k = nd0; k < n; ++k) {
-    const std::vector<double>& c = cols[k - nd0];
-    for (int j = (mode == 2 ? 0 : nd0); j < n; ++j) {
-      double v = c[j];
-      if (j >= nd0) v = 0.5 * (c[j] + cols[j - nd0][k]);
-      H[(size_t)k * n + j] = v; H[(size_t)j * n + k] = v;
-    }
-  }
-  P.set_x(x.data());
-}
-
 // -----------------------------------------------------------------------------
 inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
   IpmResult res;
@@ -243,7 +216,6 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
   std::vector<double> Dw(n, 1.0);
   const double fscale = P.in.mass * kGravity / 4.0;
   for (int j = 0; j < n; ++j) if (vkind[j] == 1) Dw[j] = 1.0 / (fscale * fscale);
-  { const char* e_ = std::getenv("ORC_DUR_W"); if (e_) { double dwv = std::atof(e_); for (int j = 0; j < n; ++j) if (vkind[j] == 2) Dw[j] = dwv; } }
 
   // ---- first evaluation, scaling ------------------------------------------
   P.eval(x.data(), &fraw, graw.data(), craw.data(), J.data(), H.data());
@@ -393,15 +365,13 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
     for (int i = 0; i < m; ++i) { if (pos_row[i] >= Nb) continue; const double* Jr = &J[(size_t)i * n]; for (int j = 0; j < n; ++j) if (Jr[j] != 0.0 && pos_var[j] < Nb) w = std::max(w, std::abs(pos_row[i] - pos_var[j])); }
     res.bandwidth = std::max(res.bandwidth, w);
 
-    std::vector<double> Dwe(Dw);
-    { static const char* e_ = std::getenv("ORC_MARQ"); if (e_) { double eps_ = std::atof(e_); for (int a = 0; a < n; ++a) Dwe[a] = std::max(Dw[a] * eps_, H[(size_t)a * n + a]); } }
     bool ok = false, used_soc = false; double alpha = 0, a_du = 1.0; int nls = 0, attempt = 0;
     for (attempt = 0; attempt < opt.max_attempts; ++attempt) {
       K.resize(Nb, bcount, w);
       for (int a = 0; a < n; ++a) {
         const double* Hr = &H[(size_t)a * n];
         for (int b2 = 0; b2 < a; ++b2) if (Hr[b2] != 0.0) K.add(pos_var[a], pos_var[b2], Hr[b2]);
-        K.add(pos_var[a], pos_var[a], Hr[a] + dw * Dwe[a]);
+        K.add(pos_var[a], pos_var[a], Hr[a] + dw * Dw[a]);
       }
       for (int i = 0; i < m; ++i) {
         const double* Jr = &J[(size_t)i * n];
@@ -409,7 +379,7 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
         K.add(pos_row[i], pos_row[i], -D[i]);
       }
       K.factor(); ++res.n_factor;
-      K.solve(rhs.data(), sol.data(), 1);   // one step of iterative refinement (iteration counts are insensitive to 0/1/2 on the test set)
+      K.solve(rhs.data(), sol.data(), 1);      // one step of iterative refinement
       for (int j = 0; j < n; ++j) dx[j] = sol[pos_var[j]];
       for (int i = 0; i < m; ++i) dlam[i] = sol[pos_row[i]];
       double a_pr = 1.0; a_du = 1.0;
@@ -425,7 +395,7 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
       double cn = 0; for (int i = 0; i < m; ++i) cn += std::fabs(r[i]);
       double gdx = 0; for (int j = 0; j < n; ++j) gdx += g[j] * dx[j];
       double dHd = 0;
-      for (int a = 0; a < n; ++a) { const double* Hr = &H[(size_t)a * n]; double sum = 0; for (int b2 = 0; b2 < n; ++b2) sum += Hr[b2] * dx[b2]; dHd += dx[a] * sum + dw * Dwe[a] * dx[a] * dx[a]; }
+      for (int a = 0; a < n; ++a) { const double* Hr = &H[(size_t)a * n]; double sum = 0; for (int b2 = 0; b2 < n; ++b2) sum += Hr[b2] * dx[b2]; dHd += dx[a] * sum + dw * Dw[a] * dx[a] * dx[a]; }
       dHd += sSds;
       double dphi_bar = gdx + dbar;
       if (cn > 1e-14) { double nut = (dphi_bar + 0.5 * std::max(dHd, 0.0)) / ((1 - 0.1) * cn); if (nut > nu) nu = nut * 1.1 + 1e-8; }

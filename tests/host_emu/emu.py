@@ -89,7 +89,7 @@ class EmuProblem:
 
     def results(self):
         cap = self.sizes(0)['cap']
-        od = np.zeros(6 * 8 + 3 * 10 * cap * 3 + 16); oi = np.zeros(8 + 3 * 4 * cap, dtype=np.int32)
+        od = np.zeros(6 * 8 + 3 * 10 * cap * 3 + 24); oi = np.zeros(8 + 3 * 4 * cap, dtype=np.int32)
         lib().emu_get_out(self.h, _p(od), oi.ctypes.data_as(C.POINTER(C.c_int)))
         stats = od[:48].reshape(6, 8)
         snaps = []
