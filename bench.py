@@ -54,9 +54,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=4)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--batch', type=int, default=BATCH, help=argparse.SUPPRESS)
-    ap.add_argument('--pipeline', type=int, default=2,
+    ap.add_argument('--pipeline', type=int, default=4,
                     help='steps in flight at once, each on its own HIP stream (1 = strictly one batch after the other)')
     ap.add_argument('--no-cpu-baseline', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()

@@ -1354,6 +1354,7 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, GD* g, const GD* lam) {
     for (int p = pp + 1; p <= pi; ++p) first[s * fstride + p] = i;
   }
   CHD_SYNC();
+  long long tg_ = CHD_CLOCK();
   // ---- node variables: one thread per (spline, node group, dimension)
   int tot_nodes = 0;
   for (int s = 0; s < 6; ++s) tot_nodes += q->sp[s].n_nodes;
@@ -1375,6 +1376,12 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, GD* g, const GD* lam) {
     const int ti = s < 2 ? s : 2;
     const double wdat = S->w_data[ti], wvel = S->w_vel[ti], wacc = S->w_acc[ti];
     const GD* dat = q->cd + q->o_data[s];
+    // Contributions are summed in thread-private accumulators keyed by (own node value, neighbour node value) and
+    // written to the KKT storage once each (instead of one global read-modify-write per residual).
+    enum { NSLOT = 24 };
+    double hloc[4][NSLOT], gloc[4];
+    for (int a = 0; a < 4; ++a) { gloc[a] = 0.0; for (int b = 0; b < NSLOT; ++b) hloc[a][b] = 0.0; }
+    const int nbase = nd - 4;
     // residual kinds: 0 data(i), 1 position difference (i, i+1), 2 velocity difference (i, i+1)
     for (int kind = 0; kind < 3; ++kind) {
       const double wt = kind == 0 ? wdat : kind == 1 ? wvel : wacc;
@@ -1394,20 +1401,40 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, GD* g, const GD* lam) {
         }
         for (int x1 = 0; x1 < su.n; ++x1) {
           if (su.node[x1] < nd || su.node[x1] > nd_hi) continue;
-          const int v = vo[su.node[x1] * 6 + su.dq[x1] * 3 + dim];
-          if (v < 0) continue;
-          const int gv = sp.var_off + v, P = c.pos_var[gv];
-          g[gv] += c.sf * wt * r * su.g[x1];
+          const int oi = (su.node[x1] - nd) * 2 + su.dq[x1];
+          gloc[oi] += wt * r * su.g[x1];
           for (int x2 = 0; x2 < su.n; ++x2) {
-            const int v2 = vo[su.node[x2] * 6 + su.dq[x2] * 3 + dim];
-            if (v2 < 0) continue;
-            const int Q = c.pos_var[sp.var_off + v2];
-            if (Q <= P) kadd(c, P, Q, c.sf * wt * su.g[x1] * su.g[x2]);
+            const int sl = (su.node[x2] - nbase) * 2 + su.dq[x2];
+            if (sl >= 0 && sl < NSLOT) hloc[oi][sl] += wt * su.g[x1] * su.g[x2];
+            else {      // support wider than the accumulator window (very short polynomials): write through
+              const int v = vo[su.node[x1] * 6 + su.dq[x1] * 3 + dim], v2 = vo[su.node[x2] * 6 + su.dq[x2] * 3 + dim];
+              if (v >= 0 && v2 >= 0) { const int P = c.pos_var[sp.var_off + v], Q = c.pos_var[sp.var_off + v2]; if (Q <= P) kadd(c, P, Q, c.sf * wt * su.g[x1] * su.g[x2]); }
+            }
           }
         }
       }
     }
+    for (int oi = 0; oi < 4; ++oi) {
+      const int node = nd + oi / 2, dq = oi % 2;
+      if (node > nd_hi) continue;
+      const int v = vo[node * 6 + dq * 3 + dim];
+      if (v < 0) continue;
+      const int gv = sp.var_off + v, P = c.pos_var[gv];
+      g[gv] += c.sf * gloc[oi];
+      for (int sl = 0; sl < NSLOT; ++sl) {
+        const double val = hloc[oi][sl];
+        if (val == 0.0) continue;
+        const int n2 = nbase + sl / 2;
+        if (n2 < 0 || n2 >= sp.n_nodes) continue;
+        const int v2 = vo[n2 * 6 + (sl % 2) * 3 + dim];
+        if (v2 < 0) continue;
+        const int Q = c.pos_var[sp.var_off + v2];
+        if (Q <= P) kadd(c, P, Q, c.sf * val);
+      }
+    }
   }
+  CHD_SYNC();
+  c.tacc[13] += CHD_CLOCK() - tg_; tg_ = CHD_CLOCK();
   // ---- duration variables (stage 3 only)
   if (S->opt_dur && lam) {
     // residual-weighted curvature of the cost terms, one table slot per data sample:
@@ -1450,6 +1477,8 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, GD* g, const GD* lam) {
       }
     }
   }
+  CHD_SYNC();
+  c.tacc[14] += CHD_CLOCK() - tg_; tg_ = CHD_CLOCK();
   if (S->opt_dur) {
     int tot = 0;
     for (int e = 0; e < 4; ++e) tot += (q->n_phase[e] - 1) * (q->sp[2 + e].n_var + q->n_phase[e] - 1);
@@ -1529,6 +1558,7 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, GD* g, const GD* lam) {
     }
   }
   CHD_SYNC();
+  c.tacc[15] += CHD_CLOCK() - tg_;
 }
 
 // Full evaluation at x.  Returns the (scaled) objective; fills c_out (scaled rows), and in
@@ -1544,12 +1574,16 @@ CHD_DEV double eval_nlp(Ctx& c, const GD* x, int mode, GD* c_out, GD* g, const G
     }
   }
   fill_sample_cache(c);      // ends with a sync (also orders kzero before the kadd's below)
+  if (mode == EV_FULL) c.tacc[21] += CHD_CLOCK() - tic_;
+  long long te_ = CHD_CLOCK();
   eval_rows(c, mode, c_out, lam);
   const double f = c.sf * eval_cost_value(c);
   if (mode == EV_FULL) {
     CHD_SYNC();
+    c.tacc[22] += CHD_CLOCK() - te_; te_ = CHD_CLOCK();
     eval_cost_grad_hess(c, g, lam);
     c.err = block_max(c, (double)c.err) > 0.5 ? 1 : 0;     // a band overflow seen by any thread
+    c.tacc[23] += CHD_CLOCK() - te_;
   }
   CHD_SYNC();
   TOC(c, mode == EV_FULL ? 0 : 1);

@@ -58,3 +58,55 @@ def test_solve_matches_oracle(solver, oracle_lib, seed, F):
             assert e[key] < 1e-3, (k, key, e)
     for stg in range(len(ostats)):
         assert r.stage_status[stg] == ostats[stg][0]
+
+
+def test_batch_slot_independence_and_constraints(solver):
+    """Full-size property checks (no oracle needed): a sequence gives bit-identical results wherever it sits in a
+    batch and whatever its neighbours are (owner-computes accumulation, fixed-tree reductions), every stage reports
+    a small constraint violation, and the contact flags of the first two snapshots follow the input schedule."""
+    seqs = [make_walk(seed=s, F=90, randomize=True) for s in range(12)]
+    res_a, _ = solver.solve(seqs)
+    order = [7, 3, 11, 0, 5]
+    res_b, _ = solver.solve([seqs[i] for i in order])
+    for j, i in enumerate(order):
+        for k in range(3):
+            a, b = res_a[i].snapshots[k], res_b[j].snapshots[k]
+            assert np.array_equal(a.base_lin, b.base_lin) and np.array_equal(a.ee_force, b.ee_force) and np.array_equal(a.ee_pos, b.ee_pos)
+        assert res_a[i].stage_iters == res_b[j].stage_iters
+    for i, r in enumerate(res_a):
+        for stg in range(5):
+            assert r.stage_status[stg] in (0, -1, -2)
+            if r.stage_status[stg] == 0:
+                assert r.stage_constr_viol[stg] < 1e-3
+        for k in range(3):
+            assert r.snapshots[k].base_lin.shape == (90, 3) and np.isfinite(r.snapshots[k].ee_force).all()
+        toe_l = np.asarray(seqs[i].contacts[:, 1])
+        assert np.abs(r.snapshots[0].contact[0][:-1] - toe_l[:-1]).sum() <= len(seqs[i].durations[0])
+        # stance feet do not move: the foot position is constant wherever the solver says "contact" (snapshot before durations move)
+        c0 = r.snapshots[1].contact[0].astype(bool)
+        p0 = r.snapshots[1].ee_pos[0]
+        runs = np.flatnonzero(c0[1:] & c0[:-1])
+        assert np.abs(p0[runs + 1] - p0[runs]).max() < 1e-9
+
+
+def test_file_interface_round_trip(solver, tmp_path):
+    """chd_phys_solve_dirs: the four input files in, the three solution files + success_log out, parsed by the
+    line-indexed reader of towr_utils.load_results; identical to the in-memory interface."""
+    from chd_amd import io_formats as iof
+    seq = make_walk(seed=2, F=40, randomize=True)
+    din = str(tmp_path / 'phys_optim_in_ybot'); dout = str(tmp_path / 'phys_optim_out_ybot')
+    iof.write_inputs(seq, din)
+    import os
+    os.makedirs(dout)
+    st = solver.solve_dirs([din], [dout], [seq.F])
+    assert st == [0]
+    assert sorted(os.listdir(dout)) == ['sol_out_durations.txt', 'sol_out_dynamics.txt', 'sol_out_no_dynamics.txt', 'success_log.txt']
+    mem, _ = solver.solve([iof.read_inputs(din, seq.F)])
+    for k, name in enumerate(('sol_out_no_dynamics.txt', 'sol_out_dynamics.txt', 'sol_out_durations.txt')):
+        sol = iof.load_results(os.path.join(dout, name))
+        assert sol.num_frames == seq.F
+        assert np.allclose(sol.base_lin, mem[0].snapshots[k].base_lin, rtol=1e-8, atol=1e-9)
+        assert np.allclose(sol.ee_force, mem[0].snapshots[k].ee_force, rtol=1e-8, atol=1e-7)
+        assert np.array_equal(sol.contact, mem[0].snapshots[k].contact)
+    log = open(os.path.join(dout, 'success_log.txt')).read().split()
+    assert log[0] == 'dynamics' and log[2] == 'durations' and log[1] in '01' and log[3] in '01'
