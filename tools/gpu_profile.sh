@@ -8,7 +8,7 @@ cd $R
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 tail -c 2500 $OUT/bench.json
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/trace_bench.json 2> $OUT/trace.err
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $R/bench.py --no-cpu-baseline > $OUT/trace_bench.json 2> $OUT/trace.err
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o fetch -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/fetch_bench.json 2> $OUT/fetch.err
 timeout 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o write -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/write_bench.json 2> $OUT/write.err
 find $OUT -type f | head -40
