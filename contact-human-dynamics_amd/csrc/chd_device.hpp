@@ -59,6 +59,7 @@ struct StageDesc {
   double w_data[3], w_vel[3], w_acc[3], w_dur;
   // offsets into ci
   int o_pos_var, o_pos_row, o_task;     // task: 4 ints (type, a, b, row0)
+  int o_env;                            // 2 ints per band position: first / last coupled band position (envelope of the KKT matrix)
   // offsets into cd
   int o_cl, o_cu, o_Dw, o_task_t;
 };

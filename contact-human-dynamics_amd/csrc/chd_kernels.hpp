@@ -96,6 +96,7 @@ struct Ctx {
   int n, m, N, Nb, bc, w, W2, LD;
   GD* K0b; GD* K0x; GD* Kfb; GD* Kfx;
   const GI* pos_var; const GI* pos_row;
+  const GI* env;        // [2p] first, [2p+1] last band position coupled to p (envelope)
   double sf;            // objective scaling
   double tol;           // IPOPT tol of the stage (phys_optim.cpp:578)
   int err;              // sticky error flag (band overflow), uniform across the workgroup after a sync
@@ -421,7 +422,7 @@ CHD_NOINLINE CHD_DEV void kmatvec(Ctx& c, const GD* x, GD* y, const GD* diag) {
   TIC();
   const int Nb = c.Nb, w = c.w, W2 = c.W2, LD = c.LD, bc = c.bc;
   GROUP_FOR(i, Nb) {
-    const int lo = i - w < 0 ? 0 : i - w, hi = i + w >= Nb ? Nb - 1 : i + w;
+    const int lo = c.env[2 * i], hi = c.env[2 * i + 1];      // nothing is stored outside the envelope
     const GD* row = c.K0b + (long long)i * W2 + (w - i);
     double acc = 0, acc1 = 0, acc2 = 0, acc3 = 0;
     int k = lo + lane_;
@@ -531,14 +532,40 @@ CHD_DEV void diag_block(Ctx& c, const GI* sign, LdsD* dv, LdsD* PT, const int ld
 }
 #endif
 
-// ---- trailing update: window -= L_below D L_below^T (lower triangle) ------------------------------
+// ---- active rows of a panel's window (sorted): u in [0, wr) with u >= nbelow (border) or efirst[i0 + u] <= last_col
+#ifdef CHD_HOST_EMU
+CHD_DEV void build_active_rows(Ctx& c, int* act, int* nact, int wr, int nbelow, int i0, int last_col) {
+  int n = 0;
+  for (int u = 0; u < wr; ++u) if (u >= nbelow || c.env[2 * (i0 + u)] <= last_col) act[n++] = u;
+  *nact = n;
+}
+#else
+typedef __attribute__((address_space(3))) int LdsI;
+CHD_DEV void build_active_rows(Ctx& c, int* act_, int* nact_, int wr, int nbelow, int i0, int last_col) {
+  if (threadIdx.x < 64) {       // one wavefront: ballot + prefix count keeps the list sorted
+    LdsI* act = (LdsI*)act_; LdsI* nact = (LdsI*)nact_;
+    int base = 0;
+    for (int u0 = 0; u0 < wr; u0 += 64) {
+      const int u = u0 + threadIdx.x;
+      const bool on = u < wr && (u >= nbelow || c.env[2 * (i0 + u)] <= last_col);
+      const unsigned long long m = __ballot(on);
+      if (on) act[base + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = u;
+      base += __popcll(m);
+    }
+    if (threadIdx.x == 0) *nact = base;
+  }
+}
+#endif
+
+// ---- trailing update: window -= L_below D L_below^T (lower triangle), restricted to the active rows ----------
 // window rows/cols u = 0..wr-1 live at PT rows NB+u; u < nbelow are band rows i0+u, the rest border rows
 #ifdef CHD_HOST_EMU
 template <int NB>
-CHD_DEV void trailing_update(Ctx& c, const LdsD* dv, const LdsD* PT, const int ldp, const int wr, const int nbelow, const int i0) {
+CHD_DEV void trailing_update(Ctx& c, const LdsD* dv, const LdsD* PT, const int ldp, const int wr, const int nbelow, const int i0, const int* act, const int nact) {
   const int W1 = c.w + 1, w = c.w, LD = c.LD, Nb = c.Nb;
-  for (int ur = 0; ur < wr; ++ur)
-    for (int uc = 0; uc <= ur; ++uc) {
+  for (int tr = 0; tr < nact; ++tr)
+    for (int tc = 0; tc <= tr; ++tc) {
+      const int ur = act[tr], uc = act[tc];
       double v = 0;
       for (int j = 0; j < NB; ++j) v += PT[j * ldp + NB + ur] * (PT[j * ldp + NB + uc] * dv[j]);
       if (ur < nbelow) { const int i = i0 + ur, k = i0 + uc; c.Kfb[(long long)i * W1 + (k - i + w)] -= v; }
@@ -548,16 +575,18 @@ CHD_DEV void trailing_update(Ctx& c, const LdsD* dv, const LdsD* PT, const int l
 }
 #else
 typedef double chd_f64x4 __attribute__((ext_vector_type(4)));
-// one 16x16 output tile per wavefront pass, K = NB in steps of 4 on the fp64 matrix core
+// one 16x16 tile of the COMPACTED window per wavefront pass, K = NB in steps of 4 on the fp64 matrix core
 // (v_mfma_f64_16x16x4_f64: A[row = lane & 15][k = lane >> 4], B[k = lane >> 4][col = lane & 15],
 //  D[row = (lane >> 4) + 4 * reg][col = lane & 15])
 template <int NB>
-CHD_DEV void trailing_update(Ctx& c, const LdsD* dv, const LdsD* PT, const int ldp, const int wr, const int nbelow, const int i0) {
+CHD_DEV void trailing_update(Ctx& c, const LdsD* dv, const LdsD* PT, const int ldp, const int wr, const int nbelow, const int i0, const int* act_, const int nact) {
   const int W1 = c.w + 1, w = c.w, LD = c.LD, Nb = c.Nb;
+  const LdsI* act = (const LdsI*)act_;
   const int wave = threadIdx.x >> 6, nwv = blockDim.x >> 6, lane = threadIdx.x & 63;
   const int lr = lane & 15, lk = lane >> 4;
-  const int nt = (wr + 15) >> 4;
+  const int nt = (nact + 15) >> 4;
   const int ntri = nt * (nt + 1) / 2;
+  const int zrow = wr + 8;          // a zero (padding) row of the panel
   auto tile_of = [](int t, int& tr, int& tc) {
     tr = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
     while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
@@ -581,13 +610,15 @@ CHD_DEV void trailing_update(Ctx& c, const LdsD* dv, const LdsD* PT, const int l
       const bool live = t < ntri;
       int tr, tc;
       tile_of(live ? t : t0, tr, tc);
-      const int uc = 16 * tc + lr;
-      pa[u] = PT + NB + 16 * tr + lr; pb[u] = PT + NB + 16 * tc + lr;
+      const int ira = 16 * tr + lr, icb = 16 * tc + lr;           // compact indices of this lane's A row / B column
+      const int ua = ira < nact ? act[ira] : zrow, ub = icb < nact ? act[icb] : zrow;
+      pa[u] = PT + NB + ua; pb[u] = PT + NB + ub;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int ur = 16 * tr + lk + 4 * r;
-        ok[u][r] = live && ur < wr && uc <= ur;
-        pd[u][r] = dest(ok[u][r] ? ur : 0, ok[u][r] ? uc : 0);
+        const int irr = 16 * tr + lk + 4 * r;                     // compact row index of D register r
+        ok[u][r] = live && irr < nact && icb < nact && icb <= irr;
+        const int ur = ok[u][r] ? act[irr] : 0;
+        pd[u][r] = dest(ok[u][r] ? ur : 0, ok[u][r] ? ub : 0);
         old_[u][r] = ok[u][r] ? *pd[u][r] : 0.0;
       }
     }
@@ -628,25 +659,31 @@ CHD_NOINLINE CHD_DEV void kfactor_band(Ctx& c, const GI* sign, LdsD* dv, LdsD* P
       double v[8];
       const bool band = a < jb || (a >= NB && a < NB + nbelow), bord = a >= NB + nbelow && a < pr;
       const int i = c0 + (a < jb ? a : jb + a - NB);
-      const double* src = band ? c.Kfb + (long long)i * W1 + (c0 + j0 - i + w) : c.Kfx + (long long)(bord ? a - NB - nbelow : 0) * LD + c0 + j0;
+      const GD* src = band ? c.Kfb + (long long)i * W1 + (c0 + j0 - i + w) : c.Kfx + (long long)(bord ? a - NB - nbelow : 0) * LD + c0 + j0;
+      const int ef = band ? c.env[2 * i] : 0;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int j = j0 + q, k = c0 + j;
-        const bool ok = j < jb && ((band && k <= i && i - k <= w) || bord);
+        const bool ok = j < jb && ((band && k <= i && k >= ef) || bord);
         v[q] = ok ? src[q] : 0.0;
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q) PT[(j0 + q) * ldp + a] = (j0 + q >= jb && a == j0 + q) ? 1.0 : v[q];
     }
+    // window rows that this panel can touch: band rows whose envelope reaches the panel, and every border row
+    int* act = (int*)(PT + (long long)ldp * NB);
+    int* nact_p = act + (w + bc + 64);
+    build_active_rows(c, act, nact_p, pr - NB, nbelow, c0 + jb, c0 + jb - 1);
     CHD_SYNC();
+    const int nact = *nact_p;
     c.tacc[7] += CHD_CLOCK() - tp_; tp_ = CHD_CLOCK();
     // ---- (A) NB x NB diagonal block: unit-lower L in place, pivots to dv
     diag_block<NB>(c, sign, dv, PT, ldp, c0, jb);
     CHD_SYNC();
     c.tacc[8] += CHD_CLOCK() - tp_; tp_ = CHD_CLOCK();
     // ---- (B) rows below: y_j = A(a,j) - sum_{k<j} y_k L(j,k);  L(a,j) = y_j / d_j   (one thread per row)
-    PAR_FOR(a2, pr - NB) {
-      const int a = NB + a2;
+    PAR_FOR(t2, nact) {           // compacted: inactive rows stay zero
+      const int a = NB + act[t2];
       double y[NB];
 #pragma unroll
       for (int j = 0; j < NB; ++j) y[j] = PT[j * ldp + a];
@@ -666,13 +703,15 @@ CHD_NOINLINE CHD_DEV void kfactor_band(Ctx& c, const GI* sign, LdsD* dv, LdsD* P
       if (a >= jb && a < NB) continue;
       const bool band = a < jb || a < NB + nbelow;
       const int i = c0 + (a < jb ? a : jb + a - NB);
-      double* dst = band ? c.Kfb + (long long)i * W1 + (c0 + j0 - i + w) : c.Kfx + (long long)(a - NB - nbelow) * LD + c0 + j0;
+      GD* dst = band ? c.Kfb + (long long)i * W1 + (c0 + j0 - i + w) : c.Kfx + (long long)(a - NB - nbelow) * LD + c0 + j0;
+      const int ef = band ? c.env[2 * i] : 0;
+      if (band && a >= NB && ef > c0 + jb - 1) continue;      // row untouched by this panel
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int j = j0 + q, k = c0 + j;
         if (j >= jb) break;
         if (band) {
-          if (k < i && i - k <= w) dst[q] = PT[j * ldp + a];
+          if (k < i && k >= ef) dst[q] = PT[j * ldp + a];
           else if (k == i) dst[q] = dv[j];
         } else dst[q] = PT[j * ldp + a];
       }
@@ -680,7 +719,7 @@ CHD_NOINLINE CHD_DEV void kfactor_band(Ctx& c, const GI* sign, LdsD* dv, LdsD* P
     CHD_SYNC();
     c.tacc[10] += CHD_CLOCK() - tp_; tp_ = CHD_CLOCK();
     // ---- trailing update of the window
-    trailing_update<NB>(c, dv, PT, ldp, pr - NB, nbelow, c0 + jb);
+    trailing_update<NB>(c, dv, PT, ldp, pr - NB, nbelow, c0 + jb, act, nact);
     CHD_SYNC();
     c.tacc[11] += CHD_CLOCK() - tp_;
   }
@@ -724,8 +763,8 @@ CHD_NOINLINE CHD_DEV void kfactor(Ctx& c, const GD* diag, const GI* sign) {
   c.tacc[6] += CHD_CLOCK() - tic_;
   // panel width from the LDS budget
   LdsD* dv = c.lds + LDS_RED;            // pivots of the current panel (<= 32)
-  LdsD* PT = dv + 32;                    // panel
-  const int avail = c.lds_cap - LDS_RED - 32;
+  LdsD* PT = dv + 32;                    // panel (the list of active window rows follows it)
+  const int avail = c.lds_cap - LDS_RED - 32 - (w + bc + 64) / 2 - 8;      // ints of the active-row list
   int nb = 32;
   while (nb > 8 && (long long)(nb + w + bc + 18) * nb > avail) nb >>= 1;
   const int ldp = (nb + w + bc + 17) | 1;  // odd leading dimension (conflict-free column walks), >= 16 rows of zero padding
@@ -827,7 +866,7 @@ CHD_DEV void ksolve_impl(Ctx& c, const GD* rhs, GD* x, YP y, SP Sp, const int ld
     ts_ = CHD_CLOCK();
     GROUP_FOR(a, jb) {
       const int i = c0 + a;
-      const int lo = i - w < 0 ? 0 : i - w;
+      const int lo = c.env[2 * i];          // L(i, k) = 0 left of the envelope
       const GD* row = c.Kfb + (long long)i * W1 + (w - i);
       double acc = 0, acc1 = 0, acc2 = 0, acc3 = 0;
       int k = lo + lane_;
@@ -899,7 +938,8 @@ CHD_DEV void ksolve_impl(Ctx& c, const GD* rhs, GD* x, YP y, SP Sp, const int ld
     const int k0 = c0 - w < 0 ? 0 : c0 - w;
     for (int k = k0 + CHD_TID; k < c0; k += CHD_NT) {
       // rows i = c0 + a reach column k while i - k <= w
-      const int amax = (w - (c0 - k)) < jb - 1 ? (w - (c0 - k)) : jb - 1;
+      int amax = (w - (c0 - k)) < jb - 1 ? (w - (c0 - k)) : jb - 1;
+      if (c.env[2 * k + 1] - c0 < amax) amax = c.env[2 * k + 1] - c0;      // no row beyond this one reaches column k
       const GD* col = c.Kfb + (long long)c0 * W1 + (k - c0 + w);      // L(c0 + a, k) = col[a * (W1 - 1)]
       double acc = 0, acc1 = 0, acc2 = 0, acc3 = 0;
       int a = 0;
@@ -1908,7 +1948,7 @@ CHD_DEV void bind_stage(Ctx& c, const SeqDesc* q, int stage) {
   c.n = c.S->n; c.m = c.S->m; c.N = c.n + c.m; c.Nb = c.S->Nb; c.bc = c.S->bc; c.w = c.S->w;
   c.W2 = 2 * c.w + 1; c.LD = c.N;
   c.K0b = q->wd + q->o_K0b; c.K0x = q->wd + q->o_K0x; c.Kfb = q->wd + q->o_Kfb; c.Kfx = q->wd + q->o_Kfx;
-  c.pos_var = q->ci + c.S->o_pos_var; c.pos_row = q->ci + c.S->o_pos_row;
+  c.pos_var = q->ci + c.S->o_pos_var; c.pos_row = q->ci + c.S->o_pos_row; c.env = q->ci + c.S->o_env;
   c.sf = 1.0; c.err = 0; c.n_bad_pivots = 0;
 }
 

@@ -565,6 +565,43 @@ class SeqModel {
         }
       }
     }
+    // ---- envelope of the banded part: efirst[p] / elast[p] = smallest / largest band position coupled to p.
+    // L D L^T without pivoting keeps its fill inside this envelope, so the substitution, the mat-vec and the panel
+    // row solves only visit [efirst[p], p] (and by symmetry up to elast[p]).
+    std::vector<int> efirst(Nb), elast(Nb);
+    for (int p = 0; p < Nb; ++p) { efirst[p] = p; elast[p] = p; }
+    auto couple = [&](const std::vector<int>& pos) {       // all positions in `pos` are mutually coupled
+      int lo = 1 << 30, hi = -1;
+      for (int p : pos) if (p < Nb) { lo = std::min(lo, p); hi = std::max(hi, p); }
+      if (hi < 0) return;
+      for (int p : pos) if (p < Nb) { efirst[p] = std::min(efirst[p], lo); elast[p] = std::max(elast[p], hi); }
+    };
+    {
+      std::vector<int> pos;
+      for (int i = 0; i < m; ++i) {      // a row couples with each of its variables (not the variables with each other)
+        if (pos_row[i] >= Nb) continue;
+        for (int v : sup_wide[i]) { pos.assign({pos_row[i], pos_var[v]}); couple(pos); }
+      }
+      for (int s = 0; s < 6; ++s) {      // Gauss-Newton couplings of the cost terms, per dimension
+        const HostSpline& h = hs[s];
+        const double* tc = &cd[d.o_tcost];
+        for (int i = 0; i + 1 < d.F + 1; ++i) {
+          int p0 = locate(pe[s], tc[i]), p1 = locate(pe[s], tc[std::min(i + 1, d.F)]);
+          int lo = std::min(p0, p1), hi = std::max(p0, p1);
+          if (S.opt_dur && h.phase_based) {
+            const double t0 = lo > 0 ? pe[s][lo - 1] : 0.0;
+            if (tc[i] - t0 < kSlack && lo > 0) --lo;
+            if (pe[s][hi] - tc[std::min(i + 1, d.F)] < kSlack && hi + 1 < h.n_polys) ++hi;
+          }
+          for (int k = 0; k < 3; ++k) {
+            pos.clear();
+            for (int nd = lo; nd <= hi + 1; ++nd)
+              for (int dq = 0; dq < 2; ++dq) { int v = h.var_of[nd * 6 + dq * 3 + k]; if (v >= 0) pos.push_back(pos_var[h.var_off + v]); }
+            couple(pos);
+          }
+        }
+      }
+    }
     S.w = w; S.valid = 1;
 
     // ---- store
@@ -572,10 +609,10 @@ class SeqModel {
       int mcap = m, tcap = S.n_tasks;
       if (stage == 5) { int extra = n_height_cand; mcap = m + extra; tcap = S.n_tasks + extra; }   // durations may have moved
       stage_m_cap[stage] = mcap; stage_task_cap[stage] = tcap;
-      S.o_pos_var = reserve_i(n); S.o_pos_row = reserve_i(mcap); S.o_task = reserve_i(4 * tcap);
+      S.o_pos_var = reserve_i(n); S.o_pos_row = reserve_i(mcap); S.o_task = reserve_i(4 * tcap); S.o_env = reserve_i(2 * (n + mcap));
       S.o_cl = reserve_d(mcap); S.o_cu = reserve_d(mcap); S.o_Dw = reserve_d(n); S.o_task_t = reserve_d(tcap);
     } else {
-      S.o_pos_var = keep.o_pos_var; S.o_pos_row = keep.o_pos_row; S.o_task = keep.o_task;
+      S.o_pos_var = keep.o_pos_var; S.o_pos_row = keep.o_pos_row; S.o_task = keep.o_task; S.o_env = keep.o_env;
       S.o_cl = keep.o_cl; S.o_cu = keep.o_cu; S.o_Dw = keep.o_Dw; S.o_task_t = keep.o_task_t;
       if (m > stage_m_cap[stage] || S.n_tasks > stage_task_cap[stage] || w > w_cap || bc > bc_cap || n + m > N_cap) S.valid = 0;
     }
@@ -583,6 +620,12 @@ class SeqModel {
       std::copy(pos_var.begin(), pos_var.end(), ci.begin() + S.o_pos_var);
       std::copy(pos_row.begin(), pos_row.end(), ci.begin() + S.o_pos_row);
       std::copy(task.begin(), task.end(), ci.begin() + S.o_task);
+      {   // second entry: last row whose envelope reaches column p (covers the fill-in of the factor as well)
+        std::vector<int> clast(Nb);
+        for (int p = 0; p < Nb; ++p) clast[p] = elast[p];
+        for (int i = 0; i < Nb; ++i) for (int k = efirst[i]; k <= i; ++k) clast[k] = std::max(clast[k], i);
+        for (int p = 0; p < Nb; ++p) { ci[S.o_env + 2 * p] = efirst[p]; ci[S.o_env + 2 * p + 1] = clast[p]; }
+      }
       std::copy(cl.begin(), cl.end(), cd.begin() + S.o_cl);
       std::copy(cu.begin(), cu.end(), cd.begin() + S.o_cu);
       std::copy(Dw.begin(), Dw.end(), cd.begin() + S.o_Dw);

@@ -261,8 +261,8 @@ int chd_batch_solve(chd_handle* h, chd_batch* b) {
       const StageDesc& S = M.d.st[5];
       b->descs[i].st[5] = S;
       if (S.valid) {
-        // the stage's regions are contiguous in the pools: [o_pos_var, o_task + 4*task_cap) and [o_cl, o_task_t + task_cap)
-        const long long i0 = S.o_pos_var, i1 = S.o_task + 4LL * M.stage_task_cap[5];
+        // the stage's regions are contiguous in the pools: [o_pos_var, o_env + 2*(n + m_cap)) and [o_cl, o_task_t + task_cap)
+        const long long i0 = S.o_pos_var, i1 = S.o_env + 2LL * (S.n + M.stage_m_cap[5]);
         const long long d0 = S.o_cl, d1 = S.o_task_t + (long long)M.stage_task_cap[5];
         HIP_TRY(h, hipMemcpy(b->d_ci + b->off_ci[i] + i0, M.ci.data() + i0, (i1 - i0) * 4, hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(b->d_cd + b->off_cd[i] + d0, M.cd.data() + d0, (d1 - d0) * 8, hipMemcpyHostToDevice));

@@ -110,3 +110,24 @@ void emu_get_out(void* h, double* od, int* oi) {
   std::copy(e->out_i.begin(), e->out_i.end(), oi);
 }
 }
+
+// envelope statistics of the unfactored KKT matrix of `stage` at the initial point (analysis helper)
+extern "C" void emu_envelope(void* h, int stage, double* out) {
+  Emu* e = (Emu*)h; e->bind();
+  double fo[2];
+  debug_eval(&e->M.d, stage, 0, e->lds.data(), (int)e->lds.size(), fo);
+  Ctx c; c.lds = e->lds.data(); c.lds_cap = (int)e->lds.size();
+  bind_stage(c, &e->M.d, stage);
+  long long env = 0, band = 0;
+  int maxreach = 0;
+  std::vector<int> hist(8, 0);
+  for (int i = 0; i < c.Nb; ++i) {
+    int first = i;
+    for (int k = std::max(0, i - c.w); k < i; ++k) if (c.K0b[(long long)i * c.W2 + (k - i + c.w)] != 0.0) { first = k; break; }
+    env += i - first; band += std::min(i, c.w);
+    maxreach = std::max(maxreach, i - first);
+    hist[std::min(7, (i - first) * 8 / (c.w + 1))]++;
+  }
+  out[0] = (double)env; out[1] = (double)band; out[2] = maxreach; out[3] = c.w; out[4] = c.Nb;
+  for (int k = 0; k < 8; ++k) out[5 + k] = hist[k];
+}
