@@ -73,6 +73,7 @@ namespace chd {
 #define CHD_CONSTR_VIOL_TOL 1e-4
 #define CHD_MAX_BACKTRACK 3
 #define CHD_MAX_ATTEMPTS 12
+#define CHD_STALL_WINDOW 150
 #define CHD_G 9.80665
 #define CHD_MU_FRICTION 0.5
 #define CHD_INF 1e19
@@ -84,7 +85,7 @@ enum { VN_X = 0, VN_G, VN_DUALX, VN_DX, VN_XT, VN_XS, VN_COUNT };
 enum { VM_C = 0, VM_S, VM_ZL, VM_ZU, VM_LAM, VM_L, VM_U, VM_SC, VM_SIGMA, VM_RS, VM_D, VM_R, VM_DLAM, VM_DS, VM_DZL, VM_DZU,
        VM_ST, VM_CT, VM_RT, VM_SS2, VM_COUNT };
 // N-sized vectors
-enum { VK_RHS = 0, VK_SOL, VK_RHS2, VK_SOL2, VK_T1, VK_T2, VK_DIAG, VK_Y, VK_COUNT };
+enum { VK_RHS = 0, VK_SOL, VK_RHS2, VK_SOL2, VK_T1, VK_T2, VK_DIAG, VK_Y, VK_HIST, VK_COUNT };
 // row flags
 enum { RF_EQ = 1, RF_L = 2, RF_U = 4 };
 
@@ -1521,14 +1522,14 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, GD* g, const GD* lam) {
   c.tacc[14] += CHD_CLOCK() - tg_; tg_ = CHD_CLOCK();
   if (S->opt_dur) {
     int tot = 0;
-    for (int e = 0; e < 4; ++e) tot += (q->n_phase[e] - 1) * (q->sp[2 + e].n_var + q->n_phase[e] - 1);
-    PAR_FOR(idx0, tot) {
+    for (int e = 0; e < 4; ++e) tot += (q->n_phase[e] - 1) * (q->n_phase[e] - 1);
+    PAR_FOR(idx0, tot) {       // (T_k, T_k2) entries
       int idx = idx0, e = 0;
-      while (idx >= (q->n_phase[e] - 1) * (q->sp[2 + e].n_var + q->n_phase[e] - 1)) { idx -= (q->n_phase[e] - 1) * (q->sp[2 + e].n_var + q->n_phase[e] - 1); ++e; }
+      while (idx >= (q->n_phase[e] - 1) * (q->n_phase[e] - 1)) { idx -= (q->n_phase[e] - 1) * (q->n_phase[e] - 1); ++e; }
       const int s = 2 + e;
       const SplineDesc& sp = q->sp[s];
-      const int ntar = sp.n_var + q->n_phase[e] - 1;
-      const int k = idx / ntar, tar = idx % ntar;
+      const int ntar = q->n_phase[e] - 1;
+      const int k = idx / ntar, tar = sp.n_var + idx % ntar;
       const int Pk = c.pos_var[S->dur_off[e] + k];
       const double wdat = S->w_data[2], wvel = S->w_vel[2];
       const int nsm = n_smooth(q, s);
@@ -1566,34 +1567,61 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, GD* g, const GD* lam) {
         }
         kadd(c, Pk, c.pos_var[S->dur_off[e] + k2], c.sf * hacc);
         if (k2 == k) g[S->dur_off[e] + k] = c.sf * gacc;
-      } else {
-        // ---- (T_k, node variable): residuals whose polynomial touches the variable's node(s)
-        const int ent = q->ci[q->o_varnode + sp.var_off + tar];
-        const int nd = ent / 6, dq0 = (ent % 6) / 3, dm = ent % 3;
-        const GI* pinfo = q->ci + q->o_pinfo + sp.poly_off * 4;
-        const int nd_hi = (dq0 == 0 && nd < sp.n_polys && pinfo[nd * 4 + 3]) ? nd + 1 : nd;
-        const int pa = nd - 1 < 0 ? 0 : nd - 1, pb = nd_hi > sp.n_polys - 1 ? sp.n_polys - 1 : nd_hi;
-        const int i_lo = first[s * fstride + pa];
-        int i_hi = first[s * fstride + pb + 1] - 1;
-        double hacc = 0;
-        for (int kind = 0; kind < 2; ++kind) {
-          const double wt = kind == 0 ? wdat : wvel;
-          if (wt < 0) continue;
-          int r_lo = i_lo, r_hi = i_hi;
-          if (kind > 0) { r_lo = i_lo - 1 < 0 ? 0 : i_lo - 1; if (r_hi > nsm - 1) r_hi = nsm - 1; }
-          else if (r_hi > F - 1) r_hi = F - 1;
-          for (int i = r_lo; i <= r_hi; ++i) {
+      }
+    }
+    // ---- (T_k, node variable) entries: one thread per node variable of an ee-motion spline gathers the residuals
+    // that touch the variable's node(s) once and accumulates the entries of up to 8 durations at a time in registers
+    int tot_v = 0;
+    for (int e = 0; e < 4; ++e) tot_v += q->sp[2 + e].n_var;
+    PAR_FOR(idx0, tot_v) {
+      int tar = idx0, e = 0;
+      while (tar >= q->sp[2 + e].n_var) { tar -= q->sp[2 + e].n_var; ++e; }
+      const int s = 2 + e;
+      const SplineDesc& sp = q->sp[s];
+      const int nv = q->n_phase[e] - 1;
+      const double wdat = S->w_data[2], wvel = S->w_vel[2];
+      const int nsm = n_smooth(q, s);
+      const int ent = q->ci[q->o_varnode + sp.var_off + tar];
+      const int nd = ent / 6, dq0 = (ent % 6) / 3, dm = ent % 3;
+      const GI* pinfo = q->ci + q->o_pinfo + sp.poly_off * 4;
+      const int nd_hi = (dq0 == 0 && nd < sp.n_polys && pinfo[nd * 4 + 3]) ? nd + 1 : nd;
+      const int pa = nd - 1 < 0 ? 0 : nd - 1, pb = nd_hi > sp.n_polys - 1 ? sp.n_polys - 1 : nd_hi;
+      const int i_lo = first[s * fstride + pa];
+      const int i_hi = first[s * fstride + pb + 1] - 1;
+      const int Pv = c.pos_var[sp.var_off + tar];
+      // weight of this variable in p(t_i): the sample's polynomial touches node poly (side 0) and poly + 1 (side 1)
+      auto own_weight = [&](const GD* a) -> double {
+        const int poly = (int)a[SC_POLY];
+        double g_ = 0;
+        if (poly >= nd && poly <= nd_hi) g_ += a[SC_WP + dq0];
+        if (poly + 1 >= nd && poly + 1 <= nd_hi) g_ += a[SC_WP + 2 + dq0];
+        return g_;
+      };
+      for (int k0 = 0; k0 < nv; k0 += 8) {
+        double hk[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) hk[kk] = 0.0;
+        if (wdat >= 0) {
+          const int r_hi = i_hi > F - 1 ? F - 1 : i_hi;
+          for (int i = i_lo; i <= r_hi; ++i) {
             const GD* a = scache(q, s, i);
-            Supp su; su.n = 0;
-            double gk;
-            if (kind == 0) { supp_add_sample(su, a, 0, -1.0); gk = -cache_djac(a, dm, k); }
-            else { const GD* b = scache(q, s, i + 1); supp_add_sample(su, b, 0, 1.0); supp_add_sample(su, a, 0, -1.0); gk = cache_djac(b, dm, k) - cache_djac(a, dm, k); }
-            double gt = 0;
-            for (int x1 = 0; x1 < su.n; ++x1) if (su.node[x1] >= nd && su.node[x1] <= nd_hi && su.dq[x1] == dq0) gt += su.g[x1];
-            hacc += wt * gk * gt;
+            const double gt = -wdat * own_weight(a);             // r = data - p
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) if (k0 + kk < nv) hk[kk] += gt * (-cache_djac(a, dm, k0 + kk));
           }
         }
-        if (hacc != 0.0) kadd(c, Pk, c.pos_var[sp.var_off + tar], c.sf * hacc);
+        if (wvel >= 0) {
+          const int r_lo = i_lo - 1 < 0 ? 0 : i_lo - 1, r_hi = i_hi > nsm - 1 ? nsm - 1 : i_hi;
+          for (int i = r_lo; i <= r_hi; ++i) {
+            const GD* a = scache(q, s, i); const GD* b = scache(q, s, i + 1);
+            const double gt = wvel * (own_weight(b) - own_weight(a));      // r = p_{i+1} - p_i
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) if (k0 + kk < nv) hk[kk] += gt * (cache_djac(b, dm, k0 + kk) - cache_djac(a, dm, k0 + kk));
+          }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+          if (k0 + kk < nv && hk[kk] != 0.0) kadd(c, c.pos_var[S->dur_off[e] + k0 + kk], Pv, c.sf * hk[kk]);
       }
     }
   }
@@ -1766,6 +1794,17 @@ CHD_NOINLINE CHD_DEV void solve_stage(Ctx& c, StageResult& res) {
     e_d = d1 / s_d;
     E0 = fmax(e_d, fmax(e_p, compl_error(c, 0.0) / s_c));
     if (E0 <= tol_ && e_pu <= CHD_CONSTR_VIOL_TOL) { status = 0; break; }
+    // stall guard: no factor-2 reduction of the optimality error over the last CHD_STALL_WINDOW iterations -> status -2
+    // instead of running to the iteration cap (stage 3 then takes the reference's stage-4 fallback, phys_optim.cpp:714)
+    {
+      GD* hist = VK(c, VK_HIST);
+      const int slot = it % CHD_STALL_WINDOW;
+      const bool stalled = it >= CHD_STALL_WINDOW && E0 > 0.5 * hist[slot];
+      CHD_SYNC();
+      if (stalled) { status = -2; break; }
+      if (CHD_TID == 0) hist[slot] = E0;
+      CHD_SYNC();
+    }
     // ---- monotone barrier update
     while (true) {
       const double Emu = fmax(e_d, fmax(e_p, compl_error(c, mu) / s_c));

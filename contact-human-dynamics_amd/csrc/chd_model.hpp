@@ -651,7 +651,7 @@ class SeqModel {
   }
 
   // ---- workspace layout ---------------------------------------------------------
-  enum { NV_N = 10, NV_M = 24, NV_NN = 8 };    // number of n-, m- and N-sized solver vectors (chd_kernels.hpp)
+  enum { NV_N = 10, NV_M = 24, NV_NN = 9 };    // number of n-, m- and N-sized solver vectors (chd_kernels.hpp)
   void layout_workspace() {
     long long o = 0;
     auto take = [&](long long cnt) { long long r = o; o += (cnt + 1) & ~1LL; return (int)r; };

@@ -12,6 +12,7 @@
 //   * termination on IPOPT's scaled optimality error E_0 <= tol (tol = 1e-3 is
 //     the reference's option, phys_optim.cpp:578),
 //   * symmetric indefinite (quasi-definite) KKT solve  [H+dw*Dw  J^T; J  -D].
+//   * a stall guard (optimality error not halved within 150 iterations => status -2).
 // Deliberate differences from IPOPT (the reference binary cannot be run here, so
 // its iterates are not reproducible anyway; SURVEY.md §7 "Hard parts"):
 //   * Hessian: Gauss-Newton Hessian of the sum-of-squares objective, plus the exact duration-duration
@@ -333,6 +334,7 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
   std::vector<double> Sigma(m), rs(m), D(m), rhs(N), sol(N), dx(n), dlam(m), ds(m), dzL(m), dzU(m);
   std::vector<double> xt(n), st(m), ct(m), rt(m), Hdx(n), rhs2(N), sol2(N), xs(n), ss2(m), lraw(m);
   int status = -1, it = 0;
+  std::vector<double> e0_hist(150, 0.0);
   double last_alpha = 0; int last_nls = 0, last_att = 0; bool last_soc = false;
   for (it = 0; it < opt.max_iter; ++it) {
     double E0 = errors(0.0);
@@ -340,6 +342,13 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
     if (opt.verbose) { int wi = 0; double wv = 0; for (int i = 0; i < m; ++i) { double v = std::fabs(eq[i] ? c[i] - l[i] : c[i] - s[i]); if (v > wv) { wv = v; wi = i; } } std::printf("[worst row %d fam %d eq %d c=%.4e s=%.4e l=%.3e u=%.3e lam=%.3e] ", wi, P.row_family[wi], (int)eq[wi], c[wi], s[wi], l[wi], u[wi], lam[wi]); }
     if (opt.verbose) std::printf("%4d f=%.6e E0=%.2e (d %.1e p %.1e pu %.1e c %.1e) mu=%.1e nu=%.1e dw=%.1e | last a=%.2e nls=%d att=%d soc=%d\n", it, f / sf, E0, e_d, e_p, e_p_unscaled, e_c, mu, nu, dw, last_alpha, last_nls, last_att, (int)last_soc);
     if (E0 <= tol && e_p_unscaled <= opt.constr_viol_tol) { status = 0; break; }
+    // stall guard: no factor-2 reduction of the optimality error over the last 150 iterations -> give up (status -2,
+    // "numerical failure") instead of running to the iteration cap; stage 3 then takes the reference's stage-4 fallback
+    {
+      const int W = 150;
+      if (it >= W && E0 > 0.5 * e0_hist[it % W]) { status = -2; break; }
+      e0_hist[it % W] = E0;
+    }
     while (true) {
       double Emu = errors(mu);
       if (Emu <= kappa_eps * mu && mu > tol / 10) mu = std::max(tol / 10, std::min(kappa_mu * mu, std::pow(mu, theta_mu)));
