@@ -150,6 +150,13 @@ CHD_DEV double group_sum(double v) {
   return v;
 }
 #endif
+#ifdef CHD_HOST_EMU
+#define CHD_PAIR 1
+CHD_DEV double pair_sum(double v) { return v; }
+#else
+#define CHD_PAIR 2
+CHD_DEV double pair_sum(double v) { return v + __shfl_xor(v, 1); }
+#endif
 #define LDS_RED 64     // doubles reserved at the start of lds for the reductions
 
 // ------------------------------------------------------------------------------------------
@@ -793,9 +800,10 @@ CHD_NOINLINE CHD_DEV void kfactor(Ctx& c, const GD* diag, const GI* sign) {
 
 // in-block triangular solves for the substitution (wave-cooperative on the device)
 #define CHD_SOLVE_NB 64
+#define CHD_TILE_LD 65
 #ifdef CHD_HOST_EMU
 template <class YP>
-CHD_DEV void tri_forward(Ctx& c, YP y, int c0, int jb) {
+CHD_DEV void tri_forward(Ctx& c, YP y, int c0, int jb, const LdsD*) {
   const int W1 = c.w + 1, w = c.w;
   for (int i = 1; i < jb; ++i) {
     double s = y[c0 + i];
@@ -804,7 +812,7 @@ CHD_DEV void tri_forward(Ctx& c, YP y, int c0, int jb) {
   }
 }
 template <class YP>
-CHD_DEV void tri_backward(Ctx& c, YP y, int c0, int jb) {
+CHD_DEV void tri_backward(Ctx& c, YP y, int c0, int jb, const LdsD*) {
   const int W1 = c.w + 1, w = c.w;
   for (int i = jb - 2; i >= 0; --i) {
     double s = y[c0 + i];
@@ -816,15 +824,20 @@ CHD_DEV void tri_backward(Ctx& c, YP y, int c0, int jb) {
 // lane i owns row c0+i of the 64x64 diagonal block; its entries are fetched up front (independent loads) so that
 // the dependent chain below runs out of registers
 template <class YP>
-CHD_NOINLINE CHD_DEV void tri_forward(Ctx& c, YP y, int c0, int jb) {
+CHD_NOINLINE CHD_DEV void tri_forward(Ctx& c, YP y, int c0, int jb, const LdsD* tile) {
   if (threadIdx.x < 64) {
     const int W1 = c.w + 1, w = c.w, i = threadIdx.x;
     const bool act = i < jb;
     double yi = act ? y[c0 + i] : 0.0;
-    const GD* row = c.Kfb + (long long)(c0 + (act ? i : 0)) * W1 + (w - (act ? i : 0));
     double l[CHD_SOLVE_NB];
+    if (tile) {
 #pragma unroll
-    for (int j = 0; j < CHD_SOLVE_NB; ++j) l[j] = (act && j < i) ? row[j] : 0.0;
+      for (int j = 0; j < CHD_SOLVE_NB; ++j) l[j] = (act && j < i) ? tile[i * CHD_TILE_LD + j] : 0.0;
+    } else {
+      const GD* row = c.Kfb + (long long)(c0 + (act ? i : 0)) * W1 + (w - (act ? i : 0));
+#pragma unroll
+      for (int j = 0; j < CHD_SOLVE_NB; ++j) l[j] = (act && j < i) ? row[j] : 0.0;
+    }
 #pragma unroll
     for (int j = 0; j < CHD_SOLVE_NB - 1; ++j) {
       const double yj = __shfl(yi, j);
@@ -834,14 +847,19 @@ CHD_NOINLINE CHD_DEV void tri_forward(Ctx& c, YP y, int c0, int jb) {
   }
 }
 template <class YP>
-CHD_NOINLINE CHD_DEV void tri_backward(Ctx& c, YP y, int c0, int jb) {
+CHD_NOINLINE CHD_DEV void tri_backward(Ctx& c, YP y, int c0, int jb, const LdsD* tile) {
   if (threadIdx.x < 64) {
     const int W1 = c.w + 1, w = c.w, i = threadIdx.x;
     const bool act = i < jb;
     double yi = act ? y[c0 + i] : 0.0;
     double l[CHD_SOLVE_NB];
+    if (tile) {
 #pragma unroll
-    for (int j = 0; j < CHD_SOLVE_NB; ++j) l[j] = (act && j > i && j < jb) ? c.Kfb[(long long)(c0 + j) * W1 + (i - j + w)] : 0.0;
+      for (int j = 0; j < CHD_SOLVE_NB; ++j) l[j] = (act && j > i && j < jb) ? tile[j * CHD_TILE_LD + i] : 0.0;
+    } else {
+#pragma unroll
+      for (int j = 0; j < CHD_SOLVE_NB; ++j) l[j] = (act && j > i && j < jb) ? c.Kfb[(long long)(c0 + j) * W1 + (i - j + w)] : 0.0;
+    }
 #pragma unroll
     for (int j = CHD_SOLVE_NB - 1; j > 0; --j) {
       const double yj = __shfl(yi, j);
@@ -852,9 +870,24 @@ CHD_NOINLINE CHD_DEV void tri_backward(Ctx& c, YP y, int c0, int jb) {
 }
 #endif
 
+// strictly-lower part of the diagonal block of `Kf` starting at c0 -> LDS tile (coalesced along the rows)
+CHD_DEV void load_diag_tile(Ctx& c, LdsD* tile, int c0, int jb) {
+  const int W1 = c.w + 1, w = c.w;
+  PAR_FOR(t, CHD_SOLVE_NB * 8) {            // 8 tasks per row, 8 consecutive entries each, loads issued together
+    const int a = t >> 3, j0 = (t & 7) << 3;
+    if (a >= jb || j0 >= a) continue;
+    const GD* src = c.Kfb + (long long)(c0 + a) * W1 + (j0 - a + w);
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = (j0 + q < a) ? src[q] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) if (j0 + q < a) tile[a * CHD_TILE_LD + j0 + q] = v[q];
+  }
+}
+
 // x = K^{-1} rhs using the factor.  y: work vector of N doubles, S: the dense border factor (both in LDS when they fit).
 template <class YP, class SP>
-CHD_DEV void ksolve_impl(Ctx& c, const GD* rhs, GD* x, YP y, SP Sp, const int lds_, const bool stage_s) {
+CHD_DEV void ksolve_impl(Ctx& c, const GD* rhs, GD* x, YP y, SP Sp, const int lds_, const bool stage_s, LdsD* tile) {
   const int Nb = c.Nb, w = c.w, W1 = c.w + 1, LD = c.LD, bc = c.bc, N = c.N;
   PAR_FOR(i, N) y[i] = rhs[i];
   if (stage_s) PAR_FOR(idx, bc * bc) { const int r = idx / bc, k = idx % bc; Sp[idx] = c.Kfx[(long long)r * LD + Nb + k]; }
@@ -879,9 +912,10 @@ CHD_DEV void ksolve_impl(Ctx& c, const GD* rhs, GD* x, YP y, SP Sp, const int ld
       acc = group_sum((acc + acc1) + (acc2 + acc3));
       if (lane_ == 0) y[i] -= acc;
     }
+    if (tile) load_diag_tile(c, tile, c0, jb);
     CHD_SYNC();
     c.tacc[16] += CHD_CLOCK() - ts_; ts_ = CHD_CLOCK();
-    tri_forward(c, y, c0, jb);
+    tri_forward(c, y, c0, jb, tile);
     CHD_SYNC();
     c.tacc[17] += CHD_CLOCK() - ts_;
   }
@@ -929,11 +963,12 @@ CHD_DEV void ksolve_impl(Ctx& c, const GD* rhs, GD* x, YP y, SP Sp, const int ld
   c.tacc[18] += CHD_CLOCK() - ts_;
   // backward, band
   const int nblk = (Nb + nb - 1) / nb;
+  if (tile) { load_diag_tile(c, tile, (nblk - 1) * nb, Nb - (nblk - 1) * nb); CHD_SYNC(); }
   for (int bk = nblk - 1; bk >= 0; --bk) {
     const int c0 = bk * nb;
     const int jb = Nb - c0 < nb ? Nb - c0 : nb;
     ts_ = CHD_CLOCK();
-    tri_backward(c, y, c0, jb);
+    tri_backward(c, y, c0, jb, tile);
     CHD_SYNC();
     c.tacc[19] += CHD_CLOCK() - ts_; ts_ = CHD_CLOCK();
     const int k0 = c0 - w < 0 ? 0 : c0 - w;
@@ -951,6 +986,7 @@ CHD_DEV void ksolve_impl(Ctx& c, const GD* rhs, GD* x, YP y, SP Sp, const int ld
       for (; a <= amax; ++a) acc += col[(long long)a * (W1 - 1)] * y[c0 + a];
       y[k] -= (acc + acc1) + (acc2 + acc3);
     }
+    if (tile && bk > 0) load_diag_tile(c, tile, c0 - nb, nb);
     CHD_SYNC();
     c.tacc[20] += CHD_CLOCK() - ts_;
   }
@@ -962,9 +998,13 @@ CHD_NOINLINE CHD_DEV void ksolve_once(Ctx& c, const GD* rhs, GD* x) {
   TIC();
   const int N = c.N, bc = c.bc, Npad = (N + 1) & ~1;
   const int room = c.lds_cap - LDS_RED;
-  if (room >= Npad + bc * bc) ksolve_impl(c, rhs, x, c.lds + LDS_RED, c.lds + LDS_RED + Npad, bc, true);
-  else if (room >= N) ksolve_impl(c, rhs, x, c.lds + LDS_RED, c.Kfx + c.Nb, c.LD, false);
-  else ksolve_impl(c, rhs, x, VK(c, VK_Y), c.Kfx + c.Nb, c.LD, false);
+  const int tsz = CHD_SOLVE_NB * CHD_TILE_LD + 1;
+  LdsD* base = c.lds + LDS_RED;
+  if (room >= Npad + bc * bc + tsz) ksolve_impl(c, rhs, x, base, base + Npad, bc, true, base + Npad + bc * bc);
+  else if (room >= Npad + bc * bc) ksolve_impl(c, rhs, x, base, base + Npad, bc, true, (LdsD*)nullptr);
+  else if (room >= Npad + tsz) ksolve_impl(c, rhs, x, base, c.Kfx + c.Nb, c.LD, false, base + Npad);
+  else if (room >= N) ksolve_impl(c, rhs, x, base, c.Kfx + c.Nb, c.LD, false, (LdsD*)nullptr);
+  else ksolve_impl(c, rhs, x, VK(c, VK_Y), c.Kfx + c.Nb, c.LD, false, (LdsD*)nullptr);
   TOC(c, 3);
 }
 
@@ -1862,14 +1902,11 @@ CHD_NOINLINE CHD_DEV void solve_stage(Ctx& c, StageResult& res) {
         ds[i] = dsi; dzL[i] = dl; dzU[i] = du;
       }
       a_pr = block_min(c, a_pr); a_du = block_min(c, adu); dbar = block_sum(c, dbar); sSds = block_sum(c, sSds);
-      // dx^T (H + dw Dw) dx through K0 [dx; 0]
-      PAR_FOR(i, N) t1[i] = 0.0;
-      CHD_SYNC();
-      PAR_FOR(j, n) t1[pos_var[j]] = dx[j];
-      CHD_SYNC();
-      kmatvec(c, t1, sol2, nullptr);
+      // dx^T (H + dw Dw) dx without a mat-vec, from the two block rows of the KKT system just solved:
+      //   (H + dw Dw) dx + J^T dlam = -dualx ,   J dx - D dlam = rhs_row
       double dHd = 0; gdx = 0;
-      PAR_FOR(j, n) { dHd += dx[j] * (sol2[pos_var[j]] + dw * Dw[j] * dx[j]); gdx += g[j] * dx[j]; }
+      PAR_FOR(j, n) { dHd -= dx[j] * dualx[j]; gdx += g[j] * dx[j]; }
+      PAR_FOR(i, m) dHd -= (rhs[pos_row[i]] + D[i] * dlam[i]) * dlam[i];
       dHd = block_sum(c, dHd) + sSds; gdx = block_sum(c, gdx);
       const double dphi_bar = gdx + dbar;
       if (cn > 1e-14) { const double nut = (dphi_bar + 0.5 * fmax(dHd, 0.0)) / ((1 - 0.1) * cn); if (nut > nu) nu = nut * 1.1 + 1e-8; }
@@ -1923,7 +1960,7 @@ CHD_NOINLINE CHD_DEV void solve_stage(Ctx& c, StageResult& res) {
       if (dw > CHD_DELTA_W_MAX) break;
     }
     if (!ok) { status = -2; break; }
-    if (attempt == 0 && nls == 0) dw = fmax(CHD_DELTA_W_MIN, dw / 3.0);
+    if (attempt == 0 && nls == 0) dw = fmax(CHD_DELTA_W_MIN, dw / 2.0);
     else if (nls >= 1) dw *= 4.0;
     PAR_FOR(j, n) x[j] = used_soc ? xs[j] : x[j] + alpha * dx[j];
     PAR_FOR(i, m) {

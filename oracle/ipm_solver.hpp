@@ -403,8 +403,11 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
       }
       double cn = 0; for (int i = 0; i < m; ++i) cn += std::fabs(r[i]);
       double gdx = 0; for (int j = 0; j < n; ++j) gdx += g[j] * dx[j];
+      // dx^T (H + dw Dw) dx without a mat-vec, from the two block rows of the KKT system just solved:
+      //   (H + dw Dw) dx + J^T dlam = -dualx ,   J dx - D dlam = rhs_row
       double dHd = 0;
-      for (int a = 0; a < n; ++a) { const double* Hr = &H[(size_t)a * n]; double sum = 0; for (int b2 = 0; b2 < n; ++b2) sum += Hr[b2] * dx[b2]; dHd += dx[a] * sum + dw * Dw[a] * dx[a] * dx[a]; }
+      for (int j = 0; j < n; ++j) dHd -= dx[j] * dualx[j];
+      for (int i = 0; i < m; ++i) dHd -= (rhs[pos_row[i]] + D[i] * dlam[i]) * dlam[i];
       dHd += sSds;
       double dphi_bar = gdx + dbar;
       if (cn > 1e-14) { double nut = (dphi_bar + 0.5 * std::max(dHd, 0.0)) / ((1 - 0.1) * cn); if (nut > nu) nu = nut * 1.1 + 1e-8; }
@@ -455,7 +458,7 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
       if (dw > opt.delta_w_max) break;
     }
     if (!ok) { status = -2; P.set_x(x.data()); break; }
-    if (attempt == 0 && nls == 0) dw = std::max(opt.delta_w_min, dw / 3.0);
+    if (attempt == 0 && nls == 0) dw = std::max(opt.delta_w_min, dw / 2.0);
     else if (nls >= 1) dw *= 4.0;
     last_alpha = alpha; last_nls = nls; last_att = attempt; last_soc = used_soc;
     if (used_soc) { for (int j = 0; j < n; ++j) x[j] = xs[j]; } else { for (int j = 0; j < n; ++j) x[j] += alpha * dx[j]; }
