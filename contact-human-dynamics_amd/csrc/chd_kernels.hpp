@@ -37,14 +37,22 @@
 #define CHD_NT ((int)blockDim.x)
 #define CHD_SYNC() __syncthreads()
 #define CHD_GL 16
-#define CHD_NOINLINE __attribute__((noinline))
+// internal linkage: with every caller known the compiler drops the callee-saved register convention (no
+// prologue/epilogue scratch traffic in functions that need more than the 144 caller-saved VGPRs)
+#define CHD_NOINLINE static __attribute__((noinline))
 #endif
 // LDS data is addressed through an explicit local-address-space pointer: a generic `double*` would make
 // hipcc emit flat_load/flat_store for every access instead of ds_read/ds_write
 #ifdef CHD_HOST_EMU
 typedef double LdsD;
+typedef int LdsI;
+#define CHD_SCHED_FENCE() ((void)0)
+#define CHD_LOAD_T0 0
 #else
 typedef __attribute__((address_space(3))) double LdsD;
+typedef __attribute__((address_space(3))) int LdsI;
+#define CHD_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define CHD_LOAD_T0 64         // threads below this one factor the diagonal block while the rest load the panel
 #endif
 #ifdef CHD_HOST_EMU
 #define CHD_WAVE_ID 0
@@ -155,7 +163,7 @@ CHD_DEV double group_sum(double v) {
 CHD_DEV double pair_sum(double v) { return v; }
 #else
 #define CHD_PAIR 2
-CHD_DEV double pair_sum(double v) { return v + __shfl_xor(v, 1); }
+CHD_DEV double pair_sum(double v) { return v + __shfl_xor(v, 32); }
 #endif
 #define LDS_RED 64     // doubles reserved at the start of lds for the reductions
 
@@ -425,46 +433,67 @@ CHD_DEV void kzero(Ctx& c) {
   for (long long i = CHD_TID; i < nx_; i += CHD_NT) c.K0x[i] = 0.0;
 }
 
+
+// sum_k a[k] * b[k] over k = k0, k0 + st, ... < kend with up to 16 loads in flight per lane (the operands live in HBM /
+// L2 and these loops are latency bound), four accumulators
+template <class AP, class BP>
+CHD_DEV double dot_strided(AP a, BP b, int k, const int kend, const int st) {
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  for (; k + 15 * st < kend; k += 16 * st) {
+    double v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = a[k + q * st];
+#pragma unroll
+    for (int q = 0; q < 16; q += 4) {
+      s0 += v[q] * b[k + q * st]; s1 += v[q + 1] * b[k + (q + 1) * st];
+      s2 += v[q + 2] * b[k + (q + 2) * st]; s3 += v[q + 3] * b[k + (q + 3) * st];
+    }
+  }
+  for (; k + 3 * st < kend; k += 4 * st) {
+    s0 += a[k] * b[k]; s1 += a[k + st] * b[k + st]; s2 += a[k + 2 * st] * b[k + 2 * st]; s3 += a[k + 3 * st] * b[k + 3 * st];
+  }
+  for (; k < kend; k += st) s0 += a[k] * b[k];
+  return (s0 + s1) + (s2 + s3);
+}
+// sum_r col[r * ld] * b[r] for r = r0 .. rend-1 (a column of a row-major matrix), same load depth
+template <class AP, class BP>
+CHD_DEV double dot_column(AP col, const long long ld, BP b, int r, const int rend) {
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  for (; r + 15 < rend; r += 16) {
+    double v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = col[(r + q) * ld];
+#pragma unroll
+    for (int q = 0; q < 16; q += 4) { s0 += v[q] * b[r + q]; s1 += v[q + 1] * b[r + q + 1]; s2 += v[q + 2] * b[r + q + 2]; s3 += v[q + 3] * b[r + q + 3]; }
+  }
+  for (; r + 3 < rend; r += 4) {
+    s0 += col[r * ld] * b[r]; s1 += col[(r + 1) * ld] * b[r + 1]; s2 += col[(r + 2) * ld] * b[r + 2]; s3 += col[(r + 3) * ld] * b[r + 3];
+  }
+  for (; r < rend; ++r) s0 += col[r * ld] * b[r];
+  return (s0 + s1) + (s2 + s3);
+}
 // y = K0 x (+ diag .* x)
-CHD_NOINLINE CHD_DEV void kmatvec(Ctx& c, const GD* x, GD* y, const GD* diag) {
+// `only` (optional): rows whose entry is <= 0 are skipped (their y is left untouched)
+CHD_NOINLINE CHD_DEV void kmatvec(Ctx& c, const GD* x, GD* y, const GD* diag, const GI* only) {
   TIC();
   const int Nb = c.Nb, w = c.w, W2 = c.W2, LD = c.LD, bc = c.bc;
   GROUP_FOR(i, Nb) {
+    if (only && only[i] <= 0) continue;
     const int lo = c.env[2 * i], hi = c.env[2 * i + 1];      // nothing is stored outside the envelope
     const GD* row = c.K0b + (long long)i * W2 + (w - i);
-    double acc = 0, acc1 = 0, acc2 = 0, acc3 = 0;
-    int k = lo + lane_;
-    for (; k + 3 * CHD_GL <= hi; k += 4 * CHD_GL) {
-      acc += row[k] * x[k]; acc1 += row[k + CHD_GL] * x[k + CHD_GL];
-      acc2 += row[k + 2 * CHD_GL] * x[k + 2 * CHD_GL]; acc3 += row[k + 3 * CHD_GL] * x[k + 3 * CHD_GL];
-    }
-    for (; k <= hi; k += CHD_GL) acc += row[k] * x[k];
-    acc = group_sum((acc + acc1) + (acc2 + acc3));
+    const double acc = group_sum(dot_strided(row, x, lo + lane_, hi + 1, CHD_GL));
     if (lane_ == 0) y[i] = acc + (diag ? diag[i] * x[i] : 0.0);
   }
   GROUP_FOR(r, bc) {
+    if (only && only[Nb + r] <= 0) continue;
     const GD* row = c.K0x + (long long)r * LD;
-    double acc = 0, acc1 = 0, acc2 = 0, acc3 = 0;
-    int k = lane_;
-    for (; k + 3 * CHD_GL < LD; k += 4 * CHD_GL) {
-      acc += row[k] * x[k]; acc1 += row[k + CHD_GL] * x[k + CHD_GL];
-      acc2 += row[k + 2 * CHD_GL] * x[k + 2 * CHD_GL]; acc3 += row[k + 3 * CHD_GL] * x[k + 3 * CHD_GL];
-    }
-    for (; k < LD; k += CHD_GL) acc += row[k] * x[k];
-    acc = group_sum((acc + acc1) + (acc2 + acc3));
+    const double acc = group_sum(dot_strided(row, x, lane_, LD, CHD_GL));
     if (lane_ == 0) y[Nb + r] = acc + (diag ? diag[Nb + r] * x[Nb + r] : 0.0);
   }
   CHD_SYNC();
   PAR_FOR(i, Nb) {
-    double acc = 0, acc1 = 0, acc2 = 0, acc3 = 0;
-    const GD* col = c.K0x + i;
-    int r = 0;
-    for (; r + 3 < bc; r += 4) {
-      acc += col[(long long)r * LD] * x[Nb + r]; acc1 += col[(long long)(r + 1) * LD] * x[Nb + r + 1];
-      acc2 += col[(long long)(r + 2) * LD] * x[Nb + r + 2]; acc3 += col[(long long)(r + 3) * LD] * x[Nb + r + 3];
-    }
-    for (; r < bc; ++r) acc += col[(long long)r * LD] * x[Nb + r];
-    y[i] += (acc + acc1) + (acc2 + acc3);
+    if (only && only[i] <= 0) continue;
+    y[i] += dot_column(c.K0x + i, LD, x + Nb, 0, bc);
   }
   CHD_SYNC();
   TOC(c, 4);
@@ -493,13 +522,15 @@ CHD_DEV double pivot_fix(Ctx& c, double d, int sg) {
 
 // ---- diagonal block of a panel (NB x NB, in LDS column-major PT[j * ldp + a]) -------------------
 #ifdef CHD_HOST_EMU
+// dv: pivots, dv + 32: their reciprocals, DL: dense copy of the unit-lower block, DL[k * NB + j] = L(j, k)
 template <int NB>
-CHD_DEV void diag_block(Ctx& c, const GI* sign, LdsD* dv, LdsD* PT, const int ldp, const int c0, const int jb) {
+CHD_DEV void diag_block(Ctx& c, const GI* sign, LdsD* dv, LdsD* DL, LdsD* PT, const int ldp, const int c0, const int jb) {
   for (int j = 0; j < NB; ++j) {
     double d = PT[j * ldp + j];
     if (j < jb) d = pivot_fix(c, d, sign[c0 + j]);
-    for (int a = j + 1; a < NB; ++a) PT[j * ldp + a] /= d;
-    dv[j] = d;
+    const double inv = 1.0 / d;
+    for (int a = j + 1; a < NB; ++a) { PT[j * ldp + a] *= inv; DL[j * NB + a] = PT[j * ldp + a]; }
+    dv[j] = d; dv[32 + j] = inv;
     for (int jj = j + 1; jj < NB; ++jj)
       for (int a = jj; a < NB; ++a) PT[jj * ldp + a] -= PT[j * ldp + a] * d * PT[j * ldp + jj];
   }
@@ -511,12 +542,19 @@ CHD_DEV double readlane_f64(double v, int l) {
   return __hiloint2double(hi, lo);
 }
 // one wavefront: lane a keeps row a of the block in registers; column j's pivot and multipliers are
-// broadcast with v_readlane, so the whole right-looking elimination runs without touching LDS
+// broadcast with v_readlane, so the whole right-looking elimination runs without an LDS or HBM round trip
+CHD_DEV double rcp_f64(double d) {
+  double x = __builtin_amdgcn_rcp(d);
+  x = __builtin_fma(__builtin_fma(-d, x, 1.0), x, x);
+  x = __builtin_fma(__builtin_fma(-d, x, 1.0), x, x);
+  return x;
+}
 template <int NB>
-CHD_DEV void diag_block(Ctx& c, const GI* sign, LdsD* dv, LdsD* PT, const int ldp, const int c0, const int jb) {
+CHD_NOINLINE CHD_DEV void diag_block(Ctx& c, const GI* sign, LdsD* dv, LdsD* DL, LdsD* PT, const int ldp, const int c0, const int jb) {
   if (threadIdx.x < 64) {
     const int a = threadIdx.x;
     const bool act = a < NB;
+    const int sg_a = a < jb ? sign[c0 + a] : 1;          // expected pivot signs, fetched once
     double r[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) r[j] = (act && j <= a) ? PT[j * ldp + a] : 0.0;
@@ -524,16 +562,14 @@ CHD_DEV void diag_block(Ctx& c, const GI* sign, LdsD* dv, LdsD* PT, const int ld
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       double d = readlane_f64(r[j], j);
-      if (j < jb) { const int sg = sign[c0 + j]; if (!(d * sg > 1e-14)) { d = sg * 1e-10; ++bad; } }
-      const double lj = r[j] / d;            // L(a, j) for a > j
-      if (act && a > j) PT[j * ldp + a] = lj;
-      if (a == j) dv[j] = d;
-      CHD_WSYNC();
+      if (j < jb) { const int sg = __builtin_amdgcn_readlane(sg_a, j); if (!(d * sg > 1e-14)) { d = sg * 1e-10; ++bad; } }
+      const double inv = rcp_f64(d);
+      const double lj = r[j] * inv;            // L(a, j) for a > j
+      if (act && a > j) { PT[j * ldp + a] = lj; DL[j * NB + a] = lj; }
+      if (a == j) { dv[j] = d; dv[32 + j] = inv; }
+      const double ljd = lj * d;
 #pragma unroll
-      for (int jj = j + 1; jj < NB; ++jj) {
-        const double ljj = PT[j * ldp + jj];          // L(jj, j), same address for every lane
-        if (a >= jj) r[jj] -= lj * d * ljj;
-      }
+      for (int jj = j + 1; jj < NB; ++jj) r[jj] -= ljd * readlane_f64(lj, jj);      // lanes a < jj hold unused values
     }
     if (threadIdx.x == 0) c.n_bad_pivots += bad;
   }
@@ -548,19 +584,19 @@ CHD_DEV void build_active_rows(Ctx& c, int* act, int* nact, int wr, int nbelow, 
   *nact = n;
 }
 #else
-typedef __attribute__((address_space(3))) int LdsI;
 CHD_DEV void build_active_rows(Ctx& c, int* act_, int* nact_, int wr, int nbelow, int i0, int last_col) {
-  if (threadIdx.x < 64) {       // one wavefront: ballot + prefix count keeps the list sorted
+  if (threadIdx.x >= 64 && threadIdx.x < 128) {       // one wavefront (the second): ballot + prefix count keeps the list sorted
     LdsI* act = (LdsI*)act_; LdsI* nact = (LdsI*)nact_;
+    const int ln = threadIdx.x - 64;
     int base = 0;
     for (int u0 = 0; u0 < wr; u0 += 64) {
-      const int u = u0 + threadIdx.x;
+      const int u = u0 + ln;
       const bool on = u < wr && (u >= nbelow || c.env[2 * (i0 + u)] <= last_col);
       const unsigned long long m = __ballot(on);
-      if (on) act[base + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = u;
+      if (on) act[base + __popcll(m & ((1ull << ln) - 1ull))] = u;
       base += __popcll(m);
     }
-    if (threadIdx.x == 0) *nact = base;
+    if (ln == 0) *nact = base;
   }
 }
 #endif
@@ -587,7 +623,7 @@ typedef double chd_f64x4 __attribute__((ext_vector_type(4)));
 // (v_mfma_f64_16x16x4_f64: A[row = lane & 15][k = lane >> 4], B[k = lane >> 4][col = lane & 15],
 //  D[row = (lane >> 4) + 4 * reg][col = lane & 15])
 template <int NB>
-CHD_DEV void trailing_update(Ctx& c, const LdsD* dv, const LdsD* PT, const int ldp, const int wr, const int nbelow, const int i0, const int* act_, const int nact) {
+CHD_NOINLINE CHD_DEV void trailing_update(Ctx& c, const LdsD* dv, const LdsD* PT, const int ldp, const int wr, const int nbelow, const int i0, const int* act_, const int nact) {
   const int W1 = c.w + 1, w = c.w, LD = c.LD, Nb = c.Nb;
   const LdsI* act = (const LdsI*)act_;
   const int wave = threadIdx.x >> 6, nwv = blockDim.x >> 6, lane = threadIdx.x & 63;
@@ -652,82 +688,125 @@ CHD_DEV void trailing_update(Ctx& c, const LdsD* dv, const LdsD* PT, const int l
 // Banded part of the factorisation, NB columns per panel.  Panel in LDS, column-major PT[j * ldp + a];
 // local rows: [0, NB) diagonal block (rows >= jb of a short last block are identity padding),
 // [NB, NB + nbelow) band rows below it, then the bc border rows.
+// Every phase is its own function: each gets its own register allocation (the row solve and the MFMA update
+// want ~200 VGPRs each, and inlined together they spill).
+struct Panel {
+  int c0, jb, nbelow, pr, ldp;
+  LdsD* dv; LdsD* DL; LdsD* PT;
+  int* act; int* nact_p;
+};
+
+// ---- load (zero padded; identity in the padding columns); one task = 8 consecutive columns of one row
+// part 0: the diagonal block rows (all threads); part 1: everything below, by the threads past the first
+// wavefront (which factors the diagonal block meanwhile), plus the list of active window rows
 template <int NB>
-CHD_NOINLINE CHD_DEV void kfactor_band(Ctx& c, const GI* sign, LdsD* dv, LdsD* PT, const int ldp) {
-  const int Nb = c.Nb, w = c.w, W1 = c.w + 1, LD = c.LD, bc = c.bc;
+CHD_NOINLINE CHD_DEV void panel_load(Ctx& c, const Panel P, const int part) {
+  const int W1 = c.w + 1, w = c.w, LD = c.LD;
+  const int c0 = P.c0, jb = P.jb, nbelow = P.nbelow, pr = P.pr, ldp = P.ldp;
+  LdsD* PT = P.PT;
+  const int t_first = part == 0 ? CHD_TID : NB * (NB / 8) + CHD_TID - CHD_LOAD_T0;
+  const int t_end = part == 0 ? NB * (NB / 8) : ldp * (NB / 8);
+  const int t_step = part == 0 ? CHD_NT : CHD_NT - CHD_LOAD_T0;
+  if (part == 1 && CHD_TID < CHD_LOAD_T0) return;
+  for (int idx = t_first; idx < t_end; idx += t_step) {
+    const int a = idx / (NB / 8), j0 = (idx % (NB / 8)) * 8;
+    double v[8];
+    const bool band = a < jb || (a >= NB && a < NB + nbelow), bord = a >= NB + nbelow && a < pr;
+    const int i = c0 + (a < jb ? a : jb + a - NB);
+    const GD* src = band ? c.Kfb + (long long)i * W1 + (c0 + j0 - i + w) : c.Kfx + (long long)(bord ? a - NB - nbelow : 0) * LD + c0 + j0;
+    const int ef = band ? c.env[2 * i] : 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int j = j0 + q, k = c0 + j;
+      const bool ok = j < jb && ((band && k <= i && k >= ef) || bord);
+      v[q] = ok ? src[q] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) PT[(j0 + q) * ldp + a] = (j0 + q >= jb && a == j0 + q) ? 1.0 : v[q];
+  }
+  // window rows that this panel can touch: band rows whose envelope reaches the panel, and every border row
+  if (part == 1) build_active_rows(c, P.act, P.nact_p, pr - NB, nbelow, c0 + jb, c0 + jb - 1);
+}
+
+// ---- (B) rows below: y_j = A(a,j) - sum_{k<j} y_k L(j,k);  L(a,j) = y_j / d_j
+//      two rows per thread share each broadcast read of L; the block is read from its dense copy
+template <int NB>
+CHD_NOINLINE CHD_DEV void panel_rows(Ctx& c, const Panel P, const int nact) {
+  const int ldp = P.ldp;
+  LdsD* PT = P.PT; const LdsD* DL = P.DL; const LdsD* dv = P.dv; const LdsI* act = (const LdsI*)P.act;
+  PAR_FOR(t2, (nact + 1) >> 1) {           // compacted: inactive rows stay zero
+    const int a0 = NB + act[2 * t2];
+    const int a1 = 2 * t2 + 1 < nact ? NB + act[2 * t2 + 1] : P.pr + 8;      // odd count: a zero padding row
+    double y0[NB], y1[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) { y0[j] = PT[j * ldp + a0]; y1[j] = PT[j * ldp + a1]; }
+#pragma unroll
+    for (int k = 0; k < NB - 1; ++k) {       // y_j -= y_k L(j,k) for all j > k: independent FMAs
+#pragma unroll
+      for (int j = k + 1; j < NB; ++j) { const double l = DL[k * NB + j]; y0[j] -= y0[k] * l; y1[j] -= y1[k] * l; }
+      CHD_SCHED_FENCE();                      // keep the L reads of later columns from being hoisted (register pressure)
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) { const double inv = dv[32 + j]; PT[j * ldp + a0] = y0[j] * inv; PT[j * ldp + a1] = y1[j] * inv; }
+  }
+}
+
+// ---- write the panel back (8 consecutive columns of one row per task)
+template <int NB>
+CHD_NOINLINE CHD_DEV void panel_store(Ctx& c, const Panel P) {
+  const int W1 = c.w + 1, w = c.w, LD = c.LD;
+  const int c0 = P.c0, jb = P.jb, nbelow = P.nbelow, pr = P.pr, ldp = P.ldp;
+  const LdsD* PT = P.PT; const LdsD* dv = P.dv;
+  PAR_FOR(idx, pr * (NB / 8)) {
+    const int a = idx / (NB / 8), j0 = (idx % (NB / 8)) * 8;
+    if (a >= jb && a < NB) continue;
+    const bool band = a < jb || a < NB + nbelow;
+    const int i = c0 + (a < jb ? a : jb + a - NB);
+    GD* dst = band ? c.Kfb + (long long)i * W1 + (c0 + j0 - i + w) : c.Kfx + (long long)(a - NB - nbelow) * LD + c0 + j0;
+    const int ef = band ? c.env[2 * i] : 0;
+    if (band && a >= NB && ef > c0 + jb - 1) continue;      // row untouched by this panel
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int j = j0 + q, k = c0 + j;
+      if (j >= jb) break;
+      if (band) {
+        if (k < i && k >= ef) dst[q] = PT[j * ldp + a];
+        else if (k == i) dst[q] = dv[j];
+      } else dst[q] = PT[j * ldp + a];
+    }
+  }
+}
+
+template <int NB>
+CHD_DEV void kfactor_band(Ctx& c, const GI* sign, LdsD* dv, LdsD* DL, LdsD* PT, const int ldp) {
+  const int Nb = c.Nb, w = c.w, bc = c.bc;
   for (int c0 = 0; c0 < Nb; c0 += NB) {
-    const int jb = Nb - c0 < NB ? Nb - c0 : NB;
-    const int nbr = (Nb - c0 < jb + w) ? Nb - c0 : jb + w;     // band rows touched by this panel
-    const int nbelow = nbr - jb;
-    const int pr = NB + nbelow + bc;
+    Panel P;
+    P.c0 = c0; P.jb = Nb - c0 < NB ? Nb - c0 : NB;
+    const int nbr = (Nb - c0 < P.jb + w) ? Nb - c0 : P.jb + w;     // band rows touched by this panel
+    P.nbelow = nbr - P.jb;
+    P.pr = NB + P.nbelow + bc; P.ldp = ldp;
+    P.dv = dv; P.DL = DL; P.PT = PT;
+    P.act = (int*)(PT + (long long)ldp * NB);
+    P.nact_p = P.act + (w + bc + 64);
     long long tp_ = CHD_CLOCK();
-    // ---- load (zero padded; identity in the padding columns); one task = 8 consecutive columns of one row
-    PAR_FOR(idx, ldp * (NB / 8)) {
-      const int a = idx / (NB / 8), j0 = (idx % (NB / 8)) * 8;
-      double v[8];
-      const bool band = a < jb || (a >= NB && a < NB + nbelow), bord = a >= NB + nbelow && a < pr;
-      const int i = c0 + (a < jb ? a : jb + a - NB);
-      const GD* src = band ? c.Kfb + (long long)i * W1 + (c0 + j0 - i + w) : c.Kfx + (long long)(bord ? a - NB - nbelow : 0) * LD + c0 + j0;
-      const int ef = band ? c.env[2 * i] : 0;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int j = j0 + q, k = c0 + j;
-        const bool ok = j < jb && ((band && k <= i && k >= ef) || bord);
-        v[q] = ok ? src[q] : 0.0;
-      }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) PT[(j0 + q) * ldp + a] = (j0 + q >= jb && a == j0 + q) ? 1.0 : v[q];
-    }
-    // window rows that this panel can touch: band rows whose envelope reaches the panel, and every border row
-    int* act = (int*)(PT + (long long)ldp * NB);
-    int* nact_p = act + (w + bc + 64);
-    build_active_rows(c, act, nact_p, pr - NB, nbelow, c0 + jb, c0 + jb - 1);
+    panel_load<NB>(c, P, 0);
     CHD_SYNC();
-    const int nact = *nact_p;
     c.tacc[7] += CHD_CLOCK() - tp_; tp_ = CHD_CLOCK();
-    // ---- (A) NB x NB diagonal block: unit-lower L in place, pivots to dv
-    diag_block<NB>(c, sign, dv, PT, ldp, c0, jb);
+    // ---- (A) NB x NB diagonal block: unit-lower L in place, pivots to dv (first wavefront), while the other
+    //      wavefronts fetch the rows below it
+    diag_block<NB>(c, sign, dv, DL, PT, ldp, c0, P.jb);
+    panel_load<NB>(c, P, 1);
     CHD_SYNC();
+    const int nact = *(const LdsI*)P.nact_p;
     c.tacc[8] += CHD_CLOCK() - tp_; tp_ = CHD_CLOCK();
-    // ---- (B) rows below: y_j = A(a,j) - sum_{k<j} y_k L(j,k);  L(a,j) = y_j / d_j   (one thread per row)
-    PAR_FOR(t2, nact) {           // compacted: inactive rows stay zero
-      const int a = NB + act[t2];
-      double y[NB];
-#pragma unroll
-      for (int j = 0; j < NB; ++j) y[j] = PT[j * ldp + a];
-#pragma unroll
-      for (int k = 0; k < NB - 1; ++k) {       // y_j -= y_k L(j,k) for all j > k: independent FMAs, L(.,k) contiguous in LDS
-#pragma unroll
-        for (int j = k + 1; j < NB; ++j) y[j] -= y[k] * PT[k * ldp + j];
-      }
-#pragma unroll
-      for (int j = 0; j < NB; ++j) PT[j * ldp + a] = y[j] / dv[j];
-    }
+    panel_rows<NB>(c, P, nact);
     CHD_SYNC();
     c.tacc[9] += CHD_CLOCK() - tp_; tp_ = CHD_CLOCK();
-    // ---- write the panel back (8 consecutive columns of one row per task)
-    PAR_FOR(idx, pr * (NB / 8)) {
-      const int a = idx / (NB / 8), j0 = (idx % (NB / 8)) * 8;
-      if (a >= jb && a < NB) continue;
-      const bool band = a < jb || a < NB + nbelow;
-      const int i = c0 + (a < jb ? a : jb + a - NB);
-      GD* dst = band ? c.Kfb + (long long)i * W1 + (c0 + j0 - i + w) : c.Kfx + (long long)(a - NB - nbelow) * LD + c0 + j0;
-      const int ef = band ? c.env[2 * i] : 0;
-      if (band && a >= NB && ef > c0 + jb - 1) continue;      // row untouched by this panel
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int j = j0 + q, k = c0 + j;
-        if (j >= jb) break;
-        if (band) {
-          if (k < i && k >= ef) dst[q] = PT[j * ldp + a];
-          else if (k == i) dst[q] = dv[j];
-        } else dst[q] = PT[j * ldp + a];
-      }
-    }
-    CHD_SYNC();
+    panel_store<NB>(c, P);                     // stores of the panel columns; the update below touches other columns
     c.tacc[10] += CHD_CLOCK() - tp_; tp_ = CHD_CLOCK();
     // ---- trailing update of the window
-    trailing_update<NB>(c, dv, PT, ldp, pr - NB, nbelow, c0 + jb, act, nact);
+    trailing_update<NB>(c, dv, PT, ldp, P.pr - NB, P.nbelow, c0 + P.jb, P.act, nact);
     CHD_SYNC();
     c.tacc[11] += CHD_CLOCK() - tp_;
   }
@@ -756,29 +835,57 @@ CHD_NOINLINE CHD_DEV void kfactor(Ctx& c, const GD* diag, const GI* sign) {
   TIC();
   const int Nb = c.Nb, w = c.w, W2 = c.W2, W1 = c.w + 1, LD = c.LD, bc = c.bc;
   if (CHD_TID == 0) c.n_bad_pivots = 0;
-  // copy the lower triangle (+ diagonal shift) into the factor storage: one wavefront per row
-  for (int i = CHD_WAVE_ID; i < Nb; i += CHD_NWAVES) {
-    const GD* src = c.K0b + (long long)i * W2;
-    GD* dst = c.Kfb + (long long)i * W1;
-    for (int cc = CHD_LANE; cc < W1; cc += CHD_WAVE_SZ) dst[cc] = src[cc] + (cc == w ? diag[i] : 0.0);
+  // copy the lower triangle (+ diagonal shift) into the factor storage: four rows per wavefront pass, all loads
+  // of a pass issued before the first store (the copy is latency bound, not bandwidth bound)
+  {
+    constexpr int RP = 4, QP = 6;                      // QP * wave size covers W1 <= 384; wider bands take the tail loop
+    for (int i0 = CHD_WAVE_ID * RP; i0 < Nb; i0 += CHD_NWAVES * RP) {
+      double v[RP][QP];
+#pragma unroll
+      for (int r = 0; r < RP; ++r)
+#pragma unroll
+        for (int q = 0; q < QP; ++q) {
+          const int i = i0 + r, cc = CHD_LANE + q * CHD_WAVE_SZ;
+          v[r][q] = (i < Nb && cc < W1) ? c.K0b[(long long)i * W2 + cc] : 0.0;
+        }
+#pragma unroll
+      for (int r = 0; r < RP; ++r)
+#pragma unroll
+        for (int q = 0; q < QP; ++q) {
+          const int i = i0 + r, cc = CHD_LANE + q * CHD_WAVE_SZ;
+          if (i < Nb && cc < W1) c.Kfb[(long long)i * W1 + cc] = v[r][q] + (cc == w ? diag[i] : 0.0);
+        }
+      for (int r = 0; r < RP; ++r)
+        for (int cc = CHD_LANE + QP * CHD_WAVE_SZ; cc < W1 && i0 + r < Nb; cc += CHD_WAVE_SZ)
+          c.Kfb[(long long)(i0 + r) * W1 + cc] = c.K0b[(long long)(i0 + r) * W2 + cc] + (cc == w ? diag[i0 + r] : 0.0);
+    }
   }
   for (int r = CHD_WAVE_ID; r < bc; r += CHD_NWAVES) {
     const GD* src = c.K0x + (long long)r * LD;
     GD* dst = c.Kfx + (long long)r * LD;
-    for (int k = CHD_LANE; k < LD; k += CHD_WAVE_SZ) dst[k] = src[k] + (k == Nb + r ? diag[Nb + r] : 0.0);
+    int k = CHD_LANE;
+    for (; k + 7 * CHD_WAVE_SZ < LD; k += 8 * CHD_WAVE_SZ) {
+      double v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = src[k + q * CHD_WAVE_SZ];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) dst[k + q * CHD_WAVE_SZ] = v[q] + (k + q * CHD_WAVE_SZ == Nb + r ? diag[Nb + r] : 0.0);
+    }
+    for (; k < LD; k += CHD_WAVE_SZ) dst[k] = src[k] + (k == Nb + r ? diag[Nb + r] : 0.0);
   }
   CHD_SYNC();
   c.tacc[6] += CHD_CLOCK() - tic_;
   // panel width from the LDS budget
-  LdsD* dv = c.lds + LDS_RED;            // pivots of the current panel (<= 32)
-  LdsD* PT = dv + 32;                    // panel (the list of active window rows follows it)
-  const int avail = c.lds_cap - LDS_RED - 32 - (w + bc + 64) / 2 - 8;      // ints of the active-row list
+  LdsD* dv = c.lds + LDS_RED;            // pivots of the current panel (<= 32) and their reciprocals
+  LdsD* DL = dv + 64;                    // dense copy of the panel's unit-lower diagonal block
+  LdsD* PT = DL + 32 * 32;               // panel (the list of active window rows follows it)
+  const int avail = c.lds_cap - LDS_RED - 64 - 32 * 32 - (w + bc + 64) / 2 - 8;      // ints of the active-row list
   int nb = 32;
   while (nb > 8 && (long long)(nb + w + bc + 18) * nb > avail) nb >>= 1;
   const int ldp = (nb + w + bc + 17) | 1;  // odd leading dimension (conflict-free column walks), >= 16 rows of zero padding
-  if (nb == 32) kfactor_band<32>(c, sign, dv, PT, ldp);
-  else if (nb == 16) kfactor_band<16>(c, sign, dv, PT, ldp);
-  else kfactor_band<8>(c, sign, dv, PT, ldp);
+  if (nb == 32) kfactor_band<32>(c, sign, dv, DL, PT, ldp);
+  else if (nb == 16) kfactor_band<16>(c, sign, dv, DL, PT, ldp);
+  else kfactor_band<8>(c, sign, dv, DL, PT, ldp);
   // ---- dense L D L^T of the border Schur complement (rows/cols Nb..N-1)
   const long long td_ = CHD_CLOCK();
   if (bc > 0) {
@@ -840,7 +947,7 @@ CHD_NOINLINE CHD_DEV void tri_forward(Ctx& c, YP y, int c0, int jb, const LdsD* 
     }
 #pragma unroll
     for (int j = 0; j < CHD_SOLVE_NB - 1; ++j) {
-      const double yj = __shfl(yi, j);
+      const double yj = readlane_f64(yi, j);      // j is a constant after unrolling: v_readlane, no LDS round trip
       yi -= l[j] * yj;
     }
     if (act) y[c0 + i] = yi;
@@ -862,7 +969,7 @@ CHD_NOINLINE CHD_DEV void tri_backward(Ctx& c, YP y, int c0, int jb, const LdsD*
     }
 #pragma unroll
     for (int j = CHD_SOLVE_NB - 1; j > 0; --j) {
-      const double yj = __shfl(yi, j);
+      const double yj = readlane_f64(yi, j);      // j is a constant after unrolling: v_readlane, no LDS round trip
       yi -= l[j] * yj;
     }
     if (act) y[c0 + i] = yi;
@@ -902,14 +1009,7 @@ CHD_DEV void ksolve_impl(Ctx& c, const GD* rhs, GD* x, YP y, SP Sp, const int ld
       const int i = c0 + a;
       const int lo = c.env[2 * i];          // L(i, k) = 0 left of the envelope
       const GD* row = c.Kfb + (long long)i * W1 + (w - i);
-      double acc = 0, acc1 = 0, acc2 = 0, acc3 = 0;
-      int k = lo + lane_;
-      for (; k + 3 * CHD_GL < c0; k += 4 * CHD_GL) {       // four loads in flight per lane
-        acc += row[k] * y[k]; acc1 += row[k + CHD_GL] * y[k + CHD_GL];
-        acc2 += row[k + 2 * CHD_GL] * y[k + 2 * CHD_GL]; acc3 += row[k + 3 * CHD_GL] * y[k + 3 * CHD_GL];
-      }
-      for (; k < c0; k += CHD_GL) acc += row[k] * y[k];
-      acc = group_sum((acc + acc1) + (acc2 + acc3));
+      const double acc = group_sum(dot_strided(row, y, lo + lane_, c0, CHD_GL));
       if (lane_ == 0) y[i] -= acc;
     }
     if (tile) load_diag_tile(c, tile, c0, jb);
@@ -923,14 +1023,7 @@ CHD_DEV void ksolve_impl(Ctx& c, const GD* rhs, GD* x, YP y, SP Sp, const int ld
   // forward, border rows: band part of L_border
   GROUP_FOR(r, bc) {
     const GD* row = c.Kfx + (long long)r * LD;
-    double acc = 0, acc1 = 0, acc2 = 0, acc3 = 0;
-    int k = lane_;
-    for (; k + 3 * CHD_GL < Nb; k += 4 * CHD_GL) {
-      acc += row[k] * y[k]; acc1 += row[k + CHD_GL] * y[k + CHD_GL];
-      acc2 += row[k + 2 * CHD_GL] * y[k + 2 * CHD_GL]; acc3 += row[k + 3 * CHD_GL] * y[k + 3 * CHD_GL];
-    }
-    for (; k < Nb; k += CHD_GL) acc += row[k] * y[k];
-    acc = group_sum((acc + acc1) + (acc2 + acc3));
+    const double acc = group_sum(dot_strided(row, y, lane_, Nb, CHD_GL));
     if (lane_ == 0) y[Nb + r] -= acc;
   }
   CHD_SYNC();
@@ -949,15 +1042,7 @@ CHD_DEV void ksolve_impl(Ctx& c, const GD* rhs, GD* x, YP y, SP Sp, const int ld
     CHD_SYNC();
   }
   PAR_FOR(k, Nb) {
-    double acc = 0, acc1 = 0, acc2 = 0, acc3 = 0;
-    const GD* col = c.Kfx + k;
-    int r = 0;
-    for (; r + 3 < bc; r += 4) {
-      acc += col[(long long)r * LD] * y[Nb + r]; acc1 += col[(long long)(r + 1) * LD] * y[Nb + r + 1];
-      acc2 += col[(long long)(r + 2) * LD] * y[Nb + r + 2]; acc3 += col[(long long)(r + 3) * LD] * y[Nb + r + 3];
-    }
-    for (; r < bc; ++r) acc += col[(long long)r * LD] * y[Nb + r];
-    y[k] -= (acc + acc1) + (acc2 + acc3);
+    y[k] -= dot_column(c.Kfx + k, LD, y + Nb, 0, bc);
   }
   CHD_SYNC();
   c.tacc[18] += CHD_CLOCK() - ts_;
@@ -972,19 +1057,20 @@ CHD_DEV void ksolve_impl(Ctx& c, const GD* rhs, GD* x, YP y, SP Sp, const int ld
     CHD_SYNC();
     c.tacc[19] += CHD_CLOCK() - ts_; ts_ = CHD_CLOCK();
     const int k0 = c0 - w < 0 ? 0 : c0 - w;
-    for (int k = k0 + CHD_TID; k < c0; k += CHD_NT) {
+    // two half-waves per 32 columns (rows a < 32 and a >= 32 of the block), combined with one xor-32 shuffle
+    const int ncol = c0 - k0, cpw = CHD_WAVE_SZ / CHD_PAIR;
+    for (int base = CHD_WAVE_ID * cpw; base < ncol; base += CHD_NWAVES * cpw) {
+      const int kk = base + CHD_LANE % cpw, half = CHD_LANE / cpw;
+      const bool live = kk < ncol;
+      const int k = k0 + (live ? kk : 0);
       // rows i = c0 + a reach column k while i - k <= w
       int amax = (w - (c0 - k)) < jb - 1 ? (w - (c0 - k)) : jb - 1;
       if (c.env[2 * k + 1] - c0 < amax) amax = c.env[2 * k + 1] - c0;      // no row beyond this one reaches column k
       const GD* col = c.Kfb + (long long)c0 * W1 + (k - c0 + w);      // L(c0 + a, k) = col[a * (W1 - 1)]
-      double acc = 0, acc1 = 0, acc2 = 0, acc3 = 0;
-      int a = 0;
-      for (; a + 3 <= amax; a += 4) {
-        acc += col[(long long)a * (W1 - 1)] * y[c0 + a]; acc1 += col[(long long)(a + 1) * (W1 - 1)] * y[c0 + a + 1];
-        acc2 += col[(long long)(a + 2) * (W1 - 1)] * y[c0 + a + 2]; acc3 += col[(long long)(a + 3) * (W1 - 1)] * y[c0 + a + 3];
-      }
-      for (; a <= amax; ++a) acc += col[(long long)a * (W1 - 1)] * y[c0 + a];
-      y[k] -= (acc + acc1) + (acc2 + acc3);
+      const int a0 = CHD_PAIR == 2 ? half * (CHD_SOLVE_NB / 2) : 0;
+      const int aend = CHD_PAIR == 2 ? (half == 0 ? (amax < CHD_SOLVE_NB / 2 - 1 ? amax : CHD_SOLVE_NB / 2 - 1) : amax) : amax;
+      const double acc = pair_sum(dot_column(col, W1 - 1, y + c0, a0, aend + 1));
+      if (half == 0 && live) y[k] -= acc;
     }
     if (tile && bk > 0) load_diag_tile(c, tile, c0 - nb, nb);
     CHD_SYNC();
@@ -1012,7 +1098,7 @@ CHD_DEV void ksolve(Ctx& c, const GD* rhs, GD* x, const GD* diag, int refine) {
   ksolve_once(c, rhs, x);
   GD* t1 = VK(c, VK_T1); GD* t2 = VK(c, VK_T2);
   for (int it = 0; it < refine; ++it) {
-    kmatvec(c, x, t1, diag);
+    kmatvec(c, x, t1, diag, nullptr);
     PAR_FOR(i, c.N) t1[i] = rhs[i] - t1[i];
     CHD_SYNC();
     ksolve_once(c, t1, t2);
@@ -1816,7 +1902,7 @@ CHD_NOINLINE CHD_DEV void solve_stage(Ctx& c, StageResult& res) {
     CHD_SYNC();
     PAR_FOR(i, m) t1[pos_row[i]] = lam[i];
     CHD_SYNC();
-    kmatvec(c, t1, sol2, nullptr);                 // J^T lam at the variable positions
+    kmatvec(c, t1, sol2, nullptr, sign);           // J^T lam, evaluated at the variable positions only
     double d1 = 0, sumlam = 0, sumz = 0, cnt = 0, ep = 0, epu = 0;
     PAR_FOR(j, n) { const double v = g[j] + sol2[pos_var[j]]; dualx[j] = v; d1 = fmax(d1, fabs(v)); }
     residual(c, cc, s, r);

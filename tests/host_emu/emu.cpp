@@ -83,7 +83,7 @@ int emu_linsolve(void* h, int stage, double dw, double dval, const double* b, do
   ksolve(c, rhs, sol, diag, refine);
   for (int i = 0; i < c.N; ++i) x[i] = sol[i];
   // residual check: K x - b
-  kmatvec(c, sol, VK(c, VK_T1), diag);
+  kmatvec(c, sol, VK(c, VK_T1), diag, nullptr);
   double worst = 0;
   for (int i = 0; i < c.N; ++i) worst = std::max(worst, std::fabs(VK(c, VK_T1)[i] - b[i]));
   std::fprintf(stderr, "emu_linsolve: N=%d Nb=%d bc=%d w=%d bad_pivots=%d residual=%.3e\n", c.N, c.Nb, c.bc, c.w, c.n_bad_pivots, worst);
