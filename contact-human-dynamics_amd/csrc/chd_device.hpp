@@ -54,6 +54,7 @@ struct StageDesc {
   int n, m, n_dur, dur_off[N_EE];
   int Nb, bc, w;            // KKT layout: banded part, border, half-bandwidth
   int n_tasks;
+  int dyn_first, n_dyn;     // the dynamics samples are a contiguous run of tasks (a lane group works on each)
   int nnz_jac;
   int valid;
   double w_data[3], w_vel[3], w_acc[3], w_dur;

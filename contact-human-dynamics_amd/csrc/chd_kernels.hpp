@@ -1219,6 +1219,97 @@ CHD_DEV int frame_index(const SeqDesc* q, double t) {       // humanoid_rigid_bo
   return idx;
 }
 
+// One dynamics sample (6 rows): humanoid_dynamic_constraint.cpp:63-143, humanoid_rigid_body_dynamics.cpp:89-206.
+// Only the positions / forces of the four end-effectors are kept from the first pass; their spline weights are
+// re-evaluated one end-effector at a time for the Jacobian (ten live spline evaluations would not fit the register file).
+CHD_DEV void dyn_rows(Ctx& c, const int ti, const bool J, const bool D2, GD* cout_, const GD* lam, const GD* sc) {
+  const SeqDesc* q = c.q; const StageDesc* S = c.S;
+  const GI* tk = q->ci + S->o_task + 4 * ti;
+  const int B = tk[2], row0 = tk[3];
+  const double t = q->cd[S->o_task_t + ti];
+  PE pl, pa;
+  spline_eval(q, 0, t, pl); spline_eval(q, 1, t, pa);
+  double pmp[4][3], pfp[4][3];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    PE tmp;
+    spline_eval(q, 2 + e, t, tmp); for (int k = 0; k < 3; ++k) pmp[e][k] = tmp.p[k];
+    spline_eval(q, 6 + e, t, tmp); for (int k = 0; k < 3; ++k) pfp[e][k] = tmp.p[k];
+  }
+  const GD* I6 = q->cd + q->o_inertia + frame_index(q, t) * 6;
+  const double Ib[3][3] = {{I6[0], I6[3], I6[4]}, {I6[3], I6[1], I6[5]}, {I6[4], I6[5], I6[2]}};   // humanoid_rigid_body_dynamics.cpp:47-56
+  double ang[3], d0[3][3], d1[3][3], d2[3][3];
+  angular_term(pa.p, pa.v, pa.a, Ib, J, ang, d0, d1, d2);
+  double tau[3] = {0, 0, 0}, fsum[3] = {0, 0, 0};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    double rr[3] = {pl.p[0] - pmp[e][0], pl.p[1] - pmp[e][1], pl.p[2] - pmp[e][2]}, tq[3];
+    cross3(pfp[e], rr, tq);
+    for (int k = 0; k < 3; ++k) { tau[k] += tq[k]; fsum[k] += pfp[e][k]; }
+  }
+  for (int k = 0; k < 3; ++k) {
+    cout_[row0 + k] = sc[row0 + k] * (ang[k] - tau[k]);
+    cout_[row0 + 3 + k] = sc[row0 + 3 + k] * (q->mass * pl.a[k] - fsum[k] - q->mass * CHD_G * q->gdir[k]);
+  }
+  if (!J) return;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    RowW ra{&c, c.pos_row[row0 + i], sc[row0 + i], true};
+    RowW rl{&c, c.pos_row[row0 + 3 + i], sc[row0 + 3 + i], true};
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+    // (v x u)_i = v_{i1} u_{i2} - v_{i2} u_{i1}  ->  coefficients on u: [i2] = v_{i1}, [i1] = -v_{i2}
+    double cf[3] = {0, 0, 0};
+    cf[i2] -= fsum[i1]; cf[i1] += fsum[i2];           // -sum_e (f_e x dc)_i
+    row_nodes(ra, 0, pl, 0, cf, 7 & ~(1 << i));
+    double cm[3] = {0, 0, 0}; cm[i] = q->mass;
+    row_nodes(rl, 0, pl, 2, cm, 1 << i);
+    row_nodes(ra, 1, pa, 0, d0[i], 7);
+    row_nodes(ra, 1, pa, 1, d1[i], 7);
+    row_nodes(ra, 1, pa, 2, d2[i], 7);
+  }
+  double La[3] = {0, 0, 0}, Ll[3] = {0, 0, 0};
+  if (D2) for (int k = 0; k < 3; ++k) { La[k] = lam[row0 + k] * sc[row0 + k]; Ll[k] = lam[row0 + 3 + k] * sc[row0 + 3 + k]; }
+  for (int e = 0; e < 4; ++e) {
+    PE pme, pfe;
+    spline_eval(q, 2 + e, t, pme); spline_eval(q, 6 + e, t, pfe);
+    const double rr[3] = {pl.p[0] - pme.p[0], pl.p[1] - pme.p[1], pl.p[2] - pme.p[2]};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      RowW ra{&c, c.pos_row[row0 + i], sc[row0 + i], true};
+      RowW rl{&c, c.pos_row[row0 + 3 + i], sc[row0 + 3 + i], true};
+      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+      double xr[3] = {0, 0, 0}, xf[3] = {0, 0, 0}, ml[3] = {0, 0, 0};
+      xr[i2] = rr[i1]; xr[i1] = -rr[i2];              // +(r x df)_i
+      xf[i2] = pfe.p[i1]; xf[i1] = -pfe.p[i2];        // +(f x dp)_i
+      ml[i] = -1.0;
+      row_nodes(ra, 6 + e, pfe, 0, xr, 7 & ~(1 << i));
+      row_nodes(rl, 6 + e, pfe, 0, ml, 1 << i);
+      row_nodes(ra, 2 + e, pme, 0, xf, 7 & ~(1 << i));
+      row_durs(ra, 6 + e, t, pfe, xr);                // humanoid_dynamic_constraint.cpp:112-118
+      row_durs(rl, 6 + e, t, pfe, ml);
+      row_durs(ra, 2 + e, t, pme, xf);
+    }
+    if (D2) {
+      // rows: ang_i - sum_e (F_e x r_e)_i with r_e = c - p_e, and m a_i - sum_e F_e,i.  With La / Ll the multipliers of the
+      // angular / linear rows:  d2L = -La . [Q^F x r - (G^F_k x G^p_l + G^F_l x G^p_k) - F x Q^p] - Ll . Q^F
+      DurJac2 dF, dP; dur_jac2(q, 6 + e, t, pfe, dF); dur_jac2(q, 2 + e, t, pme, dP);
+      double S3[3];
+      for (int cls = 0; cls < 3; ++cls) {
+        const double* QF = cls == 0 ? dF.Qee : cls == 1 ? dF.Qec : dF.Qcc;
+        const double* QP = cls == 0 ? dP.Qee : cls == 1 ? dP.Qec : dP.Qcc;
+        const double* GFx = cls == 2 ? dF.Gc : dF.Ge; const double* GFy = cls == 0 ? dF.Ge : dF.Gc;
+        const double* GPx = cls == 2 ? dP.Gc : dP.Ge; const double* GPy = cls == 0 ? dP.Ge : dP.Gc;
+        double a1[3], a2[3], a3[3], a4[3];
+        cross3(QF, rr, a1); cross3(GFx, GPy, a2); cross3(GFy, GPx, a3); cross3(pfe.p, QP, a4);
+        double v = 0;
+        for (int k = 0; k < 3; ++k) v += -La[k] * (a1[k] - a2[k] - a3[k] - a4[k]) - Ll[k] * QF[k];
+        S3[cls] = v;
+      }
+      d2_store(q, e, B, dF.cur, S3[0], S3[1], S3[2]);
+    }
+  }
+}
+
 CHD_NOINLINE CHD_DEV void eval_rows(Ctx& c, int mode, GD* cout_, const GD* lam) {
   const SeqDesc* q = c.q; const StageDesc* S = c.S;
   const GD* sc = VM(c, VM_SC);
@@ -1305,77 +1396,7 @@ CHD_NOINLINE CHD_DEV void eval_rows(Ctx& c, int mode, GD* cout_, const GD* lam) 
           }
         }
       } break;
-      case T_DYN: {          // humanoid_dynamic_constraint.cpp:63-143, humanoid_rigid_body_dynamics.cpp:89-206
-        PE pl, pa, pm[4], pf[4];
-        spline_eval(q, 0, t, pl); spline_eval(q, 1, t, pa);
-        for (int e = 0; e < 4; ++e) { spline_eval(q, 2 + e, t, pm[e]); spline_eval(q, 6 + e, t, pf[e]); }
-        const GD* I6 = q->cd + q->o_inertia + frame_index(q, t) * 6;
-        const double Ib[3][3] = {{I6[0], I6[3], I6[4]}, {I6[3], I6[1], I6[5]}, {I6[4], I6[5], I6[2]}};   // humanoid_rigid_body_dynamics.cpp:47-56
-        double ang[3], d0[3][3], d1[3][3], d2[3][3];
-        angular_term(pa.p, pa.v, pa.a, Ib, J, ang, d0, d1, d2);
-        double tau[3] = {0, 0, 0}, fsum[3] = {0, 0, 0};
-        for (int e = 0; e < 4; ++e) {
-          double rr[3] = {pl.p[0] - pm[e].p[0], pl.p[1] - pm[e].p[1], pl.p[2] - pm[e].p[2]}, tq[3];
-          cross3(pf[e].p, rr, tq);
-          for (int k = 0; k < 3; ++k) { tau[k] += tq[k]; fsum[k] += pf[e].p[k]; }
-        }
-        for (int k = 0; k < 3; ++k) {
-          cout_[row0 + k] = sc[row0 + k] * (ang[k] - tau[k]);
-          cout_[row0 + 3 + k] = sc[row0 + 3 + k] * (q->mass * pl.a[k] - fsum[k] - q->mass * CHD_G * q->gdir[k]);
-        }
-        if (J) {
-          for (int i = 0; i < 3; ++i) {
-            RowW ra{&c, c.pos_row[row0 + i], sc[row0 + i], true};
-            RowW rl{&c, c.pos_row[row0 + 3 + i], sc[row0 + 3 + i], true};
-            const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
-            // (v x u)_i = v_{i1} u_{i2} - v_{i2} u_{i1}  ->  coefficients on u: [i2] = v_{i1}, [i1] = -v_{i2}
-            double cf[3] = {0, 0, 0};
-            for (int e = 0; e < 4; ++e) { cf[i2] -= pf[e].p[i1]; cf[i1] += pf[e].p[i2]; }     // -sum_e (f_e x dc)_i
-            row_nodes(ra, 0, pl, 0, cf, 7 & ~(1 << i));
-            double cm[3] = {0, 0, 0}; cm[i] = q->mass;
-            row_nodes(rl, 0, pl, 2, cm, 1 << i);
-            row_nodes(ra, 1, pa, 0, d0[i], 7);
-            row_nodes(ra, 1, pa, 1, d1[i], 7);
-            row_nodes(ra, 1, pa, 2, d2[i], 7);
-            for (int e = 0; e < 4; ++e) {
-              const double rr[3] = {pl.p[0] - pm[e].p[0], pl.p[1] - pm[e].p[1], pl.p[2] - pm[e].p[2]};
-              double xr[3] = {0, 0, 0}, xf[3] = {0, 0, 0}, ml[3] = {0, 0, 0};
-              xr[i2] = rr[i1]; xr[i1] = -rr[i2];              // +(r x df)_i
-              xf[i2] = pf[e].p[i1]; xf[i1] = -pf[e].p[i2];    // +(f x dp)_i
-              ml[i] = -1.0;
-              row_nodes(ra, 6 + e, pf[e], 0, xr, 7 & ~(1 << i));
-              row_nodes(rl, 6 + e, pf[e], 0, ml, 1 << i);
-              row_nodes(ra, 2 + e, pm[e], 0, xf, 7 & ~(1 << i));
-              row_durs(ra, 6 + e, t, pf[e], xr);              // humanoid_dynamic_constraint.cpp:112-118
-              row_durs(rl, 6 + e, t, pf[e], ml);
-              row_durs(ra, 2 + e, t, pm[e], xf);
-            }
-          }
-          if (D2) {
-            // rows: ang_i - sum_e (F_e x r_e)_i with r_e = c - p_e, and m a_i - sum_e F_e,i.  With La / Ll the multipliers of the
-            // angular / linear rows:  d2L = -La . [Q^F x r - (G^F_k x G^p_l + G^F_l x G^p_k) - F x Q^p] - Ll . Q^F
-            double La[3], Ll[3];
-            for (int k = 0; k < 3; ++k) { La[k] = lam[row0 + k] * sc[row0 + k]; Ll[k] = lam[row0 + 3 + k] * sc[row0 + 3 + k]; }
-            for (int e = 0; e < 4; ++e) {
-              DurJac2 dF, dP; dur_jac2(q, 6 + e, t, pf[e], dF); dur_jac2(q, 2 + e, t, pm[e], dP);
-              const double rr[3] = {pl.p[0] - pm[e].p[0], pl.p[1] - pm[e].p[1], pl.p[2] - pm[e].p[2]};
-              double S3[3];
-              for (int cls = 0; cls < 3; ++cls) {
-                const double* QF = cls == 0 ? dF.Qee : cls == 1 ? dF.Qec : dF.Qcc;
-                const double* QP = cls == 0 ? dP.Qee : cls == 1 ? dP.Qec : dP.Qcc;
-                const double* GFx = cls == 2 ? dF.Gc : dF.Ge; const double* GFy = cls == 0 ? dF.Ge : dF.Gc;
-                const double* GPx = cls == 2 ? dP.Gc : dP.Ge; const double* GPy = cls == 0 ? dP.Ge : dP.Gc;
-                double a1[3], a2[3], a3[3], a4[3];
-                cross3(QF, rr, a1); cross3(GFx, GPy, a2); cross3(GFy, GPx, a3); cross3(pf[e].p, QP, a4);
-                double v = 0;
-                for (int k = 0; k < 3; ++k) v += -La[k] * (a1[k] - a2[k] - a3[k] - a4[k]) - Ll[k] * QF[k];
-                S3[cls] = v;
-              }
-              d2_store(q, e, B, dF.cur, S3[0], S3[1], S3[2]);
-            }
-          }
-        }
-      } break;
+      case T_DYN: dyn_rows(c, ti, J, D2, cout_, lam, sc); break;
       case T_FORCE: {        // TOWR ForceConstraint: normal force range + friction pyramid
         const SplineDesc& sp = q->sp[6 + A];
         const GD* nv = q->wd + q->o_node + sp.node_off + B * 6;
@@ -1514,91 +1535,101 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, GD* g, const GD* lam) {
   PAR_FOR(idx, 6 * fstride) first[idx] = F;
   PAR_FOR(j, c.n) g[j] = 0.0;
   CHD_SYNC();
+  int gap = 1;              // largest polynomial-index step between consecutive samples
   PAR_FOR(idx, 6 * F) {
     const int s = idx / F, i = idx % F;
     const int pi = (int)scache(q, s, i)[SC_POLY];
     const int pp = i > 0 ? (int)scache(q, s, i - 1)[SC_POLY] : -1;
     for (int p = pp + 1; p <= pi; ++p) first[s * fstride + p] = i;
+    if (i > 0 && pi - pp > gap) gap = pi - pp;
   }
-  CHD_SYNC();
+  gap = (int)block_max(c, (double)gap);       // (ends with a barrier)
   long long tg_ = CHD_CLOCK();
-  // ---- node variables: one thread per (spline, node group, dimension)
+  // ---- node variables.  Every cost residual is linear in the node values for fixed durations,
+  //   r = sum_v G(v) x_v + const, with G the Hermite weights of the sample(s) the residual touches, so the
+  //   Gauss-Newton block is the Gram matrix of the G's.  One thread per entry (row coefficient, column coefficient
+  //   at most `reach` nodes back) sums its products in a register; a stance pair (two nodes, one variable) is one
+  //   coefficient whose weight is the sum over both nodes.  The weights do not depend on the dimension.
   int tot_nodes = 0;
   for (int s = 0; s < 6; ++s) tot_nodes += q->sp[s].n_nodes;
-  PAR_FOR(idx, tot_nodes * 3) {
-    const int dim = idx % 3;
-    int nd = idx / 3, s = 0;
-    while (nd >= q->sp[s].n_nodes) { nd -= q->sp[s].n_nodes; ++s; }
+  const int reach = gap + 2, ncol = (reach + 1) * 2;
+  auto second_of_pair = [&](const SplineDesc& sp, const GI* pinfo, int n) { return sp.phase_based && n > 0 && pinfo[(n - 1) * 4 + 3] != 0; };
+  auto group_end = [&](const SplineDesc& sp, const GI* pinfo, int n) { return (sp.phase_based && n < sp.n_polys && pinfo[n * 4 + 3]) ? n + 1 : n; };
+  // weight of the coefficient (nodes n..nh, derivative dq) in the position (which = 0) / velocity (1) of a sample
+  auto wgt = [](const GD* a, int which, int n, int nh, int dq) {
+    const int p = (int)a[SC_POLY];
+    const GD* W = a + (which ? SC_WV : SC_WP);
+    double v = 0.0;
+    if (p >= n && p <= nh) v += W[dq];
+    if (p + 1 >= n && p + 1 <= nh) v += W[2 + dq];
+    return v;
+  };
+  PAR_FOR(idx, tot_nodes * 2 * ncol) {
+    const int col = idx % ncol, row = idx / ncol;
+    const int dq1 = row % 2, back = col / 2, dq2 = col % 2;
+    int n1 = row / 2, s = 0;
+    while (n1 >= q->sp[s].n_nodes) { n1 -= q->sp[s].n_nodes; ++s; }
     const SplineDesc& sp = q->sp[s];
     const GI* pinfo = q->ci + q->o_pinfo + sp.poly_off * 4;
     const GI* vo = q->ci + q->o_varof + sp.node_off;
-    if (sp.phase_based && nd > 0 && pinfo[(nd - 1) * 4 + 3]) continue;       // second node of a stance pair: owned by the first
-    const int nd_hi = (sp.phase_based && nd < sp.n_polys && pinfo[nd * 4 + 3]) ? nd + 1 : nd;
+    const int n2 = n1 - back;
+    if (n2 < 0 || (back == 0 && dq2 > dq1)) continue;
+    if (second_of_pair(sp, pinfo, n1) || second_of_pair(sp, pinfo, n2)) continue;       // folded into the pair's first node
+    const int h1 = group_end(sp, pinfo, n1), h2 = group_end(sp, pinfo, n2);
     bool any = false;
-    for (int n2 = nd; n2 <= nd_hi; ++n2) for (int dq = 0; dq < 2; ++dq) any = any || vo[n2 * 6 + dq * 3 + dim] >= 0;
+    for (int dim = 0; dim < 3; ++dim) any = any || (vo[n1 * 6 + dq1 * 3 + dim] >= 0 && vo[n2 * 6 + dq2 * 3 + dim] >= 0);
     if (!any) continue;
-    const int pa = nd - 1 < 0 ? 0 : nd - 1, pb = nd_hi > sp.n_polys - 1 ? sp.n_polys - 1 : nd_hi;
+    const int pa = n1 - 1 < 0 ? 0 : n1 - 1, pb = h1 > sp.n_polys - 1 ? sp.n_polys - 1 : h1;
+    const int i_lo = first[s * fstride + pa], i_hi = first[s * fstride + pb + 1] - 1;
+    const int nsm = n_smooth(q, s);
+    const int ti = s < 2 ? s : 2;
+    const double wdat = S->w_data[ti], wvel = S->w_vel[ti], wacc = S->w_acc[ti];
+    double acc = 0.0;
+    for (int i = i_lo; i <= i_hi && i < F; ++i) {
+      const GD* a = scache(q, s, i);
+      acc += wdat * wgt(a, 0, n1, h1, dq1) * wgt(a, 0, n2, h2, dq2);
+    }
+    if (wvel >= 0 || wacc >= 0)
+      for (int i = i_lo - 1 < 0 ? 0 : i_lo - 1; i <= i_hi && i < nsm; ++i) {
+        const GD* a = scache(q, s, i); const GD* b = scache(q, s, i + 1);
+        if (wvel >= 0) acc += wvel * (wgt(b, 0, n1, h1, dq1) - wgt(a, 0, n1, h1, dq1)) * (wgt(b, 0, n2, h2, dq2) - wgt(a, 0, n2, h2, dq2));
+        if (wacc >= 0) acc += wacc * (wgt(b, 1, n1, h1, dq1) - wgt(a, 1, n1, h1, dq1)) * (wgt(b, 1, n2, h2, dq2) - wgt(a, 1, n2, h2, dq2));
+      }
+    if (acc == 0.0) continue;
+    for (int dim = 0; dim < 3; ++dim) {
+      const int v1 = vo[n1 * 6 + dq1 * 3 + dim], v2 = vo[n2 * 6 + dq2 * 3 + dim];
+      if (v1 >= 0 && v2 >= 0) kadd(c, c.pos_var[sp.var_off + v1], c.pos_var[sp.var_off + v2], c.sf * acc);
+    }
+  }
+  // gradient: one thread per (coefficient, dimension)
+  PAR_FOR(idx, tot_nodes * 2 * 3) {
+    const int dim = idx % 3, row = idx / 3, dq1 = row % 2;
+    int n1 = row / 2, s = 0;
+    while (n1 >= q->sp[s].n_nodes) { n1 -= q->sp[s].n_nodes; ++s; }
+    const SplineDesc& sp = q->sp[s];
+    const GI* pinfo = q->ci + q->o_pinfo + sp.poly_off * 4;
+    const GI* vo = q->ci + q->o_varof + sp.node_off;
+    const int v1 = vo[n1 * 6 + dq1 * 3 + dim];
+    if (v1 < 0 || second_of_pair(sp, pinfo, n1)) continue;
+    const int h1 = group_end(sp, pinfo, n1);
+    const int pa = n1 - 1 < 0 ? 0 : n1 - 1, pb = h1 > sp.n_polys - 1 ? sp.n_polys - 1 : h1;
     const int i_lo = first[s * fstride + pa], i_hi = first[s * fstride + pb + 1] - 1;
     const int nsm = n_smooth(q, s);
     const int ti = s < 2 ? s : 2;
     const double wdat = S->w_data[ti], wvel = S->w_vel[ti], wacc = S->w_acc[ti];
     const GD* dat = q->cd + q->o_data[s];
-    // Contributions are summed in thread-private accumulators keyed by (own node value, neighbour node value) and
-    // written to the KKT storage once each (instead of one global read-modify-write per residual).
-    enum { NSLOT = 24 };
-    double hloc[4][NSLOT], gloc[4];
-    for (int a = 0; a < 4; ++a) { gloc[a] = 0.0; for (int b = 0; b < NSLOT; ++b) hloc[a][b] = 0.0; }
-    const int nbase = nd - 4;
-    // residual kinds: 0 data(i), 1 position difference (i, i+1), 2 velocity difference (i, i+1)
-    for (int kind = 0; kind < 3; ++kind) {
-      const double wt = kind == 0 ? wdat : kind == 1 ? wvel : wacc;
-      if (wt < 0) continue;
-      int r_lo = i_lo, r_hi = i_hi;
-      if (kind > 0) { r_lo = i_lo - 1 < 0 ? 0 : i_lo - 1; if (r_hi > nsm - 1) r_hi = nsm - 1; }
-      else if (r_hi > F - 1) r_hi = F - 1;
-      for (int i = r_lo; i <= r_hi; ++i) {
-        const GD* a = scache(q, s, i);
-        Supp su; su.n = 0;
-        double r;
-        if (kind == 0) { supp_add_sample(su, a, 0, -1.0); r = dat[i * 3 + dim] - a[SC_P + dim]; }
-        else {
-          const GD* b = scache(q, s, i + 1);
-          supp_add_sample(su, b, kind - 1, 1.0); supp_add_sample(su, a, kind - 1, -1.0);
-          r = kind == 1 ? b[SC_P + dim] - a[SC_P + dim] : b[SC_V + dim] - a[SC_V + dim];
-        }
-        for (int x1 = 0; x1 < su.n; ++x1) {
-          if (su.node[x1] < nd || su.node[x1] > nd_hi) continue;
-          const int oi = (su.node[x1] - nd) * 2 + su.dq[x1];
-          gloc[oi] += wt * r * su.g[x1];
-          for (int x2 = 0; x2 < su.n; ++x2) {
-            const int sl = (su.node[x2] - nbase) * 2 + su.dq[x2];
-            if (sl >= 0 && sl < NSLOT) hloc[oi][sl] += wt * su.g[x1] * su.g[x2];
-            else {      // support wider than the accumulator window (very short polynomials): write through
-              const int v = vo[su.node[x1] * 6 + su.dq[x1] * 3 + dim], v2 = vo[su.node[x2] * 6 + su.dq[x2] * 3 + dim];
-              if (v >= 0 && v2 >= 0) { const int P = c.pos_var[sp.var_off + v], Q = c.pos_var[sp.var_off + v2]; if (Q <= P) kadd(c, P, Q, c.sf * wt * su.g[x1] * su.g[x2]); }
-            }
-          }
-        }
-      }
+    double acc = 0.0;
+    for (int i = i_lo; i <= i_hi && i < F; ++i) {
+      const GD* a = scache(q, s, i);
+      acc -= wdat * (dat[i * 3 + dim] - a[SC_P + dim]) * wgt(a, 0, n1, h1, dq1);
     }
-    for (int oi = 0; oi < 4; ++oi) {
-      const int node = nd + oi / 2, dq = oi % 2;
-      if (node > nd_hi) continue;
-      const int v = vo[node * 6 + dq * 3 + dim];
-      if (v < 0) continue;
-      const int gv = sp.var_off + v, P = c.pos_var[gv];
-      g[gv] += c.sf * gloc[oi];
-      for (int sl = 0; sl < NSLOT; ++sl) {
-        const double val = hloc[oi][sl];
-        if (val == 0.0) continue;
-        const int n2 = nbase + sl / 2;
-        if (n2 < 0 || n2 >= sp.n_nodes) continue;
-        const int v2 = vo[n2 * 6 + (sl % 2) * 3 + dim];
-        if (v2 < 0) continue;
-        const int Q = c.pos_var[sp.var_off + v2];
-        if (Q <= P) kadd(c, P, Q, c.sf * val);
+    if (wvel >= 0 || wacc >= 0)
+      for (int i = i_lo - 1 < 0 ? 0 : i_lo - 1; i <= i_hi && i < nsm; ++i) {
+        const GD* a = scache(q, s, i); const GD* b = scache(q, s, i + 1);
+        if (wvel >= 0) acc += wvel * (b[SC_P + dim] - a[SC_P + dim]) * (wgt(b, 0, n1, h1, dq1) - wgt(a, 0, n1, h1, dq1));
+        if (wacc >= 0) acc += wacc * (b[SC_V + dim] - a[SC_V + dim]) * (wgt(b, 1, n1, h1, dq1) - wgt(a, 1, n1, h1, dq1));
       }
-    }
+    g[sp.var_off + v1] += c.sf * acc;
   }
   CHD_SYNC();
   c.tacc[13] += CHD_CLOCK() - tg_; tg_ = CHD_CLOCK();

@@ -422,6 +422,7 @@ class SeqModel {
           at_time(2 + pr, trom_[k], all, r); at_time(4 + pr, trom_[k], all, r);
           dur_at(pr, trom_[k], r); dur_at(pr + 2, trom_[k], r);
         }
+    S.dyn_first = (int)task_t.size(); S.n_dyn = (S.families & FAM_DYNAMIC) ? d.n_tdyn : 0;
     if (S.families & FAM_DYNAMIC)      // HumanoidDynamicConstraint (humanoid_dynamic_constraint.cpp:63-143)
       for (int k = 0; k < d.n_tdyn; ++k) {
         add_task(T_DYN, 0, k, tdyn_[k]);
