@@ -481,7 +481,7 @@ CHD_NOINLINE CHD_DEV void kmatvec(Ctx& c, const GD* x, GD* y, const GD* diag, co
     if (only && only[i] <= 0) continue;
     const int lo = c.env[2 * i], hi = c.env[2 * i + 1];      // nothing is stored outside the envelope
     const GD* row = c.K0b + (long long)i * W2 + (w - i);
-    const double acc = group_sum(dot_strided(row, x, lo + lane_, hi + 1, CHD_GL));
+    const double acc = group_sum(dot_strided(row, x, lo + lane_, hi + 1, CHD_GL));      // (16-byte requests were tried: same rate, the limit is lines in flight)
     if (lane_ == 0) y[i] = acc + (diag ? diag[i] * x[i] : 0.0);
   }
   GROUP_FOR(r, bc) {
@@ -516,7 +516,7 @@ CHD_DEV double pivot_fix(Ctx& c, double d, int sg) {
 #define CHD_WAVE0 (threadIdx.x < 64)
 #define CHD_WLANE ((int)threadIdx.x)
 #define CHD_WSTEP 64
-#define CHD_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#define CHD_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 #endif
 
 
@@ -992,30 +992,79 @@ CHD_DEV void load_diag_tile(Ctx& c, LdsD* tile, int c0, int jb) {
   }
 }
 
+// ---- pieces of the substitution.  `wv0`/`nwv`: the wavefronts [wv0, wv0 + nwv) take part (the first wavefront is
+// busy with a triangular block meanwhile when wv0 == 1)
+#ifdef CHD_HOST_EMU
+#define CHD_REST_W0 0
+#define CHD_REST_NW 1
+#else
+#define CHD_REST_W0 1
+#define CHD_REST_NW (CHD_NWAVES - 1)
+#endif
+// y[i] -= sum_{k in [kbeg, kend)} L(i, k) y[k] for the rows i = r0 .. r0 + nr - 1 (clipped to each row's envelope)
+template <class YP>
+CHD_DEV void fwd_rows_dot(Ctx& c, YP y, const int r0, const int nr, const int kbeg, const int kend, const int wv0, const int nwv) {
+  const int W1 = c.w + 1, w = c.w;
+  const int gpw = CHD_WAVE_SZ / CHD_GL;                    // lane groups per wavefront
+  if (CHD_WAVE_ID < wv0 || CHD_WAVE_ID >= wv0 + nwv) return;
+  const int lane_ = CHD_LANE % CHD_GL;
+  for (int a = (CHD_WAVE_ID - wv0) * gpw + CHD_LANE / CHD_GL; a < nr; a += nwv * gpw) {
+    const int i = r0 + a;
+    const int lo = c.env[2 * i] > kbeg ? c.env[2 * i] : kbeg;          // L(i, k) = 0 left of the envelope
+    const GD* row = c.Kfb + (long long)i * W1 + (w - i);
+    const double acc = group_sum(dot_strided(row, y, lo + lane_, kend, CHD_GL));
+    if (lane_ == 0) y[i] -= acc;
+  }
+}
+// y[k] -= sum_a L(c0 + a, k) y[c0 + a] for the columns k in [kbeg, kend), rows of the block at c0:
+// two half-waves per 32 columns (rows a < 32 and a >= 32 of the block), combined with one xor-32 shuffle
+template <class YP>
+CHD_DEV void bwd_cols_scatter(Ctx& c, YP y, const int c0, const int jb, const int kbeg, const int kend, const int wv0, const int nwv) {
+  const int W1 = c.w + 1, w = c.w;
+  if (CHD_WAVE_ID < wv0 || CHD_WAVE_ID >= wv0 + nwv) return;
+  const int ncol = kend - kbeg, cpw = CHD_WAVE_SZ / CHD_PAIR;
+  for (int base = (CHD_WAVE_ID - wv0) * cpw; base < ncol; base += nwv * cpw) {
+    const int kk = base + CHD_LANE % cpw, half = CHD_LANE / cpw;
+    const bool live = kk < ncol;
+    const int k = kbeg + (live ? kk : 0);
+    // rows i = c0 + a reach column k while i - k <= w
+    int amax = (w - (c0 - k)) < jb - 1 ? (w - (c0 - k)) : jb - 1;
+    if (c.env[2 * k + 1] - c0 < amax) amax = c.env[2 * k + 1] - c0;      // no row beyond this one reaches column k
+    const GD* col = c.Kfb + (long long)c0 * W1 + (k - c0 + w);      // L(c0 + a, k) = col[a * (W1 - 1)]
+    const int a0 = CHD_PAIR == 2 ? half * (CHD_SOLVE_NB / 2) : 0;
+    const int aend = CHD_PAIR == 2 ? (half == 0 ? (amax < CHD_SOLVE_NB / 2 - 1 ? amax : CHD_SOLVE_NB / 2 - 1) : amax) : amax;
+    const double acc = pair_sum(dot_column(col, W1 - 1, y + c0, a0, aend + 1));
+    if (half == 0 && live) y[k] -= acc;
+  }
+}
+
 // x = K^{-1} rhs using the factor.  y: work vector of N doubles, S: the dense border factor (both in LDS when they fit).
+// The 64x64 triangular blocks are a one-wavefront dependent chain; the other wavefronts spend that time on the part
+// of the next block's update that does not need the chain's result.
 template <class YP, class SP>
 CHD_DEV void ksolve_impl(Ctx& c, const GD* rhs, GD* x, YP y, SP Sp, const int lds_, const bool stage_s, LdsD* tile) {
   const int Nb = c.Nb, w = c.w, W1 = c.w + 1, LD = c.LD, bc = c.bc, N = c.N;
   PAR_FOR(i, N) y[i] = rhs[i];
   if (stage_s) PAR_FOR(idx, bc * bc) { const int r = idx / bc, k = idx % bc; Sp[idx] = c.Kfx[(long long)r * LD + Nb + k]; }
-  CHD_SYNC();
   const int nb = CHD_SOLVE_NB;
+  const int nblk = (Nb + nb - 1) / nb;
+  if (tile) load_diag_tile(c, tile, 0, Nb < nb ? Nb : nb);
+  CHD_SYNC();
   long long ts_ = CHD_CLOCK();
   // forward, band
-  for (int c0 = 0; c0 < Nb; c0 += nb) {
+  for (int bk = 0; bk < nblk; ++bk) {
+    const int c0 = bk * nb, c1 = c0 + nb;
     const int jb = Nb - c0 < nb ? Nb - c0 : nb;
+    const int jb1 = bk + 1 < nblk ? (Nb - c1 < nb ? Nb - c1 : nb) : 0;
     ts_ = CHD_CLOCK();
-    GROUP_FOR(a, jb) {
-      const int i = c0 + a;
-      const int lo = c.env[2 * i];          // L(i, k) = 0 left of the envelope
-      const GD* row = c.Kfb + (long long)i * W1 + (w - i);
-      const double acc = group_sum(dot_strided(row, y, lo + lane_, c0, CHD_GL));
-      if (lane_ == 0) y[i] -= acc;
-    }
-    if (tile) load_diag_tile(c, tile, c0, jb);
+    tri_forward(c, y, c0, jb, tile);                                                  // first wavefront
+    if (jb1 > 0 && c0 > 0) fwd_rows_dot(c, y, c1, jb1, 0, c0, CHD_REST_W0, CHD_REST_NW);     // the others: columns left of this block
     CHD_SYNC();
     c.tacc[16] += CHD_CLOCK() - ts_; ts_ = CHD_CLOCK();
-    tri_forward(c, y, c0, jb, tile);
+    if (jb1 > 0) {
+      fwd_rows_dot(c, y, c1, jb1, c0, c1, 0, CHD_NWAVES);                             // columns of the block just solved
+      if (tile) load_diag_tile(c, tile, c1, jb1);
+    }
     CHD_SYNC();
     c.tacc[17] += CHD_CLOCK() - ts_;
   }
@@ -1027,52 +1076,47 @@ CHD_DEV void ksolve_impl(Ctx& c, const GD* rhs, GD* x, YP y, SP Sp, const int ld
     if (lane_ == 0) y[Nb + r] -= acc;
   }
   CHD_SYNC();
-  for (int j = 0; j + 1 < bc; ++j) {       // dense unit-lower part of the border
-    const double yj = y[Nb + j];
-    for (int r = j + 1 + CHD_TID; r < bc; r += CHD_NT) y[Nb + r] -= Sp[(long long)r * lds_ + j] * yj;
-    CHD_SYNC();
+  // dense unit-lower part of the border: one wavefront, ordered through LDS (no workgroup barrier per column)
+  if (CHD_WAVE0) {
+    for (int j = 0; j + 1 < bc; ++j) {
+      const double yj = y[Nb + j];
+      for (int r = j + 1 + CHD_WLANE; r < bc; r += CHD_WSTEP) y[Nb + r] -= Sp[(long long)r * lds_ + j] * yj;
+      CHD_WSYNC();
+    }
   }
+  CHD_SYNC();
   // diagonal
   PAR_FOR(i, N) y[i] /= (i < Nb ? c.Kfb[(long long)i * W1 + w] : c.Kfx[(long long)(i - Nb) * LD + i]);
   CHD_SYNC();
   // backward, border
-  for (int j = bc - 1; j > 0; --j) {
-    const double yj = y[Nb + j];
-    for (int r = CHD_TID; r < j; r += CHD_NT) y[Nb + r] -= Sp[(long long)j * lds_ + r] * yj;
-    CHD_SYNC();
+  if (CHD_WAVE0) {
+    for (int j = bc - 1; j > 0; --j) {
+      const double yj = y[Nb + j];
+      for (int r = CHD_WLANE; r < j; r += CHD_WSTEP) y[Nb + r] -= Sp[(long long)j * lds_ + r] * yj;
+      CHD_WSYNC();
+    }
   }
+  CHD_SYNC();
   PAR_FOR(k, Nb) {
     y[k] -= dot_column(c.Kfx + k, LD, y + Nb, 0, bc);
   }
+  if (tile) load_diag_tile(c, tile, (nblk - 1) * nb, Nb - (nblk - 1) * nb);
   CHD_SYNC();
   c.tacc[18] += CHD_CLOCK() - ts_;
   // backward, band
-  const int nblk = (Nb + nb - 1) / nb;
-  if (tile) { load_diag_tile(c, tile, (nblk - 1) * nb, Nb - (nblk - 1) * nb); CHD_SYNC(); }
-  for (int bk = nblk - 1; bk >= 0; --bk) {
-    const int c0 = bk * nb;
+  tri_backward(c, y, (nblk - 1) * nb, Nb - (nblk - 1) * nb, tile);
+  CHD_SYNC();
+  for (int bk = nblk - 1; bk >= 1; --bk) {
+    const int c0 = bk * nb, cp = c0 - nb;
     const int jb = Nb - c0 < nb ? Nb - c0 : nb;
+    const int k0 = c0 - w < 0 ? 0 : c0 - w;
     ts_ = CHD_CLOCK();
-    tri_backward(c, y, c0, jb, tile);
+    bwd_cols_scatter(c, y, c0, jb, k0 > cp ? k0 : cp, c0, 0, CHD_NWAVES);             // into the previous block
+    if (tile) load_diag_tile(c, tile, cp, nb);
     CHD_SYNC();
     c.tacc[19] += CHD_CLOCK() - ts_; ts_ = CHD_CLOCK();
-    const int k0 = c0 - w < 0 ? 0 : c0 - w;
-    // two half-waves per 32 columns (rows a < 32 and a >= 32 of the block), combined with one xor-32 shuffle
-    const int ncol = c0 - k0, cpw = CHD_WAVE_SZ / CHD_PAIR;
-    for (int base = CHD_WAVE_ID * cpw; base < ncol; base += CHD_NWAVES * cpw) {
-      const int kk = base + CHD_LANE % cpw, half = CHD_LANE / cpw;
-      const bool live = kk < ncol;
-      const int k = k0 + (live ? kk : 0);
-      // rows i = c0 + a reach column k while i - k <= w
-      int amax = (w - (c0 - k)) < jb - 1 ? (w - (c0 - k)) : jb - 1;
-      if (c.env[2 * k + 1] - c0 < amax) amax = c.env[2 * k + 1] - c0;      // no row beyond this one reaches column k
-      const GD* col = c.Kfb + (long long)c0 * W1 + (k - c0 + w);      // L(c0 + a, k) = col[a * (W1 - 1)]
-      const int a0 = CHD_PAIR == 2 ? half * (CHD_SOLVE_NB / 2) : 0;
-      const int aend = CHD_PAIR == 2 ? (half == 0 ? (amax < CHD_SOLVE_NB / 2 - 1 ? amax : CHD_SOLVE_NB / 2 - 1) : amax) : amax;
-      const double acc = pair_sum(dot_column(col, W1 - 1, y + c0, a0, aend + 1));
-      if (half == 0 && live) y[k] -= acc;
-    }
-    if (tile && bk > 0) load_diag_tile(c, tile, c0 - nb, nb);
+    tri_backward(c, y, cp, nb, tile);                                                 // first wavefront
+    if (k0 < cp) bwd_cols_scatter(c, y, c0, jb, k0, cp, CHD_REST_W0, CHD_REST_NW);    // the others: columns further left
     CHD_SYNC();
     c.tacc[20] += CHD_CLOCK() - ts_;
   }
@@ -1080,12 +1124,218 @@ CHD_DEV void ksolve_impl(Ctx& c, const GD* rhs, GD* x, YP y, SP Sp, const int ld
   CHD_SYNC();
 }
 
+#ifndef CHD_HOST_EMU
+// ---- device fast path of the substitution (y, the packed border factor and one 64x64 tile in LDS; 64 <= w <= 384).
+// Every entry of L that a block step needs is requested one block step ahead and waits in registers, so a step is
+// LDS traffic, FMAs and two barriers instead of two dependent HBM round trips.
+//   forward, block B:  rows of B  x  columns left of block B-1   ("far",  lane groups of 16: rows g and g + 32)
+//                      rows of B  x  columns of block B-1        ("near", 8 lanes per row, 8 columns each)
+//   backward, block B: columns of block B-1  x  rows of B        ("near", 8 columns per wavefront, 8 rows per lane)
+//                      columns left of B-1   x  rows of B        ("far",  16 columns x 4 row quarters per wavefront pass)
+#define CHD_NQ 24
+#define CHD_BP 3
+CHD_DEV void tri_chain_fwd(LdsD* y, const LdsD* tile, const int c0, const int jb) {
+  const int i = threadIdx.x;
+  const bool act = i < jb;
+  double yi = act ? y[c0 + i] : 0.0;
+#pragma unroll
+  for (int j0 = 0; j0 < CHD_SOLVE_NB; j0 += 8) {
+    double l8[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) l8[q] = (act && j0 + q < i) ? tile[i * CHD_TILE_LD + j0 + q] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) if (j0 + q < CHD_SOLVE_NB - 1) yi -= l8[q] * readlane_f64(yi, j0 + q);
+    CHD_SCHED_FENCE();
+  }
+  if (act) y[c0 + i] = yi;
+}
+CHD_DEV void tri_chain_bwd(LdsD* y, const LdsD* tile, const int c0, const int jb) {
+  const int i = threadIdx.x;
+  const bool act = i < jb;
+  double yi = act ? y[c0 + i] : 0.0;
+#pragma unroll
+  for (int j0 = CHD_SOLVE_NB - 8; j0 >= 0; j0 -= 8) {
+    double l8[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) l8[q] = (act && j0 + q > i && j0 + q < jb) ? tile[(j0 + q) * CHD_TILE_LD + i] : 0.0;
+#pragma unroll
+    for (int q = 7; q >= 0; --q) if (j0 + q > 0) yi -= l8[q] * readlane_f64(yi, j0 + q);
+    CHD_SCHED_FENCE();
+  }
+  if (act) y[c0 + i] = yi;
+}
+CHD_DEV void ksolve_fast(Ctx& c, const GD* rhs, GD* x, LdsD* y, LdsD* Sp, LdsD* tile) {
+  const int Nb = c.Nb, w = c.w, W1 = c.w + 1, LD = c.LD, bc = c.bc, N = c.N;
+  const int nb = CHD_SOLVE_NB, nblk = (Nb + nb - 1) / nb;
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int g16 = tid >> 4, l16 = tid & 15;
+  const int r8 = tid >> 3, c8 = (tid & 7) << 3;
+  const GD* Kfb = c.Kfb;
+  const GD* safe = c.Kfb + w;            // a valid address for the predicated-off requests (loads are never branched around)
+  PAR_FOR(i, N) y[i] = rhs[i];
+  PAR_FOR(idx, bc * bc) { const int r = idx / bc, k = idx % bc; if (k <= r) Sp[r * (r + 1) / 2 + k] = c.Kfx[(long long)r * LD + Nb + k]; }
+  double fr[2][CHD_NQ], nr[8], tl[8];
+  int flo[2] = {0, 0};
+  const GI* env = c.env;
+  int elo[2] = {0, 0};       // envelope starts of the rows whose far part is requested next (fetched one step ahead as well)
+  // -- requests (block index B; all predicated, so B may run past the last block)
+#define CHD_LOAD_TILE(B) do { const int c0_ = (B) * nb, jb_ = Nb - c0_ < nb ? Nb - c0_ : nb; \
+    const bool ok_ = (B) >= 0 && (B) < nblk && r8 < jb_; \
+    const GD* row_ = Kfb + (long long)(ok_ ? c0_ + r8 : 0) * W1 + (w - r8); \
+    _Pragma("unroll") for (int q = 0; q < 8; ++q) { const bool v_ = ok_ && c8 + q < r8; tl[q] = *(v_ ? row_ + c8 + q : safe); } } while (0)
+#define CHD_WRITE_TILE() do { _Pragma("unroll") for (int q = 0; q < 8; ++q) if (c8 + q < r8) tile[r8 * CHD_TILE_LD + c8 + q] = tl[q]; } while (0)
+#define CHD_LOAD_FAR(B) do { const int c0_ = (B) * nb, jb_ = Nb - c0_ < nb ? Nb - c0_ : nb, kend_ = c0_ - nb; \
+    _Pragma("unroll") for (int p = 0; p < 2; ++p) { const int a_ = g16 + 32 * p, i_ = c0_ + a_; \
+      const bool ok_ = (B) < nblk && a_ < jb_ && kend_ > 0; \
+      const int lo_ = elo[p]; flo[p] = lo_; \
+      const GD* row_ = Kfb + (long long)(ok_ ? i_ : 0) * W1 + (w - (ok_ ? i_ : 0)); \
+      _Pragma("unroll") for (int q = 0; q < CHD_NQ; ++q) { const int k_ = lo_ + l16 + 16 * q; const bool v_ = ok_ && k_ < kend_; \
+        fr[p][q] = *(v_ ? row_ + k_ : safe); } \
+      const int in_ = i_ + nb; elo[p] = env[((B) + 1 < nblk && in_ < Nb) ? 2 * in_ : 0]; } } while (0)
+#define CHD_USE_FAR(B) do { const int c0_ = (B) * nb, jb_ = Nb - c0_ < nb ? Nb - c0_ : nb, kend_ = c0_ - nb; \
+    _Pragma("unroll") for (int p = 0; p < 2; ++p) { const int a_ = g16 + 32 * p; \
+      double s0_ = 0, s1_ = 0; \
+      _Pragma("unroll") for (int q = 0; q < CHD_NQ; q += 2) { const int k_ = flo[p] + l16 + 16 * q; \
+        s0_ += fr[p][q] * ((a_ < jb_ && k_ < kend_) ? y[k_] : 0.0); s1_ += fr[p][q + 1] * ((a_ < jb_ && k_ + 16 < kend_) ? y[k_ + 16] : 0.0); } \
+      const double acc_ = group_sum(s0_ + s1_); \
+      if (l16 == 0 && a_ < jb_ && kend_ > 0) y[c0_ + a_] -= acc_; } } while (0)
+#define CHD_LOAD_NEAR(B) do { const int c0_ = (B) * nb, jb_ = Nb - c0_ < nb ? Nb - c0_ : nb; \
+    const bool ok_ = (B) < nblk && r8 < jb_; const int i_ = c0_ + r8, kb_ = c0_ - nb + c8; \
+    const GD* row_ = Kfb + (long long)(ok_ ? i_ : 0) * W1 + (w - (ok_ ? i_ : 0)); \
+    _Pragma("unroll") for (int q = 0; q < 8; ++q) { const bool v_ = ok_ && i_ - (kb_ + q) <= w; nr[q] = *(v_ ? row_ + kb_ + q : safe); } } while (0)
+#define CHD_USE_NEAR(B) do { const int c0_ = (B) * nb, jb_ = Nb - c0_ < nb ? Nb - c0_ : nb, kb_ = c0_ - nb + c8; \
+    double s_ = 0; _Pragma("unroll") for (int q = 0; q < 8; ++q) s_ += nr[q] * ((r8 < jb_ && c0_ + r8 - (kb_ + q) <= w) ? y[kb_ + q] : 0.0); \
+    s_ += __shfl_xor(s_, 4); s_ += __shfl_xor(s_, 2); s_ += __shfl_xor(s_, 1); \
+    if ((tid & 7) == 0 && r8 < jb_) y[c0_ + r8] -= s_; } while (0)
+  CHD_LOAD_TILE(0);
+  CHD_WRITE_TILE();
+  CHD_LOAD_FAR(0); CHD_LOAD_FAR(1); CHD_LOAD_NEAR(1); CHD_LOAD_TILE(1);      // (FAR(0), FAR(1) are empty: they only fetch the envelope starts)
+  CHD_SYNC();
+  long long ts_ = CHD_CLOCK(), t16_ = 0, t17_ = 0, t19_ = 0, t20_ = 0;     // (kept in registers: a store to the context would wait for the requests in flight)
+  // forward, band
+  for (int bk = 0; bk < nblk; ++bk) {
+    const int c0 = bk * nb, jb = Nb - c0 < nb ? Nb - c0 : nb;
+    ts_ = CHD_CLOCK();
+    if (wv == 0) tri_chain_fwd(y, tile, c0, jb);
+    if (bk + 1 < nblk) CHD_USE_FAR(bk + 1);
+    CHD_LOAD_FAR(bk + 2);
+    CHD_SYNC();
+    t16_ += CHD_CLOCK() - ts_; ts_ = CHD_CLOCK();
+    if (bk + 1 < nblk) { CHD_USE_NEAR(bk + 1); CHD_WRITE_TILE(); }
+    CHD_LOAD_NEAR(bk + 2); CHD_LOAD_TILE(bk + 2);
+    CHD_SYNC();
+    t17_ += CHD_CLOCK() - ts_;
+  }
+  ts_ = CHD_CLOCK();
+  // requests for the first backward steps travel while the border is processed
+  double bf[CHD_BP][16], bn[8];
+  const int rg = lane >> 3, cl8 = lane & 7, qd = lane >> 4, cl16 = lane & 15;
+#define CHD_LOAD_BNEAR(B) do { const int c0_ = (B) * nb, jb_ = Nb - c0_ < nb ? Nb - c0_ : nb; \
+    const int k_ = c0_ - nb + 8 * wv + cl8; \
+    _Pragma("unroll") for (int q = 0; q < 8; ++q) { const int a_ = rg * 8 + q, i_ = c0_ + a_; \
+      const bool v_ = (B) >= 1 && a_ < jb_ && i_ - k_ <= w; bn[q] = *(v_ ? Kfb + (long long)i_ * W1 + (k_ - i_ + w) : safe); } } while (0)
+#define CHD_USE_BNEAR(B) do { const int c0_ = (B) * nb, jb_ = Nb - c0_ < nb ? Nb - c0_ : nb; \
+    const int kn_ = c0_ - nb + 8 * wv + cl8; \
+    double s_ = 0; _Pragma("unroll") for (int q = 0; q < 8; ++q) { const int a_ = rg * 8 + q; s_ += bn[q] * ((a_ < jb_ && c0_ + a_ - kn_ <= w) ? y[c0_ + a_] : 0.0); } \
+    s_ += __shfl_xor(s_, 8); s_ += __shfl_xor(s_, 16); s_ += __shfl_xor(s_, 32); \
+    if (rg == 0) y[c0_ - nb + 8 * wv + cl8] -= s_; } while (0)
+#define CHD_LOAD_BFAR(B) do { const int c0_ = (B) * nb, jb_ = Nb - c0_ < nb ? Nb - c0_ : nb; \
+    const int k0_ = c0_ - w < 0 ? 0 : c0_ - w, kend_ = c0_ - nb; \
+    _Pragma("unroll") for (int p = 0; p < CHD_BP; ++p) { const int k_ = k0_ + (p * 8 + wv) * 16 + cl16; \
+      const bool okc_ = (B) >= 1 && k_ < kend_; \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) { const int a_ = qd * 16 + r, i_ = c0_ + a_; \
+        const bool v_ = okc_ && a_ < jb_ && i_ - k_ <= w; bf[p][r] = *(v_ ? Kfb + (long long)i_ * W1 + (k_ - i_ + w) : safe); } } } while (0)
+#define CHD_USE_BFAR(B) do { const int c0_ = (B) * nb, jb_ = Nb - c0_ < nb ? Nb - c0_ : nb; \
+    const int k0_ = c0_ - w < 0 ? 0 : c0_ - w, kend_ = c0_ - nb; \
+    _Pragma("unroll") for (int p = 0; p < CHD_BP; ++p) { const int k_ = k0_ + (p * 8 + wv) * 16 + cl16; \
+      double s0_ = 0, s1_ = 0; \
+      _Pragma("unroll") for (int r = 0; r < 16; r += 2) { const int a_ = qd * 16 + r; \
+        s0_ += bf[p][r] * ((k_ < kend_ && a_ < jb_ && c0_ + a_ - k_ <= w) ? y[c0_ + a_] : 0.0); \
+        s1_ += bf[p][r + 1] * ((k_ < kend_ && a_ + 1 < jb_ && c0_ + a_ + 1 - k_ <= w) ? y[c0_ + a_ + 1] : 0.0); } \
+      double s_ = s0_ + s1_; s_ += __shfl_xor(s_, 16); s_ += __shfl_xor(s_, 32); \
+      if (qd == 0 && k_ < kend_) y[k_] -= s_; } } while (0)
+  CHD_LOAD_TILE(nblk - 1); CHD_LOAD_BNEAR(nblk - 1); CHD_LOAD_BFAR(nblk - 1);
+  // forward, border rows: band part of L_border
+  GROUP_FOR(r, bc) {
+    const GD* row = c.Kfx + (long long)r * LD;
+    const double acc = group_sum(dot_strided(row, y, lane_, Nb, CHD_GL));
+    if (lane_ == 0) y[Nb + r] -= acc;
+  }
+  CHD_SYNC();
+  // dense unit-lower part of the border: one wavefront, ordered through LDS (no workgroup barrier per column)
+  if (wv == 0) {
+    for (int j = 0; j + 1 < bc; ++j) {
+      const double yj = y[Nb + j];
+      for (int r = j + 1 + lane; r < bc; r += 64) y[Nb + r] -= Sp[r * (r + 1) / 2 + j] * yj;
+      CHD_WSYNC();
+    }
+  }
+  CHD_SYNC();
+  // diagonal
+  PAR_FOR(i, N) y[i] /= (i < Nb ? c.Kfb[(long long)i * W1 + w] : c.Kfx[(long long)(i - Nb) * LD + i]);
+  CHD_SYNC();
+  // backward, border
+  if (wv == 0) {
+    for (int j = bc - 1; j > 0; --j) {
+      const double yj = y[Nb + j];
+      for (int r = lane; r < j; r += 64) y[Nb + r] -= Sp[j * (j + 1) / 2 + r] * yj;
+      CHD_WSYNC();
+    }
+  }
+  CHD_SYNC();
+  PAR_FOR(k, Nb) {
+    y[k] -= dot_column(c.Kfx + k, LD, y + Nb, 0, bc);
+  }
+  CHD_WRITE_TILE();
+  CHD_SYNC();
+  c.tacc[18] += CHD_CLOCK() - ts_;
+  // backward, band
+  CHD_LOAD_TILE(nblk - 2);
+  if (wv == 0) tri_chain_bwd(y, tile, (nblk - 1) * nb, Nb - (nblk - 1) * nb);
+  CHD_SYNC();
+  for (int bk = nblk - 1; bk >= 1; --bk) {
+    ts_ = CHD_CLOCK();
+    CHD_USE_BNEAR(bk);
+    CHD_WRITE_TILE();
+    CHD_LOAD_BNEAR(bk - 1); CHD_LOAD_TILE(bk - 2);
+    CHD_SYNC();
+    t19_ += CHD_CLOCK() - ts_; ts_ = CHD_CLOCK();
+    if (wv == 0) tri_chain_bwd(y, tile, (bk - 1) * nb, nb);
+    CHD_USE_BFAR(bk);
+    CHD_LOAD_BFAR(bk - 1);
+    CHD_SYNC();
+    t20_ += CHD_CLOCK() - ts_;
+  }
+  PAR_FOR(i, N) x[i] = y[i];
+  CHD_SYNC();
+  c.tacc[16] += t16_; c.tacc[17] += t17_; c.tacc[19] += t19_; c.tacc[20] += t20_;
+#undef CHD_LOAD_TILE
+#undef CHD_WRITE_TILE
+#undef CHD_LOAD_FAR
+#undef CHD_USE_FAR
+#undef CHD_LOAD_NEAR
+#undef CHD_USE_NEAR
+#undef CHD_LOAD_BNEAR
+#undef CHD_USE_BNEAR
+#undef CHD_LOAD_BFAR
+#undef CHD_USE_BFAR
+}
+#endif
+
 CHD_NOINLINE CHD_DEV void ksolve_once(Ctx& c, const GD* rhs, GD* x) {
   TIC();
   const int N = c.N, bc = c.bc, Npad = (N + 1) & ~1;
   const int room = c.lds_cap - LDS_RED;
   const int tsz = CHD_SOLVE_NB * CHD_TILE_LD + 1;
   LdsD* base = c.lds + LDS_RED;
+#ifndef CHD_HOST_EMU
+  const int spk = (bc * (bc + 1) / 2 + 1) & ~1;
+  if (room >= Npad + spk + tsz && c.w >= CHD_SOLVE_NB && c.w <= 16 * CHD_NQ && c.w - CHD_SOLVE_NB <= CHD_BP * 128) {
+    ksolve_fast(c, rhs, x, base, base + Npad, base + Npad + spk);
+    TOC(c, 3);
+    return;
+  }
+#endif
   if (room >= Npad + bc * bc + tsz) ksolve_impl(c, rhs, x, base, base + Npad, bc, true, base + Npad + bc * bc);
   else if (room >= Npad + bc * bc) ksolve_impl(c, rhs, x, base, base + Npad, bc, true, (LdsD*)nullptr);
   else if (room >= Npad + tsz) ksolve_impl(c, rhs, x, base, c.Kfx + c.Nb, c.LD, false, base + Npad);
