@@ -18,6 +18,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# One HIP stream per step in flight; the runtime multiplexes streams onto this many hardware queues (its default of 4
+# would cap the number of concurrently running launches at 4).  Must be set before the HIP runtime initialises.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
 
 BATCH = 128
 FRAMES = 90
@@ -53,10 +56,10 @@ def cpu_baseline(max_workers=8):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=4)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=16)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=BATCH, help=argparse.SUPPRESS)
-    ap.add_argument('--pipeline', type=int, default=4,
+    ap.add_argument('--pipeline', type=int, default=16,
                     help='steps in flight at once, each on its own HIP stream (1 = strictly one batch after the other)')
     ap.add_argument('--no-cpu-baseline', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -86,8 +89,8 @@ def main():
     seqs = make_batch(B, F=FRAMES, seed0=rank * B)
     # A step is one full staged solve of one batch.  With --pipeline D > 1, D steps are in flight at once: each has its
     # own solver handle (own HIP stream) and its own device-resident copy of the batch, and is driven by its own host
-    # thread (the C call releases the GIL).  128 workgroups occupy half of the 256 CUs, so two steps run side by side and
-    # the long-running sequences of one step overlap with the next step's work.
+    # thread (the C call releases the GIL).  128 workgroups occupy half of the 256 CUs and a launch lasts as long as its
+    # slowest sequence (several times the mean), so many launches must be in flight to keep every CU busy.
     depth = max(1, min(args.pipeline, max(1, args.steps)))
     solvers = [PhysOptim(device=local, config=default_config()) for _ in range(depth)]      # reference iteration caps and tol
     batches = [sv.upload(seqs) for sv in solvers]                                            # inputs + tables -> HBM (not timed)
@@ -140,6 +143,16 @@ def main():
         # algorithmic bytes of rank 0's launches / average launch duration (HIP events); with overlapping launches the
         # per-launch rate is what the roofline of the kernel is compared with
         ach = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        # fp64 work of the factorisations / substitutions / products (band N_b, half-width w, border b; multiply-add = 2),
+        # from the mean problem size of the batch -- a secondary view: the trailing update of the factorisation runs on
+        # the fp64 matrix cores
+        Nb_ = sum(r.sizes['kkt_dim'] - r.sizes['border'] for r in res) / len(res)
+        w_ = sum(r.sizes['halfband'] for r in res) / len(res)
+        b_ = sum(r.sizes['border'] for r in res) / len(res)
+        fl_fact = Nb_ * w_ * w_ + 2 * Nb_ * w_ * b_ + Nb_ * b_ * b_ + b_ ** 3 / 3
+        fl_solve = 4 * (Nb_ * w_ + Nb_ * b_) + 2 * b_ * b_
+        fl_mv = 2 * (Nb_ * (2 * w_ + 1) + 2 * Nb_ * b_ + b_ * b_)
+        flops = nfact * (fl_fact + 2 * fl_solve + fl_mv) + iters * fl_mv
         traffic = None
         tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tfile):
@@ -161,7 +174,11 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
                          'traffic': traffic, 'kernel': 'chd_solve_kernel', 'launches': launches,
                          'avg_launch_ms': kernel_ms / max(1, launches),
-                         'algorithmic_bytes_per_launch': alg_bytes / max(1, launches)},
+                         'algorithmic_bytes_per_launch': alg_bytes / max(1, launches),
+                         'launches_in_flight': depth,
+                         'achieved_all_launches': alg_bytes / elapsed / 1e9,        # rank 0: bytes of every launch / wall time of the timed region
+                         'fp64': {'achieved': flops / elapsed / 1e12, 'peak': 78.6, 'unit': 'TFLOP/s', 'frac': flops / elapsed / 1e12 / 78.6,
+                                  'note': 'rank 0; band LDL^T + substitutions + products; MI355X fp64 vector = matrix peak 78.6 TFLOP/s (AMD spec; not in MI355X_MICROARCH.md)'}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()

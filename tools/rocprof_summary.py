@@ -30,7 +30,7 @@ con = sqlite3.connect(find_db('trace'))
 rows = list(con.execute('select name, total_calls, total_duration, average, percentage from top_kernels'))
 disp = list(con.execute("select name, duration, grid_x, workgroup_x, lds_size, scratch_size, vgpr_count, accum_vgpr_count, sgpr_count from kernels where name like 'chd_solve_kernel%' order by start"))
 with open(os.path.join(out, tag + '_kernel_stats.md'), 'w') as f:
-    f.write('# rocprofv3 --kernel-trace --stats  (python bench.py --no-cpu-baseline, i.e. the default 4 steps in flight + 1 warm-up)\n\n')
+    f.write('# rocprofv3 --kernel-trace --stats  (python bench.py --no-cpu-baseline: default steps / warm-up / launches in flight)\n\n')
     f.write('| kernel | calls | total (ms) | average (ms) | % |\n|---|---|---|---|---|\n')
     for n, c, t, a, p in rows:
         f.write('| `%s` | %d | %.3f | %.3f | %.3f |\n' % (n, c, t / 1e3, a / 1e3, p))      # top_kernels is in microseconds
