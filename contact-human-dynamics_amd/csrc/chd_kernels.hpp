@@ -430,7 +430,19 @@ CHD_DEV double kget(const Ctx& c, int p, int qq) {
 CHD_DEV void kzero(Ctx& c) {
   const long long nb_ = (long long)c.Nb * c.W2, nx_ = (long long)c.bc * c.LD;
   for (long long i = CHD_TID; i < nb_; i += CHD_NT) c.K0b[i] = 0.0;
-  for (long long i = CHD_TID; i < nx_; i += CHD_NT) c.K0x[i] = 0.0;
+  // border rows: nothing is ever stored left of the row's first coupled band position (env[2 (Nb + r)])
+  for (int r = CHD_WAVE_ID; r < c.bc; r += CHD_NWAVES) {
+    GD* row = c.K0x + (long long)r * c.LD;
+    for (int k = c.env[2 * (c.Nb + r)] + CHD_LANE; k < c.LD; k += CHD_WAVE_SZ) row[k] = 0.0;
+  }
+  (void)nx_;
+}
+// start of a stage: the border blocks are reused with a new layout, and their structurally-zero left parts are
+// neither cleared nor copied again afterwards
+CHD_DEV void kreset(Ctx& c) {
+  const long long nx_ = (long long)c.bc * c.LD;
+  for (long long i = CHD_TID; i < nx_; i += CHD_NT) { c.K0x[i] = 0.0; c.Kfx[i] = 0.0; }
+  CHD_SYNC();
 }
 
 
@@ -487,7 +499,7 @@ CHD_NOINLINE CHD_DEV void kmatvec(Ctx& c, const GD* x, GD* y, const GD* diag, co
   GROUP_FOR(r, bc) {
     if (only && only[Nb + r] <= 0) continue;
     const GD* row = c.K0x + (long long)r * LD;
-    const double acc = group_sum(dot_strided(row, x, lane_, LD, CHD_GL));
+    const double acc = group_sum(dot_strided(row, x, c.env[2 * (Nb + r)] + lane_, LD, CHD_GL));
     if (lane_ == 0) y[Nb + r] = acc + (diag ? diag[Nb + r] * x[Nb + r] : 0.0);
   }
   CHD_SYNC();
@@ -576,11 +588,12 @@ CHD_NOINLINE CHD_DEV void diag_block(Ctx& c, const GI* sign, LdsD* dv, LdsD* DL,
 }
 #endif
 
-// ---- active rows of a panel's window (sorted): u in [0, wr) with u >= nbelow (border) or efirst[i0 + u] <= last_col
+// ---- active rows of a panel's window (sorted): u in [0, wr) whose first coupled column (efirst of a band row i0 + u,
+//      bfirst of a border row u - nbelow) is <= last_col
 #ifdef CHD_HOST_EMU
 CHD_DEV void build_active_rows(Ctx& c, int* act, int* nact, int wr, int nbelow, int i0, int last_col) {
   int n = 0;
-  for (int u = 0; u < wr; ++u) if (u >= nbelow || c.env[2 * (i0 + u)] <= last_col) act[n++] = u;
+  for (int u = 0; u < wr; ++u) if (c.env[2 * (u >= nbelow ? c.Nb + u - nbelow : i0 + u)] <= last_col) act[n++] = u;
   *nact = n;
 }
 #else
@@ -591,7 +604,7 @@ CHD_DEV void build_active_rows(Ctx& c, int* act_, int* nact_, int wr, int nbelow
     int base = 0;
     for (int u0 = 0; u0 < wr; u0 += 64) {
       const int u = u0 + ln;
-      const bool on = u < wr && (u >= nbelow || c.env[2 * (i0 + u)] <= last_col);
+      const bool on = u < wr && c.env[2 * (u >= nbelow ? c.Nb + u - nbelow : i0 + u)] <= last_col;
       const unsigned long long m = __ballot(on);
       if (on) act[base + __popcll(m & ((1ull << ln) - 1ull))] = u;
       base += __popcll(m);
@@ -711,7 +724,8 @@ CHD_NOINLINE CHD_DEV void panel_load(Ctx& c, const Panel P, const int part) {
   for (int idx = t_first; idx < t_end; idx += t_step) {
     const int a = idx / (NB / 8), j0 = (idx % (NB / 8)) * 8;
     double v[8];
-    const bool band = a < jb || (a >= NB && a < NB + nbelow), bord = a >= NB + nbelow && a < pr;
+    const bool band = a < jb || (a >= NB && a < NB + nbelow);
+    const bool bord = a >= NB + nbelow && a < pr && c.env[2 * (c.Nb + (a < pr && a >= NB + nbelow ? a - NB - nbelow : 0))] <= c0 + jb - 1;
     const int i = c0 + (a < jb ? a : jb + a - NB);
     const GD* src = band ? c.Kfb + (long long)i * W1 + (c0 + j0 - i + w) : c.Kfx + (long long)(bord ? a - NB - nbelow : 0) * LD + c0 + j0;
     const int ef = band ? c.env[2 * i] : 0;
@@ -765,6 +779,7 @@ CHD_NOINLINE CHD_DEV void panel_store(Ctx& c, const Panel P) {
     GD* dst = band ? c.Kfb + (long long)i * W1 + (c0 + j0 - i + w) : c.Kfx + (long long)(a - NB - nbelow) * LD + c0 + j0;
     const int ef = band ? c.env[2 * i] : 0;
     if (band && a >= NB && ef > c0 + jb - 1) continue;      // row untouched by this panel
+    if (!band && c.env[2 * (c.Nb + a - NB - nbelow)] > c0 + jb - 1) continue;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int j = j0 + q, k = c0 + j;
@@ -863,7 +878,10 @@ CHD_NOINLINE CHD_DEV void kfactor(Ctx& c, const GD* diag, const GI* sign) {
   for (int r = CHD_WAVE_ID; r < bc; r += CHD_NWAVES) {
     const GD* src = c.K0x + (long long)r * LD;
     GD* dst = c.Kfx + (long long)r * LD;
-    int k = CHD_LANE;
+    int k = c.env[2 * (Nb + r)] + CHD_LANE;         // zero (in both) left of the first coupled band position
+#ifdef CHD_HOST_EMU
+    for (int kk = 0; kk < c.env[2 * (Nb + r)]; ++kk) if (src[kk] != 0.0 || dst[kk] != 0.0) { c.err = 2; std::fprintf(stderr, "border structure violated: row %d col %d first %d\n", r, kk, c.env[2 * (Nb + r)]); break; }      // structure check
+#endif
     for (; k + 7 * CHD_WAVE_SZ < LD; k += 8 * CHD_WAVE_SZ) {
       double v[8];
 #pragma unroll
@@ -1072,7 +1090,7 @@ CHD_DEV void ksolve_impl(Ctx& c, const GD* rhs, GD* x, YP y, SP Sp, const int ld
   // forward, border rows: band part of L_border
   GROUP_FOR(r, bc) {
     const GD* row = c.Kfx + (long long)r * LD;
-    const double acc = group_sum(dot_strided(row, y, lane_, Nb, CHD_GL));
+    const double acc = group_sum(dot_strided(row, y, c.env[2 * (Nb + r)] + lane_, Nb, CHD_GL));
     if (lane_ == 0) y[Nb + r] -= acc;
   }
   CHD_SYNC();
@@ -1258,7 +1276,7 @@ CHD_DEV void ksolve_fast(Ctx& c, const GD* rhs, GD* x, LdsD* y, LdsD* Sp, LdsD* 
   // forward, border rows: band part of L_border
   GROUP_FOR(r, bc) {
     const GD* row = c.Kfx + (long long)r * LD;
-    const double acc = group_sum(dot_strided(row, y, lane_, Nb, CHD_GL));
+    const double acc = group_sum(dot_strided(row, y, c.env[2 * (Nb + r)] + lane_, Nb, CHD_GL));
     if (lane_ == 0) y[Nb + r] -= acc;
   }
   CHD_SYNC();
@@ -2422,6 +2440,7 @@ CHD_DEV void run_sequence(const SeqDesc* q, LdsD* lds, int lds_cap, double tol, 
     GD* rs = q->out_d + stage * RS_STRIDE;
     if (!q->st[stage].valid) { if (CHD_TID == 0) { rs[RS_STATUS] = -3; rs[RS_ITERS] = 0; } continue; }
     bind_stage(c, q, stage);
+    kreset(c);
     c.tol = tol;
     StageResult r;
     solve_stage(c, r);
@@ -2448,6 +2467,7 @@ CHD_DEV void debug_eval(const SeqDesc* q, int stage, int use_x, LdsD* lds, int l
   for (int k = 0; k < 24; ++k) c.tacc[k] = 0;
   init_state(q);
   bind_stage(c, q, stage);
+  kreset(c);
   c.tol = 1e-3;
   GD* x = VN(c, VN_X);
   if (use_x) { PAR_FOR(j, c.n) x[j] = VN(c, VN_XT)[j]; CHD_SYNC(); state_from_x(c, x); }

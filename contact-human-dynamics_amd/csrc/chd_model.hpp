@@ -603,6 +603,47 @@ class SeqModel {
         }
       }
     }
+    // ---- first band position coupled to each border position (Nb = none): left of it the border row of the KKT matrix
+    // and of its factor is structurally zero, so the row joins the factorisation only from that panel on
+    std::vector<int> bfirst(bc, Nb);
+    {
+      auto reach = [&](int pb, int p) { if (pb >= Nb && p >= 0 && p < Nb) bfirst[pb - Nb] = std::min(bfirst[pb - Nb], p); };
+      for (int i = 0; i < m; ++i)
+        for (int v : sup_wide[i]) { reach(pos_var[v], pos_row[i]); reach(pos_row[i], pos_var[v]); }
+      std::vector<int> pos;
+      for (int s = 0; s < 6; ++s) {      // Gauss-Newton couplings of the cost terms (same sample windows as above)
+        const HostSpline& h = hs[s];
+        const double* tc = &cd[d.o_tcost];
+        for (int i = 0; i + 1 < d.F + 1; ++i) {
+          int p0 = locate(pe[s], tc[i]), p1 = locate(pe[s], tc[std::min(i + 1, d.F)]);
+          int lo = std::min(p0, p1), hi = std::max(p0, p1);
+          if (S.opt_dur && h.phase_based) {
+            const double t0 = lo > 0 ? pe[s][lo - 1] : 0.0;
+            if (tc[i] - t0 < kSlack && lo > 0) --lo;
+            if (pe[s][hi] - tc[std::min(i + 1, d.F)] < kSlack && hi + 1 < h.n_polys) ++hi;
+          }
+          for (int k = 0; k < 3; ++k) {
+            pos.clear();
+            for (int nd = lo; nd <= hi + 1; ++nd)
+              for (int dq = 0; dq < 2; ++dq) { int v = h.var_of[nd * 6 + dq * 3 + k]; if (v >= 0) pos.push_back(pos_var[h.var_off + v]); }
+            int lob = Nb;
+            for (int pp : pos) if (pp < Nb) lob = std::min(lob, pp);
+            for (int pp : pos) reach(pp, lob < Nb ? lob : -1);
+          }
+        }
+      }
+      if (S.opt_dur)      // a duration moves every later sample of its end-effector: couples with all node values from its phase on
+        for (int e = 0; e < N_EE; ++e) {
+          const HostSpline& h = hs[2 + e];
+          const int nv = d.n_phase[e] - 1;
+          for (int k = 0; k < nv; ++k) {
+            int pk = 0;
+            while (pk < h.n_polys && h.ph[pk] < k) ++pk;
+            for (int nd = pk; nd < h.n_nodes; ++nd)
+              for (int q6 = 0; q6 < 6; ++q6) { int v = h.var_of[nd * 6 + q6]; if (v >= 0) reach(pos_var[S.dur_off[e] + k], pos_var[h.var_off + v]); }
+          }
+        }
+    }
     S.w = w; S.valid = 1;
 
     // ---- store
@@ -626,6 +667,7 @@ class SeqModel {
         for (int p = 0; p < Nb; ++p) clast[p] = elast[p];
         for (int i = 0; i < Nb; ++i) for (int k = efirst[i]; k <= i; ++k) clast[k] = std::max(clast[k], i);
         for (int p = 0; p < Nb; ++p) { ci[S.o_env + 2 * p] = efirst[p]; ci[S.o_env + 2 * p + 1] = clast[p]; }
+        for (int r = 0; r < bc; ++r) { ci[S.o_env + 2 * (Nb + r)] = bfirst[r]; ci[S.o_env + 2 * (Nb + r) + 1] = Nb; }
       }
       std::copy(cl.begin(), cl.end(), cd.begin() + S.o_cl);
       std::copy(cu.begin(), cu.end(), cd.begin() + S.o_cu);

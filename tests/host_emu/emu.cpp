@@ -131,3 +131,21 @@ extern "C" void emu_envelope(void* h, int stage, double* out) {
   out[0] = (double)env; out[1] = (double)band; out[2] = maxreach; out[3] = c.w; out[4] = c.Nb;
   for (int k = 0; k < 8; ++k) out[5 + k] = hist[k];
 }
+
+// border statistics of the unfactored KKT matrix of `stage` at the initial point (analysis helper):
+// out[0] = mean over border rows of the fraction of band columns right of the row's first nonzero, out[1] = bc
+extern "C" void emu_border_first(void* h, int stage, double* out, int* first_out) {
+  Emu* e = (Emu*)h; e->bind();
+  double fo[2];
+  debug_eval(&e->M.d, stage, 0, e->lds.data(), (int)e->lds.size(), fo);
+  Ctx c; c.lds = e->lds.data(); c.lds_cap = (int)e->lds.size();
+  bind_stage(c, &e->M.d, stage);
+  double acc = 0;
+  for (int r = 0; r < c.bc; ++r) {
+    int first = c.Nb;
+    for (int k = 0; k < c.Nb; ++k) if (c.K0x[(long long)r * c.LD + k] != 0.0) { first = k; break; }
+    if (first_out) { first_out[r] = first; first_out[512 + r] = c.env[2 * (c.Nb + r)]; }
+    acc += (double)(c.Nb - first) / c.Nb;
+  }
+  out[0] = c.bc ? acc / c.bc : 0; out[1] = c.bc; out[2] = c.Nb; out[3] = c.w;
+}
