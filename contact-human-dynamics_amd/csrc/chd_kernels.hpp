@@ -486,15 +486,23 @@ CHD_DEV double dot_column(AP col, const long long ld, BP b, int r, const int ren
 }
 // y = K0 x (+ diag .* x)
 // `only` (optional): rows whose entry is <= 0 are skipped (their y is left untouched)
-CHD_NOINLINE CHD_DEV void kmatvec(Ctx& c, const GD* x, GD* y, const GD* diag, const GI* only) {
-  TIC();
+template <class XP>
+CHD_DEV void kmatvec_impl(Ctx& c, XP x, GD* y, const GD* diag, const GI* only) {
   const int Nb = c.Nb, w = c.w, W2 = c.W2, LD = c.LD, bc = c.bc;
-  GROUP_FOR(i, Nb) {
-    if (only && only[i] <= 0) continue;
-    const int lo = c.env[2 * i], hi = c.env[2 * i + 1];      // nothing is stored outside the envelope
-    const GD* row = c.K0b + (long long)i * W2 + (w - i);
-    const double acc = group_sum(dot_strided(row, x, lo + lane_, hi + 1, CHD_GL));      // (16-byte requests were tried: same rate, the limit is lines in flight)
-    if (lane_ == 0) y[i] = acc + (diag ? diag[i] * x[i] : 0.0);
+  {
+    const int step = CHD_NT / CHD_GL, lane_ = CHD_TID % CHD_GL;
+    int i = CHD_TID / CHD_GL;
+    int lo = i < Nb ? c.env[2 * i] : 0, hi = i < Nb ? c.env[2 * i + 1] : 0;      // nothing is stored outside the envelope
+    for (; i < Nb; i += step) {
+      const int in = i + step;
+      const int nlo = in < Nb ? c.env[2 * in] : 0, nhi = in < Nb ? c.env[2 * in + 1] : 0;      // next row's envelope, one pass ahead
+      if (!(only && only[i] <= 0)) {
+        const GD* row = c.K0b + (long long)i * W2 + (w - i);
+        const double acc = group_sum(dot_strided(row, x, lo + lane_, hi + 1, CHD_GL));      // (16-byte requests were tried: same rate, the limit is lines in flight)
+        if (lane_ == 0) y[i] = acc + (diag ? diag[i] * x[i] : 0.0);
+      }
+      lo = nlo; hi = nhi;
+    }
   }
   GROUP_FOR(r, bc) {
     if (only && only[Nb + r] <= 0) continue;
@@ -508,6 +516,15 @@ CHD_NOINLINE CHD_DEV void kmatvec(Ctx& c, const GD* x, GD* y, const GD* diag, co
     y[i] += dot_column(c.K0x + i, LD, x + Nb, 0, bc);
   }
   CHD_SYNC();
+}
+CHD_NOINLINE CHD_DEV void kmatvec(Ctx& c, const GD* x, GD* y, const GD* diag, const GI* only) {
+  TIC();
+  if (c.N <= c.lds_cap - LDS_RED) {          // x is read 2 w + 1 times: keep it in LDS
+    LdsD* xs = c.lds + LDS_RED;
+    PAR_FOR(i, c.N) xs[i] = x[i];
+    CHD_SYNC();
+    kmatvec_impl(c, (const LdsD*)xs, y, diag, only);
+  } else kmatvec_impl(c, x, y, diag, only);
   TOC(c, 4);
 }
 
@@ -567,6 +584,7 @@ CHD_NOINLINE CHD_DEV void diag_block(Ctx& c, const GI* sign, LdsD* dv, LdsD* DL,
     const int a = threadIdx.x;
     const bool act = a < NB;
     const int sg_a = a < jb ? sign[c0 + a] : 1;          // expected pivot signs, fetched once
+    const unsigned long long sg_pos = __ballot(sg_a > 0);
     double r[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) r[j] = (act && j <= a) ? PT[j * ldp + a] : 0.0;
@@ -574,14 +592,15 @@ CHD_NOINLINE CHD_DEV void diag_block(Ctx& c, const GI* sign, LdsD* dv, LdsD* DL,
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       double d = readlane_f64(r[j], j);
-      if (j < jb) { const int sg = __builtin_amdgcn_readlane(sg_a, j); if (!(d * sg > 1e-14)) { d = sg * 1e-10; ++bad; } }
+      if (j < jb) { const double sg = ((sg_pos >> j) & 1ull) ? 1.0 : -1.0; if (!(d * sg > 1e-14)) { d = sg * 1e-10; ++bad; } }
       const double inv = rcp_f64(d);
       const double lj = r[j] * inv;            // L(a, j) for a > j
       if (act && a > j) { PT[j * ldp + a] = lj; DL[j * NB + a] = lj; }
       if (a == j) { dv[j] = d; dv[32 + j] = inv; }
       const double ljd = lj * d;
+      // (an LDS write / broadcast-read round trip per column was measured at ~0.9 us per column; v_readlane is 3x faster)
 #pragma unroll
-      for (int jj = j + 1; jj < NB; ++jj) r[jj] -= ljd * readlane_f64(lj, jj);      // lanes a < jj hold unused values
+      for (int jj = j + 1; jj < NB; ++jj) r[jj] -= ljd * readlane_f64(lj, jj);      // lanes a < jj hold unused values (ds_bpermute: 4x slower)
     }
     if (threadIdx.x == 0) c.n_bad_pivots += bad;
   }
