@@ -104,6 +104,7 @@ struct SeqDesc {
   long long sz_K0b, sz_K0x, sz_Kfb, sz_Kfx;
   // wi offsets
   int o_flags, o_first, o_sign;
+  int o_envw;           // working copy of the stage's envelope (2 ints per KKT position): widened when an entry lands outside it
   StageDesc st[N_STAGES];
 };
 

@@ -105,7 +105,7 @@ struct Ctx {
   int n, m, N, Nb, bc, w, W2, LD;
   GD* K0b; GD* K0x; GD* Kfb; GD* Kfx;
   const GI* pos_var; const GI* pos_row;
-  const GI* env;        // [2p] first, [2p+1] last band position coupled to p (envelope)
+  GI* env;              // [2p] first, [2p+1] last band position coupled to p (envelope): the stage's working copy
   double sf;            // objective scaling
   double tol;           // IPOPT tol of the stage (phys_optim.cpp:578)
   int err;              // sticky error flag (band overflow), uniform across the workgroup after a sync
@@ -405,14 +405,33 @@ CHD_NOINLINE CHD_DEV void angular_term(const double e[3], const double ed[3], co
 // those) form a dense border.  K0 (unfactored, both triangles): band rows Nb x (2w+1), border
 // rows bc x N.  Kf (factor, lower): band rows Nb x (w+1), border rows bc x N.
 // ------------------------------------------------------------------------------------------
+// The envelope comes from the structure at the durations the stage starts with (plus head-room); in stage 3 the
+// durations can carry a sample into a polynomial that structure did not foresee.  An entry (row hi, column lo < hi)
+// left of row hi's envelope start widens the working copy: the row starts at lo, and the columns in between are
+// reached by row hi.  (min / max updates: the result does not depend on the order the threads arrive in.)
+#ifdef CHD_HOST_EMU
+CHD_DEV void env_min(GI* p, int v) { if (v < *p) *p = v; }
+CHD_DEV void env_max(GI* p, int v) { if (v > *p) *p = v; }
+#else
+CHD_DEV void env_min(GI* p, int v) { __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+CHD_DEV void env_max(GI* p, int v) { __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#endif
+CHD_DEV void env_cover(Ctx& c, const int hi, const int lo) {
+  const int first = c.env[2 * hi];
+  if (lo >= first) return;
+  env_min(c.env + 2 * hi, lo);
+  if (hi < c.Nb) for (int k = lo; k < first && k < hi; ++k) env_max(c.env + 2 * k + 1, hi);
+}
 CHD_DEV void kadd(Ctx& c, int p, int qq, double val) {
   if (p < c.Nb && qq < c.Nb) {
     int dlt = qq - p;
     if (dlt > c.w || dlt < -c.w) { c.err = 1; return; }
+    if (dlt != 0) env_cover(c, dlt < 0 ? p : qq, dlt < 0 ? qq : p);
     c.K0b[(long long)p * c.W2 + (dlt + c.w)] += val;
     if (dlt != 0) c.K0b[(long long)qq * c.W2 + (c.w - dlt)] += val;
   } else {
     const int hi = p > qq ? p : qq, lo = p > qq ? qq : p;
+    if (lo < c.Nb) env_cover(c, hi, lo);
     c.K0x[(long long)(hi - c.Nb) * c.LD + lo] += val;
     if (lo >= c.Nb && lo != hi) c.K0x[(long long)(lo - c.Nb) * c.LD + hi] += val;
   }
@@ -440,8 +459,11 @@ CHD_DEV void kzero(Ctx& c) {
 // start of a stage: the border blocks are reused with a new layout, and their structurally-zero left parts are
 // neither cleared nor copied again afterwards
 CHD_DEV void kreset(Ctx& c) {
+  PAR_FOR(i, 2 * c.N) c.env[i] = c.q->ci[c.S->o_env + i];
   const long long nx_ = (long long)c.bc * c.LD;
   for (long long i = CHD_TID; i < nx_; i += CHD_NT) { c.K0x[i] = 0.0; c.Kfx[i] = 0.0; }
+  const long long nf_ = (long long)c.Nb * (c.w + 1);
+  for (long long i = CHD_TID; i < nf_; i += CHD_NT) c.Kfb[i] = 0.0;       // the copy into the factor only covers each row's envelope
   CHD_SYNC();
 }
 
@@ -874,23 +896,32 @@ CHD_NOINLINE CHD_DEV void kfactor(Ctx& c, const GD* diag, const GI* sign) {
   {
     constexpr int RP = 4, QP = 6;                      // QP * wave size covers W1 <= 384; wider bands take the tail loop
     for (int i0 = CHD_WAVE_ID * RP; i0 < Nb; i0 += CHD_NWAVES * RP) {
+      // only the envelope [efirst_i, i] of each row: the rest of the factor storage is zero since the start of the stage
       double v[RP][QP];
+      int clo[RP];
+#pragma unroll
+      for (int r = 0; r < RP; ++r) { const int i = i0 + r < Nb ? i0 + r : Nb - 1; clo[r] = c.env[2 * i] - i + w; }
+#ifdef CHD_HOST_EMU
+      for (int r = 0; r < RP; ++r)
+        for (int cc = 0; cc < clo[r] && i0 + r < Nb; ++cc)
+          if (c.K0b[(long long)(i0 + r) * W2 + cc] != 0.0 || c.Kfb[(long long)(i0 + r) * W1 + cc] != 0.0) { c.err = 2; std::fprintf(stderr, "band envelope violated: row %d col offset %d first %d (K0 %g Kf %g)\n", i0 + r, cc, clo[r], c.K0b[(long long)(i0 + r) * W2 + cc], c.Kfb[(long long)(i0 + r) * W1 + cc]); break; }      // structure check
+#endif
 #pragma unroll
       for (int r = 0; r < RP; ++r)
 #pragma unroll
         for (int q = 0; q < QP; ++q) {
-          const int i = i0 + r, cc = CHD_LANE + q * CHD_WAVE_SZ;
-          v[r][q] = (i < Nb && cc < W1) ? c.K0b[(long long)i * W2 + cc] : 0.0;
+          const int i = i0 + r, cc = clo[r] + CHD_LANE + q * CHD_WAVE_SZ;
+          v[r][q] = *((i < Nb && cc < W1) ? c.K0b + (long long)i * W2 + cc : c.K0b + w);      // predicated-off lanes re-read one valid address
         }
 #pragma unroll
       for (int r = 0; r < RP; ++r)
 #pragma unroll
         for (int q = 0; q < QP; ++q) {
-          const int i = i0 + r, cc = CHD_LANE + q * CHD_WAVE_SZ;
+          const int i = i0 + r, cc = clo[r] + CHD_LANE + q * CHD_WAVE_SZ;
           if (i < Nb && cc < W1) c.Kfb[(long long)i * W1 + cc] = v[r][q] + (cc == w ? diag[i] : 0.0);
         }
       for (int r = 0; r < RP; ++r)
-        for (int cc = CHD_LANE + QP * CHD_WAVE_SZ; cc < W1 && i0 + r < Nb; cc += CHD_WAVE_SZ)
+        for (int cc = clo[r] + CHD_LANE + QP * CHD_WAVE_SZ; cc < W1 && i0 + r < Nb; cc += CHD_WAVE_SZ)
           c.Kfb[(long long)(i0 + r) * W1 + cc] = c.K0b[(long long)(i0 + r) * W2 + cc] + (cc == w ? diag[i0 + r] : 0.0);
     }
   }
@@ -1266,6 +1297,7 @@ CHD_DEV void ksolve_fast(Ctx& c, const GD* rhs, GD* x, LdsD* y, LdsD* Sp, LdsD* 
   ts_ = CHD_CLOCK();
   // requests for the first backward steps travel while the border is processed
   double bf[CHD_BP][16], bn[8];
+  int ecl[CHD_BP], bcl[CHD_BP];        // last row reaching each far column (fetched one step ahead) / the value the held entries were masked with
   const int rg = lane >> 3, cl8 = lane & 7, qd = lane >> 4, cl16 = lane & 15;
 #define CHD_LOAD_BNEAR(B) do { const int c0_ = (B) * nb, jb_ = Nb - c0_ < nb ? Nb - c0_ : nb; \
     const int k_ = c0_ - nb + 8 * wv + cl8; \
@@ -1278,19 +1310,27 @@ CHD_DEV void ksolve_fast(Ctx& c, const GD* rhs, GD* x, LdsD* y, LdsD* Sp, LdsD* 
     if (rg == 0) y[c0_ - nb + 8 * wv + cl8] -= s_; } while (0)
 #define CHD_LOAD_BFAR(B) do { const int c0_ = (B) * nb, jb_ = Nb - c0_ < nb ? Nb - c0_ : nb; \
     const int k0_ = c0_ - w < 0 ? 0 : c0_ - w, kend_ = c0_ - nb; \
+    const int c0n_ = c0_ - nb, k0n_ = c0n_ - w < 0 ? 0 : c0n_ - w; \
     _Pragma("unroll") for (int p = 0; p < CHD_BP; ++p) { const int k_ = k0_ + (p * 8 + wv) * 16 + cl16; \
       const bool okc_ = (B) >= 1 && k_ < kend_; \
+      const int cl_ = ecl[p]; bcl[p] = cl_; \
       _Pragma("unroll") for (int r = 0; r < 16; ++r) { const int a_ = qd * 16 + r, i_ = c0_ + a_; \
-        const bool v_ = okc_ && a_ < jb_ && i_ - k_ <= w; bf[p][r] = *(v_ ? Kfb + (long long)i_ * W1 + (k_ - i_ + w) : safe); } } } while (0)
+        const bool v_ = okc_ && a_ < jb_ && i_ - k_ <= w && i_ <= cl_; bf[p][r] = *(v_ ? Kfb + (long long)i_ * W1 + (k_ - i_ + w) : safe); } \
+      const int kn_ = k0n_ + (p * 8 + wv) * 16 + cl16; ecl[p] = env[((B) >= 2 && kn_ < c0n_ - nb) ? 2 * kn_ + 1 : 1]; } } while (0)
 #define CHD_USE_BFAR(B) do { const int c0_ = (B) * nb, jb_ = Nb - c0_ < nb ? Nb - c0_ : nb; \
     const int k0_ = c0_ - w < 0 ? 0 : c0_ - w, kend_ = c0_ - nb; \
     _Pragma("unroll") for (int p = 0; p < CHD_BP; ++p) { const int k_ = k0_ + (p * 8 + wv) * 16 + cl16; \
       double s0_ = 0, s1_ = 0; \
       _Pragma("unroll") for (int r = 0; r < 16; r += 2) { const int a_ = qd * 16 + r; \
-        s0_ += bf[p][r] * ((k_ < kend_ && a_ < jb_ && c0_ + a_ - k_ <= w) ? y[c0_ + a_] : 0.0); \
-        s1_ += bf[p][r + 1] * ((k_ < kend_ && a_ + 1 < jb_ && c0_ + a_ + 1 - k_ <= w) ? y[c0_ + a_ + 1] : 0.0); } \
+        s0_ += bf[p][r] * ((k_ < kend_ && a_ < jb_ && c0_ + a_ - k_ <= w && c0_ + a_ <= bcl[p]) ? y[c0_ + a_] : 0.0); \
+        s1_ += bf[p][r + 1] * ((k_ < kend_ && a_ + 1 < jb_ && c0_ + a_ + 1 - k_ <= w && c0_ + a_ + 1 <= bcl[p]) ? y[c0_ + a_ + 1] : 0.0); } \
       double s_ = s0_ + s1_; s_ += __shfl_xor(s_, 16); s_ += __shfl_xor(s_, 32); \
       if (qd == 0 && k_ < kend_) y[k_] -= s_; } } while (0)
+  {
+    const int c0_ = (nblk - 1) * nb, k0_ = c0_ - w < 0 ? 0 : c0_ - w;
+#pragma unroll
+    for (int p = 0; p < CHD_BP; ++p) { const int k_ = k0_ + (p * 8 + wv) * 16 + cl16; ecl[p] = env[(nblk >= 2 && k_ < c0_ - nb) ? 2 * k_ + 1 : 1]; bcl[p] = 0; }
+  }
   CHD_LOAD_TILE(nblk - 1); CHD_LOAD_BNEAR(nblk - 1); CHD_LOAD_BFAR(nblk - 1);
   // forward, border rows: band part of L_border
   GROUP_FOR(r, bc) {
@@ -2428,7 +2468,7 @@ CHD_DEV void bind_stage(Ctx& c, const SeqDesc* q, int stage) {
   c.n = c.S->n; c.m = c.S->m; c.N = c.n + c.m; c.Nb = c.S->Nb; c.bc = c.S->bc; c.w = c.S->w;
   c.W2 = 2 * c.w + 1; c.LD = c.N;
   c.K0b = q->wd + q->o_K0b; c.K0x = q->wd + q->o_K0x; c.Kfb = q->wd + q->o_Kfb; c.Kfx = q->wd + q->o_Kfx;
-  c.pos_var = q->ci + c.S->o_pos_var; c.pos_row = q->ci + c.S->o_pos_row; c.env = q->ci + c.S->o_env;
+  c.pos_var = q->ci + c.S->o_pos_var; c.pos_row = q->ci + c.S->o_pos_row; c.env = q->wi + q->o_envw;
   c.sf = 1.0; c.err = 0; c.n_bad_pivots = 0;
 }
 

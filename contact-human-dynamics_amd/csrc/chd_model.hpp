@@ -725,6 +725,7 @@ class SeqModel {
     d.o_flags = take_i(d.max_m);
     d.o_first = take_i(6LL * (d.max_polys + 2));
     d.o_sign = take_i(d.max_N);
+    d.o_envw = take_i(2LL * d.max_N);
     wi_size = oi;
   }
 
