@@ -1200,7 +1200,7 @@ CHD_DEV void ksolve_impl(Ctx& c, const GD* rhs, GD* x, YP y, SP Sp, const int ld
 //                      rows of B  x  columns of block B-1        ("near", 8 lanes per row, 8 columns each)
 //   backward, block B: columns of block B-1  x  rows of B        ("near", 8 columns per wavefront, 8 rows per lane)
 //                      columns left of B-1   x  rows of B        ("far",  16 columns x 4 row quarters per wavefront pass)
-#define CHD_NQ 24
+#define CHD_NQ 20
 #define CHD_BP 3
 CHD_DEV void tri_chain_fwd(LdsD* y, const LdsD* tile, const int c0, const int jb) {
   const int i = threadIdx.x;
@@ -1236,16 +1236,16 @@ CHD_DEV void ksolve_fast(Ctx& c, const GD* rhs, GD* x, LdsD* y, LdsD* Sp, LdsD* 
   const int Nb = c.Nb, w = c.w, W1 = c.w + 1, LD = c.LD, bc = c.bc, N = c.N;
   const int nb = CHD_SOLVE_NB, nblk = (Nb + nb - 1) / nb;
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-  const int g16 = tid >> 4, l16 = tid & 15;
+  const int g16 = (tid - 64) >> 4, l16 = tid & 15;      // far parts: the 28 lane groups of wavefronts 1..7 (wavefront 0 runs the triangular chain)
   const int r8 = tid >> 3, c8 = (tid & 7) << 3;
   const GD* Kfb = c.Kfb;
   const GD* safe = c.Kfb + w;            // a valid address for the predicated-off requests (loads are never branched around)
   PAR_FOR(i, N) y[i] = rhs[i];
   PAR_FOR(idx, bc * bc) { const int r = idx / bc, k = idx % bc; if (k <= r) Sp[r * (r + 1) / 2 + k] = c.Kfx[(long long)r * LD + Nb + k]; }
-  double fr[2][CHD_NQ], nr[8], tl[8];
-  int flo[2] = {0, 0};
+  double fr[3][CHD_NQ], nr[8], tl[8];
+  int flo[3] = {0, 0, 0};
   const GI* env = c.env;
-  int elo[2] = {0, 0};       // envelope starts of the rows whose far part is requested next (fetched one step ahead as well)
+  int elo[3] = {0, 0, 0};       // envelope starts of the rows whose far part is requested next (fetched one step ahead as well)
   // -- requests (block index B; all predicated, so B may run past the last block)
 #define CHD_LOAD_TILE(B) do { const int c0_ = (B) * nb, jb_ = Nb - c0_ < nb ? Nb - c0_ : nb; \
     const bool ok_ = (B) >= 0 && (B) < nblk && r8 < jb_; \
@@ -1253,20 +1253,20 @@ CHD_DEV void ksolve_fast(Ctx& c, const GD* rhs, GD* x, LdsD* y, LdsD* Sp, LdsD* 
     _Pragma("unroll") for (int q = 0; q < 8; ++q) { const bool v_ = ok_ && c8 + q < r8; tl[q] = *(v_ ? row_ + c8 + q : safe); } } while (0)
 #define CHD_WRITE_TILE() do { _Pragma("unroll") for (int q = 0; q < 8; ++q) if (c8 + q < r8) tile[r8 * CHD_TILE_LD + c8 + q] = tl[q]; } while (0)
 #define CHD_LOAD_FAR(B) do { const int c0_ = (B) * nb, jb_ = Nb - c0_ < nb ? Nb - c0_ : nb, kend_ = c0_ - nb; \
-    _Pragma("unroll") for (int p = 0; p < 2; ++p) { const int a_ = g16 + 32 * p, i_ = c0_ + a_; \
-      const bool ok_ = (B) < nblk && a_ < jb_ && kend_ > 0; \
+    _Pragma("unroll") for (int p = 0; p < 3; ++p) { const int a_ = g16 + 28 * p, i_ = c0_ + a_; \
+      const bool ok_ = wv > 0 && (B) < nblk && a_ < jb_ && kend_ > 0; \
       const int lo_ = elo[p]; flo[p] = lo_; \
       const GD* row_ = Kfb + (long long)(ok_ ? i_ : 0) * W1 + (w - (ok_ ? i_ : 0)); \
       _Pragma("unroll") for (int q = 0; q < CHD_NQ; ++q) { const int k_ = lo_ + l16 + 16 * q; const bool v_ = ok_ && k_ < kend_; \
         fr[p][q] = *(v_ ? row_ + k_ : safe); } \
-      const int in_ = i_ + nb; elo[p] = env[((B) + 1 < nblk && in_ < Nb) ? 2 * in_ : 0]; } } while (0)
+      const int in_ = i_ + nb; elo[p] = env[(wv > 0 && (B) + 1 < nblk && a_ < nb && in_ < Nb) ? 2 * in_ : 0]; } } while (0)
 #define CHD_USE_FAR(B) do { const int c0_ = (B) * nb, jb_ = Nb - c0_ < nb ? Nb - c0_ : nb, kend_ = c0_ - nb; \
-    _Pragma("unroll") for (int p = 0; p < 2; ++p) { const int a_ = g16 + 32 * p; \
+    _Pragma("unroll") for (int p = 0; p < 3; ++p) { const int a_ = g16 + 28 * p; \
       double s0_ = 0, s1_ = 0; \
       _Pragma("unroll") for (int q = 0; q < CHD_NQ; q += 2) { const int k_ = flo[p] + l16 + 16 * q; \
         s0_ += fr[p][q] * ((a_ < jb_ && k_ < kend_) ? y[k_] : 0.0); s1_ += fr[p][q + 1] * ((a_ < jb_ && k_ + 16 < kend_) ? y[k_ + 16] : 0.0); } \
       const double acc_ = group_sum(s0_ + s1_); \
-      if (l16 == 0 && a_ < jb_ && kend_ > 0) y[c0_ + a_] -= acc_; } } while (0)
+      if (l16 == 0 && wv > 0 && a_ < jb_ && kend_ > 0) y[c0_ + a_] -= acc_; } } while (0)
 #define CHD_LOAD_NEAR(B) do { const int c0_ = (B) * nb, jb_ = Nb - c0_ < nb ? Nb - c0_ : nb; \
     const bool ok_ = (B) < nblk && r8 < jb_; const int i_ = c0_ + r8, kb_ = c0_ - nb + c8; \
     const GD* row_ = Kfb + (long long)(ok_ ? i_ : 0) * W1 + (w - (ok_ ? i_ : 0)); \
@@ -1285,8 +1285,10 @@ CHD_DEV void ksolve_fast(Ctx& c, const GD* rhs, GD* x, LdsD* y, LdsD* Sp, LdsD* 
     const int c0 = bk * nb, jb = Nb - c0 < nb ? Nb - c0 : nb;
     ts_ = CHD_CLOCK();
     if (wv == 0) tri_chain_fwd(y, tile, c0, jb);
-    if (bk + 1 < nblk) CHD_USE_FAR(bk + 1);
-    CHD_LOAD_FAR(bk + 2);
+    else {
+      if (bk + 1 < nblk) CHD_USE_FAR(bk + 1);
+      CHD_LOAD_FAR(bk + 2);
+    }
     CHD_SYNC();
     t16_ += CHD_CLOCK() - ts_; ts_ = CHD_CLOCK();
     if (bk + 1 < nblk) { CHD_USE_NEAR(bk + 1); CHD_WRITE_TILE(); }
@@ -1311,25 +1313,25 @@ CHD_DEV void ksolve_fast(Ctx& c, const GD* rhs, GD* x, LdsD* y, LdsD* Sp, LdsD* 
 #define CHD_LOAD_BFAR(B) do { const int c0_ = (B) * nb, jb_ = Nb - c0_ < nb ? Nb - c0_ : nb; \
     const int k0_ = c0_ - w < 0 ? 0 : c0_ - w, kend_ = c0_ - nb; \
     const int c0n_ = c0_ - nb, k0n_ = c0n_ - w < 0 ? 0 : c0n_ - w; \
-    _Pragma("unroll") for (int p = 0; p < CHD_BP; ++p) { const int k_ = k0_ + (p * 8 + wv) * 16 + cl16; \
-      const bool okc_ = (B) >= 1 && k_ < kend_; \
+    _Pragma("unroll") for (int p = 0; p < CHD_BP; ++p) { const int k_ = k0_ + (p * 7 + wv - 1) * 16 + cl16; \
+      const bool okc_ = wv > 0 && (B) >= 1 && k_ < kend_; \
       const int cl_ = ecl[p]; bcl[p] = cl_; \
       _Pragma("unroll") for (int r = 0; r < 16; ++r) { const int a_ = qd * 16 + r, i_ = c0_ + a_; \
         const bool v_ = okc_ && a_ < jb_ && i_ - k_ <= w && i_ <= cl_; bf[p][r] = *(v_ ? Kfb + (long long)i_ * W1 + (k_ - i_ + w) : safe); } \
-      const int kn_ = k0n_ + (p * 8 + wv) * 16 + cl16; ecl[p] = env[((B) >= 2 && kn_ < c0n_ - nb) ? 2 * kn_ + 1 : 1]; } } while (0)
+      const int kn_ = k0n_ + (p * 7 + wv - 1) * 16 + cl16; ecl[p] = env[(wv > 0 && (B) >= 2 && kn_ < c0n_ - nb) ? 2 * kn_ + 1 : 1]; } } while (0)
 #define CHD_USE_BFAR(B) do { const int c0_ = (B) * nb, jb_ = Nb - c0_ < nb ? Nb - c0_ : nb; \
     const int k0_ = c0_ - w < 0 ? 0 : c0_ - w, kend_ = c0_ - nb; \
-    _Pragma("unroll") for (int p = 0; p < CHD_BP; ++p) { const int k_ = k0_ + (p * 8 + wv) * 16 + cl16; \
+    _Pragma("unroll") for (int p = 0; p < CHD_BP; ++p) { const int k_ = k0_ + (p * 7 + wv - 1) * 16 + cl16; \
       double s0_ = 0, s1_ = 0; \
       _Pragma("unroll") for (int r = 0; r < 16; r += 2) { const int a_ = qd * 16 + r; \
         s0_ += bf[p][r] * ((k_ < kend_ && a_ < jb_ && c0_ + a_ - k_ <= w && c0_ + a_ <= bcl[p]) ? y[c0_ + a_] : 0.0); \
         s1_ += bf[p][r + 1] * ((k_ < kend_ && a_ + 1 < jb_ && c0_ + a_ + 1 - k_ <= w && c0_ + a_ + 1 <= bcl[p]) ? y[c0_ + a_ + 1] : 0.0); } \
       double s_ = s0_ + s1_; s_ += __shfl_xor(s_, 16); s_ += __shfl_xor(s_, 32); \
-      if (qd == 0 && k_ < kend_) y[k_] -= s_; } } while (0)
+      if (qd == 0 && wv > 0 && k_ < kend_) y[k_] -= s_; } } while (0)
   {
     const int c0_ = (nblk - 1) * nb, k0_ = c0_ - w < 0 ? 0 : c0_ - w;
 #pragma unroll
-    for (int p = 0; p < CHD_BP; ++p) { const int k_ = k0_ + (p * 8 + wv) * 16 + cl16; ecl[p] = env[(nblk >= 2 && k_ < c0_ - nb) ? 2 * k_ + 1 : 1]; bcl[p] = 0; }
+    for (int p = 0; p < CHD_BP; ++p) { const int k_ = k0_ + (p * 7 + wv - 1) * 16 + cl16; ecl[p] = env[(wv > 0 && nblk >= 2 && k_ < c0_ - nb) ? 2 * k_ + 1 : 1]; bcl[p] = 0; }
   }
   CHD_LOAD_TILE(nblk - 1); CHD_LOAD_BNEAR(nblk - 1); CHD_LOAD_BFAR(nblk - 1);
   // forward, border rows: band part of L_border
@@ -1378,8 +1380,10 @@ CHD_DEV void ksolve_fast(Ctx& c, const GD* rhs, GD* x, LdsD* y, LdsD* Sp, LdsD* 
     CHD_SYNC();
     t19_ += CHD_CLOCK() - ts_; ts_ = CHD_CLOCK();
     if (wv == 0) tri_chain_bwd(y, tile, (bk - 1) * nb, nb);
-    CHD_USE_BFAR(bk);
-    CHD_LOAD_BFAR(bk - 1);
+    else {
+      CHD_USE_BFAR(bk);
+      CHD_LOAD_BFAR(bk - 1);
+    }
     CHD_SYNC();
     t20_ += CHD_CLOCK() - ts_;
   }
@@ -1407,7 +1411,7 @@ CHD_NOINLINE CHD_DEV void ksolve_once(Ctx& c, const GD* rhs, GD* x) {
   LdsD* base = c.lds + LDS_RED;
 #ifndef CHD_HOST_EMU
   const int spk = (bc * (bc + 1) / 2 + 1) & ~1;
-  if (room >= Npad + spk + tsz && c.w >= CHD_SOLVE_NB && c.w <= 16 * CHD_NQ && c.w - CHD_SOLVE_NB <= CHD_BP * 128) {
+  if (room >= Npad + spk + tsz && c.w >= CHD_SOLVE_NB && c.w - CHD_SOLVE_NB <= 16 * CHD_NQ && c.w - CHD_SOLVE_NB <= CHD_BP * 112) {
     ksolve_fast(c, rhs, x, base, base + Npad, base + Npad + spk);
     TOC(c, 3);
     return;
