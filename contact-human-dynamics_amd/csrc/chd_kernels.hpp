@@ -426,14 +426,17 @@ CHD_DEV void kadd(Ctx& c, int p, int qq, double val) {
   if (p < c.Nb && qq < c.Nb) {
     int dlt = qq - p;
     if (dlt > c.w || dlt < -c.w) { c.err = 1; return; }
-    if (dlt != 0) env_cover(c, dlt < 0 ? p : qq, dlt < 0 ? qq : p);
+    const int hi_ = dlt < 0 ? p : qq, lo_ = dlt < 0 ? qq : p;
+    const int first_ = c.env[2 * hi_];                  // (looked up alongside the K0 accesses; the widening itself is rare)
     c.K0b[(long long)p * c.W2 + (dlt + c.w)] += val;
     if (dlt != 0) c.K0b[(long long)qq * c.W2 + (c.w - dlt)] += val;
+    if (lo_ < first_) env_cover(c, hi_, lo_);
   } else {
     const int hi = p > qq ? p : qq, lo = p > qq ? qq : p;
-    if (lo < c.Nb) env_cover(c, hi, lo);
+    const int first_ = c.env[2 * hi];
     c.K0x[(long long)(hi - c.Nb) * c.LD + lo] += val;
     if (lo >= c.Nb && lo != hi) c.K0x[(long long)(lo - c.Nb) * c.LD + hi] += val;
+    if (lo < c.Nb && lo < first_) env_cover(c, hi, lo);
   }
 }
 CHD_DEV double kget(const Ctx& c, int p, int qq) {
@@ -895,12 +898,19 @@ CHD_NOINLINE CHD_DEV void kfactor(Ctx& c, const GD* diag, const GI* sign) {
   // of a pass issued before the first store (the copy is latency bound, not bandwidth bound)
   {
     constexpr int RP = 4, QP = 6;                      // QP * wave size covers W1 <= 384; wider bands take the tail loop
+    int cnext[RP];                                     // envelope starts of the next pass's rows (fetched one pass ahead)
+#pragma unroll
+    for (int r = 0; r < RP; ++r) { const int i = CHD_WAVE_ID * RP + r < Nb ? CHD_WAVE_ID * RP + r : Nb - 1; cnext[r] = c.env[2 * i] - i + w; }
     for (int i0 = CHD_WAVE_ID * RP; i0 < Nb; i0 += CHD_NWAVES * RP) {
       // only the envelope [efirst_i, i] of each row: the rest of the factor storage is zero since the start of the stage
       double v[RP][QP];
       int clo[RP];
 #pragma unroll
-      for (int r = 0; r < RP; ++r) { const int i = i0 + r < Nb ? i0 + r : Nb - 1; clo[r] = c.env[2 * i] - i + w; }
+      for (int r = 0; r < RP; ++r) {
+        clo[r] = cnext[r];
+        const int in = i0 + CHD_NWAVES * RP + r < Nb ? i0 + CHD_NWAVES * RP + r : Nb - 1;
+        cnext[r] = c.env[2 * in] - in + w;
+      }
 #ifdef CHD_HOST_EMU
       for (int r = 0; r < RP; ++r)
         for (int cc = 0; cc < clo[r] && i0 + r < Nb; ++cc)
