@@ -1253,7 +1253,7 @@ CHD_DEV void ksolve_fast(Ctx& c, const GD* rhs, GD* x, LdsD* y, LdsD* Sp, LdsD* 
   PAR_FOR(i, N) y[i] = rhs[i];
   PAR_FOR(idx, bc * bc) { const int r = idx / bc, k = idx % bc; if (k <= r) Sp[r * (r + 1) / 2 + k] = c.Kfx[(long long)r * LD + Nb + k]; }
   double fr[3][CHD_NQ], nr[8], tl[8];
-  int flo[3] = {0, 0, 0};
+  int flo[3] = {0, 0, 0}, fmk[3] = {0, 0, 0};      // envelope starts / chunk masks the held far entries were requested with
   const GI* env = c.env;
   int elo[3] = {0, 0, 0};       // envelope starts of the rows whose far part is requested next (fetched one step ahead as well)
   // -- requests (block index B; all predicated, so B may run past the last block)
@@ -1267,14 +1267,19 @@ CHD_DEV void ksolve_fast(Ctx& c, const GD* rhs, GD* x, LdsD* y, LdsD* Sp, LdsD* 
       const bool ok_ = wv > 0 && (B) < nblk && a_ < jb_ && kend_ > 0; \
       const int lo_ = elo[p]; flo[p] = lo_; \
       const GD* row_ = Kfb + (long long)(ok_ ? i_ : 0) * W1 + (w - (ok_ ? i_ : 0)); \
-      _Pragma("unroll") for (int q = 0; q < CHD_NQ; ++q) { const int k_ = lo_ + l16 + 16 * q; const bool v_ = ok_ && k_ < kend_; \
-        fr[p][q] = *(v_ ? row_ + k_ : safe); } \
+      int m_ = 0; \
+      _Pragma("unroll") for (int ch = 0; ch < CHD_NQ / 4; ++ch) {        /* 64-column chunks nobody in the wavefront needs are skipped */ \
+        if (__any(ok_ && lo_ + l16 + 64 * ch < kend_)) { m_ |= 1 << ch; \
+          _Pragma("unroll") for (int q = 4 * ch; q < 4 * ch + 4; ++q) { const int k_ = lo_ + l16 + 16 * q; const bool v_ = ok_ && k_ < kend_; \
+            fr[p][q] = *(v_ ? row_ + k_ : safe); } } } \
+      fmk[p] = m_; \
       const int in_ = i_ + nb; elo[p] = env[(wv > 0 && (B) + 1 < nblk && a_ < nb && in_ < Nb) ? 2 * in_ : 0]; } } while (0)
 #define CHD_USE_FAR(B) do { const int c0_ = (B) * nb, jb_ = Nb - c0_ < nb ? Nb - c0_ : nb, kend_ = c0_ - nb; \
     _Pragma("unroll") for (int p = 0; p < 3; ++p) { const int a_ = g16 + 28 * p; \
       double s0_ = 0, s1_ = 0; \
-      _Pragma("unroll") for (int q = 0; q < CHD_NQ; q += 2) { const int k_ = flo[p] + l16 + 16 * q; \
-        s0_ += fr[p][q] * ((a_ < jb_ && k_ < kend_) ? y[k_] : 0.0); s1_ += fr[p][q + 1] * ((a_ < jb_ && k_ + 16 < kend_) ? y[k_ + 16] : 0.0); } \
+      _Pragma("unroll") for (int ch = 0; ch < CHD_NQ / 4; ++ch) if ((fmk[p] >> ch) & 1) { \
+        _Pragma("unroll") for (int q = 4 * ch; q < 4 * ch + 4; q += 2) { const int k_ = flo[p] + l16 + 16 * q; \
+          s0_ += fr[p][q] * ((a_ < jb_ && k_ < kend_) ? y[k_] : 0.0); s1_ += fr[p][q + 1] * ((a_ < jb_ && k_ + 16 < kend_) ? y[k_ + 16] : 0.0); } } \
       const double acc_ = group_sum(s0_ + s1_); \
       if (l16 == 0 && wv > 0 && a_ < jb_ && kend_ > 0) y[c0_ + a_] -= acc_; } } while (0)
 #define CHD_LOAD_NEAR(B) do { const int c0_ = (B) * nb, jb_ = Nb - c0_ < nb ? Nb - c0_ : nb; \
@@ -1309,6 +1314,7 @@ CHD_DEV void ksolve_fast(Ctx& c, const GD* rhs, GD* x, LdsD* y, LdsD* Sp, LdsD* 
   ts_ = CHD_CLOCK();
   // requests for the first backward steps travel while the border is processed
   double bf[CHD_BP][16], bn[8];
+  int bmk[CHD_BP] = {0, 0, 0};
   int ecl[CHD_BP], bcl[CHD_BP];        // last row reaching each far column (fetched one step ahead) / the value the held entries were masked with
   const int rg = lane >> 3, cl8 = lane & 7, qd = lane >> 4, cl16 = lane & 15;
 #define CHD_LOAD_BNEAR(B) do { const int c0_ = (B) * nb, jb_ = Nb - c0_ < nb ? Nb - c0_ : nb; \
@@ -1326,16 +1332,22 @@ CHD_DEV void ksolve_fast(Ctx& c, const GD* rhs, GD* x, LdsD* y, LdsD* Sp, LdsD* 
     _Pragma("unroll") for (int p = 0; p < CHD_BP; ++p) { const int k_ = k0_ + (p * 7 + wv - 1) * 16 + cl16; \
       const bool okc_ = wv > 0 && (B) >= 1 && k_ < kend_; \
       const int cl_ = ecl[p]; bcl[p] = cl_; \
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) { const int a_ = qd * 16 + r, i_ = c0_ + a_; \
-        const bool v_ = okc_ && a_ < jb_ && i_ - k_ <= w && i_ <= cl_; bf[p][r] = *(v_ ? Kfb + (long long)i_ * W1 + (k_ - i_ + w) : safe); } \
+      int m_ = 0; \
+      _Pragma("unroll") for (int ch = 0; ch < 4; ++ch) {      /* validity falls with the row: a 4-row chunk is needed iff its first row is, for some lane */ \
+        const int a0_ = qd * 16 + 4 * ch; \
+        if (__any(okc_ && a0_ < jb_ && c0_ + a0_ - k_ <= w && c0_ + a0_ <= cl_)) { m_ |= 1 << ch; \
+          _Pragma("unroll") for (int r = 4 * ch; r < 4 * ch + 4; ++r) { const int a_ = qd * 16 + r, i_ = c0_ + a_; \
+            const bool v_ = okc_ && a_ < jb_ && i_ - k_ <= w && i_ <= cl_; bf[p][r] = *(v_ ? Kfb + (long long)i_ * W1 + (k_ - i_ + w) : safe); } } } \
+      bmk[p] = m_; \
       const int kn_ = k0n_ + (p * 7 + wv - 1) * 16 + cl16; ecl[p] = env[(wv > 0 && (B) >= 2 && kn_ < c0n_ - nb) ? 2 * kn_ + 1 : 1]; } } while (0)
 #define CHD_USE_BFAR(B) do { const int c0_ = (B) * nb, jb_ = Nb - c0_ < nb ? Nb - c0_ : nb; \
     const int k0_ = c0_ - w < 0 ? 0 : c0_ - w, kend_ = c0_ - nb; \
     _Pragma("unroll") for (int p = 0; p < CHD_BP; ++p) { const int k_ = k0_ + (p * 7 + wv - 1) * 16 + cl16; \
       double s0_ = 0, s1_ = 0; \
-      _Pragma("unroll") for (int r = 0; r < 16; r += 2) { const int a_ = qd * 16 + r; \
-        s0_ += bf[p][r] * ((k_ < kend_ && a_ < jb_ && c0_ + a_ - k_ <= w && c0_ + a_ <= bcl[p]) ? y[c0_ + a_] : 0.0); \
-        s1_ += bf[p][r + 1] * ((k_ < kend_ && a_ + 1 < jb_ && c0_ + a_ + 1 - k_ <= w && c0_ + a_ + 1 <= bcl[p]) ? y[c0_ + a_ + 1] : 0.0); } \
+      _Pragma("unroll") for (int ch = 0; ch < 4; ++ch) if ((bmk[p] >> ch) & 1) { \
+        _Pragma("unroll") for (int r = 4 * ch; r < 4 * ch + 4; r += 2) { const int a_ = qd * 16 + r; \
+          s0_ += bf[p][r] * ((k_ < kend_ && a_ < jb_ && c0_ + a_ - k_ <= w && c0_ + a_ <= bcl[p]) ? y[c0_ + a_] : 0.0); \
+          s1_ += bf[p][r + 1] * ((k_ < kend_ && a_ + 1 < jb_ && c0_ + a_ + 1 - k_ <= w && c0_ + a_ + 1 <= bcl[p]) ? y[c0_ + a_ + 1] : 0.0); } } \
       double s_ = s0_ + s1_; s_ += __shfl_xor(s_, 16); s_ += __shfl_xor(s_, 32); \
       if (qd == 0 && wv > 0 && k_ < kend_) y[k_] -= s_; } } while (0)
   {
