@@ -1573,40 +1573,43 @@ CHD_DEV int frame_index(const SeqDesc* q, double t) {       // humanoid_rigid_bo
 }
 
 // One dynamics sample (6 rows): humanoid_dynamic_constraint.cpp:63-143, humanoid_rigid_body_dynamics.cpp:89-206.
-// Only the positions / forces of the four end-effectors are kept from the first pass; their spline weights are
-// re-evaluated one end-effector at a time for the Jacobian (ten live spline evaluations would not fit the register file).
-CHD_DEV void dyn_rows(Ctx& c, const int ti, const bool J, const bool D2, GD* cout_, const GD* lam, const GD* sc) {
+// The Jacobian of a sample is ~500 read-modify-writes of K0; done by one thread they form one dependent chain
+// (~0.6 ms).  The sample is therefore split into 16 units that touch disjoint entries, one thread each:
+//   unit 0: the six row values          units 1-3: base (linear + angular) columns of rows i = unit - 1
+//   units 4-15: end-effector e = (unit - 4) / 3, rows i = (unit - 4) % 3 (force nodes, position nodes, durations;
+//               the unit with i = 0 also stores the second-order duration terms of e)
+// Every unit evaluates only the splines it needs.
+CHD_DEV void dyn_unit(Ctx& c, const int ti, const int unit, const bool D2, GD* cout_, const GD* lam, const GD* sc) {
   const SeqDesc* q = c.q; const StageDesc* S = c.S;
   const GI* tk = q->ci + S->o_task + 4 * ti;
   const int B = tk[2], row0 = tk[3];
   const double t = q->cd[S->o_task_t + ti];
-  PE pl, pa;
-  spline_eval(q, 0, t, pl); spline_eval(q, 1, t, pa);
-  double pmp[4][3], pfp[4][3];
+  PE pl;
+  spline_eval(q, 0, t, pl);
+  if (unit < 4) {
+    PE pa;
+    spline_eval(q, 1, t, pa);
+    double tau[3] = {0, 0, 0}, fsum[3] = {0, 0, 0};
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    PE tmp;
-    spline_eval(q, 2 + e, t, tmp); for (int k = 0; k < 3; ++k) pmp[e][k] = tmp.p[k];
-    spline_eval(q, 6 + e, t, tmp); for (int k = 0; k < 3; ++k) pfp[e][k] = tmp.p[k];
-  }
-  const GD* I6 = q->cd + q->o_inertia + frame_index(q, t) * 6;
-  const double Ib[3][3] = {{I6[0], I6[3], I6[4]}, {I6[3], I6[1], I6[5]}, {I6[4], I6[5], I6[2]}};   // humanoid_rigid_body_dynamics.cpp:47-56
-  double ang[3], d0[3][3], d1[3][3], d2[3][3];
-  angular_term(pa.p, pa.v, pa.a, Ib, J, ang, d0, d1, d2);
-  double tau[3] = {0, 0, 0}, fsum[3] = {0, 0, 0};
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    double rr[3] = {pl.p[0] - pmp[e][0], pl.p[1] - pmp[e][1], pl.p[2] - pmp[e][2]}, tq[3];
-    cross3(pfp[e], rr, tq);
-    for (int k = 0; k < 3; ++k) { tau[k] += tq[k]; fsum[k] += pfp[e][k]; }
-  }
-  for (int k = 0; k < 3; ++k) {
-    cout_[row0 + k] = sc[row0 + k] * (ang[k] - tau[k]);
-    cout_[row0 + 3 + k] = sc[row0 + 3 + k] * (q->mass * pl.a[k] - fsum[k] - q->mass * CHD_G * q->gdir[k]);
-  }
-  if (!J) return;
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
+    for (int e = 0; e < 4; ++e) {
+      PE pm, pf;
+      spline_eval(q, 2 + e, t, pm); spline_eval(q, 6 + e, t, pf);
+      double rr[3] = {pl.p[0] - pm.p[0], pl.p[1] - pm.p[1], pl.p[2] - pm.p[2]}, tq[3];
+      cross3(pf.p, rr, tq);
+      for (int k = 0; k < 3; ++k) { tau[k] += tq[k]; fsum[k] += pf.p[k]; }
+    }
+    const GD* I6 = q->cd + q->o_inertia + frame_index(q, t) * 6;
+    const double Ib[3][3] = {{I6[0], I6[3], I6[4]}, {I6[3], I6[1], I6[5]}, {I6[4], I6[5], I6[2]}};   // humanoid_rigid_body_dynamics.cpp:47-56
+    double ang[3], d0[3][3], d1[3][3], d2[3][3];
+    angular_term(pa.p, pa.v, pa.a, Ib, unit > 0, ang, d0, d1, d2);
+    if (unit == 0) {
+      for (int k = 0; k < 3; ++k) {
+        cout_[row0 + k] = sc[row0 + k] * (ang[k] - tau[k]);
+        cout_[row0 + 3 + k] = sc[row0 + 3 + k] * (q->mass * pl.a[k] - fsum[k] - q->mass * CHD_G * q->gdir[k]);
+      }
+      return;
+    }
+    const int i = unit - 1;
     RowW ra{&c, c.pos_row[row0 + i], sc[row0 + i], true};
     RowW rl{&c, c.pos_row[row0 + 3 + i], sc[row0 + 3 + i], true};
     const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
@@ -1619,47 +1622,46 @@ CHD_DEV void dyn_rows(Ctx& c, const int ti, const bool J, const bool D2, GD* cou
     row_nodes(ra, 1, pa, 0, d0[i], 7);
     row_nodes(ra, 1, pa, 1, d1[i], 7);
     row_nodes(ra, 1, pa, 2, d2[i], 7);
+    return;
   }
-  double La[3] = {0, 0, 0}, Ll[3] = {0, 0, 0};
-  if (D2) for (int k = 0; k < 3; ++k) { La[k] = lam[row0 + k] * sc[row0 + k]; Ll[k] = lam[row0 + 3 + k] * sc[row0 + 3 + k]; }
-  for (int e = 0; e < 4; ++e) {
-    PE pme, pfe;
-    spline_eval(q, 2 + e, t, pme); spline_eval(q, 6 + e, t, pfe);
-    const double rr[3] = {pl.p[0] - pme.p[0], pl.p[1] - pme.p[1], pl.p[2] - pme.p[2]};
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      RowW ra{&c, c.pos_row[row0 + i], sc[row0 + i], true};
-      RowW rl{&c, c.pos_row[row0 + 3 + i], sc[row0 + 3 + i], true};
-      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
-      double xr[3] = {0, 0, 0}, xf[3] = {0, 0, 0}, ml[3] = {0, 0, 0};
-      xr[i2] = rr[i1]; xr[i1] = -rr[i2];              // +(r x df)_i
-      xf[i2] = pfe.p[i1]; xf[i1] = -pfe.p[i2];        // +(f x dp)_i
-      ml[i] = -1.0;
-      row_nodes(ra, 6 + e, pfe, 0, xr, 7 & ~(1 << i));
-      row_nodes(rl, 6 + e, pfe, 0, ml, 1 << i);
-      row_nodes(ra, 2 + e, pme, 0, xf, 7 & ~(1 << i));
-      row_durs(ra, 6 + e, t, pfe, xr);                // humanoid_dynamic_constraint.cpp:112-118
-      row_durs(rl, 6 + e, t, pfe, ml);
-      row_durs(ra, 2 + e, t, pme, xf);
+  const int e = (unit - 4) / 3, i = (unit - 4) % 3;
+  PE pme, pfe;
+  spline_eval(q, 2 + e, t, pme); spline_eval(q, 6 + e, t, pfe);
+  const double rr[3] = {pl.p[0] - pme.p[0], pl.p[1] - pme.p[1], pl.p[2] - pme.p[2]};
+  {
+    RowW ra{&c, c.pos_row[row0 + i], sc[row0 + i], true};
+    RowW rl{&c, c.pos_row[row0 + 3 + i], sc[row0 + 3 + i], true};
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+    double xr[3] = {0, 0, 0}, xf[3] = {0, 0, 0}, ml[3] = {0, 0, 0};
+    xr[i2] = rr[i1]; xr[i1] = -rr[i2];              // +(r x df)_i
+    xf[i2] = pfe.p[i1]; xf[i1] = -pfe.p[i2];        // +(f x dp)_i
+    ml[i] = -1.0;
+    row_nodes(ra, 6 + e, pfe, 0, xr, 7 & ~(1 << i));
+    row_nodes(rl, 6 + e, pfe, 0, ml, 1 << i);
+    row_nodes(ra, 2 + e, pme, 0, xf, 7 & ~(1 << i));
+    row_durs(ra, 6 + e, t, pfe, xr);                // humanoid_dynamic_constraint.cpp:112-118
+    row_durs(rl, 6 + e, t, pfe, ml);
+    row_durs(ra, 2 + e, t, pme, xf);
+  }
+  if (D2 && i == 0) {
+    // rows: ang_i - sum_e (F_e x r_e)_i with r_e = c - p_e, and m a_i - sum_e F_e,i.  With La / Ll the multipliers of the
+    // angular / linear rows:  d2L = -La . [Q^F x r - (G^F_k x G^p_l + G^F_l x G^p_k) - F x Q^p] - Ll . Q^F
+    double La[3], Ll[3];
+    for (int k = 0; k < 3; ++k) { La[k] = lam[row0 + k] * sc[row0 + k]; Ll[k] = lam[row0 + 3 + k] * sc[row0 + 3 + k]; }
+    DurJac2 dF, dP; dur_jac2(q, 6 + e, t, pfe, dF); dur_jac2(q, 2 + e, t, pme, dP);
+    double S3[3];
+    for (int cls = 0; cls < 3; ++cls) {
+      const double* QF = cls == 0 ? dF.Qee : cls == 1 ? dF.Qec : dF.Qcc;
+      const double* QP = cls == 0 ? dP.Qee : cls == 1 ? dP.Qec : dP.Qcc;
+      const double* GFx = cls == 2 ? dF.Gc : dF.Ge; const double* GFy = cls == 0 ? dF.Ge : dF.Gc;
+      const double* GPx = cls == 2 ? dP.Gc : dP.Ge; const double* GPy = cls == 0 ? dP.Ge : dP.Gc;
+      double a1[3], a2[3], a3[3], a4[3];
+      cross3(QF, rr, a1); cross3(GFx, GPy, a2); cross3(GFy, GPx, a3); cross3(pfe.p, QP, a4);
+      double v = 0;
+      for (int k = 0; k < 3; ++k) v += -La[k] * (a1[k] - a2[k] - a3[k] - a4[k]) - Ll[k] * QF[k];
+      S3[cls] = v;
     }
-    if (D2) {
-      // rows: ang_i - sum_e (F_e x r_e)_i with r_e = c - p_e, and m a_i - sum_e F_e,i.  With La / Ll the multipliers of the
-      // angular / linear rows:  d2L = -La . [Q^F x r - (G^F_k x G^p_l + G^F_l x G^p_k) - F x Q^p] - Ll . Q^F
-      DurJac2 dF, dP; dur_jac2(q, 6 + e, t, pfe, dF); dur_jac2(q, 2 + e, t, pme, dP);
-      double S3[3];
-      for (int cls = 0; cls < 3; ++cls) {
-        const double* QF = cls == 0 ? dF.Qee : cls == 1 ? dF.Qec : dF.Qcc;
-        const double* QP = cls == 0 ? dP.Qee : cls == 1 ? dP.Qec : dP.Qcc;
-        const double* GFx = cls == 2 ? dF.Gc : dF.Ge; const double* GFy = cls == 0 ? dF.Ge : dF.Gc;
-        const double* GPx = cls == 2 ? dP.Gc : dP.Ge; const double* GPy = cls == 0 ? dP.Ge : dP.Gc;
-        double a1[3], a2[3], a3[3], a4[3];
-        cross3(QF, rr, a1); cross3(GFx, GPy, a2); cross3(GFy, GPx, a3); cross3(pfe.p, QP, a4);
-        double v = 0;
-        for (int k = 0; k < 3; ++k) v += -La[k] * (a1[k] - a2[k] - a3[k] - a4[k]) - Ll[k] * QF[k];
-        S3[cls] = v;
-      }
-      d2_store(q, e, B, dF.cur, S3[0], S3[1], S3[2]);
-    }
+    d2_store(q, e, B, dF.cur, S3[0], S3[1], S3[2]);
   }
 }
 
@@ -1669,6 +1671,8 @@ CHD_NOINLINE CHD_DEV void eval_rows(Ctx& c, int mode, GD* cout_, const GD* lam) 
   const bool J = mode == EV_FULL;
   const bool D2 = J && S->opt_dur && lam != nullptr;      // exact duration block of the Lagrangian Hessian
   const int slot_height = q->n_tdyn, slot_rom = 2 * q->n_tdyn, slot_heel = 2 * q->n_tdyn + q->n_trom;
+  if (J) { PAR_FOR(u, S->n_dyn * 16) dyn_unit(c, S->dyn_first + u / 16, u % 16, D2, cout_, lam, sc); }
+  else { PAR_FOR(u, S->n_dyn) dyn_unit(c, S->dyn_first + u, 0, false, cout_, lam, sc); }
   PAR_FOR(ti, S->n_tasks) {
     const GI* tk = q->ci + S->o_task + 4 * ti;
     const int type = tk[0], A = tk[1], B = tk[2], row0 = tk[3];
@@ -1749,7 +1753,7 @@ CHD_NOINLINE CHD_DEV void eval_rows(Ctx& c, int mode, GD* cout_, const GD* lam) 
           }
         }
       } break;
-      case T_DYN: dyn_rows(c, ti, J, D2, cout_, lam, sc); break;
+      case T_DYN: break;     // dyn_unit above
       case T_FORCE: {        // TOWR ForceConstraint: normal force range + friction pyramid
         const SplineDesc& sp = q->sp[6 + A];
         const GD* nv = q->wd + q->o_node + sp.node_off + B * 6;
