@@ -1913,81 +1913,91 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, GD* g, const GD* lam) {
   auto second_of_pair = [&](const SplineDesc& sp, const GI* pinfo, int n) { return sp.phase_based && n > 0 && pinfo[(n - 1) * 4 + 3] != 0; };
   auto group_end = [&](const SplineDesc& sp, const GI* pinfo, int n) { return (sp.phase_based && n < sp.n_polys && pinfo[n * 4 + 3]) ? n + 1 : n; };
   // weight of the coefficient (nodes n..nh, derivative dq) in the position (which = 0) / velocity (1) of a sample
-  auto wgt = [](const GD* a, int which, int n, int nh, int dq) {
+  auto wgt = [](auto a, int which, int n, int nh, int dq) {
     const int p = (int)a[SC_POLY];
-    const GD* W = a + (which ? SC_WV : SC_WP);
+    auto W = a + (which ? SC_WV : SC_WP);
     double v = 0.0;
     if (p >= n && p <= nh) v += W[dq];
     if (p + 1 >= n && p + 1 <= nh) v += W[2 + dq];
     return v;
   };
-  PAR_FOR(idx, tot_nodes * 2 * ncol) {
-    const int col = idx % ncol, row = idx / ncol;
-    const int dq1 = row % 2, back = col / 2, dq2 = col % 2;
-    int n1 = row / 2, s = 0;
-    while (n1 >= q->sp[s].n_nodes) { n1 -= q->sp[s].n_nodes; ++s; }
-    const SplineDesc& sp = q->sp[s];
-    const GI* pinfo = q->ci + q->o_pinfo + sp.poly_off * 4;
-    const GI* vo = q->ci + q->o_varof + sp.node_off;
-    const int n2 = n1 - back;
-    if (n2 < 0 || (back == 0 && dq2 > dq1)) continue;
-    if (second_of_pair(sp, pinfo, n1) || second_of_pair(sp, pinfo, n2)) continue;       // folded into the pair's first node
-    const int h1 = group_end(sp, pinfo, n1), h2 = group_end(sp, pinfo, n2);
-    bool any = false;
-    for (int dim = 0; dim < 3; ++dim) any = any || (vo[n1 * 6 + dq1 * 3 + dim] >= 0 && vo[n2 * 6 + dq2 * 3 + dim] >= 0);
-    if (!any) continue;
-    const int pa = n1 - 1 < 0 ? 0 : n1 - 1, pb = h1 > sp.n_polys - 1 ? sp.n_polys - 1 : h1;
-    const int i_lo = first[s * fstride + pa], i_hi = first[s * fstride + pb + 1] - 1;
-    const int nsm = n_smooth(q, s);
-    const int ti = s < 2 ? s : 2;
-    const double wdat = S->w_data[ti], wvel = S->w_vel[ti], wacc = S->w_acc[ti];
-    double acc = 0.0;
-    for (int i = i_lo; i <= i_hi && i < F; ++i) {
-      const GD* a = scache(q, s, i);
-      acc += wdat * wgt(a, 0, n1, h1, dq1) * wgt(a, 0, n2, h2, dq2);
-    }
-    if (wvel >= 0 || wacc >= 0)
-      for (int i = i_lo - 1 < 0 ? 0 : i_lo - 1; i <= i_hi && i < nsm; ++i) {
-        const GD* a = scache(q, s, i); const GD* b = scache(q, s, i + 1);
-        if (wvel >= 0) acc += wvel * (wgt(b, 0, n1, h1, dq1) - wgt(a, 0, n1, h1, dq1)) * (wgt(b, 0, n2, h2, dq2) - wgt(a, 0, n2, h2, dq2));
-        if (wacc >= 0) acc += wacc * (wgt(b, 1, n1, h1, dq1) - wgt(a, 1, n1, h1, dq1)) * (wgt(b, 1, n2, h2, dq2) - wgt(a, 1, n2, h2, dq2));
+  auto node_terms = [&](auto sample) {
+    PAR_FOR(idx, tot_nodes * 2 * ncol) {
+      const int col = idx % ncol, row = idx / ncol;
+      const int dq1 = row % 2, back = col / 2, dq2 = col % 2;
+      int n1 = row / 2, s = 0;
+      while (n1 >= q->sp[s].n_nodes) { n1 -= q->sp[s].n_nodes; ++s; }
+      const SplineDesc& sp = q->sp[s];
+      const GI* pinfo = q->ci + q->o_pinfo + sp.poly_off * 4;
+      const GI* vo = q->ci + q->o_varof + sp.node_off;
+      const int n2 = n1 - back;
+      if (n2 < 0 || (back == 0 && dq2 > dq1)) continue;
+      if (second_of_pair(sp, pinfo, n1) || second_of_pair(sp, pinfo, n2)) continue;       // folded into the pair's first node
+      const int h1 = group_end(sp, pinfo, n1), h2 = group_end(sp, pinfo, n2);
+      bool any = false;
+      for (int dim = 0; dim < 3; ++dim) any = any || (vo[n1 * 6 + dq1 * 3 + dim] >= 0 && vo[n2 * 6 + dq2 * 3 + dim] >= 0);
+      if (!any) continue;
+      const int pa = n1 - 1 < 0 ? 0 : n1 - 1, pb = h1 > sp.n_polys - 1 ? sp.n_polys - 1 : h1;
+      const int i_lo = first[s * fstride + pa], i_hi = first[s * fstride + pb + 1] - 1;
+      const int nsm = n_smooth(q, s);
+      const int ti = s < 2 ? s : 2;
+      const double wdat = S->w_data[ti], wvel = S->w_vel[ti], wacc = S->w_acc[ti];
+      double acc = 0.0;
+      for (int i = i_lo; i <= i_hi && i < F; ++i) {
+        auto a = sample(s, i);
+        acc += wdat * wgt(a, 0, n1, h1, dq1) * wgt(a, 0, n2, h2, dq2);
       }
-    if (acc == 0.0) continue;
-    for (int dim = 0; dim < 3; ++dim) {
-      const int v1 = vo[n1 * 6 + dq1 * 3 + dim], v2 = vo[n2 * 6 + dq2 * 3 + dim];
-      if (v1 >= 0 && v2 >= 0) kadd(c, c.pos_var[sp.var_off + v1], c.pos_var[sp.var_off + v2], c.sf * acc);
-    }
-  }
-  // gradient: one thread per (coefficient, dimension)
-  PAR_FOR(idx, tot_nodes * 2 * 3) {
-    const int dim = idx % 3, row = idx / 3, dq1 = row % 2;
-    int n1 = row / 2, s = 0;
-    while (n1 >= q->sp[s].n_nodes) { n1 -= q->sp[s].n_nodes; ++s; }
-    const SplineDesc& sp = q->sp[s];
-    const GI* pinfo = q->ci + q->o_pinfo + sp.poly_off * 4;
-    const GI* vo = q->ci + q->o_varof + sp.node_off;
-    const int v1 = vo[n1 * 6 + dq1 * 3 + dim];
-    if (v1 < 0 || second_of_pair(sp, pinfo, n1)) continue;
-    const int h1 = group_end(sp, pinfo, n1);
-    const int pa = n1 - 1 < 0 ? 0 : n1 - 1, pb = h1 > sp.n_polys - 1 ? sp.n_polys - 1 : h1;
-    const int i_lo = first[s * fstride + pa], i_hi = first[s * fstride + pb + 1] - 1;
-    const int nsm = n_smooth(q, s);
-    const int ti = s < 2 ? s : 2;
-    const double wdat = S->w_data[ti], wvel = S->w_vel[ti], wacc = S->w_acc[ti];
-    const GD* dat = q->cd + q->o_data[s];
-    double acc = 0.0;
-    for (int i = i_lo; i <= i_hi && i < F; ++i) {
-      const GD* a = scache(q, s, i);
-      acc -= wdat * (dat[i * 3 + dim] - a[SC_P + dim]) * wgt(a, 0, n1, h1, dq1);
-    }
-    if (wvel >= 0 || wacc >= 0)
-      for (int i = i_lo - 1 < 0 ? 0 : i_lo - 1; i <= i_hi && i < nsm; ++i) {
-        const GD* a = scache(q, s, i); const GD* b = scache(q, s, i + 1);
-        if (wvel >= 0) acc += wvel * (b[SC_P + dim] - a[SC_P + dim]) * (wgt(b, 0, n1, h1, dq1) - wgt(a, 0, n1, h1, dq1));
-        if (wacc >= 0) acc += wacc * (b[SC_V + dim] - a[SC_V + dim]) * (wgt(b, 1, n1, h1, dq1) - wgt(a, 1, n1, h1, dq1));
+      if (wvel >= 0 || wacc >= 0)
+        for (int i = i_lo - 1 < 0 ? 0 : i_lo - 1; i <= i_hi && i < nsm; ++i) {
+          auto a = sample(s, i); auto b = sample(s, i + 1);
+          if (wvel >= 0) acc += wvel * (wgt(b, 0, n1, h1, dq1) - wgt(a, 0, n1, h1, dq1)) * (wgt(b, 0, n2, h2, dq2) - wgt(a, 0, n2, h2, dq2));
+          if (wacc >= 0) acc += wacc * (wgt(b, 1, n1, h1, dq1) - wgt(a, 1, n1, h1, dq1)) * (wgt(b, 1, n2, h2, dq2) - wgt(a, 1, n2, h2, dq2));
+        }
+      if (acc == 0.0) continue;
+      for (int dim = 0; dim < 3; ++dim) {
+        const int v1 = vo[n1 * 6 + dq1 * 3 + dim], v2 = vo[n2 * 6 + dq2 * 3 + dim];
+        if (v1 >= 0 && v2 >= 0) kadd(c, c.pos_var[sp.var_off + v1], c.pos_var[sp.var_off + v2], c.sf * acc);
       }
-    g[sp.var_off + v1] += c.sf * acc;
-  }
+    }
+    // gradient: one thread per (coefficient, dimension)
+    PAR_FOR(idx, tot_nodes * 2 * 3) {
+      const int dim = idx % 3, row = idx / 3, dq1 = row % 2;
+      int n1 = row / 2, s = 0;
+      while (n1 >= q->sp[s].n_nodes) { n1 -= q->sp[s].n_nodes; ++s; }
+      const SplineDesc& sp = q->sp[s];
+      const GI* pinfo = q->ci + q->o_pinfo + sp.poly_off * 4;
+      const GI* vo = q->ci + q->o_varof + sp.node_off;
+      const int v1 = vo[n1 * 6 + dq1 * 3 + dim];
+      if (v1 < 0 || second_of_pair(sp, pinfo, n1)) continue;
+      const int h1 = group_end(sp, pinfo, n1);
+      const int pa = n1 - 1 < 0 ? 0 : n1 - 1, pb = h1 > sp.n_polys - 1 ? sp.n_polys - 1 : h1;
+      const int i_lo = first[s * fstride + pa], i_hi = first[s * fstride + pb + 1] - 1;
+      const int nsm = n_smooth(q, s);
+      const int ti = s < 2 ? s : 2;
+      const double wdat = S->w_data[ti], wvel = S->w_vel[ti], wacc = S->w_acc[ti];
+      const GD* dat = q->cd + q->o_data[s];
+      double acc = 0.0;
+      for (int i = i_lo; i <= i_hi && i < F; ++i) {
+        auto a = sample(s, i);
+        acc -= wdat * (dat[i * 3 + dim] - a[SC_P + dim]) * wgt(a, 0, n1, h1, dq1);
+      }
+      if (wvel >= 0 || wacc >= 0)
+        for (int i = i_lo - 1 < 0 ? 0 : i_lo - 1; i <= i_hi && i < nsm; ++i) {
+          auto a = sample(s, i); auto b = sample(s, i + 1);
+          if (wvel >= 0) acc += wvel * (b[SC_P + dim] - a[SC_P + dim]) * (wgt(b, 0, n1, h1, dq1) - wgt(a, 0, n1, h1, dq1));
+          if (wacc >= 0) acc += wacc * (b[SC_V + dim] - a[SC_V + dim]) * (wgt(b, 1, n1, h1, dq1) - wgt(a, 1, n1, h1, dq1));
+        }
+      g[sp.var_off + v1] += c.sf * acc;
+    }
+  };
+  // the per-sample weights are read ~10^5 times by the entry tasks: keep the first 18 fields of the cache in LDS
+  const int sstride = 18;
+  if (6 * (F + 2) * sstride <= c.lds_cap - LDS_RED) {
+    LdsD* ws = c.lds + LDS_RED;
+    PAR_FOR(idx, 6 * (F + 2) * sstride) { const int si = idx / sstride, fld = idx % sstride; ws[idx] = (q->wd + q->o_scache + (long long)si * SC_STRIDE)[fld]; }
+    CHD_SYNC();
+    node_terms([&](int s, int i) { return (const LdsD*)(ws + ((long long)s * (F + 2) + i) * sstride); });
+  } else node_terms([&](int s, int i) { return scache(q, s, i); });
   CHD_SYNC();
   c.tacc[13] += CHD_CLOCK() - tg_; tg_ = CHD_CLOCK();
   // ---- duration variables (stage 3 only)
