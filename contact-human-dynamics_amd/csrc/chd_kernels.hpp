@@ -603,6 +603,10 @@ CHD_DEV double rcp_f64(double d) {
   x = __builtin_fma(__builtin_fma(-d, x, 1.0), x, x);
   return x;
 }
+// Left-looking: at column j lane a forms A(a,j) - sum_{k<j} [L(a,k) d_k] L(j,k).  Row j of L was written to the dense
+// LDS copy column by column at the earlier steps, so it arrives as pipelined broadcast reads issued one step ahead;
+// only L(j, j-1) and the pivot travel by v_readlane (whose result takes tens of cycles to reach the VALU -- the
+// right-looking form needed 31 - j of them per column and took ~11 us per block).
 template <int NB>
 CHD_NOINLINE CHD_DEV void diag_block(Ctx& c, const GI* sign, LdsD* dv, LdsD* DL, LdsD* PT, const int ldp, const int c0, const int jb) {
   if (threadIdx.x < 64) {
@@ -610,22 +614,35 @@ CHD_NOINLINE CHD_DEV void diag_block(Ctx& c, const GI* sign, LdsD* dv, LdsD* DL,
     const bool act = a < NB;
     const int sg_a = a < jb ? sign[c0 + a] : 1;          // expected pivot signs, fetched once
     const unsigned long long sg_pos = __ballot(sg_a > 0);
-    double r[NB];
+    double u[NB], row[NB];           // u[k] = L(a,k) d_k; row[k] = L(j,k) of the column being formed
 #pragma unroll
-    for (int j = 0; j < NB; ++j) r[j] = (act && j <= a) ? PT[j * ldp + a] : 0.0;
+    for (int k = 0; k < NB; ++k) { u[k] = 0.0; row[k] = 0.0; }
+    double lprev = 0.0;
+    double aj = (act && 0 <= a) ? PT[a] : 0.0;       // A(a, 0)
     int bad = 0;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      double d = readlane_f64(r[j], j);
+      if (j > 0) row[j - 1] = readlane_f64(lprev, j);          // L(j, j-1): produced by the previous column
+      double s0 = aj, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+      for (int k = 0; k + 3 < j; k += 4) { s0 -= u[k] * row[k]; s1 -= u[k + 1] * row[k + 1]; s2 -= u[k + 2] * row[k + 2]; s3 -= u[k + 3] * row[k + 3]; }
+#pragma unroll
+      for (int k = j & ~3; k < j; ++k) s0 -= u[k] * row[k];
+      const double v = (s0 + s1) + (s2 + s3);
+      // row j + 1 of L up to column j - 1 (written at earlier columns) and the next entry of A: requested now, they
+      // arrive while the pivot chain below runs
+      if (j + 1 < NB) {
+#pragma unroll
+        for (int k = 0; k < j; ++k) row[k] = DL[k * NB + (j + 1)];
+        aj = (act && j + 1 <= a) ? PT[(j + 1) * ldp + a] : 0.0;
+      }
+      double d = readlane_f64(v, j);
       if (j < jb) { const double sg = ((sg_pos >> j) & 1ull) ? 1.0 : -1.0; if (!(d * sg > 1e-14)) { d = sg * 1e-10; ++bad; } }
       const double inv = rcp_f64(d);
-      const double lj = r[j] * inv;            // L(a, j) for a > j
+      const double lj = v * inv;            // L(a, j) for a > j
+      u[j] = v; lprev = lj;
       if (act && a > j) { PT[j * ldp + a] = lj; DL[j * NB + a] = lj; }
       if (a == j) { dv[j] = d; dv[32 + j] = inv; }
-      const double ljd = lj * d;
-      // (an LDS write / broadcast-read round trip per column was measured at ~0.9 us per column; v_readlane is 3x faster)
-#pragma unroll
-      for (int jj = j + 1; jj < NB; ++jj) r[jj] -= ljd * readlane_f64(lj, jj);      // lanes a < jj hold unused values (ds_bpermute: 4x slower)
     }
     if (threadIdx.x == 0) c.n_bad_pivots += bad;
   }
