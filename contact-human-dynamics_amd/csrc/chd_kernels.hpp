@@ -662,8 +662,20 @@ CHD_DEV void build_active_rows(Ctx& c, int* act_, int* nact_, int wr, int nbelow
   if (threadIdx.x >= 64 && threadIdx.x < 128) {       // one wavefront (the second): ballot + prefix count keeps the list sorted
     LdsI* act = (LdsI*)act_; LdsI* nact = (LdsI*)nact_;
     const int ln = threadIdx.x - 64;
+    constexpr int MR = 10;                       // 64 MR >= w + b: the envelope starts are fetched together
+    int ef[MR];
+#pragma unroll
+    for (int r = 0; r < MR; ++r) { const int u = 64 * r + ln; ef[r] = c.env[u < wr ? 2 * (u >= nbelow ? c.Nb + u - nbelow : i0 + u) : 0]; }
     int base = 0;
-    for (int u0 = 0; u0 < wr; u0 += 64) {
+#pragma unroll
+    for (int r = 0; r < MR; ++r) {
+      const int u = 64 * r + ln;
+      const bool on = u < wr && ef[r] <= last_col;
+      const unsigned long long m = __ballot(on);
+      if (on) act[base + __popcll(m & ((1ull << ln) - 1ull))] = u;
+      base += __popcll(m);
+    }
+    for (int u0 = 64 * MR; u0 < wr; u0 += 64) {
       const int u = u0 + ln;
       const bool on = u < wr && c.env[2 * (u >= nbelow ? c.Nb + u - nbelow : i0 + u)] <= last_col;
       const unsigned long long m = __ballot(on);
@@ -771,36 +783,54 @@ struct Panel {
 };
 
 // ---- load (zero padded; identity in the padding columns); one task = 8 consecutive columns of one row
-// part 0: the diagonal block rows (all threads); part 1: everything below, by the threads past the first
-// wavefront (which factors the diagonal block meanwhile), plus the list of active window rows
+// part 0: the diagonal block rows (all threads) and the sorted list of active window rows (second wavefront);
+// part 1: the active rows below, by the threads past the first wavefront (which factors the diagonal block
+// meanwhile).  Rows that are not active keep whatever an earlier panel left in the LDS panel: nothing reads them.
 template <int NB>
 CHD_NOINLINE CHD_DEV void panel_load(Ctx& c, const Panel P, const int part) {
   const int W1 = c.w + 1, w = c.w, LD = c.LD;
   const int c0 = P.c0, jb = P.jb, nbelow = P.nbelow, pr = P.pr, ldp = P.ldp;
   LdsD* PT = P.PT;
-  const int t_first = part == 0 ? CHD_TID : NB * (NB / 8) + CHD_TID - CHD_LOAD_T0;
-  const int t_end = part == 0 ? NB * (NB / 8) : ldp * (NB / 8);
-  const int t_step = part == 0 ? CHD_NT : CHD_NT - CHD_LOAD_T0;
-  if (part == 1 && CHD_TID < CHD_LOAD_T0) return;
-  for (int idx = t_first; idx < t_end; idx += t_step) {
-    const int a = idx / (NB / 8), j0 = (idx % (NB / 8)) * 8;
+  if (part == 0) {
+    PAR_FOR(idx, NB * (NB / 8)) {
+      const int a = idx / (NB / 8), j0 = (idx % (NB / 8)) * 8;
+      double v[8];
+      const int i = c0 + a;
+      const GD* src = c.Kfb + (long long)(a < jb ? i : c0) * W1 + (c0 + j0 - (a < jb ? i : c0) + w);
+      const int ef = a < jb ? c.env[2 * i] : 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int j = j0 + q, k = c0 + j;
+        const bool ok = a < jb && j < jb && k <= i && k >= ef;
+        v[q] = ok ? src[q] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) PT[(j0 + q) * ldp + a] = (j0 + q >= jb && a == j0 + q) ? 1.0 : v[q];
+    }
+    PAR_FOR(j, NB) PT[j * ldp + pr + 8] = 0.0;      // the zero padding row of this panel (an earlier, longer panel may have used it)
+    // window rows that this panel can touch: rows whose envelope reaches the panel
+    build_active_rows(c, P.act, P.nact_p, pr - NB, nbelow, c0 + jb, c0 + jb - 1);
+    return;
+  }
+  if (CHD_TID < CHD_LOAD_T0) return;
+  const LdsI* act = (const LdsI*)P.act;
+  const int nact = *(const LdsI*)P.nact_p;
+  for (int idx = CHD_TID - CHD_LOAD_T0; idx < nact * (NB / 8); idx += CHD_NT - CHD_LOAD_T0) {
+    const int u = act[idx / (NB / 8)], a = NB + u, j0 = (idx % (NB / 8)) * 8;
+    const bool band = u < nbelow;
+    const int i = c0 + jb + u;
+    // left of a row's envelope the factor storage is zero (kreset + envelope-limited copy): only the band limit is checked
+    const GD* src = band ? c.Kfb + (long long)i * W1 + (c0 + j0 - i + w) : c.Kfx + (long long)(u - nbelow) * LD + c0 + j0;
     double v[8];
-    const bool band = a < jb || (a >= NB && a < NB + nbelow);
-    const bool bord = a >= NB + nbelow && a < pr && c.env[2 * (c.Nb + (a < pr && a >= NB + nbelow ? a - NB - nbelow : 0))] <= c0 + jb - 1;
-    const int i = c0 + (a < jb ? a : jb + a - NB);
-    const GD* src = band ? c.Kfb + (long long)i * W1 + (c0 + j0 - i + w) : c.Kfx + (long long)(bord ? a - NB - nbelow : 0) * LD + c0 + j0;
-    const int ef = band ? c.env[2 * i] : 0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int j = j0 + q, k = c0 + j;
-      const bool ok = j < jb && ((band && k <= i && k >= ef) || bord);
+      const bool ok = j < jb && (!band || i - k <= w);
       v[q] = ok ? src[q] : 0.0;
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) PT[(j0 + q) * ldp + a] = (j0 + q >= jb && a == j0 + q) ? 1.0 : v[q];
+    for (int q = 0; q < 8; ++q) PT[(j0 + q) * ldp + a] = v[q];
   }
-  // window rows that this panel can touch: band rows whose envelope reaches the panel, and every border row
-  if (part == 1) build_active_rows(c, P.act, P.nact_p, pr - NB, nbelow, c0 + jb, c0 + jb - 1);
 }
 
 // ---- (B) rows below: y_j = A(a,j) - sum_{k<j} y_k L(j,k);  L(a,j) = y_j / d_j
@@ -868,13 +898,13 @@ CHD_DEV void kfactor_band(Ctx& c, const GI* sign, LdsD* dv, LdsD* DL, LdsD* PT, 
     long long tp_ = CHD_CLOCK();
     panel_load<NB>(c, P, 0);
     CHD_SYNC();
+    const int nact = *(const LdsI*)P.nact_p;
     c.tacc[7] += CHD_CLOCK() - tp_; tp_ = CHD_CLOCK();
     // ---- (A) NB x NB diagonal block: unit-lower L in place, pivots to dv (first wavefront), while the other
     //      wavefronts fetch the rows below it
     diag_block<NB>(c, sign, dv, DL, PT, ldp, c0, P.jb);
     panel_load<NB>(c, P, 1);
     CHD_SYNC();
-    const int nact = *(const LdsI*)P.nact_p;
     c.tacc[8] += CHD_CLOCK() - tp_; tp_ = CHD_CLOCK();
     panel_rows<NB>(c, P, nact);
     CHD_SYNC();
@@ -978,6 +1008,8 @@ CHD_NOINLINE CHD_DEV void kfactor(Ctx& c, const GD* diag, const GI* sign) {
   int nb = 32;
   while (nb > 8 && (long long)(nb + w + bc + 18) * nb > avail) nb >>= 1;
   const int ldp = (nb + w + bc + 17) | 1;  // odd leading dimension (conflict-free column walks), >= 16 rows of zero padding
+  PAR_FOR(i, ldp * nb) PT[i] = 0.0;          // rows a panel does not load (inactive, padding) must read as zero
+  CHD_SYNC();
   if (nb == 32) kfactor_band<32>(c, sign, dv, DL, PT, ldp);
   else if (nb == 16) kfactor_band<16>(c, sign, dv, DL, PT, ldp);
   else kfactor_band<8>(c, sign, dv, DL, PT, ldp);
