@@ -918,23 +918,26 @@ CHD_DEV void kfactor_band(Ctx& c, const GI* sign, LdsD* dv, LdsD* DL, LdsD* PT, 
   }
 }
 
-// in-place L D L^T of a dense symmetric n x n matrix (lower triangle, leading dimension ld)
+// in-place L D L^T of a dense symmetric n x n matrix (lower triangle, leading dimension ld).
+// The columns stay unscaled (L D) while the elimination runs -- later columns never touch them -- and are divided
+// by their pivots in one pass at the end: one workgroup barrier per column instead of three.
 template <class P>
 CHD_DEV void dense_ldlt(Ctx& c, P Sp, const int ld, const int n, const GI* sign) {
+  int sg_next = n > 0 ? sign[0] : 1;
   for (int j = 0; j < n; ++j) {
-    const double d = pivot_fix(c, Sp[(long long)j * ld + j], sign[j]);
+    const int sg = sg_next;
+    if (j + 1 < n) sg_next = sign[j + 1];            // (fetched a column ahead)
+    const double d = pivot_fix(c, Sp[(long long)j * ld + j], sg);
     const double id = 1.0 / d;
-    CHD_SYNC();
-    for (int r = j + 1 + CHD_TID; r < n; r += CHD_NT) Sp[(long long)r * ld + j] *= id;
     if (CHD_TID == 0) Sp[(long long)j * ld + j] = d;
-    CHD_SYNC();
-    const int nr = n - j - 1;
-    PAR_FOR(idx, nr * nr) {
-      const int r = j + 1 + idx / nr, k = j + 1 + idx % nr;
-      if (k <= r) Sp[(long long)r * ld + k] -= Sp[(long long)r * ld + j] * d * Sp[(long long)k * ld + j];
+    for (int r = j + 1 + CHD_TID / 8; r < n; r += CHD_NT / 8 > 0 ? CHD_NT / 8 : 1) {
+      const double f = Sp[(long long)r * ld + j] * id;
+      for (int k = j + 1 + CHD_TID % 8; k <= r; k += CHD_NT >= 8 ? 8 : 1) Sp[(long long)r * ld + k] -= f * Sp[(long long)k * ld + j];
     }
     CHD_SYNC();
   }
+  PAR_FOR(idx, n * n) { const int r = idx / n, k = idx % n; if (k < r) Sp[(long long)r * ld + k] /= Sp[(long long)k * ld + k]; }
+  CHD_SYNC();
 }
 
 CHD_NOINLINE CHD_DEV void kfactor(Ctx& c, const GD* diag, const GI* sign) {
