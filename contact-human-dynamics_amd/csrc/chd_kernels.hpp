@@ -515,16 +515,22 @@ template <class XP>
 CHD_DEV void kmatvec_impl(Ctx& c, XP x, GD* y, const GD* diag, const GI* only) {
   const int Nb = c.Nb, w = c.w, W2 = c.W2, LD = c.LD, bc = c.bc;
   {
-    const int step = CHD_NT / CHD_GL, lane_ = CHD_TID % CHD_GL;
-    int i = CHD_TID / CHD_GL;
+    // 8 lanes per band row (an envelope holds ~100-200 entries: 16 requests in flight per lane), 64 rows per pass
+    const int gl = CHD_NT >= 8 ? 8 : 1;
+    const int step = CHD_NT / gl, lane_ = CHD_TID % gl;
+    int i = CHD_TID / gl;
     int lo = i < Nb ? c.env[2 * i] : 0, hi = i < Nb ? c.env[2 * i + 1] : 0;      // nothing is stored outside the envelope
     for (; i < Nb; i += step) {
       const int in = i + step;
       const int nlo = in < Nb ? c.env[2 * in] : 0, nhi = in < Nb ? c.env[2 * in + 1] : 0;      // next row's envelope, one pass ahead
       if (!(only && only[i] <= 0)) {
+        const double dterm = diag ? diag[i] * x[i] : 0.0;
         const GD* row = c.K0b + (long long)i * W2 + (w - i);
-        const double acc = group_sum(dot_strided(row, x, lo + lane_, hi + 1, CHD_GL));      // (16-byte requests were tried: same rate, the limit is lines in flight)
-        if (lane_ == 0) y[i] = acc + (diag ? diag[i] * x[i] : 0.0);
+        double acc = dot_strided(row, x, lo + lane_, hi + 1, gl);      // (16-byte requests were tried: same rate, the limit is lines in flight)
+#ifndef CHD_HOST_EMU
+        acc += __shfl_xor(acc, 4); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 1);
+#endif
+        if (lane_ == 0) y[i] = acc + dterm;
       }
       lo = nlo; hi = nhi;
     }
@@ -971,7 +977,8 @@ CHD_NOINLINE CHD_DEV void kfactor(Ctx& c, const GD* diag, const GI* sign) {
 #pragma unroll
         for (int q = 0; q < QP; ++q) {
           const int i = i0 + r, cc = clo[r] + CHD_LANE + q * CHD_WAVE_SZ;
-          v[r][q] = *((i < Nb && cc < W1) ? c.K0b + (long long)i * W2 + cc : c.K0b + w);      // predicated-off lanes re-read one valid address
+          if (i < Nb && clo[r] + q * CHD_WAVE_SZ < W1)      // (uniform over the wavefront: whole requests beyond the row's envelope are skipped)
+            v[r][q] = *(cc < W1 ? c.K0b + (long long)i * W2 + cc : c.K0b + w);      // predicated-off lanes re-read one valid address
         }
 #pragma unroll
       for (int r = 0; r < RP; ++r)
