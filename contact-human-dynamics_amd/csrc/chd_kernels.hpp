@@ -580,19 +580,25 @@ CHD_DEV double pivot_fix(Ctx& c, double d, int sg) {
 #endif
 
 
-// ---- diagonal block of a panel (NB x NB, in LDS column-major PT[j * ldp + a]) -------------------
+// ---- diagonal block of a panel: the NB x NB block of Kf at (c0, c0) -> unit-lower L (dense LDS copy DL[k * NB + j]
+//      = L(j, k)), pivots dv[0..NB) and their reciprocals dv[32..).  Rows >= jb of a short last block are identity.
+//      The block is read straight from HBM by one wavefront (lane a = row a), so it can be factored while the other
+//      wavefronts are still busy with the previous panel's trailing update (look-ahead).
 #ifdef CHD_HOST_EMU
-// dv: pivots, dv + 32: their reciprocals, DL: dense copy of the unit-lower block, DL[k * NB + j] = L(j, k)
 template <int NB>
-CHD_DEV void diag_block(Ctx& c, const GI* sign, LdsD* dv, LdsD* DL, LdsD* PT, const int ldp, const int c0, const int jb) {
+CHD_DEV void diag_block_g(Ctx& c, const GI* sign, LdsD* dv, LdsD* DL, const int c0, const int jb) {
+  const int W1 = c.w + 1, w = c.w;
+  double A[NB][NB];
+  for (int a = 0; a < NB; ++a)
+    for (int j = 0; j < NB; ++j) A[a][j] = (a < jb && j <= a) ? c.Kfb[(long long)(c0 + a) * W1 + (j - a + w)] : (a == j ? 1.0 : 0.0);
   for (int j = 0; j < NB; ++j) {
-    double d = PT[j * ldp + j];
+    double d = A[j][j];
     if (j < jb) d = pivot_fix(c, d, sign[c0 + j]);
     const double inv = 1.0 / d;
-    for (int a = j + 1; a < NB; ++a) { PT[j * ldp + a] *= inv; DL[j * NB + a] = PT[j * ldp + a]; }
+    for (int a = j + 1; a < NB; ++a) { A[a][j] *= inv; DL[j * NB + a] = A[a][j]; }
     dv[j] = d; dv[32 + j] = inv;
     for (int jj = j + 1; jj < NB; ++jj)
-      for (int a = jj; a < NB; ++a) PT[jj * ldp + a] -= PT[j * ldp + a] * d * PT[j * ldp + jj];
+      for (int a = jj; a < NB; ++a) A[a][jj] -= A[a][j] * d * A[jj][j];
   }
 }
 #else
@@ -601,8 +607,6 @@ CHD_DEV double readlane_f64(double v, int l) {
   lo = __builtin_amdgcn_readlane(lo, l); hi = __builtin_amdgcn_readlane(hi, l);
   return __hiloint2double(hi, lo);
 }
-// one wavefront: lane a keeps row a of the block in registers; column j's pivot and multipliers are
-// broadcast with v_readlane, so the whole right-looking elimination runs without an LDS or HBM round trip
 CHD_DEV double rcp_f64(double d) {
   double x = __builtin_amdgcn_rcp(d);
   x = __builtin_fma(__builtin_fma(-d, x, 1.0), x, x);
@@ -614,40 +618,42 @@ CHD_DEV double rcp_f64(double d) {
 // only L(j, j-1) and the pivot travel by v_readlane (whose result takes tens of cycles to reach the VALU -- the
 // right-looking form needed 31 - j of them per column and took ~11 us per block).
 template <int NB>
-CHD_NOINLINE CHD_DEV void diag_block(Ctx& c, const GI* sign, LdsD* dv, LdsD* DL, LdsD* PT, const int ldp, const int c0, const int jb) {
+CHD_DEV void diag_block_g(Ctx& c, const GI* sign, LdsD* dv, LdsD* DL, const int c0, const int jb) {
   if (threadIdx.x < 64) {
+    const int W1 = c.w + 1, w = c.w;
     const int a = threadIdx.x;
     const bool act = a < NB;
     const int sg_a = a < jb ? sign[c0 + a] : 1;          // expected pivot signs, fetched once
+    double ar[NB];                  // row a of the block (left of a row's envelope the factor storage is zero)
+    const GD* src = c.Kfb + (long long)(c0 + (a < jb ? a : 0)) * W1 + (w - (a < jb ? a : 0));
+#pragma unroll
+    for (int j = 0; j < NB; ++j) { const bool in = a < jb && j <= a; const double t = *(in ? src + j : c.Kfb + w); ar[j] = in ? t : (a == j ? 1.0 : 0.0); }
     const unsigned long long sg_pos = __ballot(sg_a > 0);
     double u[NB], row[NB];           // u[k] = L(a,k) d_k; row[k] = L(j,k) of the column being formed
 #pragma unroll
     for (int k = 0; k < NB; ++k) { u[k] = 0.0; row[k] = 0.0; }
     double lprev = 0.0;
-    double aj = (act && 0 <= a) ? PT[a] : 0.0;       // A(a, 0)
     int bad = 0;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       if (j > 0) row[j - 1] = readlane_f64(lprev, j);          // L(j, j-1): produced by the previous column
-      double s0 = aj, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      double s0 = ar[j], s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
       for (int k = 0; k + 3 < j; k += 4) { s0 -= u[k] * row[k]; s1 -= u[k + 1] * row[k + 1]; s2 -= u[k + 2] * row[k + 2]; s3 -= u[k + 3] * row[k + 3]; }
 #pragma unroll
       for (int k = j & ~3; k < j; ++k) s0 -= u[k] * row[k];
       const double v = (s0 + s1) + (s2 + s3);
-      // row j + 1 of L up to column j - 1 (written at earlier columns) and the next entry of A: requested now, they
-      // arrive while the pivot chain below runs
+      // row j + 1 of L up to column j - 1 (written at earlier columns): requested now, arrives while the pivot chain runs
       if (j + 1 < NB) {
 #pragma unroll
         for (int k = 0; k < j; ++k) row[k] = DL[k * NB + (j + 1)];
-        aj = (act && j + 1 <= a) ? PT[(j + 1) * ldp + a] : 0.0;
       }
       double d = readlane_f64(v, j);
       if (j < jb) { const double sg = ((sg_pos >> j) & 1ull) ? 1.0 : -1.0; if (!(d * sg > 1e-14)) { d = sg * 1e-10; ++bad; } }
       const double inv = rcp_f64(d);
       const double lj = v * inv;            // L(a, j) for a > j
       u[j] = v; lprev = lj;
-      if (act && a > j) { PT[j * ldp + a] = lj; DL[j * NB + a] = lj; }
+      if (act && a > j) DL[j * NB + a] = lj;
       if (a == j) { dv[j] = d; dv[32 + j] = inv; }
     }
     if (threadIdx.x == 0) c.n_bad_pivots += bad;
@@ -697,7 +703,7 @@ CHD_DEV void build_active_rows(Ctx& c, int* act_, int* nact_, int wr, int nbelow
 // window rows/cols u = 0..wr-1 live at PT rows NB+u; u < nbelow are band rows i0+u, the rest border rows
 #ifdef CHD_HOST_EMU
 template <int NB>
-CHD_DEV void trailing_update(Ctx& c, const LdsD* dv, const LdsD* PT, const int ldp, const int wr, const int nbelow, const int i0, const int* act, const int nact) {
+CHD_DEV void trailing_update(Ctx& c, const LdsD* dv, const LdsD* PT, const int ldp, const int wr, const int nbelow, const int i0, const int* act, const int nact, const bool) {
   const int W1 = c.w + 1, w = c.w, LD = c.LD, Nb = c.Nb;
   for (int tr = 0; tr < nact; ++tr)
     for (int tc = 0; tc <= tr; ++tc) {
@@ -714,8 +720,10 @@ typedef double chd_f64x4 __attribute__((ext_vector_type(4)));
 // one 16x16 tile of the COMPACTED window per wavefront pass, K = NB in steps of 4 on the fp64 matrix core
 // (v_mfma_f64_16x16x4_f64: A[row = lane & 15][k = lane >> 4], B[k = lane >> 4][col = lane & 15],
 //  D[row = (lane >> 4) + 4 * reg][col = lane & 15])
+// `split`: the first wavefront only takes the three tiles that cover the next panel's diagonal block (it goes on to
+// factor that block), the other wavefronts share the rest; otherwise all wavefronts share all tiles
 template <int NB>
-CHD_NOINLINE CHD_DEV void trailing_update(Ctx& c, const LdsD* dv, const LdsD* PT, const int ldp, const int wr, const int nbelow, const int i0, const int* act_, const int nact) {
+CHD_DEV void trailing_update(Ctx& c, const LdsD* dv, const LdsD* PT, const int ldp, const int wr, const int nbelow, const int i0, const int* act_, const int nact, const bool split) {
   const int W1 = c.w + 1, w = c.w, LD = c.LD, Nb = c.Nb;
   const LdsI* act = (const LdsI*)act_;
   const int wave = threadIdx.x >> 6, nwv = blockDim.x >> 6, lane = threadIdx.x & 63;
@@ -737,13 +745,16 @@ CHD_NOINLINE CHD_DEV void trailing_update(Ctx& c, const LdsD* dv, const LdsD* PT
   // TP independent tiles per pass: the old window values of all of them are requested before the MFMA
   // chains start (memory-level parallelism), and the chains interleave on the matrix pipe
   constexpr int TP = 4;
-  for (int t0 = wave; t0 < ntri; t0 += TP * nwv) {
+  const int t_first = !split ? wave : wave == 0 ? 0 : 3 + (wave - 1);
+  const int t_stride = !split ? nwv : wave == 0 ? 1 : nwv - 1;                 // between the TP tiles of one pass
+  const int t_limit = (split && wave == 0) ? (ntri < 3 ? ntri : 3) : ntri;
+  for (int t0 = t_first; t0 < t_limit; t0 += TP * t_stride) {
     GD* pd[TP][4]; double old_[TP][4]; bool ok[TP][4];
     const LdsD* pa[TP]; const LdsD* pb[TP];
 #pragma unroll
     for (int u = 0; u < TP; ++u) {
-      const int t = t0 + u * nwv;
-      const bool live = t < ntri;
+      const int t = t0 + u * t_stride;
+      const bool live = t < t_limit;
       int tr, tc;
       tile_of(live ? t : t0, tr, tc);
       const int ira = 16 * tr + lr, icb = 16 * tc + lr;           // compact indices of this lane's A row / B column
@@ -777,6 +788,18 @@ CHD_NOINLINE CHD_DEV void trailing_update(Ctx& c, const LdsD* dv, const LdsD* PT
 }
 #endif
 
+template <int NB>
+CHD_NOINLINE CHD_DEV void trailing_phase(Ctx& c, const GI* sign, const LdsD* dv, const LdsD* PT, const int ldp, const int wr, const int nbelow, const int i0,
+                                         const int* act, const int nact, const bool more, LdsD* dv_n, LdsD* DL_n, const int c0n, const int jbn) {
+  trailing_update<NB>(c, dv, PT, ldp, wr, nbelow, i0, act, nact, more);
+  if (more) {
+#ifndef CHD_HOST_EMU
+    if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // this wavefront's window updates precede its reads below
+#endif
+    diag_block_g<NB>(c, sign, dv_n, DL_n, c0n, jbn);
+  }
+}
+
 // Banded part of the factorisation, NB columns per panel.  Panel in LDS, column-major PT[j * ldp + a];
 // local rows: [0, NB) diagonal block (rows >= jb of a short last block are identity padding),
 // [NB, NB + nbelow) band rows below it, then the bc border rows.
@@ -789,39 +812,23 @@ struct Panel {
 };
 
 // ---- load (zero padded; identity in the padding columns); one task = 8 consecutive columns of one row
-// part 0: the diagonal block rows (all threads) and the sorted list of active window rows (second wavefront);
-// part 1: the active rows below, by the threads past the first wavefront (which factors the diagonal block
-// meanwhile).  Rows that are not active keep whatever an earlier panel left in the LDS panel: nothing reads them.
+// part 0: the sorted list of active window rows (second wavefront) and this panel's zero padding row;
+// part 1: the active rows below the diagonal block (which was factored straight from HBM during the previous panel's
+// trailing update).  Rows that are not active keep whatever an earlier panel left in the LDS panel: nothing reads them.
 template <int NB>
 CHD_NOINLINE CHD_DEV void panel_load(Ctx& c, const Panel P, const int part) {
   const int W1 = c.w + 1, w = c.w, LD = c.LD;
   const int c0 = P.c0, jb = P.jb, nbelow = P.nbelow, pr = P.pr, ldp = P.ldp;
   LdsD* PT = P.PT;
   if (part == 0) {
-    PAR_FOR(idx, NB * (NB / 8)) {
-      const int a = idx / (NB / 8), j0 = (idx % (NB / 8)) * 8;
-      double v[8];
-      const int i = c0 + a;
-      const GD* src = c.Kfb + (long long)(a < jb ? i : c0) * W1 + (c0 + j0 - (a < jb ? i : c0) + w);
-      const int ef = a < jb ? c.env[2 * i] : 0;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int j = j0 + q, k = c0 + j;
-        const bool ok = a < jb && j < jb && k <= i && k >= ef;
-        v[q] = ok ? src[q] : 0.0;
-      }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) PT[(j0 + q) * ldp + a] = (j0 + q >= jb && a == j0 + q) ? 1.0 : v[q];
-    }
     PAR_FOR(j, NB) PT[j * ldp + pr + 8] = 0.0;      // the zero padding row of this panel (an earlier, longer panel may have used it)
     // window rows that this panel can touch: rows whose envelope reaches the panel
     build_active_rows(c, P.act, P.nact_p, pr - NB, nbelow, c0 + jb, c0 + jb - 1);
     return;
   }
-  if (CHD_TID < CHD_LOAD_T0) return;
   const LdsI* act = (const LdsI*)P.act;
   const int nact = *(const LdsI*)P.nact_p;
-  for (int idx = CHD_TID - CHD_LOAD_T0; idx < nact * (NB / 8); idx += CHD_NT - CHD_LOAD_T0) {
+  PAR_FOR(idx, nact * (NB / 8)) {
     const int u = act[idx / (NB / 8)], a = NB + u, j0 = (idx % (NB / 8)) * 8;
     const bool band = u < nbelow;
     const int i = c0 + jb + u;
@@ -867,7 +874,7 @@ template <int NB>
 CHD_NOINLINE CHD_DEV void panel_store(Ctx& c, const Panel P) {
   const int W1 = c.w + 1, w = c.w, LD = c.LD;
   const int c0 = P.c0, jb = P.jb, nbelow = P.nbelow, pr = P.pr, ldp = P.ldp;
-  const LdsD* PT = P.PT; const LdsD* dv = P.dv;
+  const LdsD* PT = P.PT; const LdsD* dv = P.dv; const LdsD* DL = P.DL;
   PAR_FOR(idx, pr * (NB / 8)) {
     const int a = idx / (NB / 8), j0 = (idx % (NB / 8)) * 8;
     if (a >= jb && a < NB) continue;
@@ -882,7 +889,7 @@ CHD_NOINLINE CHD_DEV void panel_store(Ctx& c, const Panel P) {
       const int j = j0 + q, k = c0 + j;
       if (j >= jb) break;
       if (band) {
-        if (k < i && k >= ef) dst[q] = PT[j * ldp + a];
+        if (k < i && k >= ef) dst[q] = a < NB ? DL[j * NB + a] : PT[j * ldp + a];      // (the diagonal block only lives in its dense copy)
         else if (k == i) dst[q] = dv[j];
       } else dst[q] = PT[j * ldp + a];
     }
@@ -890,8 +897,12 @@ CHD_NOINLINE CHD_DEV void panel_store(Ctx& c, const Panel P) {
 }
 
 template <int NB>
-CHD_DEV void kfactor_band(Ctx& c, const GI* sign, LdsD* dv, LdsD* DL, LdsD* PT, const int ldp) {
+CHD_DEV void kfactor_band(Ctx& c, const GI* sign, LdsD* dv, LdsD* DL, LdsD* dv2, LdsD* DL2, LdsD* PT, const int ldp) {
   const int Nb = c.Nb, w = c.w, bc = c.bc;
+  // look-ahead: the diagonal block of panel J + 1 is factored by the first wavefront during panel J's trailing update
+  // (after it has applied the three tiles of that update which touch the block), into the other (dv, DL) pair
+  diag_block_g<NB>(c, sign, dv, DL, 0, Nb < NB ? Nb : NB);
+  CHD_SYNC();
   for (int c0 = 0; c0 < Nb; c0 += NB) {
     Panel P;
     P.c0 = c0; P.jb = Nb - c0 < NB ? Nb - c0 : NB;
@@ -906,9 +917,6 @@ CHD_DEV void kfactor_band(Ctx& c, const GI* sign, LdsD* dv, LdsD* DL, LdsD* PT, 
     CHD_SYNC();
     const int nact = *(const LdsI*)P.nact_p;
     c.tacc[7] += CHD_CLOCK() - tp_; tp_ = CHD_CLOCK();
-    // ---- (A) NB x NB diagonal block: unit-lower L in place, pivots to dv (first wavefront), while the other
-    //      wavefronts fetch the rows below it
-    diag_block<NB>(c, sign, dv, DL, PT, ldp, c0, P.jb);
     panel_load<NB>(c, P, 1);
     CHD_SYNC();
     c.tacc[8] += CHD_CLOCK() - tp_; tp_ = CHD_CLOCK();
@@ -917,10 +925,13 @@ CHD_DEV void kfactor_band(Ctx& c, const GI* sign, LdsD* dv, LdsD* DL, LdsD* PT, 
     c.tacc[9] += CHD_CLOCK() - tp_; tp_ = CHD_CLOCK();
     panel_store<NB>(c, P);                     // stores of the panel columns; the update below touches other columns
     c.tacc[10] += CHD_CLOCK() - tp_; tp_ = CHD_CLOCK();
-    // ---- trailing update of the window
-    trailing_update<NB>(c, dv, PT, ldp, P.pr - NB, P.nbelow, c0 + P.jb, P.act, nact);
+    // ---- trailing update of the window (+ the next diagonal block)
+    const int c0n = c0 + NB;
+    const bool more = c0n < Nb;
+    trailing_phase<NB>(c, sign, dv, PT, ldp, P.pr - NB, P.nbelow, c0 + P.jb, P.act, nact, more, dv2, DL2, c0n, Nb - c0n < NB ? Nb - c0n : NB);
     CHD_SYNC();
     c.tacc[11] += CHD_CLOCK() - tp_;
+    LdsD* t_ = dv; dv = dv2; dv2 = t_; t_ = DL; DL = DL2; DL2 = t_;
   }
 }
 
@@ -1013,16 +1024,18 @@ CHD_NOINLINE CHD_DEV void kfactor(Ctx& c, const GD* diag, const GI* sign) {
   // panel width from the LDS budget
   LdsD* dv = c.lds + LDS_RED;            // pivots of the current panel (<= 32) and their reciprocals
   LdsD* DL = dv + 64;                    // dense copy of the panel's unit-lower diagonal block
-  LdsD* PT = DL + 32 * 32;               // panel (the list of active window rows follows it)
-  const int avail = c.lds_cap - LDS_RED - 64 - 32 * 32 - (w + bc + 64) / 2 - 8;      // ints of the active-row list
+  LdsD* dv2 = DL + 32 * 32;              // the same pair for the next panel (look-ahead)
+  LdsD* DL2 = dv2 + 64;
+  LdsD* PT = DL2 + 32 * 32;              // panel (the list of active window rows follows it)
+  const int avail = c.lds_cap - LDS_RED - 2 * (64 + 32 * 32) - (w + bc + 64) / 2 - 8;      // ints of the active-row list
   int nb = 32;
   while (nb > 8 && (long long)(nb + w + bc + 18) * nb > avail) nb >>= 1;
   const int ldp = (nb + w + bc + 17) | 1;  // odd leading dimension (conflict-free column walks), >= 16 rows of zero padding
   PAR_FOR(i, ldp * nb) PT[i] = 0.0;          // rows a panel does not load (inactive, padding) must read as zero
   CHD_SYNC();
-  if (nb == 32) kfactor_band<32>(c, sign, dv, DL, PT, ldp);
-  else if (nb == 16) kfactor_band<16>(c, sign, dv, DL, PT, ldp);
-  else kfactor_band<8>(c, sign, dv, DL, PT, ldp);
+  if (nb == 32) kfactor_band<32>(c, sign, dv, DL, dv2, DL2, PT, ldp);
+  else if (nb == 16) kfactor_band<16>(c, sign, dv, DL, dv2, DL2, PT, ldp);
+  else kfactor_band<8>(c, sign, dv, DL, dv2, DL2, PT, ldp);
   // ---- dense L D L^T of the border Schur complement (rows/cols Nb..N-1)
   const long long td_ = CHD_CLOCK();
   if (bc > 0) {
