@@ -450,8 +450,14 @@ CHD_DEV double kget(const Ctx& c, int p, int qq) {
 }
 
 CHD_DEV void kzero(Ctx& c) {
-  const long long nb_ = (long long)c.Nb * c.W2, nx_ = (long long)c.bc * c.LD;
-  for (long long i = CHD_TID; i < nb_; i += CHD_NT) c.K0b[i] = 0.0;
+  const long long nx_ = (long long)c.bc * c.LD;
+  // band rows: only the envelope [efirst_i, clast_i] (what the mat-vec and the factor copy read; kadd widens it first
+  // if an entry ever lands outside), one wavefront per row
+  for (int i = CHD_WAVE_ID; i < c.Nb; i += CHD_NWAVES) {
+    GD* row = c.K0b + (long long)i * c.W2 + (c.w - i);
+    const int hi = c.env[2 * i + 1];
+    for (int k = c.env[2 * i] + CHD_LANE; k <= hi; k += CHD_WAVE_SZ) row[k] = 0.0;
+  }
   // border rows: nothing is ever stored left of the row's first coupled band position (env[2 (Nb + r)])
   for (int r = CHD_WAVE_ID; r < c.bc; r += CHD_NWAVES) {
     GD* row = c.K0x + (long long)r * c.LD;
@@ -467,6 +473,8 @@ CHD_DEV void kreset(Ctx& c) {
   for (long long i = CHD_TID; i < nx_; i += CHD_NT) { c.K0x[i] = 0.0; c.Kfx[i] = 0.0; }
   const long long nf_ = (long long)c.Nb * (c.w + 1);
   for (long long i = CHD_TID; i < nf_; i += CHD_NT) c.Kfb[i] = 0.0;       // the copy into the factor only covers each row's envelope
+  const long long n0_ = (long long)c.Nb * c.W2;
+  for (long long i = CHD_TID; i < n0_; i += CHD_NT) c.K0b[i] = 0.0;       // kzero only clears the envelope
   CHD_SYNC();
 }
 
