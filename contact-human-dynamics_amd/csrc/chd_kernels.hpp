@@ -1911,7 +1911,8 @@ CHD_NOINLINE CHD_DEV void fill_sample_cache(Ctx& c) {
   CHD_SYNC();
 }
 // d p_i[dim] / d T_k from the cache
-CHD_DEV double cache_djac(const double* sc_, int dim, int k) {
+template <class SP>
+CHD_DEV double cache_djac(SP sc_, int dim, int k) {
   const int cur = (int)sc_[SC_PHASE], last = (int)sc_[SC_LAST];
   if (k > cur) return 0.0;
   if (k == cur) return last ? 0.0 : sc_[SC_DXDT + dim];
@@ -2070,14 +2071,17 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, GD* g, const GD* lam) {
       g[sp.var_off + v1] += c.sf * acc;
     }
   };
-  // the per-sample weights are read ~10^5 times by the entry tasks: keep the first 18 fields of the cache in LDS
-  const int sstride = 18;
-  if (6 * (F + 2) * sstride <= c.lds_cap - LDS_RED) {
-    LdsD* ws = c.lds + LDS_RED;
+  // the per-sample fields are read ~10^5 times by the entry tasks: keep the first 20 fields of the cache in LDS
+  const int sstride = 20;
+  const bool in_lds = 6 * (F + 2) * sstride <= c.lds_cap - LDS_RED;
+  LdsD* ws = c.lds + LDS_RED;
+  auto lds_sample = [&](int s, int i) { return (const LdsD*)(ws + ((long long)s * (F + 2) + i) * sstride); };
+  auto hbm_sample = [&](int s, int i) { return scache(q, s, i); };
+  if (in_lds) {
     PAR_FOR(idx, 6 * (F + 2) * sstride) { const int si = idx / sstride, fld = idx % sstride; ws[idx] = (q->wd + q->o_scache + (long long)si * SC_STRIDE)[fld]; }
     CHD_SYNC();
-    node_terms([&](int s, int i) { return (const LdsD*)(ws + ((long long)s * (F + 2) + i) * sstride); });
-  } else node_terms([&](int s, int i) { return scache(q, s, i); });
+    node_terms(lds_sample);
+  } else node_terms(hbm_sample);
   CHD_SYNC();
   c.tacc[13] += CHD_CLOCK() - tg_; tg_ = CHD_CLOCK();
   // ---- duration variables (stage 3 only)
@@ -2125,6 +2129,7 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, GD* g, const GD* lam) {
   CHD_SYNC();
   c.tacc[14] += CHD_CLOCK() - tg_; tg_ = CHD_CLOCK();
   if (S->opt_dur) {
+    auto dur_terms = [&](auto sample) {
     int tot = 0;
     for (int e = 0; e < 4; ++e) tot += (q->n_phase[e] - 1) * (q->n_phase[e] - 1);
     PAR_FOR(idx0, tot) {       // (T_k, T_k2) entries
@@ -2144,14 +2149,14 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, GD* g, const GD* lam) {
         if (k2 > k) continue;
         double hacc = 0, gacc = 0;
         for (int i = 0; i < F; ++i) {
-          const GD* a = scache(q, s, i);
+          auto a = sample(s, i);
           for (int dm = 0; dm < 3; ++dm) {
             const double gk = -cache_djac(a, dm, k), gk2 = -cache_djac(a, dm, k2);
             hacc += wdat * gk * gk2;
             if (k2 == k) gacc += wdat * (dat[i * 3 + dm] - a[SC_P + dm]) * gk;
           }
           if (i < nsm && wvel >= 0) {
-            const GD* b = scache(q, s, i + 1);
+            auto b = sample(s, i + 1);
             for (int dm = 0; dm < 3; ++dm) {
               const double gk = cache_djac(b, dm, k) - cache_djac(a, dm, k), gk2 = cache_djac(b, dm, k2) - cache_djac(a, dm, k2);
               hacc += wvel * gk * gk2;
@@ -2194,7 +2199,7 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, GD* g, const GD* lam) {
       const int i_hi = first[s * fstride + pb + 1] - 1;
       const int Pv = c.pos_var[sp.var_off + tar];
       // weight of this variable in p(t_i): the sample's polynomial touches node poly (side 0) and poly + 1 (side 1)
-      auto own_weight = [&](const GD* a) -> double {
+      auto own_weight = [&](auto a) -> double {
         const int poly = (int)a[SC_POLY];
         double g_ = 0;
         if (poly >= nd && poly <= nd_hi) g_ += a[SC_WP + dq0];
@@ -2208,7 +2213,7 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, GD* g, const GD* lam) {
         if (wdat >= 0) {
           const int r_hi = i_hi > F - 1 ? F - 1 : i_hi;
           for (int i = i_lo; i <= r_hi; ++i) {
-            const GD* a = scache(q, s, i);
+            auto a = sample(s, i);
             const double gt = -wdat * own_weight(a);             // r = data - p
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) if (k0 + kk < nv) hk[kk] += gt * (-cache_djac(a, dm, k0 + kk));
@@ -2217,7 +2222,7 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, GD* g, const GD* lam) {
         if (wvel >= 0) {
           const int r_lo = i_lo - 1 < 0 ? 0 : i_lo - 1, r_hi = i_hi > nsm - 1 ? nsm - 1 : i_hi;
           for (int i = r_lo; i <= r_hi; ++i) {
-            const GD* a = scache(q, s, i); const GD* b = scache(q, s, i + 1);
+            auto a = sample(s, i); auto b = sample(s, i + 1);
             const double gt = wvel * (own_weight(b) - own_weight(a));      // r = p_{i+1} - p_i
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) if (k0 + kk < nv) hk[kk] += gt * (cache_djac(b, dm, k0 + kk) - cache_djac(a, dm, k0 + kk));
@@ -2228,6 +2233,9 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, GD* g, const GD* lam) {
           if (k0 + kk < nv && hk[kk] != 0.0) kadd(c, c.pos_var[S->dur_off[e] + k0 + kk], Pv, c.sf * hk[kk]);
       }
     }
+  
+    };
+    if (in_lds) dur_terms(lds_sample); else dur_terms(hbm_sample);
   }
   CHD_SYNC();
   c.tacc[15] += CHD_CLOCK() - tg_;

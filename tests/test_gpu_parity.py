@@ -60,6 +60,27 @@ def test_solve_matches_oracle(solver, oracle_lib, seed, F):
         assert r.stage_status[stg] == ostats[stg][0]
 
 
+def test_solve_matches_golden_vectors(solver):
+    """The committed oracle outputs (tests/golden/phys_golden.npz, made by tests/golden/make_phys_golden.py): the HIP
+    path reproduces the three snapshots of every case to 1e-3 relative L2 (measured: ~1e-12), contact flags bit-exact,
+    stage statuses identical, without running the oracle."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'phys_golden.npz'))
+    cases = [(0, 60), (5, 90), (2, 40)]
+    seqs = [make_walk(seed=s, F=F, randomize=True) for s, F in cases]
+    res, _ = solver.solve(seqs)          # one ragged batch (40, 60 and 90 frames)
+    for (seed, F), r in zip(cases, res):
+        key = 's%d_F%d' % (seed, F)
+        assert list(r.stage_status[:len(g[key + '_status'])]) == list(g[key + '_status'])
+        for k in range(3):
+            sn = r.snapshots[k]
+            for name, val in (('base_lin', sn.base_lin), ('base_ang_deg', sn.base_ang_deg), ('ee_pos', sn.ee_pos), ('ee_force', sn.ee_force)):
+                ref = g['%s_snap%d_%s' % (key, k, name)]
+                err = np.linalg.norm(np.asarray(val) - ref) / max(np.linalg.norm(ref), 1e-300)
+                assert err < 1e-3, (key, k, name, err)
+            assert np.array_equal(np.asarray(sn.contact), g['%s_snap%d_contact' % (key, k)])
+
+
 def test_batch_slot_independence_and_constraints(solver):
     """Full-size property checks (no oracle needed): a sequence gives bit-identical results wherever it sits in a
     batch and whatever its neighbours are (owner-computes accumulation, fixed-tree reductions), every stage reports
