@@ -877,29 +877,35 @@ CHD_NOINLINE CHD_DEV void panel_rows(Ctx& c, const Panel P, const int nact) {
   }
 }
 
-// ---- write the panel back (8 consecutive columns of one row per task)
+// ---- write the panel back (8 consecutive columns of one row per task): the diagonal block rows and the active rows.
+//      Entries left of a row's envelope are exact zeros (as is what the storage holds there): only the band limit is checked.
 template <int NB>
-CHD_NOINLINE CHD_DEV void panel_store(Ctx& c, const Panel P) {
+CHD_NOINLINE CHD_DEV void panel_store(Ctx& c, const Panel P, const int nact) {
   const int W1 = c.w + 1, w = c.w, LD = c.LD;
-  const int c0 = P.c0, jb = P.jb, nbelow = P.nbelow, pr = P.pr, ldp = P.ldp;
+  const int c0 = P.c0, jb = P.jb, nbelow = P.nbelow, ldp = P.ldp;
   const LdsD* PT = P.PT; const LdsD* dv = P.dv; const LdsD* DL = P.DL;
-  PAR_FOR(idx, pr * (NB / 8)) {
-    const int a = idx / (NB / 8), j0 = (idx % (NB / 8)) * 8;
-    if (a >= jb && a < NB) continue;
-    const bool band = a < jb || a < NB + nbelow;
-    const int i = c0 + (a < jb ? a : jb + a - NB);
-    GD* dst = band ? c.Kfb + (long long)i * W1 + (c0 + j0 - i + w) : c.Kfx + (long long)(a - NB - nbelow) * LD + c0 + j0;
-    const int ef = band ? c.env[2 * i] : 0;
-    if (band && a >= NB && ef > c0 + jb - 1) continue;      // row untouched by this panel
-    if (!band && c.env[2 * (c.Nb + a - NB - nbelow)] > c0 + jb - 1) continue;
+  const LdsI* act = (const LdsI*)P.act;
+  PAR_FOR(idx, (jb + nact) * (NB / 8)) {
+    const int r = idx / (NB / 8), j0 = (idx % (NB / 8)) * 8;
+    if (r < jb) {                 // a row of the diagonal block (it only lives in its dense copy)
+      const int a = r, i = c0 + a;
+      GD* dst = c.Kfb + (long long)i * W1 + (c0 + j0 - i + w);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int j = j0 + q, k = c0 + j;
-      if (j >= jb) break;
-      if (band) {
-        if (k < i && k >= ef) dst[q] = a < NB ? DL[j * NB + a] : PT[j * ldp + a];      // (the diagonal block only lives in its dense copy)
-        else if (k == i) dst[q] = dv[j];
-      } else dst[q] = PT[j * ldp + a];
+      for (int q = 0; q < 8; ++q) {
+        const int j = j0 + q;
+        if (j < a) dst[q] = DL[j * NB + a];
+        else if (j == a) dst[q] = dv[j];
+      }
+    } else {
+      const int u = act[r - jb], a = NB + u;
+      const bool band = u < nbelow;
+      const int i = c0 + jb + u;
+      GD* dst = band ? c.Kfb + (long long)i * W1 + (c0 + j0 - i + w) : c.Kfx + (long long)(u - nbelow) * LD + c0 + j0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int j = j0 + q, k = c0 + j;
+        if (j < jb && (!band || i - k <= w)) dst[q] = PT[j * ldp + a];
+      }
     }
   }
 }
@@ -931,7 +937,7 @@ CHD_DEV void kfactor_band(Ctx& c, const GI* sign, LdsD* dv, LdsD* DL, LdsD* dv2,
     panel_rows<NB>(c, P, nact);
     CHD_SYNC();
     c.tacc[9] += CHD_CLOCK() - tp_; tp_ = CHD_CLOCK();
-    panel_store<NB>(c, P);                     // stores of the panel columns; the update below touches other columns
+    panel_store<NB>(c, P, nact);               // stores of the panel columns; the update below touches other columns
     c.tacc[10] += CHD_CLOCK() - tp_; tp_ = CHD_CLOCK();
     // ---- trailing update of the window (+ the next diagonal block)
     const int c0n = c0 + NB;
