@@ -975,10 +975,10 @@ CHD_NOINLINE CHD_DEV void kfactor(Ctx& c, const GD* diag, const GI* sign) {
   TIC();
   const int Nb = c.Nb, w = c.w, W2 = c.W2, W1 = c.w + 1, LD = c.LD, bc = c.bc;
   if (CHD_TID == 0) c.n_bad_pivots = 0;
-  // copy the lower triangle (+ diagonal shift) into the factor storage: four rows per wavefront pass, all loads
+  // copy the lower triangle (+ diagonal shift) into the factor storage: eight rows per wavefront pass, all loads
   // of a pass issued before the first store (the copy is latency bound, not bandwidth bound)
   {
-    constexpr int RP = 4, QP = 6;                      // QP * wave size covers W1 <= 384; wider bands take the tail loop
+    constexpr int RP = 8, QP = 6;                      // QP * wave size covers W1 <= 384; wider bands take the tail loop
     int cnext[RP];                                     // envelope starts of the next pass's rows (fetched one pass ahead)
 #pragma unroll
     for (int r = 0; r < RP; ++r) { const int i = CHD_WAVE_ID * RP + r < Nb ? CHD_WAVE_ID * RP + r : Nb - 1; cnext[r] = c.env[2 * i] - i + w; }
