@@ -61,6 +61,7 @@ struct StageDesc {
   // offsets into ci
   int o_pos_var, o_pos_row, o_task;     // task: 4 ints (type, a, b, row0)
   int o_env;                            // 2 ints per band position: first / last coupled band position (envelope of the KKT matrix)
+  int o_rcnt;                           // per band position k: number of leading border positions whose first coupled band position is <= k (the border is sorted by it)
   // offsets into cd
   int o_cl, o_cu, o_Dw, o_task_t;
 };
@@ -105,6 +106,7 @@ struct SeqDesc {
   // wi offsets
   int o_flags, o_first, o_sign;
   int o_envw;           // working copy of the stage's envelope (2 ints per KKT position): widened when an entry lands outside it
+  int o_rcntw;          // working copy of StageDesc::o_rcnt
   StageDesc st[N_STAGES];
 };
 

@@ -106,6 +106,7 @@ struct Ctx {
   GD* K0b; GD* K0x; GD* Kfb; GD* Kfx;
   const GI* pos_var; const GI* pos_row;
   GI* env;              // [2p] first, [2p+1] last band position coupled to p (envelope): the stage's working copy
+  GI* rcnt;             // [k]: the border rows [0, rcnt[k]) are the ones that can reach band column k (working copy)
   double sf;            // objective scaling
   double tol;           // IPOPT tol of the stage (phys_optim.cpp:578)
   int err;              // sticky error flag (band overflow), uniform across the workgroup after a sync
@@ -421,6 +422,7 @@ CHD_DEV void env_cover(Ctx& c, const int hi, const int lo) {
   if (lo >= first) return;
   env_min(c.env + 2 * hi, lo);
   if (hi < c.Nb) for (int k = lo; k < first && k < hi; ++k) env_max(c.env + 2 * k + 1, hi);
+  else for (int k = lo; k < first && k < c.Nb; ++k) env_max(c.rcnt + k, hi - c.Nb + 1);      // border row hi - Nb now reaches columns lo ..
 }
 CHD_DEV void kadd(Ctx& c, int p, int qq, double val) {
   if (p < c.Nb && qq < c.Nb) {
@@ -469,6 +471,7 @@ CHD_DEV void kzero(Ctx& c) {
 // neither cleared nor copied again afterwards
 CHD_DEV void kreset(Ctx& c) {
   PAR_FOR(i, 2 * c.N) c.env[i] = c.q->ci[c.S->o_env + i];
+  PAR_FOR(i, c.Nb) c.rcnt[i] = c.q->ci[c.S->o_rcnt + i];
   const long long nx_ = (long long)c.bc * c.LD;
   for (long long i = CHD_TID; i < nx_; i += CHD_NT) { c.K0x[i] = 0.0; c.Kfx[i] = 0.0; }
   const long long nf_ = (long long)c.Nb * (c.w + 1);
@@ -552,7 +555,7 @@ CHD_DEV void kmatvec_impl(Ctx& c, XP x, GD* y, const GD* diag, const GI* only) {
   CHD_SYNC();
   PAR_FOR(i, Nb) {
     if (only && only[i] <= 0) continue;
-    y[i] += dot_column(c.K0x + i, LD, x + Nb, 0, bc);
+    y[i] += dot_column(c.K0x + i, LD, x + Nb, 0, c.rcnt[i]);
   }
   CHD_SYNC();
 }
@@ -1262,7 +1265,7 @@ CHD_DEV void ksolve_impl(Ctx& c, const GD* rhs, GD* x, YP y, SP Sp, const int ld
   }
   CHD_SYNC();
   PAR_FOR(k, Nb) {
-    y[k] -= dot_column(c.Kfx + k, LD, y + Nb, 0, bc);
+    y[k] -= dot_column(c.Kfx + k, LD, y + Nb, 0, c.rcnt[k]);
   }
   if (tile) load_diag_tile(c, tile, (nblk - 1) * nb, Nb - (nblk - 1) * nb);
   CHD_SYNC();
@@ -1471,7 +1474,7 @@ CHD_DEV void ksolve_fast(Ctx& c, const GD* rhs, GD* x, LdsD* y, LdsD* Sp, LdsD* 
   }
   CHD_SYNC();
   PAR_FOR(k, Nb) {
-    y[k] -= dot_column(c.Kfx + k, LD, y + Nb, 0, bc);
+    y[k] -= dot_column(c.Kfx + k, LD, y + Nb, 0, c.rcnt[k]);
   }
   CHD_WRITE_TILE();
   CHD_SYNC();
@@ -2602,7 +2605,7 @@ CHD_DEV void bind_stage(Ctx& c, const SeqDesc* q, int stage) {
   c.n = c.S->n; c.m = c.S->m; c.N = c.n + c.m; c.Nb = c.S->Nb; c.bc = c.S->bc; c.w = c.S->w;
   c.W2 = 2 * c.w + 1; c.LD = c.N;
   c.K0b = q->wd + q->o_K0b; c.K0x = q->wd + q->o_K0x; c.Kfb = q->wd + q->o_Kfb; c.Kfx = q->wd + q->o_Kfx;
-  c.pos_var = q->ci + c.S->o_pos_var; c.pos_row = q->ci + c.S->o_pos_row; c.env = q->wi + q->o_envw;
+  c.pos_var = q->ci + c.S->o_pos_var; c.pos_row = q->ci + c.S->o_pos_row; c.env = q->wi + q->o_envw; c.rcnt = q->wi + q->o_rcntw;
   c.sf = 1.0; c.err = 0; c.n_bad_pivots = 0;
 }
 

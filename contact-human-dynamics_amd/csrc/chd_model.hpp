@@ -644,6 +644,21 @@ class SeqModel {
           }
         }
     }
+    // ---- sort the border variables by their first coupled band position: the border rows that reach a band column k are
+    // then a prefix [0, rcnt[k]) of the border, which the column passes of the substitution / mat-vec stop at
+    {
+      std::vector<int> bvars;
+      for (int j = 0; j < n; ++j) if (pos_var[j] >= Nb) bvars.push_back(j);
+      std::stable_sort(bvars.begin(), bvars.end(), [&](int a, int b) { return bfirst[pos_var[a] - Nb] < bfirst[pos_var[b] - Nb]; });
+      std::vector<int> nb_first(bc, Nb);
+      std::vector<int> newpos(n, -1);
+      for (size_t r = 0; r < bvars.size(); ++r) { newpos[bvars[r]] = Nb + (int)r; nb_first[r] = bfirst[pos_var[bvars[r]] - Nb]; }
+      for (int i = 0; i < m; ++i) if (pos_row[i] >= Nb) nb_first[pos_row[i] - Nb] = bfirst[pos_row[i] - Nb];      // border rows keep their places (after the variables)
+      for (int j : bvars) pos_var[j] = newpos[j];
+      bfirst = nb_first;
+    }
+    std::vector<int> rcnt(Nb, 0);
+    for (int r = 0; r < bc; ++r) if (bfirst[r] < Nb) for (int k = bfirst[r]; k < Nb; ++k) rcnt[k] = std::max(rcnt[k], r + 1);
     S.w = w; S.valid = 1;
 
     // ---- store
@@ -651,10 +666,10 @@ class SeqModel {
       int mcap = m, tcap = S.n_tasks;
       if (stage == 5) { int extra = n_height_cand; mcap = m + extra; tcap = S.n_tasks + extra; }   // durations may have moved
       stage_m_cap[stage] = mcap; stage_task_cap[stage] = tcap;
-      S.o_pos_var = reserve_i(n); S.o_pos_row = reserve_i(mcap); S.o_task = reserve_i(4 * tcap); S.o_env = reserve_i(2 * (n + mcap));
+      S.o_pos_var = reserve_i(n); S.o_pos_row = reserve_i(mcap); S.o_task = reserve_i(4 * tcap); S.o_env = reserve_i(2 * (n + mcap)); S.o_rcnt = reserve_i(n + mcap);
       S.o_cl = reserve_d(mcap); S.o_cu = reserve_d(mcap); S.o_Dw = reserve_d(n); S.o_task_t = reserve_d(tcap);
     } else {
-      S.o_pos_var = keep.o_pos_var; S.o_pos_row = keep.o_pos_row; S.o_task = keep.o_task; S.o_env = keep.o_env;
+      S.o_pos_var = keep.o_pos_var; S.o_pos_row = keep.o_pos_row; S.o_task = keep.o_task; S.o_env = keep.o_env; S.o_rcnt = keep.o_rcnt;
       S.o_cl = keep.o_cl; S.o_cu = keep.o_cu; S.o_Dw = keep.o_Dw; S.o_task_t = keep.o_task_t;
       if (m > stage_m_cap[stage] || S.n_tasks > stage_task_cap[stage] || w > w_cap || bc > bc_cap || n + m > N_cap) S.valid = 0;
     }
@@ -668,6 +683,7 @@ class SeqModel {
         for (int i = 0; i < Nb; ++i) for (int k = efirst[i]; k <= i; ++k) clast[k] = std::max(clast[k], i);
         for (int p = 0; p < Nb; ++p) { ci[S.o_env + 2 * p] = efirst[p]; ci[S.o_env + 2 * p + 1] = clast[p]; }
         for (int r = 0; r < bc; ++r) { ci[S.o_env + 2 * (Nb + r)] = bfirst[r]; ci[S.o_env + 2 * (Nb + r) + 1] = Nb; }
+        std::copy(rcnt.begin(), rcnt.end(), ci.begin() + S.o_rcnt);
       }
       std::copy(cl.begin(), cl.end(), cd.begin() + S.o_cl);
       std::copy(cu.begin(), cu.end(), cd.begin() + S.o_cu);
@@ -726,6 +742,7 @@ class SeqModel {
     d.o_first = take_i(6LL * (d.max_polys + 2));
     d.o_sign = take_i(d.max_N);
     d.o_envw = take_i(2LL * d.max_N);
+    d.o_rcntw = take_i(d.max_N);
     wi_size = oi;
   }
 
