@@ -149,3 +149,24 @@ extern "C" void emu_border_first(void* h, int stage, double* out, int* first_out
   }
   out[0] = c.bc ? acc / c.bc : 0; out[1] = c.bc; out[2] = c.Nb; out[3] = c.w;
 }
+
+// average number of active window rows per 32-column panel of `stage` (analysis helper): out[0] = mean nact,
+// out[1] = mean band part, out[2] = mean border part, out[3] = mean number of 16x16 tiles
+extern "C" void emu_nact_stats(void* h, int stage, double* out) {
+  Emu* e = (Emu*)h; e->bind();
+  double fo[2];
+  debug_eval(&e->M.d, stage, 0, e->lds.data(), (int)e->lds.size(), fo);
+  Ctx c; c.lds = e->lds.data(); c.lds_cap = (int)e->lds.size();
+  bind_stage(c, &e->M.d, stage);
+  double sa = 0, sb = 0, sx = 0, st = 0; int np = 0;
+  for (int c0 = 0; c0 < c.Nb; c0 += 32) {
+    const int jb = std::min(32, c.Nb - c0), last = c0 + jb - 1;
+    const int nbr = std::min(c.Nb - c0, jb + c.w), nbelow = nbr - jb;
+    int nb_ = 0, nx_ = 0;
+    for (int u = 0; u < nbelow; ++u) if (c.env[2 * (c0 + jb + u)] <= last) ++nb_;
+    for (int r = 0; r < c.bc; ++r) if (c.env[2 * (c.Nb + r)] <= last) ++nx_;
+    const int nact = nb_ + nx_, nt = (nact + 15) / 16;
+    sa += nact; sb += nb_; sx += nx_; st += nt * (nt + 1) / 2; ++np;
+  }
+  out[0] = sa / np; out[1] = sb / np; out[2] = sx / np; out[3] = st / np; out[4] = np;
+}
