@@ -862,7 +862,7 @@ CHD_NOINLINE CHD_DEV void panel_load(Ctx& c, const Panel P, const int part) {
 //      before the multiply-adds of column k, so the LDS latency is paid once, not once per column (the first version
 //      waited ~100 cycles per read pair: 9 us per panel for 2 us of arithmetic).
 template <int NB>
-CHD_NOINLINE CHD_DEV void panel_rows(Ctx& c, const Panel P, const int nact) {
+CHD_DEV void panel_rows(Ctx& c, const Panel P, const int nact) {
   const int ldp = P.ldp;
   LdsD* PT = P.PT; const LdsD* DL = P.DL; const LdsD* dv = P.dv; const LdsI* act = (const LdsI*)P.act;
   PAR_FOR(t2, nact) {           // compacted: inactive rows are never read
