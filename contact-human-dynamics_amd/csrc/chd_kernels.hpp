@@ -832,11 +832,11 @@ CHD_NOINLINE CHD_DEV void panel_load(Ctx& c, const Panel P, const int part) {
   const int c0 = P.c0, jb = P.jb, nbelow = P.nbelow, pr = P.pr, ldp = P.ldp;
   LdsD* PT = P.PT;
   if (part == 0) {
-    PAR_FOR(j, NB) PT[j * ldp + pr + 8] = 0.0;      // the zero padding row of this panel (an earlier, longer panel may have used it)
-    // window rows that this panel can touch: rows whose envelope reaches the panel
+    // window rows that this panel can touch: rows whose envelope reaches the panel (second wavefront)
     build_active_rows(c, P.act, P.nact_p, pr - NB, nbelow, c0 + jb, c0 + jb - 1);
     return;
   }
+  PAR_FOR(j, NB) PT[j * ldp + pr + 8] = 0.0;      // the zero padding row of this panel (an earlier, longer panel may have used it)
   const LdsI* act = (const LdsI*)P.act;
   const int nact = *(const LdsI*)P.nact_p;
   PAR_FOR(idx, nact * (NB / 8)) {
@@ -920,26 +920,34 @@ CHD_NOINLINE CHD_DEV void panel_store(Ctx& c, const Panel P, const int nact) {
 }
 
 template <int NB>
+CHD_DEV void panel_geometry(Ctx& c, Panel& P, const int c0, const int ldp) {
+  const int Nb = c.Nb, w = c.w, bc = c.bc;
+  P.c0 = c0; P.jb = Nb - c0 < NB ? Nb - c0 : NB;
+  const int nbr = (Nb - c0 < P.jb + w) ? Nb - c0 : P.jb + w;     // band rows touched by this panel
+  P.nbelow = nbr - P.jb;
+  P.pr = NB + P.nbelow + bc; P.ldp = ldp;
+}
+template <int NB>
 CHD_DEV void kfactor_band(Ctx& c, const GI* sign, LdsD* dv, LdsD* DL, LdsD* dv2, LdsD* DL2, LdsD* PT, const int ldp) {
   const int Nb = c.Nb, w = c.w, bc = c.bc;
   // look-ahead: the diagonal block of panel J + 1 is factored by the first wavefront during panel J's trailing update
-  // (after it has applied the three tiles of that update which touch the block), into the other (dv, DL) pair
+  // (after it has applied the three tiles of that update which touch the block), into the other (dv, DL) pair; the
+  // second wavefront builds panel J + 1's list of active rows at the start of the same phase (second list buffer)
+  const int lsz = w + bc + 64 + 2;                           // ints per list (+ its count)
+  int* actA = (int*)(PT + (long long)ldp * NB); int* actB = actA + lsz;
+  {
+    Panel P0; panel_geometry<NB>(c, P0, 0, ldp);
+    P0.dv = dv; P0.DL = DL; P0.PT = PT; P0.act = actA; P0.nact_p = actA + lsz - 2;
+    panel_load<NB>(c, P0, 0);
+  }
   diag_block_g<NB>(c, sign, dv, DL, 0, Nb < NB ? Nb : NB);
   CHD_SYNC();
   for (int c0 = 0; c0 < Nb; c0 += NB) {
-    Panel P;
-    P.c0 = c0; P.jb = Nb - c0 < NB ? Nb - c0 : NB;
-    const int nbr = (Nb - c0 < P.jb + w) ? Nb - c0 : P.jb + w;     // band rows touched by this panel
-    P.nbelow = nbr - P.jb;
-    P.pr = NB + P.nbelow + bc; P.ldp = ldp;
+    Panel P; panel_geometry<NB>(c, P, c0, ldp);
     P.dv = dv; P.DL = DL; P.PT = PT;
-    P.act = (int*)(PT + (long long)ldp * NB);
-    P.nact_p = P.act + (w + bc + 64);
+    P.act = actA; P.nact_p = actA + lsz - 2;
     long long tp_ = CHD_CLOCK();
-    panel_load<NB>(c, P, 0);
-    CHD_SYNC();
     const int nact = *(const LdsI*)P.nact_p;
-    c.tacc[7] += CHD_CLOCK() - tp_; tp_ = CHD_CLOCK();
     panel_load<NB>(c, P, 1);
     CHD_SYNC();
     c.tacc[8] += CHD_CLOCK() - tp_; tp_ = CHD_CLOCK();
@@ -948,13 +956,19 @@ CHD_DEV void kfactor_band(Ctx& c, const GI* sign, LdsD* dv, LdsD* DL, LdsD* dv2,
     c.tacc[9] += CHD_CLOCK() - tp_; tp_ = CHD_CLOCK();
     panel_store<NB>(c, P, nact);               // stores of the panel columns; the update below touches other columns
     c.tacc[10] += CHD_CLOCK() - tp_; tp_ = CHD_CLOCK();
-    // ---- trailing update of the window (+ the next diagonal block)
+    // ---- trailing update of the window (+ the next diagonal block and the next list of active rows)
     const int c0n = c0 + NB;
     const bool more = c0n < Nb;
+    if (more) {
+      Panel Pn; panel_geometry<NB>(c, Pn, c0n, ldp);
+      Pn.dv = dv2; Pn.DL = DL2; Pn.PT = PT; Pn.act = actB; Pn.nact_p = actB + lsz - 2;
+      panel_load<NB>(c, Pn, 0);
+    }
     trailing_phase<NB>(c, sign, dv, PT, ldp, P.pr - NB, P.nbelow, c0 + P.jb, P.act, nact, more, dv2, DL2, c0n, Nb - c0n < NB ? Nb - c0n : NB);
     CHD_SYNC();
     c.tacc[11] += CHD_CLOCK() - tp_;
     LdsD* t_ = dv; dv = dv2; dv2 = t_; t_ = DL; DL = DL2; DL2 = t_;
+    int* ti_ = actA; actA = actB; actB = ti_;
   }
 }
 
@@ -1050,7 +1064,7 @@ CHD_NOINLINE CHD_DEV void kfactor(Ctx& c, const GD* diag, const GI* sign) {
   LdsD* dv2 = DL + 32 * 32;              // the same pair for the next panel (look-ahead)
   LdsD* DL2 = dv2 + 64;
   LdsD* PT = DL2 + 32 * 32;              // panel (the list of active window rows follows it)
-  const int avail = c.lds_cap - LDS_RED - 2 * (64 + 32 * 32) - (w + bc + 64) / 2 - 8;      // ints of the active-row list
+  const int avail = c.lds_cap - LDS_RED - 2 * (64 + 32 * 32) - (w + bc + 66) - 8;      // ints of the two active-row lists
   int nb = 32;
   while (nb > 8 && (long long)(nb + w + bc + 18) * nb > avail) nb >>= 1;
   const int ldp = (nb + w + bc + 17) | 1;  // odd leading dimension (conflict-free column walks), >= 16 rows of zero padding
