@@ -110,3 +110,26 @@ def test_duration_block_of_lagrangian_hessian_vs_finite_differences(emu, oracle_
     o = OracleProblem(seq); o.set_stage(4)
     Ho = o.eval(x, jac=True, hess=True, lam=lam)[4]
     assert np.abs(Ho[nd:, nd:] - A).max() <= 1e-11 * np.abs(A).max()
+
+
+def test_kkt_structure_tables(emu):
+    """Host structure tables the kernel relies on (chd_model.hpp): the first band position coupled to each border
+    position is never later than the first numerically non-zero entry of that border row of the assembled KKT matrix
+    (every stage, initial point), and a full staged solve raises no structure violation
+    (the emulation build checks the band / border envelopes at every factorisation and prints on stderr)."""
+    import ctypes as C
+    seq = make_walk(seed=3, F=60, randomize=True)
+    e = emu.EmuProblem(seq)
+    for st in range(5):
+        out = (C.c_double * 8)(); first = (C.c_int * 1024)()
+        emu.lib().emu_border_first(C.c_void_p(e.h), st, out, first)
+        bc, nb = int(out[1]), int(out[2])
+        numeric = np.array(first[:bc]); structural = np.array(first[512:512 + bc])
+        assert (numeric >= structural).all(), st
+        assert (structural <= nb).all() and (structural < nb).any(), st
+        st_ = (C.c_double * 8)()
+        emu.lib().emu_nact_stats(C.c_void_p(e.h), st, st_)
+        assert 0 < st_[0] <= e.sizes(st)['w'] + bc      # mean number of active window rows per panel
+    e.solve(0, 4)
+    stats = e.results()['stats'] if isinstance(e.results(), dict) else None
+    assert stats is None or all(int(s[0]) in (0, -1, -2) for s in stats)
