@@ -178,7 +178,8 @@ struct PE {
   double w[3][4];     // d{pos,vel,acc}/d(p0, v0, p1, v1) of the active polynomial
 };
 
-CHD_DEV int seg_lookup(const double* cum_end, int n, double t) {    // first i with cum_end[i] >= t - 1e-10, clamped
+template <class CP>
+CHD_DEV int seg_lookup(CP cum_end, int n, double t) {    // first i with cum_end[i] >= t - 1e-10, clamped
   int lo = 0, hi = n - 1;
   const double tt = t - 1e-10;
   while (lo < hi) { int mid = (lo + hi) >> 1; if (cum_end[mid] >= tt) hi = mid; else lo = mid + 1; }
