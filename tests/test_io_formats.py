@@ -37,3 +37,27 @@ def test_solution_file_layout(tmp_path):
     assert back.num_frames == S
     assert np.allclose(back.base_lin, sol.base_lin, rtol=1e-9) and np.allclose(back.ee_force, sol.ee_force, rtol=1e-9)   # 10 significant digits
     assert np.array_equal(back.contact, sol.contact)
+
+
+def test_solution_file_against_reference_parser(tmp_path):
+    """tests/golden/io_golden.npz (tests/golden/make_io_golden.py): a file written by io_formats.write_solution, parsed
+    by the REFERENCE's own `towr_utils.load_results` (towr_utils.py:51-121).  The writer still produces that exact file,
+    and the arrays the reference obtained from it are the written ones in the reference's frame (y/z swapped, negated
+    with flip_coords; contact flags transposed), to the 10 significant digits of the file."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'io_golden.npz'))
+    sol = iof.Solution(dt=1 / 30, num_frames=int(g['in_base_lin'].shape[0]), base_lin=g['in_base_lin'], base_ang_deg=g['in_base_ang_deg'],
+                       ee_pos=g['in_ee_pos'], ee_force=g['in_ee_force'], contact=g['in_contact'])
+    p = str(tmp_path / 'sol.txt')
+    iof.write_solution(sol, p)
+    assert open(p, 'rb').read() == g['file_text'].tobytes()
+    swap = [0, 2, 1]
+    for tag, sgn in (('flip', -1.0), ('noflip', 1.0)):
+        assert np.allclose(g[tag + '_base_pos'], sgn * sol.base_lin[:, swap], rtol=1e-9, atol=1e-12)
+        for i in range(4):
+            assert np.allclose(g[tag + '_feet_pos'][:, i, :], sgn * sol.ee_pos[i][:, swap], rtol=1e-9, atol=1e-12)
+            assert np.allclose(g[tag + '_feet_force'][:, i, :], sgn * sol.ee_force[i][:, swap], rtol=1e-9, atol=1e-9)
+        assert np.array_equal(g[tag + '_feet_contact'], np.asarray(sol.contact).T)
+        R = g[tag + '_base_R']
+        assert np.allclose(R @ np.transpose(R, (0, 2, 1)), np.eye(3)[None], atol=1e-6)       # the reference got valid rotations
+    back = iof.load_results(p)
+    assert np.allclose(back.base_lin, sol.base_lin, rtol=1e-9) and np.array_equal(back.contact, sol.contact)
