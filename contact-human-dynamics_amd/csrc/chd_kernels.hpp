@@ -744,7 +744,7 @@ CHD_DEV void trailing_update(Ctx& c, const LdsD* dv, const LdsD* PT, const int l
   const int ntri = nt * (nt + 1) / 2;
   const int zrow = wr + 8;          // a zero (padding) row of the panel
   auto tile_of = [](int t, int& tr, int& tc) {
-    tr = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    tr = (int)((__fsqrt_rn(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);      // (single precision + the two corrections below: t < 10^4)
     while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
     while (tr * (tr + 1) / 2 > t) --tr;
     tc = t - tr * (tr + 1) / 2;
