@@ -442,6 +442,25 @@ CHD_DEV void kadd(Ctx& c, int p, int qq, double val) {
     if (lo < c.Nb && lo < first_) env_cover(c, hi, lo);
   }
 }
+// the (up to two: both triangles are stored) locations of the KKT entry (p, qq); same checks as kadd
+struct KSlot { GD* a; GD* b; };
+CHD_DEV KSlot kslot(Ctx& c, int p, int qq) {
+  KSlot sl; sl.a = nullptr; sl.b = nullptr;
+  if (p < c.Nb && qq < c.Nb) {
+    const int dlt = qq - p;
+    if (dlt > c.w || dlt < -c.w) { c.err = 1; return sl; }
+    const int hi_ = dlt < 0 ? p : qq, lo_ = dlt < 0 ? qq : p;
+    if (lo_ < c.env[2 * hi_]) env_cover(c, hi_, lo_);
+    sl.a = c.K0b + (long long)p * c.W2 + (dlt + c.w);
+    if (dlt != 0) sl.b = c.K0b + (long long)qq * c.W2 + (c.w - dlt);
+  } else {
+    const int hi = p > qq ? p : qq, lo = p > qq ? qq : p;
+    if (lo < c.Nb && lo < c.env[2 * hi]) env_cover(c, hi, lo);
+    sl.a = c.K0x + (long long)(hi - c.Nb) * c.LD + lo;
+    if (lo >= c.Nb && lo != hi) sl.b = c.K0x + (long long)(lo - c.Nb) * c.LD + hi;
+  }
+  return sl;
+}
 CHD_DEV double kget(const Ctx& c, int p, int qq) {
   if (p < c.Nb && qq < c.Nb) {
     int dlt = qq - p;
@@ -1645,20 +1664,37 @@ CHD_DEV void x_from_state(Ctx& c, GD* x) {
 struct RowW {           // where one row's Jacobian entries go
   Ctx* c; int pr; double sc; bool on;
 };
+// The (up to) 12 Jacobian entries of one row w.r.t. the four Hermite coefficients x three dimensions of the active
+// polynomial.  They are distinct KKT entries (after folding the two nodes of a stance pair, which share a variable), so
+// their read-modify-writes are issued together: all index look-ups, then all loads, then all stores -- one HBM round
+// trip per call instead of one (dependent) per entry.
 CHD_DEV void row_nodes(const RowW& r, int s, const PE& e, int which, const double coef[3], int dimmask) {
   if (!r.on) return;
-  const SeqDesc* q = r.c->q;
+  Ctx& c = *r.c;
+  const SeqDesc* q = c.q;
   const SplineDesc& sp = q->sp[s];
   const GI* vo = q->ci + q->o_varof + sp.node_off + e.poly * 6;
-  for (int side = 0; side < 2; ++side)
-    for (int dq = 0; dq < 2; ++dq) {
-      const double wgt = e.w[which][side * 2 + dq];
-      for (int k = 0; k < 3; ++k) {
-        if (!((dimmask >> k) & 1)) continue;
-        const int v = vo[side * 6 + dq * 3 + k];
-        if (v >= 0) kadd(*r.c, r.pr, r.c->pos_var[sp.var_off + v], r.sc * coef[k] * wgt);
-      }
-    }
+  int v[12]; double val[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    const int side = i / 6, dq = (i % 6) / 3, k = i % 3;
+    v[i] = ((dimmask >> k) & 1) ? vo[i] : -1;
+    val[i] = r.sc * coef[k] * e.w[which][side * 2 + dq];
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+    if (v[i] >= 0 && v[i] == v[6 + i]) { val[i] += val[6 + i]; v[6 + i] = -1; }      // stance pair: one variable, two nodes
+  int pv[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) pv[i] = c.pos_var[sp.var_off + (v[i] >= 0 ? v[i] : 0)];
+  KSlot sl[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) { sl[i].a = nullptr; sl[i].b = nullptr; if (v[i] >= 0) sl[i] = kslot(c, r.pr, pv[i]); }
+  double oa[12], ob[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) { oa[i] = *(sl[i].a ? sl[i].a : c.K0b); ob[i] = *(sl[i].b ? sl[i].b : c.K0b); }
+#pragma unroll
+  for (int i = 0; i < 12; ++i) { if (sl[i].a) *sl[i].a = oa[i] + val[i]; if (sl[i].b) *sl[i].b = ob[i] + val[i]; }
 }
 CHD_DEV void row_durs(const RowW& r, int s, double t, const PE& e, const double coef[3]) {
   if (!r.on || !r.c->S->opt_dur) return;
