@@ -461,6 +461,18 @@ CHD_DEV KSlot kslot(Ctx& c, int p, int qq) {
   }
   return sl;
 }
+// N distinct KKT entries (p[i], q[i]) += val[i] (entries with p[i] < 0 are skipped): look-ups, loads and stores of all
+// of them are issued together
+template <int N>
+CHD_DEV void kadd_batch(Ctx& c, const int* p, const int* qq, const double* val) {
+  KSlot sl[N]; double oa[N], ob[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) { sl[i].a = nullptr; sl[i].b = nullptr; if (p[i] >= 0) sl[i] = kslot(c, p[i], qq[i]); }
+#pragma unroll
+  for (int i = 0; i < N; ++i) { oa[i] = *(sl[i].a ? sl[i].a : c.K0b); ob[i] = *(sl[i].b ? sl[i].b : c.K0b); }
+#pragma unroll
+  for (int i = 0; i < N; ++i) { if (sl[i].a) *sl[i].a = oa[i] + val[i]; if (sl[i].b) *sl[i].b = ob[i] + val[i]; }
+}
 CHD_DEV double kget(const Ctx& c, int p, int qq) {
   if (p < c.Nb && qq < c.Nb) {
     int dlt = qq - p;
@@ -1704,10 +1716,26 @@ CHD_DEV void row_durs(const RowW& r, int s, double t, const PE& e, const double 
   const int ee = q->sp[s].ee;
   const int base = r.c->S->dur_off[ee];
   const double ve = coef[0] * dj.early[0] + coef[1] * dj.early[1] + coef[2] * dj.early[2];
-  for (int k = 0; k < dj.cur && k < dj.nvar; ++k) kadd(*r.c, r.pr, r.c->pos_var[base + k], r.sc * ve);
-  if (!dj.last) {
-    const double vo = coef[0] * dj.own[0] + coef[1] * dj.own[1] + coef[2] * dj.own[2];
-    kadd(*r.c, r.pr, r.c->pos_var[base + dj.cur], r.sc * vo);
+  const double vo = coef[0] * dj.own[0] + coef[1] * dj.own[1] + coef[2] * dj.own[2];
+  // entries (row, T_k) for k < cur (value ve) and k == cur (value vo, unless it is the dependent last duration):
+  // distinct KKT entries, eight at a time with their look-ups / loads / stores issued together
+  Ctx& c = *r.c;
+  const int n_early = dj.cur < dj.nvar ? dj.cur : dj.nvar;
+  const int n_ent = n_early + (dj.last ? 0 : 1);
+  for (int k0 = 0; k0 < n_ent; k0 += 8) {
+    int pv[8]; KSlot sl[8]; double oa[8], ob[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const int k = k0 + i; pv[i] = c.pos_var[base + (k < n_ent ? (k < n_early ? k : dj.cur) : 0)]; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { sl[i].a = nullptr; sl[i].b = nullptr; if (k0 + i < n_ent) sl[i] = kslot(c, r.pr, pv[i]); }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { oa[i] = *(sl[i].a ? sl[i].a : c.K0b); ob[i] = *(sl[i].b ? sl[i].b : c.K0b); }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const double val = r.sc * (k0 + i < n_early ? ve : vo);
+      if (sl[i].a) *sl[i].a = oa[i] + val;
+      if (sl[i].b) *sl[i].b = ob[i] + val;
+    }
   }
 }
 
@@ -2101,9 +2129,15 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, GD* g, const GD* lam) {
           if (wacc >= 0) acc += wacc * (wgt(b, 1, n1, h1, dq1) - wgt(a, 1, n1, h1, dq1)) * (wgt(b, 1, n2, h2, dq2) - wgt(a, 1, n2, h2, dq2));
         }
       if (acc == 0.0) continue;
-      for (int dim = 0; dim < 3; ++dim) {
-        const int v1 = vo[n1 * 6 + dq1 * 3 + dim], v2 = vo[n2 * 6 + dq2 * 3 + dim];
-        if (v1 >= 0 && v2 >= 0) kadd(c, c.pos_var[sp.var_off + v1], c.pos_var[sp.var_off + v2], c.sf * acc);
+      {
+        int pp[3], qv[3]; double vv[3];
+#pragma unroll
+        for (int dim = 0; dim < 3; ++dim) {
+          const int v1 = vo[n1 * 6 + dq1 * 3 + dim], v2 = vo[n2 * 6 + dq2 * 3 + dim];
+          const bool on = v1 >= 0 && v2 >= 0;
+          pp[dim] = on ? c.pos_var[sp.var_off + v1] : -1; qv[dim] = on ? c.pos_var[sp.var_off + v2] : 0; vv[dim] = c.sf * acc;
+        }
+        kadd_batch<3>(c, pp, qv, vv);      // the three dimensions are three different entries
       }
     }
     // gradient: one thread per (coefficient, dimension)
@@ -2294,9 +2328,15 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, GD* g, const GD* lam) {
             for (int kk = 0; kk < 8; ++kk) if (k0 + kk < nv) hk[kk] += gt * (cache_djac(b, dm, k0 + kk) - cache_djac(a, dm, k0 + kk));
           }
         }
+        {
+          int pp[8], qv[8]; double vv[8];
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk)
-          if (k0 + kk < nv && hk[kk] != 0.0) kadd(c, c.pos_var[S->dur_off[e] + k0 + kk], Pv, c.sf * hk[kk]);
+          for (int kk = 0; kk < 8; ++kk) {
+            const bool on = k0 + kk < nv && hk[kk] != 0.0;
+            pp[kk] = on ? c.pos_var[S->dur_off[e] + k0 + kk] : -1; qv[kk] = Pv; vv[kk] = c.sf * hk[kk];
+          }
+          kadd_batch<8>(c, pp, qv, vv);
+        }
       }
     }
   
