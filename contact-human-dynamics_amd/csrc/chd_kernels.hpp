@@ -487,10 +487,16 @@ CHD_DEV void kzero(Ctx& c) {
   const long long nx_ = (long long)c.bc * c.LD;
   // band rows: only the envelope [efirst_i, clast_i] (what the mat-vec and the factor copy read; kadd widens it first
   // if an entry ever lands outside), one wavefront per row
-  for (int i = CHD_WAVE_ID; i < c.Nb; i += CHD_NWAVES) {
-    GD* row = c.K0b + (long long)i * c.W2 + (c.w - i);
-    const int hi = c.env[2 * i + 1];
-    for (int k = c.env[2 * i] + CHD_LANE; k <= hi; k += CHD_WAVE_SZ) row[k] = 0.0;
+  for (int i0 = CHD_WAVE_ID * 8; i0 < c.Nb; i0 += CHD_NWAVES * 8) {       // eight rows per pass: their envelope bounds are fetched together
+    int lo[8], hi[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { const int i = i0 + r < c.Nb ? i0 + r : c.Nb - 1; lo[r] = c.env[2 * i]; hi[r] = c.env[2 * i + 1]; }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      if (i0 + r >= c.Nb) break;
+      GD* row = c.K0b + (long long)(i0 + r) * c.W2 + (c.w - (i0 + r));
+      for (int k = lo[r] + CHD_LANE; k <= hi[r]; k += CHD_WAVE_SZ) row[k] = 0.0;
+    }
   }
   // border rows: nothing is ever stored left of the row's first coupled band position (env[2 (Nb + r)])
   for (int r = CHD_WAVE_ID; r < c.bc; r += CHD_NWAVES) {
