@@ -1985,7 +1985,7 @@ CHD_NOINLINE CHD_DEV void eval_rows(Ctx& c, int mode, GD* cout_, const GD* lam) 
 // ------------------------------------------------------------------------------------------
 CHD_DEV const GD* scache(const SeqDesc* q, int s, int i) { return q->wd + q->o_scache + ((long long)s * (q->F + 2) + i) * SC_STRIDE; }
 
-CHD_NOINLINE CHD_DEV void fill_sample_cache(Ctx& c) {
+CHD_NOINLINE CHD_DEV void fill_sample_cache(Ctx& c, const bool with_dur) {       // with_dur: also the duration derivatives (full evaluations only)
   const SeqDesc* q = c.q;
   const int F1 = q->F + 1;
   PAR_FOR(idx, 6 * F1) {
@@ -1997,7 +1997,7 @@ CHD_NOINLINE CHD_DEV void fill_sample_cache(Ctx& c) {
     for (int k = 0; k < 4; ++k) { sc_[SC_WP + k] = e.w[0][k]; sc_[SC_WV + k] = e.w[1][k]; }
     for (int k = 0; k < 3; ++k) { sc_[SC_P + k] = e.p[k]; sc_[SC_V + k] = e.v[k]; sc_[SC_DXDT + k] = 0.0; }
     sc_[SC_POLY] = e.poly; sc_[SC_PHASE] = 0; sc_[SC_LAST] = 0;
-    if (c.S->opt_dur && s >= 2) {
+    if (with_dur && c.S->opt_dur && s >= 2) {
       DurJac dj;
       dur_jac(q, s, t, e, dj);
       // store own / early in a form usable per k: own[] (k == cur, not last) and early[] (k < cur)
@@ -2365,7 +2365,7 @@ CHD_DEV double eval_nlp(Ctx& c, const GD* x, int mode, GD* c_out, GD* g, const G
       PAR_FOR(i, 2 * c.q->n_trom * X2_STRIDE) c.q->wd[c.q->o_x2tab + i] = 0.0;
     }
   }
-  fill_sample_cache(c);      // ends with a sync (also orders kzero before the kadd's below)
+  fill_sample_cache(c, mode == EV_FULL);      // ends with a sync (also orders kzero before the kadd's below)
   if (mode == EV_FULL) c.tacc[21] += CHD_CLOCK() - tic_;
   long long te_ = CHD_CLOCK();
   eval_rows(c, mode, c_out, lam);
