@@ -59,8 +59,11 @@ def test_bordered_band_factorisation(emu):
         assert bad == 0 and np.isfinite(x).all()
 
 
-def test_staged_solve_parity(emu, oracle_lib):
-    seq = make_walk(seed=2, F=40, randomize=True)
+@pytest.mark.parametrize('seed,F,tilt', [(2, 40, 0.0), (6, 60, 5.0), (9, 90, 0.0)])
+def test_staged_solve_parity(emu, oracle_lib, seed, F, tilt):
+    """Kernel source (host emulation) vs oracle through all stages: same statuses, same iteration counts, snapshots to
+    1e-8 -- flat and tilted floors, 40 / 60 / 90 frames."""
+    seq = make_walk(seed=seed, F=F, randomize=True, tilt_deg=tilt)
     caps = [300] * 6
     e = emu.EmuProblem(seq, default_config(max_iter=caps))
     e.solve(0, 4)
