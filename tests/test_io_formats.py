@@ -61,3 +61,14 @@ def test_solution_file_against_reference_parser(tmp_path):
         assert np.allclose(R @ np.transpose(R, (0, 2, 1)), np.eye(3)[None], atol=1e-6)       # the reference got valid rotations
     back = iof.load_results(p)
     assert np.allclose(back.base_lin, sol.base_lin, rtol=1e-9) and np.array_equal(back.contact, sol.contact)
+
+
+def test_contact_durations_against_reference():
+    """io_golden.npz `dur*`: phase durations computed by the reference's `find_contact_durations`
+    (towr_utils.py:435-449) from random contact flags; ours are bit-identical (same `+= dt` accumulation)."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'io_golden.npz'))
+    for case in range(3):
+        c = g['dur%d_contacts' % case]; dt = float(g['dur%d_dt' % case])
+        ours = np.array(iof.contact_durations(c, dt))
+        assert ours.shape == g['dur%d_ref' % case].shape and np.array_equal(ours, g['dur%d_ref' % case])
+        assert abs(ours.sum() - (len(c) - 1) * dt) < 1e-9
