@@ -165,10 +165,15 @@ def _jacobian(x, gp, gr, parents, target_joints, dsc, tdsc, translate):
     return j
 
 
-def ik_ck(rot, pos, parents, target_joints, targets, iterations=30, damping=7.0, smoothness=0.001, translate=True, gamma=1.0):
+def ik_ck(rot, pos, parents, target_joints, targets, iterations=30, damping=7.0, smoothness=0.001, translate=True, gamma=1.0, dual=False):
     """JacobianInverseKinematicsCK.__call__ with the arguments of apply_results (no references, no angle limits, unit
     weights).  rot: (F, J, 4) local rotations, pos: (F, J, 3) local positions, targets: (T, F, 3) in the order of
-    `target_joints`.  Returns the updated (rot, pos)."""
+    `target_joints`.  Returns the updated (rot, pos).
+
+    dual=True solves the same step in its dual form, dx = J^T (J J^T + lambda^2 I)^-1 e -- identical in exact arithmetic
+    because apply_results uses unit weights, so lambda is the same for every unknown -- a 3T x 3T system (T = number of
+    targets, ~13) instead of the reference's 6J x 6J (J ~ 31 joints) LU per frame.  This is the form the HIP path will
+    use; tests/test_ik_oracle.py checks it against the reference's vectors as well."""
     rot = np.array(rot, dtype=np.float64); pos = np.array(pos, dtype=np.float64)
     parents = np.asarray(parents); target_joints = np.asarray(target_joints)
     F, J = rot.shape[:2]
@@ -191,7 +196,11 @@ def ik_ck(rot, pos, parents, target_joints, targets, iterations=30, damping=7.0,
         lam = damping * (1.0 / (w + 0.001))
         d = (lam * lam) * np.eye(x.shape[1])
         e = gamma * (endeff.reshape(F, -1) - gp[:, target_joints].reshape(F, -1))
-        dx1 = np.array([np.linalg.solve(jf.T.dot(jf) + d, jf.T.dot(ef)) for jf, ef in zip(jac, e)])
+        if dual:
+            l2 = float(lam[0] * lam[0])
+            dx1 = np.array([jf.T.dot(np.linalg.solve(jf.dot(jf.T) + l2 * np.eye(jf.shape[0]), ef)) for jf, ef in zip(jac, e)])
+        else:
+            dx1 = np.array([np.linalg.solve(jf.T.dot(jf) + d, jf.T.dot(ef)) for jf, ef in zip(jac, e)])
         xp = np.vstack((x[0], x[:F - 1]))
         xa = np.vstack((x[1:], x[F - 1]))
         dx2 = smoothness * (xp + xa - 2 * x)

@@ -56,3 +56,15 @@ def test_solver_matches_reference(gold, iters):
         e0 = np.linalg.norm(gold[k + 'gpos0'][:, tj] - tg, axis=-1).mean()
         e1 = np.linalg.norm(gp[:, tj] - tg, axis=-1).mean()
         assert e1 < e0
+
+
+def test_dual_form_matches_reference(gold):
+    """The step solved as J^T (J J^T + lambda^2 I)^-1 e (3T x 3T instead of 6J x 6J; what the HIP path will do) gives the
+    reference's result after 30 iterations to 1e-8."""
+    for ci in range(int(gold['n_cases'])):
+        k = 'c%d_' % ci
+        rot, pos = ik.ik_ck(gold[k + 'rot0'], gold[k + 'pos0'], gold[k + 'parents'], gold[k + 'target_joints'], gold[k + 'targets'],
+                            iterations=30, damping=7.0, smoothness=0.001, translate=True, dual=True)
+        gp = ik.positions_global(rot, pos, gold[k + 'parents'])
+        assert np.allclose(gp, gold['c%d_it30_gpos' % ci], rtol=1e-8, atol=1e-8)
+        assert np.allclose(pos, gold['c%d_it30_pos' % ci], rtol=1e-8, atol=1e-8)
