@@ -1,0 +1,80 @@
+// chd_ik.hip -- C ABI of the IK back-projection step (include/chd_ik.h) on HIP / gfx950.
+// One launch per solver iteration; one workgroup of 128 threads per (video, frame); the state (local rotations and
+// translations of every joint of every frame) is double-buffered in HBM because a frame reads its neighbours' previous
+// iterate.  See chd_ik_kernels.hpp for the per-frame step and its reference citations.
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "chd_ik_host.hpp"
+
+using namespace chd_ik;
+
+namespace {
+thread_local std::string g_err;
+int fail(const std::string& what, hipError_t e = hipSuccess) {
+  g_err = e == hipSuccess ? what : what + ": " + hipGetErrorString(e);
+  return 1;
+}
+}  // namespace
+
+__global__ void __launch_bounds__(128) chd_ik_step_kernel(const IkSeq* seqs, const int* frame_seq, const int* frame_idx, IkParams P,
+                                                          const int* ipool, const double* dpool, const double* Xin, double* Xout, double* jm) {
+  __shared__ IkLds L;
+  const int wg = blockIdx.x;
+  ik_step_frame(seqs[frame_seq[wg]], frame_idx[wg], P, ipool, dpool, Xin, Xout, jm, L);
+}
+
+extern "C" {
+
+const char* chd_ik_version(void) { return "chd_ik 0.1 (gfx950)"; }
+void chd_ik_config_default(chd_ik_config* cfg) {      // towr_utils.py:843
+  cfg->iterations = 30; cfg->translate = 1; cfg->damping = 7.0; cfg->smoothness = 0.001; cfg->gamma = 1.0;
+}
+const char* chd_ik_last_error(void) { return g_err.c_str(); }
+
+int chd_ik_solve_batch(const chd_ik_config* cfg, int device, int B, const chd_ik_seq* in) {
+  if (!cfg || !in || B < 1) return fail("bad arguments");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail("no HIP device (this library has no CPU path)");
+  if (device < 0 || device >= ndev) return fail("device index out of range");
+  hipError_t e;
+  if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
+  IkBatch bt;
+  if (!bt.build(B, in)) return fail(bt.err);
+  const IkParams P = params_of(cfg);
+  IkSeq* d_seqs = nullptr; int *d_fs = nullptr, *d_fi = nullptr, *d_ip = nullptr; double *d_dp = nullptr, *d_x0 = nullptr, *d_x1 = nullptr, *d_jm = nullptr;
+  auto release = [&]() { for (void* p : {(void*)d_seqs, (void*)d_fs, (void*)d_fi, (void*)d_ip, (void*)d_dp, (void*)d_x0, (void*)d_x1, (void*)d_jm}) (void)hipFree(p); };
+#define IK_TRY(call, what) if ((e = (call)) != hipSuccess) { release(); return fail(what, e); }
+  const size_t nwg = bt.frame_seq.size(), nst = bt.state.size();
+  IK_TRY(hipMalloc(&d_seqs, sizeof(IkSeq) * bt.seqs.size()), "hipMalloc seqs");
+  IK_TRY(hipMalloc(&d_fs, sizeof(int) * nwg), "hipMalloc frame map");
+  IK_TRY(hipMalloc(&d_fi, sizeof(int) * nwg), "hipMalloc frame map");
+  IK_TRY(hipMalloc(&d_ip, sizeof(int) * bt.ipool.size()), "hipMalloc ints");
+  IK_TRY(hipMalloc(&d_dp, sizeof(double) * bt.dpool.size()), "hipMalloc targets");
+  IK_TRY(hipMalloc(&d_x0, sizeof(double) * nst), "hipMalloc state");
+  IK_TRY(hipMalloc(&d_x1, sizeof(double) * nst), "hipMalloc state");
+  IK_TRY(hipMalloc(&d_jm, sizeof(double) * (size_t)bt.jm_size), "hipMalloc Jacobians");
+  IK_TRY(hipMemcpy(d_seqs, bt.seqs.data(), sizeof(IkSeq) * bt.seqs.size(), hipMemcpyHostToDevice), "copy seqs");
+  IK_TRY(hipMemcpy(d_fs, bt.frame_seq.data(), sizeof(int) * nwg, hipMemcpyHostToDevice), "copy frame map");
+  IK_TRY(hipMemcpy(d_fi, bt.frame_idx.data(), sizeof(int) * nwg, hipMemcpyHostToDevice), "copy frame map");
+  IK_TRY(hipMemcpy(d_ip, bt.ipool.data(), sizeof(int) * bt.ipool.size(), hipMemcpyHostToDevice), "copy ints");
+  IK_TRY(hipMemcpy(d_dp, bt.dpool.data(), sizeof(double) * bt.dpool.size(), hipMemcpyHostToDevice), "copy targets");
+  IK_TRY(hipMemcpy(d_x0, bt.state.data(), sizeof(double) * nst, hipMemcpyHostToDevice), "copy state");
+  double* cur = d_x0; double* nxt = d_x1;
+  for (int it = 0; it < P.iterations; ++it) {
+    hipLaunchKernelGGL(chd_ik_step_kernel, dim3((unsigned)nwg), dim3(128), 0, 0, d_seqs, d_fs, d_fi, P, d_ip, d_dp, cur, nxt, d_jm);
+    IK_TRY(hipGetLastError(), "launch");
+    double* t = cur; cur = nxt; nxt = t;
+  }
+  IK_TRY(hipDeviceSynchronize(), "synchronize");
+  std::vector<double> fin(nst);
+  IK_TRY(hipMemcpy(fin.data(), cur, sizeof(double) * nst, hipMemcpyDeviceToHost), "copy result");
+  bt.scatter(fin.data(), in);
+  release();
+#undef IK_TRY
+  g_err.clear();
+  return 0;
+}
+
+}  // extern "C"

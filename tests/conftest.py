@@ -10,6 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'gpu_next: GPU test of a row that has not been run on an MI355X yet (IK back-projection; '
+                            'run with -m gpu_next on the GPU box; not part of -m gpu until it has passed there once)')
 
 
 @pytest.fixture(scope='session')

@@ -60,3 +60,33 @@ def test_product_never_touches_the_oracle():
             if f.endswith(('.py', '.hpp', '.hip', '.h', '.cpp')):
                 txt = open(os.path.join(dp, f), errors='ignore').read()
                 assert 'liboracle' not in txt and 'from oracle' not in txt and 'import oracle' not in txt and '#include "../../oracle' not in txt, f
+
+
+# ---- IK back-projection library (include/chd_ik.h; next row) -----------------------------------------
+@pytest.fixture(scope='module')
+def ik_lib():
+    from chd_amd import ik_backproject
+    ik_backproject.build_library()
+    return C.CDLL(ik_backproject.LIB_PATH)
+
+
+def test_ik_header_and_exports_agree(ik_lib):
+    from chd_amd import ik_backproject, ik_capi
+    src = open(os.path.join(ROOT, 'include', 'chd_ik.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    names = sorted(set(re.findall(r'\b(chd_ik_[a-z_]+)\s*\(', src)))
+    assert set(names) == set(ik_backproject.EXPORTS)
+    for n in names:
+        assert hasattr(ik_lib, n), n
+    cfg = ik_capi.ChdIkConfig()
+    ik_lib.chd_ik_config_default(C.byref(cfg))
+    assert (cfg.iterations, cfg.translate, cfg.damping, cfg.smoothness, cfg.gamma) == (30, 1, 7.0, 0.001, 1.0)      # towr_utils.py:843
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU failure mode')
+def test_ik_fails_loudly_without_gpu(ik_lib):
+    from chd_amd.ik_backproject import IkBackProject
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'ik_golden.npz'))
+    case = dict(parents=g['c0_parents'], target_joints=g['c0_target_joints'], targets=g['c0_targets'], rot=g['c0_rot0'], pos=g['c0_pos0'])
+    with pytest.raises(RuntimeError):
+        IkBackProject(device=0).solve([case])
