@@ -9,8 +9,8 @@ arrays (quaternions as (..., 4) arrays in w, x, y, z order), each function citin
 Parity is PINNED: tests/golden/ik_golden.npz holds inputs and outputs of the reference solver itself, generated in the
 build container by tests/golden/make_ik_golden.py; tests/test_ik_oracle.py checks this restatement against them.
 
-Only tests/ may import this module.  There is no product path for this row yet (round 2: batched fp64 HIP kernel --
-forward kinematics, Jacobian, (J^T J + lambda^2 I) solves of size 6 J per frame -- behind the same C ABI style).
+Only tests/ may import this module.  The product path of this row is include/chd_ik.h + contact-human-dynamics_amd/csrc/
+chd_ik* (HIP, dual-form step); it never touches this file.
 """
 import numpy as np
 
