@@ -42,7 +42,11 @@ if __name__ == '__main__':
     Animation, IK, Q = load_reference()
     rng = np.random.default_rng(3)
     cases = [make_case(rng, [-1, 0, 1, 2, 0, 4, 5, 0], 5, [3, 6, 7], 2.0),
-             make_case(rng, [-1, 0, 1, 2, 3, 0, 5, 6, 7, 0, 9, 10, 11, 10, 13], 4, [4, 8, 0, 12, 14], 3.0)]
+             make_case(rng, [-1, 0, 1, 2, 3, 0, 5, 6, 7, 0, 9, 10, 11, 10, 13], 4, [4, 8, 0, 12, 14], 3.0),
+             # the size apply_results works at: a 33-joint humanoid tree (two 5-joint legs + heels, spine, head, two 6-joint
+             # arms) with 13 targets (upper body + toes + heels)
+             make_case(rng, [-1, 0, 1, 2, 3, 4, 0, 6, 7, 8, 9, 0, 11, 12, 13, 14, 13, 16, 17, 18, 19, 20, 13, 22, 23, 24, 25, 26, 3, 8, 15, 21, 27],
+                       6, [0, 11, 12, 13, 14, 15, 16, 22, 19, 25, 4, 9, 28], 2.0)]
     out = {'n_cases': np.array(len(cases))}
     for ci, cs in enumerate(cases):
         nj = len(cs['parents']); F = cs['euler0'].shape[0]
