@@ -90,3 +90,21 @@ def test_ik_fails_loudly_without_gpu(ik_lib):
     case = dict(parents=g['c0_parents'], target_joints=g['c0_target_joints'], targets=g['c0_targets'], rot=g['c0_rot0'], pos=g['c0_pos0'])
     with pytest.raises(RuntimeError):
         IkBackProject(device=0).solve([case])
+
+
+def test_launches_in_flight_fit_the_runtime_scratch_limit(tmp_path):
+    """Every HIP hardware queue owns a scratch arena sized for the whole device, and (queues x scratch bytes per lane of
+    the kernel) is bounded by the runtime: on MI355X 16 x 4288 worked, 16 x 4400 and 24 x 4288 aborted with
+    HSA_STATUS_ERROR_OUT_OF_RESOURCES.  bench.py's default number of launches in flight must stay
+    inside the known-good product for the kernel as it compiles today."""
+    import subprocess
+    sys_path = os.path.join(ROOT, 'contact-human-dynamics_amd', 'csrc', 'chd_phys.hip')
+    out = subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wno-unused-value',
+                          '-Rpass-analysis=kernel-resource-usage', sys_path, '-o', str(tmp_path / 'x.so')],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, check=True).stdout
+    m = re.search(r'Function Name: \S*chd_solve_kernel.*?ScratchSize \[bytes/lane\]: (\d+)', out, flags=re.S)
+    assert m, out[-2000:]
+    scratch = int(m.group(1))
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    in_flight = int(re.search(r'^DEFAULT_IN_FLIGHT = (\d+)', src, flags=re.M).group(1))
+    assert in_flight * scratch <= 16 * 4288, (in_flight, scratch)
