@@ -1,7 +1,7 @@
 """IK back-projection on one MI355X: batch of synthetic 33-joint skeletons (13 targets, 90 frames each) through
 libchd_ik.so, checked against the numpy oracle on the first video and timed against it.
 
-    python tools/ik_bench.py [videos=128] [frames=90]
+    python tests/tools/ik_bench.py [videos=128] [frames=90]
 
 Round 1 ended before this could be run on a GPU; it is the first measurement of round 2 for this row."""
 import os
@@ -10,7 +10,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import chd_amd  # noqa: E402,F401
 from chd_amd.ik_backproject import IkBackProject  # noqa: E402
