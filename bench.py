@@ -60,7 +60,7 @@ def cpu_baseline(max_workers=8):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=16)
+    ap.add_argument('--steps', type=int, default=2 * DEFAULT_IN_FLIGHT)       # two full rounds of the steps in flight
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=BATCH, help=argparse.SUPPRESS)
     ap.add_argument('--pipeline', type=int, default=DEFAULT_IN_FLIGHT,
