@@ -19,10 +19,13 @@ int fail(const std::string& what, hipError_t e = hipSuccess) {
 }  // namespace
 
 __global__ void __launch_bounds__(128) chd_ik_step_kernel(const IkSeq* seqs, const int* frame_seq, const int* frame_idx, IkParams P,
-                                                          const int* ipool, const double* dpool, const double* Xin, double* Xout, double* jm) {
-  __shared__ IkLds L;
+                                                          const int* ipool, const double* dpool, const double* Xin, double* Xout,
+                                                          int max_J, int max_T) {
+  extern __shared__ double scratch[];          // IkLds::doubles(max_J, max_T) doubles
+  IkLds L;
+  L.carve(scratch, max_J, max_T);
   const int wg = blockIdx.x;
-  ik_step_frame(seqs[frame_seq[wg]], frame_idx[wg], P, ipool, dpool, Xin, Xout, jm, L);
+  ik_step_frame(seqs[frame_seq[wg]], frame_idx[wg], P, ipool, dpool, Xin, Xout, L);
 }
 
 extern "C" {
@@ -43,8 +46,8 @@ int chd_ik_solve_batch(const chd_ik_config* cfg, int device, int B, const chd_ik
   IkBatch bt;
   if (!bt.build(B, in)) return fail(bt.err);
   const IkParams P = params_of(cfg);
-  IkSeq* d_seqs = nullptr; int *d_fs = nullptr, *d_fi = nullptr, *d_ip = nullptr; double *d_dp = nullptr, *d_x0 = nullptr, *d_x1 = nullptr, *d_jm = nullptr;
-  auto release = [&]() { for (void* p : {(void*)d_seqs, (void*)d_fs, (void*)d_fi, (void*)d_ip, (void*)d_dp, (void*)d_x0, (void*)d_x1, (void*)d_jm}) (void)hipFree(p); };
+  IkSeq* d_seqs = nullptr; int *d_fs = nullptr, *d_fi = nullptr, *d_ip = nullptr; double *d_dp = nullptr, *d_x0 = nullptr, *d_x1 = nullptr;
+  auto release = [&]() { for (void* p : {(void*)d_seqs, (void*)d_fs, (void*)d_fi, (void*)d_ip, (void*)d_dp, (void*)d_x0, (void*)d_x1}) (void)hipFree(p); };
 #define IK_TRY(call, what) if ((e = (call)) != hipSuccess) { release(); return fail(what, e); }
   const size_t nwg = bt.frame_seq.size(), nst = bt.state.size();
   IK_TRY(hipMalloc(&d_seqs, sizeof(IkSeq) * bt.seqs.size()), "hipMalloc seqs");
@@ -54,16 +57,16 @@ int chd_ik_solve_batch(const chd_ik_config* cfg, int device, int B, const chd_ik
   IK_TRY(hipMalloc(&d_dp, sizeof(double) * bt.dpool.size()), "hipMalloc targets");
   IK_TRY(hipMalloc(&d_x0, sizeof(double) * nst), "hipMalloc state");
   IK_TRY(hipMalloc(&d_x1, sizeof(double) * nst), "hipMalloc state");
-  IK_TRY(hipMalloc(&d_jm, sizeof(double) * (size_t)bt.jm_size), "hipMalloc Jacobians");
   IK_TRY(hipMemcpy(d_seqs, bt.seqs.data(), sizeof(IkSeq) * bt.seqs.size(), hipMemcpyHostToDevice), "copy seqs");
   IK_TRY(hipMemcpy(d_fs, bt.frame_seq.data(), sizeof(int) * nwg, hipMemcpyHostToDevice), "copy frame map");
   IK_TRY(hipMemcpy(d_fi, bt.frame_idx.data(), sizeof(int) * nwg, hipMemcpyHostToDevice), "copy frame map");
   IK_TRY(hipMemcpy(d_ip, bt.ipool.data(), sizeof(int) * bt.ipool.size(), hipMemcpyHostToDevice), "copy ints");
   IK_TRY(hipMemcpy(d_dp, bt.dpool.data(), sizeof(double) * bt.dpool.size(), hipMemcpyHostToDevice), "copy targets");
   IK_TRY(hipMemcpy(d_x0, bt.state.data(), sizeof(double) * nst, hipMemcpyHostToDevice), "copy state");
+  const size_t lds = sizeof(double) * (size_t)IkLds::doubles(bt.max_J, bt.max_T);      // 26 KB for J = 33, T = 13; 59 KB at the size limits
   double* cur = d_x0; double* nxt = d_x1;
   for (int it = 0; it < P.iterations; ++it) {
-    hipLaunchKernelGGL(chd_ik_step_kernel, dim3((unsigned)nwg), dim3(128), 0, 0, d_seqs, d_fs, d_fi, P, d_ip, d_dp, cur, nxt, d_jm);
+    hipLaunchKernelGGL(chd_ik_step_kernel, dim3((unsigned)nwg), dim3(128), lds, 0, d_seqs, d_fs, d_fi, P, d_ip, d_dp, cur, nxt, bt.max_J, bt.max_T);
     IK_TRY(hipGetLastError(), "launch");
     double* t = cur; cur = nxt; nxt = t;
   }

@@ -16,7 +16,7 @@ struct IkBatch {
   std::vector<double> dpool;
   std::vector<double> state;            // initial state (both device buffers start from it)
   std::vector<int> frame_seq, frame_idx;   // one entry per (sequence, frame) workgroup
-  long long jm_size = 0;
+  int max_J = 0, max_T = 0;             // the workgroup scratch is carved for these
   std::string err;
 
   bool build(int B, const chd_ik_seq* in) {
@@ -51,8 +51,8 @@ struct IkBatch {
         state.insert(state.end(), q.rot_in + (size_t)f * s.J * 4, q.rot_in + (size_t)(f + 1) * s.J * 4);
         state.insert(state.end(), q.pos_in + (size_t)f * s.J * 3, q.pos_in + (size_t)(f + 1) * s.J * 3);
       }
-      s.o_jm = jm_size;
-      jm_size += (long long)s.F * 3 * s.T * 6 * s.J;
+      if (s.J > max_J) max_J = s.J;
+      if (s.T > max_T) max_T = s.T;
       for (int f = 0; f < s.F; ++f) { frame_seq.push_back(b); frame_idx.push_back(f); }
       seqs.push_back(s);
     }

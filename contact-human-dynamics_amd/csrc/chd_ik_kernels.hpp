@@ -7,20 +7,25 @@
 // Differences from the reference, both exact in real arithmetic:
 //  * the step is solved in its dual form dx = J^T (J J^T + lambda^2 I)^-1 e: apply_results uses unit weights, so lambda is
 //    the same for all 6 J unknowns and the 6J x 6J LU per frame becomes a 3T x 3T Cholesky (T targets, ~13);
-//  * the rotation axes of the Jacobian are formed with rotation matrices instead of quaternion products.
+//  * the rotation axes of the Jacobian are formed with rotation matrices instead of quaternion products;
+//  * the Jacobian is never stored: an entry is one cross product of an axis with a (target - joint) offset, both already
+//    in LDS, so J J^T is accumulated per pair of targets over their common ancestors and J^T y per unknown.
 // A frame only needs its neighbours' previous iterate (smoothness term), so every iteration is one launch over all frames
-// of all videos with the state double-buffered in HBM.
+// of all videos with the state double-buffered in HBM.  Per frame the kernel touches 3 x 7J doubles of state in, 7J out
+// and 3T target coordinates; everything else lives in LDS (51 J + 6 T + 9 T^2 doubles: 26 KB for J = 33, T = 13).
 #pragma once
 #include <cmath>
 
 #ifdef CHD_HOST_EMU
 #define IK_DEV static inline
+#define IK_HD inline
 #define IK_TID 0
 #define IK_NT 1
 #define IK_SYNC() ((void)0)
 #else
 #include <hip/hip_runtime.h>
 #define IK_DEV __device__ inline
+#define IK_HD __host__ __device__ inline
 #define IK_TID ((int)threadIdx.x)
 #define IK_NT ((int)blockDim.x)
 #define IK_SYNC() __syncthreads()
@@ -39,16 +44,24 @@ struct IkSeq {
   int o_parents, o_tj, o_desc;      // int pool: parents[J], target_joints[T], desc[J * T] (bit 0: strict descendant, bit 1: or self)
   long long o_targets;              // double pool: T x F x 3
   long long o_state;                // state buffers: F x (7 J): per frame J quaternions (w x y z) then J translations
-  long long o_jm;                   // workspace: F x (3T x 6J) Jacobians
 };
 
-// per-frame workgroup scratch (LDS on the device)
+// per-frame workgroup scratch: views into one block of doubles (LDS on the device), carved for the largest J and T of the batch
 struct IkLds {
-  double x[6 * MAXJ];               // Euler angles (3J) then translations (3J)
-  double Rl[MAXJ][9], Rg[MAXJ][9], pg[MAXJ][3];
-  double es[6 * MAXJ][3];           // axes of the 3J rotation unknowns, then of the 3J translation unknowns
-  double e[MAXR], y[MAXR];
-  double G[MAXR][MAXR + 1];
+  double* x;                        // 6J: Euler angles (3J) then translations (3J)
+  double *Rl, *Rg;                  // 9J each: local / global rotation matrices, row-major
+  double* pg;                       // 3J: global positions
+  double* es;                       // 18J: axes of the 3J rotation unknowns, then of the 3J translation unknowns
+  double* dx;                       // 6J: J^T y
+  double *e, *y;                    // 3T each
+  double* G;                        // 3T rows of stride gs (odd number of doubles: conflict-free column access)
+  int gs;
+  static IK_HD int stride(int T) { return (3 * T) | 1; }
+  static IK_HD int doubles(int J, int T) { return 51 * J + 6 * T + 3 * T * stride(T); }
+  IK_HD void carve(double* b, int J, int T) {
+    x = b; b += 6 * J; Rl = b; b += 9 * J; Rg = b; b += 9 * J; pg = b; b += 3 * J; es = b; b += 18 * J; dx = b; b += 6 * J;
+    e = b; b += 3 * T; y = b; b += 3 * T; G = b; gs = stride(T);
+  }
 };
 
 IK_DEV void quat_to_mat(const double* q, double* m) {          // Quaternions.transforms (Quaternions.py:301-324)
@@ -90,96 +103,122 @@ IK_DEV void mat_vec(const double* a, const double* v, double* o) {
   for (int i = 0; i < 3; ++i) o[i] = a[3 * i] * v[0] + a[3 * i + 1] * v[1] + a[3 * i + 2] * v[2];
 }
 
+IK_DEV void cross3(const double* u, const double* v, double* o) {
+  o[0] = u[1] * v[2] - u[2] * v[1]; o[1] = u[2] * v[0] - u[0] * v[2]; o[2] = u[0] * v[1] - u[1] * v[0];
+}
+
 // One step for frame f of sequence s: reads the state `Xin` (all frames), writes frame f of `Xout`.
 IK_DEV void ik_step_frame(const IkSeq& s, const int f, const IkParams& P, const int* ipool, const double* dpool,
-                          const double* Xin, double* Xout, double* jm_pool, IkLds& L) {
+                          const double* Xin, double* Xout, const IkLds& L) {
   const int J = s.J, T = s.T, F = s.F;
-  const int nvar = P.translate ? 6 * J : 3 * J, R = 3 * T;
+  const int nvar = P.translate ? 6 * J : 3 * J, R = 3 * T, gs = L.gs;
   const int* parents = ipool + s.o_parents; const int* tj = ipool + s.o_tj; const int* desc = ipool + s.o_desc;
   const double* xin = Xin + s.o_state + (long long)f * 7 * J;
-  double* jm = jm_pool + s.o_jm + (long long)f * R * (6 * J);          // row-major R x nvar
   // ---- A: unknowns of this frame and the local rotation matrices (Animation.transforms_local)
   IK_FOR(j, J) {
     quat_to_euler(xin + 4 * j, L.x + 3 * j);
     for (int a = 0; a < 3; ++a) L.x[3 * J + 3 * j + a] = xin[4 * J + 3 * j + a];
-    quat_to_mat(xin + 4 * j, L.Rl[j]);
+    quat_to_mat(xin + 4 * j, L.Rl + 9 * j);
   }
   IK_SYNC();
   // ---- B: global transforms (Animation.transforms_global): every joint walks up its ancestor chain
   IK_FOR(j, J) {
     double Rm[9], p[3];
-    for (int k = 0; k < 9; ++k) Rm[k] = L.Rl[j][k];
+    for (int k = 0; k < 9; ++k) Rm[k] = L.Rl[9 * j + k];
     for (int a = 0; a < 3; ++a) p[a] = L.x[3 * J + 3 * j + a];
     for (int a = parents[j]; a >= 0; a = parents[a]) {
       double Rn[9], pn[3];
-      mat_mul(L.Rl[a], Rm, Rn); mat_vec(L.Rl[a], p, pn);
+      mat_mul(L.Rl + 9 * a, Rm, Rn); mat_vec(L.Rl + 9 * a, p, pn);
       for (int k = 0; k < 9; ++k) Rm[k] = Rn[k];
       for (int k = 0; k < 3; ++k) p[k] = pn[k] + L.x[3 * J + 3 * a + k];
     }
-    for (int k = 0; k < 9; ++k) L.Rg[j][k] = Rm[k];
-    for (int k = 0; k < 3; ++k) L.pg[j][k] = p[k];
+    for (int k = 0; k < 9; ++k) L.Rg[9 * j + k] = Rm[k];
+    for (int k = 0; k < 3; ++k) L.pg[3 * j + k] = p[k];
   }
   IK_SYNC();
   // ---- C: axes of the unknowns (jacobian(), InverseKinematics.py:414-426, 438-443): parent rotation x partial Euler rotations
   IK_FOR(j, J) {
-    double I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    const double* Pr = j == 0 ? I9 : L.Rg[parents[j]];          // prs[:, 0] = identity
+    const double I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    const double* Pr = j == 0 ? I9 : L.Rg + 9 * parents[j];          // prs[:, 0] = identity
     const double cy = std::cos(L.x[3 * j + 1]), sy = std::sin(L.x[3 * j + 1]), cz = std::cos(L.x[3 * j + 2]), sz = std::sin(L.x[3 * j + 2]);
     const double ax0[3] = {cz * cy, sz * cy, -sy};              // Rz(z) Ry(y) e_x
     const double ax1[3] = {-sz, cz, 0.0};                       // Rz(z) e_y
     const double ax2[3] = {0.0, 0.0, 1.0};
-    mat_vec(Pr, ax0, L.es[3 * j]); mat_vec(Pr, ax1, L.es[3 * j + 1]); mat_vec(Pr, ax2, L.es[3 * j + 2]);
-    for (int a = 0; a < 3; ++a) for (int k = 0; k < 3; ++k) L.es[3 * J + 3 * j + a][k] = Pr[3 * k + a];      // Pr e_a
+    mat_vec(Pr, ax0, L.es + 9 * j); mat_vec(Pr, ax1, L.es + 9 * j + 3); mat_vec(Pr, ax2, L.es + 9 * j + 6);
+    for (int a = 0; a < 3; ++a) for (int k = 0; k < 3; ++k) L.es[9 * J + 9 * j + 3 * a + k] = Pr[3 * k + a];      // Pr e_a
   }
   // ---- D: residual
-  IK_FOR(r, R) { const int t = r / 3, a = r % 3; L.e[r] = P.gamma * (dpool[s.o_targets + ((long long)t * F + f) * 3 + a] - L.pg[tj[t]][a]); }
+  IK_FOR(r, R) { const int t = r / 3, a = r % 3; L.e[r] = P.gamma * (dpool[s.o_targets + ((long long)t * F + f) * 3 + a] - L.pg[3 * tj[t] + a]); }
   IK_SYNC();
-  // ---- E: Jacobian (InverseKinematics.py:428-447), R x nvar
-  IK_FOR(idx, R * nvar) {
-    const int r = idx / nvar, v = idx % nvar, t = r / 3, a = r % 3;
-    double val = 0.0;
-    if (v < 3 * J) {
-      const int j = v / 3;
-      if (desc[j * T + t] & 1) {
-        const double d0 = L.pg[tj[t]][0] - L.pg[j][0], d1 = L.pg[tj[t]][1] - L.pg[j][1], d2 = L.pg[tj[t]][2] - L.pg[j][2];
-        const double* ex = L.es[v];
-        val = a == 0 ? ex[1] * d2 - ex[2] * d1 : a == 1 ? ex[2] * d0 - ex[0] * d2 : ex[0] * d1 - ex[1] * d0;
-      }
-    } else {
-      const int j = (v - 3 * J) / 3;
-      if (desc[j * T + t] & 2) val = L.es[v][a];
-    }
-    jm[(long long)r * nvar + v] = val;
-  }
-  IK_SYNC();
-  // ---- F: G = J J^T + lambda^2 I  (dual form of jf.T.dot(jf) + d, InverseKinematics.py:497-502; w = 1 => l = damping / 1.001)
+  // ---- E: G = J J^T + lambda^2 I  (dual form of jf.T.dot(jf) + d, InverseKinematics.py:497-502; w = 1 => l = damping / 1.001).
+  //         Jacobian entries (InverseKinematics.py:428-447): rows of target t, column of rotation unknown (j, a):
+  //         es[3j+a] x (p_target - p_j) if j is a strict ancestor of the target; column of translation unknown (j, a): es[3J+3j+a]
+  //         if j is an ancestor or the target itself.  One 3 x 3 block of G per pair of targets (lower triangle of blocks).
   const double lam = P.damping * (1.0 / (1.0 + 0.001));
-  IK_FOR(idx, R * R) {
-    const int r = idx / R, cc = idx % R;
-    if (cc > r) continue;
-    double acc = 0.0;
-    for (int v = 0; v < nvar; ++v) acc += jm[(long long)r * nvar + v] * jm[(long long)cc * nvar + v];
-    L.G[r][cc] = acc + (r == cc ? lam * lam : 0.0);
+  IK_FOR(idx, T * T) {
+    const int t1 = idx / T, t2 = idx % T;
+    if (t2 > t1) continue;
+    const double* p1 = L.pg + 3 * tj[t1]; const double* p2 = L.pg + 3 * tj[t2];
+    double g[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < J; ++j) {
+      const int m = desc[j * T + t1] & desc[j * T + t2];
+      if (m & 1) {
+        const double d1[3] = {p1[0] - L.pg[3 * j], p1[1] - L.pg[3 * j + 1], p1[2] - L.pg[3 * j + 2]};
+        const double d2[3] = {p2[0] - L.pg[3 * j], p2[1] - L.pg[3 * j + 1], p2[2] - L.pg[3 * j + 2]};
+        for (int a = 0; a < 3; ++a) {
+          double c1[3], c2[3];
+          cross3(L.es + 9 * j + 3 * a, d1, c1); cross3(L.es + 9 * j + 3 * a, d2, c2);
+          for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) g[3 * i + k] += c1[i] * c2[k];
+        }
+      }
+      if ((m & 2) && P.translate)
+        for (int a = 0; a < 3; ++a) {
+          const double* u = L.es + 9 * J + 9 * j + 3 * a;
+          for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) g[3 * i + k] += u[i] * u[k];
+        }
+    }
+    for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k)
+      L.G[(3 * t1 + i) * gs + 3 * t2 + k] = g[3 * i + k] + ((t1 == t2 && i == k) ? lam * lam : 0.0);      // only c <= r is read below
   }
   IK_SYNC();
-  // ---- G: Cholesky G = C C^T (lower), then C z = e, C^T y = z
+  // ---- F: Cholesky G = C C^T (lower), then C z = e, C^T y = z
   for (int k = 0; k < R; ++k) {
-    if (IK_TID == 0) L.G[k][k] = std::sqrt(L.G[k][k]);
+    if (IK_TID == 0) L.G[k * gs + k] = std::sqrt(L.G[k * gs + k]);
     IK_SYNC();
-    for (int r = k + 1 + IK_TID; r < R; r += IK_NT) L.G[r][k] /= L.G[k][k];
+    for (int r = k + 1 + IK_TID; r < R; r += IK_NT) L.G[r * gs + k] /= L.G[k * gs + k];
     IK_SYNC();
     for (int idx = IK_TID; idx < (R - k - 1) * (R - k - 1); idx += IK_NT) {
       const int r = k + 1 + idx / (R - k - 1), cc = k + 1 + idx % (R - k - 1);
-      if (cc <= r) L.G[r][cc] -= L.G[r][k] * L.G[cc][k];
+      if (cc <= r) L.G[r * gs + cc] -= L.G[r * gs + k] * L.G[cc * gs + k];
     }
     IK_SYNC();
   }
   if (IK_TID == 0) {
-    for (int r = 0; r < R; ++r) { double v = L.e[r]; for (int k = 0; k < r; ++k) v -= L.G[r][k] * L.y[k]; L.y[r] = v / L.G[r][r]; }
-    for (int r = R - 1; r >= 0; --r) { double v = L.y[r]; for (int k = r + 1; k < R; ++k) v -= L.G[k][r] * L.y[k]; L.y[r] = v / L.G[r][r]; }
+    for (int r = 0; r < R; ++r) { double v = L.e[r]; for (int k = 0; k < r; ++k) v -= L.G[r * gs + k] * L.y[k]; L.y[r] = v / L.G[r * gs + r]; }
+    for (int r = R - 1; r >= 0; --r) { double v = L.y[r]; for (int k = r + 1; k < R; ++k) v -= L.G[k * gs + r] * L.y[k]; L.y[r] = v / L.G[r * gs + r]; }
   }
   IK_SYNC();
-  // ---- H: dx1 = J^T y; smoothness term on the previous iterate of the neighbouring frames (InverseKinematics.py:506-517);
+  // ---- G: dx = J^T y, one unknown per thread: dx[v] = sum over the targets below joint j of (es[v] x d_t) . y_t = es[v] . (d_t x y_t)
+  IK_FOR(v, nvar) {
+    const bool rot = v < 3 * J;
+    const int j = rot ? v / 3 : (v - 3 * J) / 3;
+    double acc[3] = {0, 0, 0};                                   // rotation: sum of d_t x y_t; translation: sum of y_t
+    for (int t = 0; t < T; ++t) {
+      const int m = desc[j * T + t];
+      if (rot) {
+        if (m & 1) {
+          const double d[3] = {L.pg[3 * tj[t]] - L.pg[3 * j], L.pg[3 * tj[t] + 1] - L.pg[3 * j + 1], L.pg[3 * tj[t] + 2] - L.pg[3 * j + 2]};
+          double c[3];
+          cross3(d, L.y + 3 * t, c);
+          acc[0] += c[0]; acc[1] += c[1]; acc[2] += c[2];
+        }
+      } else if (m & 2) { acc[0] += L.y[3 * t]; acc[1] += L.y[3 * t + 1]; acc[2] += L.y[3 * t + 2]; }
+    }
+    const double* u = L.es + 3 * v;
+    L.dx[v] = u[0] * acc[0] + u[1] * acc[1] + u[2] * acc[2];
+  }
+  IK_SYNC();
+  // ---- H: smoothness term on the previous iterate of the neighbouring frames (InverseKinematics.py:506-517);
   //         new rotations from the new Euler angles (:540-544)
   double* xout = Xout + s.o_state + (long long)f * 7 * J;
   const double* xpv = Xin + s.o_state + (long long)(f > 0 ? f - 1 : 0) * 7 * J;
@@ -189,19 +228,13 @@ IK_DEV void ik_step_frame(const IkSeq& s, const int f, const IkParams& P, const 
     quat_to_euler(xpv + 4 * j, ep); quat_to_euler(xav + 4 * j, ea);
     for (int a = 0; a < 3; ++a) {
       const int v = 3 * j + a;
-      double dx = 0.0;
-      for (int r = 0; r < R; ++r) dx += jm[(long long)r * nvar + v] * L.y[r];
-      en[a] = L.x[v] + dx + P.smoothness * (ep[a] + ea[a] - 2 * L.x[v]);
+      en[a] = L.x[v] + L.dx[v] + P.smoothness * (ep[a] + ea[a] - 2 * L.x[v]);
     }
     euler_to_quat(en, xout + 4 * j);
     for (int a = 0; a < 3; ++a) {
       const int v = 3 * J + 3 * j + a;
       double xn = L.x[v];
-      if (P.translate) {
-        double dx = 0.0;
-        for (int r = 0; r < R; ++r) dx += jm[(long long)r * nvar + v] * L.y[r];
-        xn += dx + P.smoothness * (xpv[4 * J + 3 * j + a] + xav[4 * J + 3 * j + a] - 2 * L.x[v]);
-      }
+      if (P.translate) xn += L.dx[v] + P.smoothness * (xpv[4 * J + 3 * j + a] + xav[4 * J + 3 * j + a] - 2 * L.x[v]);
       xout[4 * J + 3 * j + a] = xn;
     }
   }

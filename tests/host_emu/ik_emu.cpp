@@ -16,12 +16,13 @@ int ik_emu_solve_batch(const chd_ik_config* cfg, int B, const chd_ik_seq* in) {
   IkBatch bt;
   if (!bt.build(B, in)) { g_err = bt.err; return 1; }
   const IkParams P = params_of(cfg);
-  std::vector<double> x0 = bt.state, x1 = bt.state, jm((size_t)bt.jm_size);
-  auto L = std::make_unique<IkLds>();
+  std::vector<double> x0 = bt.state, x1 = bt.state, scratch((size_t)IkLds::doubles(bt.max_J, bt.max_T));
+  IkLds L;
+  L.carve(scratch.data(), bt.max_J, bt.max_T);
   double* cur = x0.data(); double* nxt = x1.data();
   for (int it = 0; it < P.iterations; ++it) {
     for (size_t wg = 0; wg < bt.frame_seq.size(); ++wg)
-      ik_step_frame(bt.seqs[bt.frame_seq[wg]], bt.frame_idx[wg], P, bt.ipool.data(), bt.dpool.data(), cur, nxt, jm.data(), *L);
+      ik_step_frame(bt.seqs[bt.frame_seq[wg]], bt.frame_idx[wg], P, bt.ipool.data(), bt.dpool.data(), cur, nxt, L);
     double* t = cur; cur = nxt; nxt = t;
   }
   bt.scatter(cur, in);
