@@ -30,6 +30,18 @@
 #define IK_NT ((int)blockDim.x)
 #define IK_SYNC() __syncthreads()
 #endif
+// one-wavefront sections (short dependent chains in LDS while the other wavefront waits at the next barrier)
+#ifdef CHD_HOST_EMU
+#define IK_WAVE0 true
+#define IK_WLANE 0
+#define IK_WSTEP 1
+#define IK_WSYNC() ((void)0)
+#else
+#define IK_WAVE0 (threadIdx.x < 64)
+#define IK_WLANE ((int)threadIdx.x)
+#define IK_WSTEP 64
+#define IK_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
+#endif
 #define IK_FOR(i, n) for (int i = IK_TID; i < (n); i += IK_NT)
 
 namespace chd_ik {
@@ -54,10 +66,10 @@ struct IkLds {
   double* es;                       // 18J: axes of the 3J rotation unknowns, then of the 3J translation unknowns
   double* dx;                       // 6J: J^T y
   double *e, *y;                    // 3T each
-  double* G;                        // 3T rows of stride gs (odd number of doubles: conflict-free column access)
+  double* G;                        // 3T + 1 rows of stride gs (odd number of doubles: conflict-free column access); row 3T: residual
   int gs;
   static IK_HD int stride(int T) { return (3 * T) | 1; }
-  static IK_HD int doubles(int J, int T) { return 51 * J + 6 * T + 3 * T * stride(T); }
+  static IK_HD int doubles(int J, int T) { return 51 * J + 6 * T + (3 * T + 1) * stride(T); }
   IK_HD void carve(double* b, int J, int T) {
     x = b; b += 6 * J; Rl = b; b += 9 * J; Rg = b; b += 9 * J; pg = b; b += 3 * J; es = b; b += 18 * J; dx = b; b += 6 * J;
     e = b; b += 3 * T; y = b; b += 3 * T; G = b; gs = stride(T);
@@ -147,8 +159,8 @@ IK_DEV void ik_step_frame(const IkSeq& s, const int f, const IkParams& P, const 
     mat_vec(Pr, ax0, L.es + 9 * j); mat_vec(Pr, ax1, L.es + 9 * j + 3); mat_vec(Pr, ax2, L.es + 9 * j + 6);
     for (int a = 0; a < 3; ++a) for (int k = 0; k < 3; ++k) L.es[9 * J + 9 * j + 3 * a + k] = Pr[3 * k + a];      // Pr e_a
   }
-  // ---- D: residual
-  IK_FOR(r, R) { const int t = r / 3, a = r % 3; L.e[r] = P.gamma * (dpool[s.o_targets + ((long long)t * F + f) * 3 + a] - L.pg[3 * tj[t] + a]); }
+  // ---- D: residual, stored as row R of G (see F)
+  IK_FOR(r, R) { const int t = r / 3, a = r % 3; L.G[R * gs + r] = P.gamma * (dpool[s.o_targets + ((long long)t * F + f) * 3 + a] - L.pg[3 * tj[t] + a]); }
   IK_SYNC();
   // ---- E: G = J J^T + lambda^2 I  (dual form of jf.T.dot(jf) + d, InverseKinematics.py:497-502; w = 1 => l = damping / 1.001).
   //         Jacobian entries (InverseKinematics.py:428-447): rows of target t, column of rotation unknown (j, a):
@@ -181,21 +193,32 @@ IK_DEV void ik_step_frame(const IkSeq& s, const int f, const IkParams& P, const 
       L.G[(3 * t1 + i) * gs + 3 * t2 + k] = g[3 * i + k] + ((t1 == t2 && i == k) ? lam * lam : 0.0);      // only c <= r is read below
   }
   IK_SYNC();
-  // ---- F: Cholesky G = C C^T (lower), then C z = e, C^T y = z
+  // ---- F: (G + lambda^2 I) y = e.  G = L D L^T without pivoting or square roots (G is SPD), right-looking with unscaled
+  //         columns U[r][k] = L[r][k] d_k so that a column needs ONE workgroup barrier; the residual rides along as row R
+  //         (its eliminated entries are U[R][k] = (D^-1 L^-1 e)_k d_k, i.e. the forward substitution comes for free).
   for (int k = 0; k < R; ++k) {
-    if (IK_TID == 0) L.G[k * gs + k] = std::sqrt(L.G[k * gs + k]);
-    IK_SYNC();
-    for (int r = k + 1 + IK_TID; r < R; r += IK_NT) L.G[r * gs + k] /= L.G[k * gs + k];
-    IK_SYNC();
-    for (int idx = IK_TID; idx < (R - k - 1) * (R - k - 1); idx += IK_NT) {
-      const int r = k + 1 + idx / (R - k - 1), cc = k + 1 + idx % (R - k - 1);
-      if (cc <= r) L.G[r * gs + cc] -= L.G[r * gs + k] * L.G[cc * gs + k];
+    const double inv = 1.0 / L.G[k * gs + k];
+    const int n = R - k;                                          // rows k+1 .. R, columns k+1 .. R-1, lower triangle
+    for (int idx = IK_TID; idx < n * (n + 1) / 2 - 1; idx += IK_NT) {      // the last entry would be (R, R): not needed
+      int i = (int)((std::sqrt(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
+      while (i * (i + 1) / 2 > idx) --i;
+      while ((i + 1) * (i + 2) / 2 <= idx) ++i;
+      const int r = k + 1 + i, cc = k + 1 + (idx - i * (i + 1) / 2);
+      L.G[r * gs + cc] -= L.G[r * gs + k] * L.G[cc * gs + k] * inv;
     }
     IK_SYNC();
   }
-  if (IK_TID == 0) {
-    for (int r = 0; r < R; ++r) { double v = L.e[r]; for (int k = 0; k < r; ++k) v -= L.G[r * gs + k] * L.y[k]; L.y[r] = v / L.G[r * gs + r]; }
-    for (int r = R - 1; r >= 0; --r) { double v = L.y[r]; for (int k = r + 1; k < R; ++k) v -= L.G[k * gs + r] * L.y[k]; L.y[r] = v / L.G[r * gs + r]; }
+  IK_FOR(k, R) { L.e[k] = L.G[R * gs + k]; L.G[k * gs + k] = 1.0 / L.G[k * gs + k]; }      // right-hand side of L^T y = D^-1 (.), and 1 / d_k
+  IK_SYNC();
+  // back substitution y_k = (U[R][k] - sum_{r > k} U[r][k] y_r) / d_k by one wavefront, scatter form: once y_k is known
+  // every lane r < k takes U[k][r] y_k off its own accumulator e[r] (row k of G is contiguous)
+  if (IK_WAVE0) {
+    for (int k = R - 1; k >= 0; --k) {
+      const double yk = L.e[k] * L.G[k * gs + k];
+      for (int r = IK_WLANE; r < k; r += IK_WSTEP) L.e[r] -= L.G[k * gs + r] * yk;
+      if (IK_WLANE == 0) L.y[k] = yk;
+      IK_WSYNC();
+    }
   }
   IK_SYNC();
   // ---- G: dx = J^T y, one unknown per thread: dx[v] = sum over the targets below joint j of (es[v] x d_t) . y_t = es[v] . (d_t x y_t)
