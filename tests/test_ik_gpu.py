@@ -28,3 +28,31 @@ def test_hip_path_matches_reference_vectors():
             gp = ik.positions_global(rot, pos, cases[c]['parents'])
             assert np.allclose(gp, g['c%d_it%d_gpos' % (c, iters)], rtol=1e-8, atol=1e-8)
             assert np.allclose(pos, g['c%d_it%d_pos' % (c, iters)], rtol=1e-8, atol=1e-8)
+
+
+def test_apply_results_on_gpu_matches_reference(tmp_path):
+    """The whole back-projection (solution file + BVH in, BVH out) with the HIP solver against the reference's
+    `apply_results` vectors (tests/golden/apply_golden.npz)."""
+    torch = pytest.importorskip('torch')
+    if not torch.cuda.is_available():
+        pytest.skip('needs an MI355X')
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    from make_apply_golden import CHARACTER
+    from chd_amd import apply_results as ar
+    from chd_amd import skeleton_io as sk
+    from chd_amd.ik_backproject import IkBackProject
+    g = np.load(os.path.join(os.path.dirname(GOLD), 'apply_golden.npz'))
+    bvh = str(tmp_path / 'in.bvh'); sol = str(tmp_path / 'sol.txt')
+    open(bvh, 'wb').write(g['bvh_text'].tobytes()); open(sol, 'wb').write(g['sol_text'].tobytes())
+    s, e = [int(v) for v in g['start_end']]
+    outs = [str(tmp_path / ('out%d.bvh' % k)) for k in range(3)]
+    tasks = ar.apply_results_batch([sol] * 3, [bvh] * 3, outs, ar.Character(**CHARACTER), IkBackProject(device=0), starts=[s] * 3, ends=[e] * 3)
+    for t in tasks:
+        assert np.abs(sk.positions_global(t.motion) - g['ik_gpos']).max() < 1e-7
+        assert np.abs(t.motion.positions - g['ik_pos']).max() < 1e-7
+    ref = g['out_bvh_text'].tobytes().decode()
+    got = open(outs[2]).read()
+    a = np.array(got[got.index('Time:') + 5:].split(), dtype=np.float64)
+    b = np.array(ref[ref.index('Time:') + 5:].split(), dtype=np.float64)
+    assert got[:got.index('MOTION')] == ref[:ref.index('MOTION')] and np.abs(a - b).max() <= 2e-6
