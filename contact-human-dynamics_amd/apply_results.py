@@ -33,6 +33,21 @@ class Character:
     seg_to_joints: Dict[str, List[int]]          # get_character_seg_to_joint_map
     seg_to_mass_perc: Dict[str, float]           # get_character_seg_to_mass_perc_map (percent)
     heel_inds: Optional[Sequence[int]] = None    # get_character_heel_inds; None = not in `heeled_characters`: heels get appended
+    # only prepare_input needs these (prepare_input.py)
+    left_leg_chain: Optional[Sequence[int]] = None   # get_character_leg_chain(character, 'left'): hip ... ankle, toe
+    hip_inds: Optional[Sequence[int]] = None         # get_character_hip_inds: [left, right]
+    mass: Optional[float] = None                     # get_character_mass (kg)
+
+    @staticmethod
+    def from_json(path):
+        """A JSON object with the field names above (how a deployment carries its character tables)."""
+        import json
+        with open(path) as f:
+            d = json.load(f)
+        unknown = set(d) - set(Character.__dataclass_fields__)
+        if unknown:
+            raise ValueError('%s: unknown character fields %s' % (path, sorted(unknown)))
+        return Character(**d)
 
 
 @dataclass

@@ -4,9 +4,18 @@ Reference: ``scripts/run_phys_mocap.py`` — for every video directory it runs (
 (4) retargeting, writes ``phys_optim_in_<char>/`` and then starts ``./phys_optim`` once per video
 (:159-174).  This driver keeps the flags that concern the physics stage (:13-31, :33-44) and replaces the
 per-video child process by ONE batched call into ``libchd_phys.so`` over all directories (sharded over the
-GPUs of the node when launched with torch.distributed.run).  The upstream stages (kinematic optimisation,
-retargeting, ``towr_utils.prepare_input``) and the IK back-projection are outside this path:
-the directories must already contain ``phys_optim_in_<character>/``.
+GPUs of the node when launched with torch.distributed.run).  Kinematic optimisation and retargeting are outside
+this path.  The two stages either side of the solver are optional here:
+
+* ``--prepare`` writes ``phys_optim_in_<character>/`` from ``kinematic_results/{<character>_out.bvh, floor_out.txt,
+  foot_contacts.npy}`` (the ``towr_utils.py --anim ... --out ...`` child process of :137-150; `prepare_input.py`);
+  without it the directories must already contain ``phys_optim_in_<character>/``;
+* ``--out-bvh`` back-projects the three solution files onto the skeleton and writes
+  ``<video>_<character>_{no_dynamics,dynamics,durations}.bvh`` (the ``towr_utils.py --viz --out-bvh`` child process of
+  :180-201 without its plots / video; `apply_results.py`, one batched IK launch sequence per solution kind).
+
+Both need the character's joint / segment tables as a JSON file (``--character-json``, fields of
+``apply_results.Character``); none are baked in.
 """
 import argparse
 import os
@@ -29,6 +38,10 @@ def parse_args(argv):
     p.add_argument('--w-smooth', type=float, default=0.1)
     p.add_argument('--w-dur', type=float, default=0.1)
     p.add_argument('--batch', type=int, default=128, help='sequences per kernel launch')
+    p.add_argument('--prepare', action='store_true', help='write phys_optim_in_<character>/ from kinematic_results/ first')
+    p.add_argument('--out-bvh', action='store_true', help='back-project the solutions onto the skeleton and write BVH files')
+    p.add_argument('--character-json', default=None, help='joint / segment tables of the character (apply_results.Character)')
+    p.add_argument('--fps', type=float, default=30.0, help='frame rate of the animation (the reference reads it from the video, :90-91)')
     return p.parse_args(argv)
 
 
@@ -38,6 +51,8 @@ def count_frames(video_dir, in_dir):
         n = len([f for f in os.listdir(op) if f.endswith('.json')])     # run_phys_mocap.py:97
         if n > 0:
             return n
+    if in_dir is None:
+        return None                                                         # --prepare without OpenPose results: the whole BVH
     with open(os.path.join(in_dir, 'motion_info.txt')) as f:
         return (len(f.read().split()) - 1) // 18
 
@@ -46,9 +61,23 @@ def main(argv=None):
     a = parse_args(sys.argv[1:] if argv is None else argv)
     vids = sorted(d for d in os.listdir(a.data) if os.path.isdir(os.path.join(a.data, d)) and not d.startswith('.'))
     jobs = []
+    character = None
+    if a.prepare or a.out_bvh:
+        if not a.character_json:
+            raise SystemExit('--prepare / --out-bvh need --character-json')
+        from .apply_results import Character
+        character = Character.from_json(a.character_json)
     for v in vids:
         vd = os.path.join(a.data, v)
         ind = os.path.join(vd, 'phys_optim_in_' + a.character)
+        if a.prepare and int(os.environ.get('WORLD_SIZE', '1')) > 1:
+            raise SystemExit('--prepare writes the input directories: run it once as a single process, then launch the ranks')
+        if a.prepare:
+            from .prepare_input import prepare_input
+            kin = os.path.join(vd, 'kinematic_results')
+            n = a.nframes or count_frames(vd, None)
+            prepare_input(os.path.join(kin, a.character + '_out.bvh'), os.path.join(kin, 'floor_out.txt'), os.path.join(kin, 'foot_contacts.npy'),
+                          ind, character, start_idx=0, end_idx=n, dt=1.0 / a.fps)
         if not os.path.isdir(ind):
             print('[run_phys_mocap] %s: no %s, skipping' % (v, os.path.basename(ind)))
             continue
@@ -65,6 +94,19 @@ def main(argv=None):
         st = solver.solve_dirs([p[0] for p in part], [p[1] for p in part], [p[2] for p in part])
         bad += sum(1 for x in st if x != 0)
     solver.close()
+    if a.out_bvh:
+        from . import apply_results as ar
+        from .ik_backproject import IkBackProject
+        ik = IkBackProject(device=local)
+        for kind in ('no_dynamics', 'dynamics', 'durations'):               # run_phys_mocap.py:183-186
+            part = [jobs[i] for i in mine if os.path.exists(os.path.join(jobs[i][1], 'sol_out_%s.txt' % kind))]
+            if not part:
+                continue
+            vdirs = [os.path.dirname(p[1]) for p in part]
+            ar.apply_results_batch([os.path.join(p[1], 'sol_out_%s.txt' % kind) for p in part],
+                                   [os.path.join(vd, 'kinematic_results', a.character + '_out.bvh') for vd in vdirs],
+                                   [os.path.join(p[1], '%s_%s_%s.bvh' % (os.path.basename(vd), a.character, kind)) for p, vd in zip(part, vdirs)],
+                                   character, ik, starts=[0] * len(part), ends=[p[2] for p in part])
     print('[run_phys_mocap] rank %d/%d: %d sequences, %d I/O failures' % (rank, world, len(mine), bad))
     return 0 if bad == 0 else 1
 

@@ -5,7 +5,7 @@
 * the BVH file is written by this repo's writer (skeleton_io.save_bvh) and read by the reference's `BVH.load`;
   the reference's `BVH.save` of what it read gives the bytes our writer must reproduce;
 * the solution file is written by io_formats.write_solution and parsed by the reference's `load_results`;
-* `apply_results` is cut out of towr_utils.py with `ast` (the module as a whole needs matplotlib etc.) and run with
+* `apply_results` and `prepare_input` (towr_utils.py:451-777) are cut out of towr_utils.py with `ast` (the module as a whole needs matplotlib etc.) and run with
   the reference's own BVH / Animation / Quaternions / InverseKinematics modules; the character look-ups
   (character_info_utils getters) are replaced by the synthetic character's tables.
 
@@ -37,7 +37,8 @@ CHARACTER = dict(toe_inds=[14, 19], ankle_inds=[13, 18], upper_body=[0, 1, 2, 3,
                  seg_to_joints={'trunk': [0, 1, 2, 3], 'head': [3, 4], 'l_arm': [5, 6, 7], 'r_arm': [8, 9, 10],
                                 'l_thigh': [11, 12], 'l_shank': [12, 13], 'l_foot': [13, 14], 'r_thigh': [16, 17], 'r_shank': [17, 18], 'r_foot': [18, 19]},
                  seg_to_mass_perc={'trunk': 43.0, 'head': 7.0, 'l_arm': 5.0, 'r_arm': 5.0, 'l_thigh': 10.5, 'l_shank': 6.5, 'l_foot': 3.0,
-                                   'r_thigh': 10.5, 'r_shank': 6.5, 'r_foot': 3.0})
+                                   'r_thigh': 10.5, 'r_shank': 6.5, 'r_foot': 3.0},
+                 left_leg_chain=[11, 12, 13, 14], hip_inds=[11, 16], mass=70.0)
 
 
 def synthetic_motion(F, seed):
@@ -63,7 +64,7 @@ def load_reference():
     from Quaternions import Quaternions
     src = open(os.path.join(REF, 'utils', 'towr_utils.py')).read()
     tree = ast.parse(src)
-    want = ('TowrResults', 'load_results', 'apply_results', 'add_heel_to_anim', 'remove_heel_from_anim')
+    want = ('TowrResults', 'load_results', 'apply_results', 'add_heel_to_anim', 'remove_heel_from_anim', 'prepare_input', 'find_contact_durations')
     keep = [n for n in tree.body if isinstance(n, (ast.ClassDef, ast.FunctionDef)) and n.name in want]
     assert len(keep) == len(want)
     C = CHARACTER
@@ -71,7 +72,9 @@ def load_reference():
           'JacobianInverseKinematicsCK': JacobianInverseKinematicsCK, 'heeled_characters': [],
           'get_character_toe_inds': lambda ch: list(C['toe_inds']), 'get_character_ankle_inds': lambda ch: list(C['ankle_inds']),
           'get_character_upper_body': lambda ch: list(C['upper_body']), 'get_character_seg_to_joint_map': lambda ch: C['seg_to_joints'],
-          'get_character_seg_to_mass_perc_map': lambda ch: C['seg_to_mass_perc'], 'get_character_heel_inds': lambda ch: None}
+          'get_character_seg_to_mass_perc_map': lambda ch: C['seg_to_mass_perc'], 'get_character_heel_inds': lambda ch: None,
+          'get_character_leg_chain': lambda ch, side='left': list(C['left_leg_chain']) if side == 'left' else [16, 17, 18, 19],
+          'get_character_hip_inds': lambda ch: list(C['hip_inds']), 'get_character_mass': lambda ch: C['mass']}
     exec(compile(ast.Module(body=keep, type_ignores=[]), 'towr_utils.py', 'exec'), ns)
     return ns, BVH, Animation
 
@@ -125,5 +128,17 @@ if __name__ == '__main__':
             sa = ns['remove_heel_from_anim'](a)
             BVH.save('/tmp/apply_golden_out.bvh', sa, nm)
             out['out_bvh_text'] = np.frombuffer(open('/tmp/apply_golden_out.bvh', 'rb').read(), dtype=np.uint8)
+    # --- prepare_input (towr_utils.py:451-777) on the same file: floor and contacts as the kinematic stage leaves them
+    floor_path, contacts_path, prep_dir = '/tmp/apply_golden_floor.txt', '/tmp/apply_golden_contacts.npy', '/tmp/apply_golden_prep'
+    open(floor_path, 'w').write('0.02 0.999 -0.03\n3.0 1.5 -2.0\n')
+    fc = (rng.random((F_file, 4)) < 0.5).astype(np.int64)
+    for k in range(0, F_file, 4):
+        fc[k:k + 4] = fc[k]
+    np.save(contacts_path, fc)
+    out['prep_floor_text'] = np.frombuffer(open(floor_path, 'rb').read(), dtype=np.uint8); out['prep_contacts'] = fc
+    for tag, combined in (('prep', False), ('prepc', True)):
+        ns['prepare_input'](bvh_path, floor_path, contacts_path, prep_dir, 'synthetic', start_idx=start, end_idx=end, dt=1.0 / 30.0, combined_contacts=combined)
+        for name in ('skel_info.txt', 'motion_info.txt', 'terrain_info.txt', 'contact_info.txt'):
+            out[tag + '_' + name.split('.')[0]] = np.frombuffer(open(os.path.join(prep_dir, name), 'rb').read(), dtype=np.uint8)
     np.savez_compressed(os.path.join(HERE, 'apply_golden.npz'), **out)
     print('wrote apply_golden.npz', {k: v.shape for k, v in out.items()})
