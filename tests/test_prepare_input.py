@@ -134,9 +134,10 @@ def test_driver_out_bvh_stage(gold, tmp_path, character, monkeypatch):
     sys.path.insert(0, os.path.join(HERE, 'host_emu'))
     import ik_emu
     from make_apply_golden import CHARACTER
-    from chd_amd import ik_backproject
+    import importlib
     from chd_amd import run_phys_mocap as drv
     from chd_amd import skeleton_io as sk
+    ik_backproject = importlib.import_module(drv.__package__ + '.ik_backproject')      # the module object the driver's relative import resolves to
     kin = tmp_path / 'data' / 'clip' / 'kinematic_results'
     os.makedirs(kin)
     open(kin / 'synth_out.bvh', 'wb').write(gold['bvh_text'].tobytes())
