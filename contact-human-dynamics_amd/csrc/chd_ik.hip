@@ -12,6 +12,8 @@ using namespace chd_ik;
 
 namespace {
 thread_local std::string g_err;
+thread_local double g_kernel_ms = 0.0;
+thread_local long long g_frames = 0;
 int fail(const std::string& what, hipError_t e = hipSuccess) {
   g_err = e == hipSuccess ? what : what + ": " + hipGetErrorString(e);
   return 1;
@@ -35,6 +37,8 @@ void chd_ik_config_default(chd_ik_config* cfg) {      // towr_utils.py:843
   cfg->iterations = 30; cfg->translate = 1; cfg->damping = 7.0; cfg->smoothness = 0.001; cfg->gamma = 1.0;
 }
 const char* chd_ik_last_error(void) { return g_err.c_str(); }
+double chd_ik_last_kernel_ms(void) { return g_kernel_ms; }
+long long chd_ik_last_frames(void) { return g_frames; }
 
 int chd_ik_solve_batch(const chd_ik_config* cfg, int device, int B, const chd_ik_seq* in) {
   if (!cfg || !in || B < 1) return fail("bad arguments");
@@ -64,17 +68,29 @@ int chd_ik_solve_batch(const chd_ik_config* cfg, int device, int B, const chd_ik
   IK_TRY(hipMemcpy(d_dp, bt.dpool.data(), sizeof(double) * bt.dpool.size(), hipMemcpyHostToDevice), "copy targets");
   IK_TRY(hipMemcpy(d_x0, bt.state.data(), sizeof(double) * nst, hipMemcpyHostToDevice), "copy state");
   const size_t lds = sizeof(double) * (size_t)IkLds::doubles(bt.max_J, bt.max_T);      // 26 KB for J = 33, T = 13; 59 KB at the size limits
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  IK_TRY(hipEventCreate(&ev0), "hipEventCreate");
+  if ((e = hipEventCreate(&ev1)) != hipSuccess) { (void)hipEventDestroy(ev0); release(); return fail("hipEventCreate", e); }
+  auto drop_events = [&]() { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); };
+#undef IK_TRY
+#define IK_TRY(call, what) if ((e = (call)) != hipSuccess) { drop_events(); release(); return fail(what, e); }
   double* cur = d_x0; double* nxt = d_x1;
+  IK_TRY(hipEventRecord(ev0, 0), "hipEventRecord");
   for (int it = 0; it < P.iterations; ++it) {
     hipLaunchKernelGGL(chd_ik_step_kernel, dim3((unsigned)nwg), dim3(128), lds, 0, d_seqs, d_fs, d_fi, P, d_ip, d_dp, cur, nxt, bt.max_J, bt.max_T);
     IK_TRY(hipGetLastError(), "launch");
     double* t = cur; cur = nxt; nxt = t;
   }
+  IK_TRY(hipEventRecord(ev1, 0), "hipEventRecord");
   IK_TRY(hipDeviceSynchronize(), "synchronize");
+  float ms = 0.0f;
+  IK_TRY(hipEventElapsedTime(&ms, ev0, ev1), "hipEventElapsedTime");
   std::vector<double> fin(nst);
   IK_TRY(hipMemcpy(fin.data(), cur, sizeof(double) * nst, hipMemcpyDeviceToHost), "copy result");
   bt.scatter(fin.data(), in);
+  drop_events();
   release();
+  g_kernel_ms = ms; g_frames = (long long)nwg;
 #undef IK_TRY
   g_err.clear();
   return 0;

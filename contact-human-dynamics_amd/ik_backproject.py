@@ -25,7 +25,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_CSRC, 'libchd_ik.so')
 SOURCES = ['chd_ik.hip', 'chd_ik_kernels.hpp', 'chd_ik_host.hpp']
-EXPORTS = ['chd_ik_version', 'chd_ik_config_default', 'chd_ik_solve_batch', 'chd_ik_last_error']
+EXPORTS = ['chd_ik_version', 'chd_ik_config_default', 'chd_ik_solve_batch', 'chd_ik_last_error', 'chd_ik_last_kernel_ms', 'chd_ik_last_frames']
 
 
 def build_library(force=False, verbose=False):
@@ -46,6 +46,8 @@ def load_library():
     lib = C.CDLL(LIB_PATH)
     lib.chd_ik_version.restype = C.c_char_p
     lib.chd_ik_last_error.restype = C.c_char_p
+    lib.chd_ik_last_kernel_ms.restype = C.c_double
+    lib.chd_ik_last_frames.restype = C.c_longlong
     return lib
 
 
@@ -62,6 +64,10 @@ class IkBackProject:
         if self.lib.chd_ik_solve_batch(C.byref(self.cfg), self.device, len(seqs), arr) != 0:
             raise RuntimeError('chd_ik_solve_batch: ' + self.lib.chd_ik_last_error().decode())
         return outs
+
+    def last_kernel_ms(self):
+        """Device time of the last `solve` (HIP events around its launches) and the frames per launch."""
+        return float(self.lib.chd_ik_last_kernel_ms()), int(self.lib.chd_ik_last_frames())
 
     @staticmethod
     def targetmap_to_arrays(targetmap):

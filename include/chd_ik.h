@@ -52,6 +52,12 @@ void chd_ik_config_default(chd_ik_config* cfg);
 int chd_ik_solve_batch(const chd_ik_config* cfg, int device, int B, const chd_ik_seq* seqs);
 const char* chd_ik_last_error(void);
 
+/* Device time of the last successful chd_ik_solve_batch on the calling thread: milliseconds between HIP events placed
+ * around its `iterations` kernel launches (uploads, downloads and allocation excluded), and the number of (video, frame)
+ * workgroups per launch.  For the roofline accounting of this row ("Next row"). */
+double chd_ik_last_kernel_ms(void);
+long long chd_ik_last_frames(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,16 @@ if __name__ == '__main__':
     gp_gpu = ik.positions_global(outs[0][0], outs[0][1], vids[0]['parents'])
     gp_cpu = ik.positions_global(ro, po, vids[0]['parents'])
     err = np.abs(gp_gpu - gp_cpu).max()
+    ms, frames = solver.last_kernel_ms()
+    J, T, its = len(PARENTS), len(TARGETS), int(solver.cfg.iterations)
+    # algorithmic HBM bytes per (frame, iteration): state of the frame and its two neighbours in (3 x 7J doubles), state out
+    # (7J), targets (3T) -- DESIGN.md "Next row"; flops: J J^T blocks + LDL^T (R^3/3) + J^T y, counted as fused multiply-adds x 2
+    R = 3 * T
+    bytes_alg = 8.0 * (4 * 7 * J + 3 * T) * frames * its
+    flops = 2.0 * (T * (T + 1) / 2 * 6 * 3 * 27 + R ** 3 / 3.0 + 6 * J * T * 9) * frames * its
+    print('kernel time %.2f ms for %d launches of %d workgroups: %.1f us per launch, %.2f us per frame-step per CU slot; '
+          'algorithmic %.1f GB/s (of ~8000), ~%.2f TFLOP/s fp64 (vector peak 78.6)'
+          % (ms, its, frames, 1e3 * ms / its, 1e3 * ms / its / max(1.0, frames / 256.0), bytes_alg / (ms * 1e-3) / 1e9, flops / (ms * 1e-3) / 1e12))
     print('videos %d frames %d: GPU %.3f s (%.1f videos/s, host buffers in/out included); oracle %.2f s per video on one core; '
           'max |global joint position difference| on video 0: %.2e' % (B, F, t1 - t0, B / (t1 - t0), t3 - t2, err))
     assert err < 1e-6
