@@ -36,14 +36,19 @@ struct IkBatch {
         if (q.target_joints[t] < 0 || q.target_joints[t] >= s.J) { err = "sequence " + std::to_string(b) + ": target joint out of range"; return false; }
         ipool.push_back(q.target_joints[t]);
       }
-      // descendants_mask (AnimationStructure.py:129-150, 217) restricted to the targeted joints: bit 0 strict, bit 1 or-self
-      s.o_desc = (int)ipool.size();
-      for (int j = 0; j < s.J; ++j)
-        for (int t = 0; t < s.T; ++t) {
-          int a = q.target_joints[t], bits = (a == j) ? 2 : 0;
-          for (a = q.parents[a]; a >= 0; a = q.parents[a]) if (a == j) { bits = 3; break; }
-          ipool.push_back(bits);
-        }
+      // descendants_mask (AnimationStructure.py:129-150, 217) restricted to the targeted joints, as bit masks both ways
+      s.o_masks = (int)ipool.size();                     // == o_parents + J + T: the kernel stages the three tables with one copy
+      std::vector<unsigned> jt_strict(s.J, 0u), jt_self(s.J, 0u);
+      std::vector<unsigned long long> ta_strict(s.T, 0ull), ta_self(s.T, 0ull);
+      for (int t = 0; t < s.T; ++t) {
+        int a = q.target_joints[t];
+        jt_self[a] |= 1u << t; ta_self[t] |= 1ull << a;
+        for (a = q.parents[a]; a >= 0; a = q.parents[a]) { jt_strict[a] |= 1u << t; jt_self[a] |= 1u << t; ta_strict[t] |= 1ull << a; ta_self[t] |= 1ull << a; }
+      }
+      for (int j = 0; j < s.J; ++j) ipool.push_back((int)jt_strict[j]);
+      for (int j = 0; j < s.J; ++j) ipool.push_back((int)jt_self[j]);
+      for (int t = 0; t < s.T; ++t) { ipool.push_back((int)(unsigned)(ta_strict[t] & 0xffffffffull)); ipool.push_back((int)(unsigned)(ta_strict[t] >> 32)); }
+      for (int t = 0; t < s.T; ++t) { ipool.push_back((int)(unsigned)(ta_self[t] & 0xffffffffull)); ipool.push_back((int)(unsigned)(ta_self[t] >> 32)); }
       s.o_targets = (long long)dpool.size();
       dpool.insert(dpool.end(), q.targets, q.targets + (size_t)s.T * s.F * 3);
       s.o_state = (long long)state.size();

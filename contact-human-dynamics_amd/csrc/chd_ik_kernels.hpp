@@ -12,7 +12,7 @@
 //    in LDS, so J J^T is accumulated per pair of targets over their common ancestors and J^T y per unknown.
 // A frame only needs its neighbours' previous iterate (smoothness term), so every iteration is one launch over all frames
 // of all videos with the state double-buffered in HBM.  Per frame the kernel touches 3 x 7J doubles of state in, 7J out
-// and 3T target coordinates; everything else lives in LDS (51 J + 6 T + 9 T^2 doubles: 26 KB for J = 33, T = 13).
+// and 3T target coordinates; everything else lives in LDS (51 J + 6 T + 9 T^2 doubles + index tables: 27 KB for J = 33, T = 13).
 #pragma once
 #include <cmath>
 
@@ -53,7 +53,9 @@ struct IkParams { int iterations, translate; double damping, smoothness, gamma; 
 // one video inside the batch pools
 struct IkSeq {
   int F, J, T;
-  int o_parents, o_tj, o_desc;      // int pool: parents[J], target_joints[T], desc[J * T] (bit 0: strict descendant, bit 1: or self)
+  int o_parents, o_tj, o_masks;     // int pool: parents[J], target_joints[T], then the ancestor relation as bit masks:
+                                    //   jt_strict[J], jt_self[J]: bit t set when joint j is a strict ancestor of / an ancestor of or equal to target t's joint;
+                                    //   ta_strict[T][2], ta_self[T][2]: the same relation per target as 64-bit joint masks (low word, high word)
   long long o_targets;              // double pool: T x F x 3
   long long o_state;                // state buffers: F x (7 J): per frame J quaternions (w x y z) then J translations
 };
@@ -68,11 +70,14 @@ struct IkLds {
   double *e, *y;                    // 3T each
   double* G;                        // 3T + 1 rows of stride gs (odd number of doubles: conflict-free column access); row 3T: residual
   int gs;
+  int* itab;                        // the sequence's index tables (3J + 5T ints: parents | target joints | masks, as in the pool),
+                                    // staged once per step: the chain walks and mask tests would otherwise be dependent L2 round trips
   static IK_HD int stride(int T) { return (3 * T) | 1; }
-  static IK_HD int doubles(int J, int T) { return 51 * J + 6 * T + (3 * T + 1) * stride(T); }
+  static IK_HD int doubles(int J, int T) { return 51 * J + 6 * T + (3 * T + 1) * stride(T) + (3 * J + 5 * T + 1) / 2; }
   IK_HD void carve(double* b, int J, int T) {
     x = b; b += 6 * J; Rl = b; b += 9 * J; Rg = b; b += 9 * J; pg = b; b += 3 * J; es = b; b += 18 * J; dx = b; b += 6 * J;
-    e = b; b += 3 * T; y = b; b += 3 * T; G = b; gs = stride(T);
+    e = b; b += 3 * T; y = b; b += 3 * T; G = b; gs = stride(T); b += (3 * T + 1) * gs;
+    itab = reinterpret_cast<int*>(b);
   }
 };
 
@@ -124,8 +129,10 @@ IK_DEV void ik_step_frame(const IkSeq& s, const int f, const IkParams& P, const 
                           const double* Xin, double* Xout, const IkLds& L) {
   const int J = s.J, T = s.T, F = s.F;
   const int nvar = P.translate ? 6 * J : 3 * J, R = 3 * T, gs = L.gs;
-  const int* parents = ipool + s.o_parents; const int* tj = ipool + s.o_tj; const int* desc = ipool + s.o_desc;
   const double* xin = Xin + s.o_state + (long long)f * 7 * J;
+  IK_FOR(k, 3 * J + 5 * T) L.itab[k] = ipool[s.o_parents + k];      // parents | tj | masks are contiguous in the pool (IkBatch::build)
+  const int* parents = L.itab; const int* tj = parents + J;
+  const int* jt_strict = tj + T; const int* jt_self = jt_strict + J; const int* ta_strict = jt_self + J; const int* ta_self = ta_strict + 2 * T;
   // ---- A: unknowns of this frame and the local rotation matrices (Animation.transforms_local)
   IK_FOR(j, J) {
     quat_to_euler(xin + 4 * j, L.x + 3 * j);
@@ -172,8 +179,15 @@ IK_DEV void ik_step_frame(const IkSeq& s, const int f, const IkParams& P, const 
     if (t2 > t1) continue;
     const double* p1 = L.pg + 3 * tj[t1]; const double* p2 = L.pg + 3 * tj[t2];
     double g[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int j = 0; j < J; ++j) {
-      const int m = desc[j * T + t1] & desc[j * T + t2];
+    // joints above both targets, from the per-target joint masks
+    unsigned long long cs = ((unsigned long long)(unsigned)ta_strict[2 * t1] | ((unsigned long long)(unsigned)ta_strict[2 * t1 + 1] << 32)) &
+                            ((unsigned long long)(unsigned)ta_strict[2 * t2] | ((unsigned long long)(unsigned)ta_strict[2 * t2 + 1] << 32));
+    unsigned long long co = ((unsigned long long)(unsigned)ta_self[2 * t1] | ((unsigned long long)(unsigned)ta_self[2 * t1 + 1] << 32)) &
+                            ((unsigned long long)(unsigned)ta_self[2 * t2] | ((unsigned long long)(unsigned)ta_self[2 * t2 + 1] << 32));
+    if (!P.translate) co = 0;
+    for (unsigned long long rest = cs | co; rest; rest &= rest - 1) {
+      const int j = __builtin_ctzll(rest);
+      const int m = (int)((cs >> j) & 1) | ((int)((co >> j) & 1) << 1);
       if (m & 1) {
         const double d1[3] = {p1[0] - L.pg[3 * j], p1[1] - L.pg[3 * j + 1], p1[2] - L.pg[3 * j + 2]};
         const double d2[3] = {p2[0] - L.pg[3 * j], p2[1] - L.pg[3 * j + 1], p2[2] - L.pg[3 * j + 2]};
@@ -183,7 +197,7 @@ IK_DEV void ik_step_frame(const IkSeq& s, const int f, const IkParams& P, const 
           for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) g[3 * i + k] += c1[i] * c2[k];
         }
       }
-      if ((m & 2) && P.translate)
+      if (m & 2)
         for (int a = 0; a < 3; ++a) {
           const double* u = L.es + 9 * J + 9 * j + 3 * a;
           for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) g[3 * i + k] += u[i] * u[k];
@@ -226,16 +240,16 @@ IK_DEV void ik_step_frame(const IkSeq& s, const int f, const IkParams& P, const 
     const bool rot = v < 3 * J;
     const int j = rot ? v / 3 : (v - 3 * J) / 3;
     double acc[3] = {0, 0, 0};                                   // rotation: sum of d_t x y_t; translation: sum of y_t
-    for (int t = 0; t < T; ++t) {
-      const int m = desc[j * T + t];
+    for (unsigned rest = (unsigned)(rot ? jt_strict[j] : jt_self[j]); rest; rest &= rest - 1) {
+      const int t = __builtin_ctz(rest);
       if (rot) {
-        if (m & 1) {
+        {
           const double d[3] = {L.pg[3 * tj[t]] - L.pg[3 * j], L.pg[3 * tj[t] + 1] - L.pg[3 * j + 1], L.pg[3 * tj[t] + 2] - L.pg[3 * j + 2]};
           double c[3];
           cross3(d, L.y + 3 * t, c);
           acc[0] += c[0]; acc[1] += c[1]; acc[2] += c[2];
         }
-      } else if (m & 2) { acc[0] += L.y[3 * t]; acc[1] += L.y[3 * t + 1]; acc[2] += L.y[3 * t + 2]; }
+      } else { acc[0] += L.y[3 * t]; acc[1] += L.y[3 * t + 1]; acc[2] += L.y[3 * t + 2]; }
     }
     const double* u = L.es + 3 * v;
     L.dx[v] = u[0] * acc[0] + u[1] * acc[1] + u[2] * acc[2];
