@@ -57,6 +57,34 @@ def cpu_baseline(max_workers=8):
                       % (cores, cores - 1, sum(r[1] for r in res), wall)}
 
 
+def contact_net_rate(device, n_videos=128, frames=FRAMES, reps=20):
+    """Second half of BASELINE.json's metric, "contact-net fps": the foot-contact MLP (contact_net.py, PyTorch-ROCm, fp32)
+    on `n_videos` synthetic OpenPose sequences of `frames` frames -- (a) the forward pass alone with the windows resident
+    on the device (one launch sequence over all windows of all videos), (b) the whole detector: host pre-processing,
+    upload, forward, download, vote merge.  Frames per second = videos x frames / time.  Outside the timed region of
+    the physics metric; reported next to it, never part of `value`."""
+    import numpy as np
+    import torch
+    from chd_amd import contact_net as cn
+    torch.manual_seed(0)
+    model = cn.randomize_batchnorm_stats(cn.OpenPoseModel(), seed=0).to(device).eval()
+    vids = [cn.synthetic_keypoints(s, F=frames) for s in range(n_videos)]
+    sync = torch.cuda.synchronize if device.type == 'cuda' else (lambda: None)
+    cn.detect_contacts(vids[:2], model, device)                                   # warm-up: kernels, allocator
+    t0 = time.perf_counter(); labels, _ = cn.detect_contacts(vids, model, device); sync(); t_all = time.perf_counter() - t0
+    x = torch.from_numpy(np.concatenate([cn.make_windows(np.asarray(v, dtype=np.float64)) for v in vids], axis=0)).to(device)
+    with torch.no_grad():
+        model(x); sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            y = model(x)
+        sync(); t_fwd = (time.perf_counter() - t0) / reps
+    nfr = n_videos * frames
+    return {'fps': nfr / t_fwd, 'fps_end_to_end': nfr / t_all, 'unit': 'frames/s', 'videos': n_videos, 'frames': frames,
+            'windows': int(x.shape[0]), 'dtype': 'f32', 'device': str(device),
+            'note': 'fps: forward pass, windows resident on the device; fps_end_to_end: NumPy pre-processing + upload + forward + vote merge'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -212,6 +240,11 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out['contact_net'] = contact_net_rate(torch.device('cuda', local))
+            except Exception as exc:                                               # never lose the physics line over the side metric
+                out['contact_net'] = {'error': '%s: %s' % (type(exc).__name__, exc)}
         print(json.dumps(out), flush=True)
     for bt in batches:
         bt.free()
