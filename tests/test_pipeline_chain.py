@@ -57,3 +57,54 @@ def test_bvh_to_physics_to_bvh(tmp_path):
         assert np.linalg.norm(gp[:, j] - want, axis=1).mean() < np.linalg.norm(before[:, j] - want, axis=1).mean()      # IK pulled the toes to the optimised positions
     back, names2, _ = sk.load_bvh(out)
     assert names2 == NAMES and back.n_frames == motion.n_frames and back.n_joints == motion.n_joints
+
+
+def test_in_memory_pipeline_matches_the_file_chain(tmp_path):
+    """pipeline.run_clips (no intermediate files) against the same chain through sol_out_*.txt: same BVH up to the
+    10 significant digits of the solution file."""
+    import emu
+    import ik_emu
+    from make_apply_golden import CHARACTER
+    from chd_amd import pipeline
+    emu.build()
+    g = np.load(os.path.join(HERE, 'golden', 'apply_golden.npz'))
+    bvh = str(tmp_path / 'in.bvh')
+    open(bvh, 'wb').write(g['bvh_text'].tobytes())
+    character = ar.Character(**CHARACTER)
+    floor = (np.array([0.0, 0.0, 1.0]), np.array([0.0, 0.0, 0.0]))
+
+    class Result:
+        def __init__(self, snaps, stats):
+            self.snapshots = [iof.Solution(dt=1 / 30, num_frames=s['num_frames'], base_lin=s['base_lin'], base_ang_deg=s['base_ang_deg'],
+                                           ee_pos=s['ee_pos'], ee_force=s['ee_force'], contact=s['contact']) for s in snaps]
+            self.stage_status = [int(v) for v in stats[:, 0]]
+
+    class EmuPhys:                                            # the kernel source on the host, one sequence after the other
+        def solve(self, seqs):
+            res = []
+            for q in seqs:
+                e = emu.EmuProblem(q, default_config(max_iter=[60] * 6))
+                e.solve(0, 1)
+                stats, snaps = e.results()
+                res.append(Result(snaps, stats))
+            return res, None
+
+    class EmuIk:
+        def solve(self, seqs):
+            return ik_emu.solve(seqs)
+
+    outs = [str(tmp_path / 'a.bvh'), str(tmp_path / 'b.bvh')]
+    clips = [pipeline.Clip(bvh=bvh, floor=floor, contacts=g['prep_contacts'], out_bvh={'no_dynamics': outs[0], 'durations': str(tmp_path / 'never.bvh')}),
+             pipeline.Clip(bvh=bvh, floor=floor, contacts=g['prep_contacts'], out_bvh={'no_dynamics': outs[1]}, start=1, end=13)]
+    res = pipeline.run_clips(clips, character, EmuPhys(), EmuIk())
+    assert res[0].written == [outs[0]] and res[1].written == [outs[1]] and not os.path.exists(str(tmp_path / 'never.bvh'))      # stage not run: no file
+    assert res[0].seq.F == 14 and res[1].seq.F == 12
+    # the same clip through the text file
+    p = str(tmp_path / 'sol.txt')
+    iof.write_solution(res[0].phys.snapshots[0], p)
+    ref_out = str(tmp_path / 'file_chain.bvh')
+    ar.apply_results_batch([p], [bvh], [ref_out], character, EmuIk(), starts=[0], ends=[14])
+    a = np.array(open(outs[0]).read().split('Time:')[1].split(), dtype=np.float64)
+    b = np.array(open(ref_out).read().split('Time:')[1].split(), dtype=np.float64)
+    assert a.shape == b.shape and np.abs(a - b).max() < 1e-4
+    assert sk.load_bvh(outs[1])[0].n_frames == 12
