@@ -56,3 +56,33 @@ def test_apply_results_on_gpu_matches_reference(tmp_path):
     a = np.array(got[got.index('Time:') + 5:].split(), dtype=np.float64)
     b = np.array(ref[ref.index('Time:') + 5:].split(), dtype=np.float64)
     assert got[:got.index('MOTION')] == ref[:ref.index('MOTION')] and np.abs(a - b).max() <= 2e-6
+
+
+def test_in_memory_pipeline_on_gpu(tmp_path):
+    """pipeline.run_clips with both HIP libraries: BVH + floor + contacts in, BVH out, no intermediate files."""
+    torch = pytest.importorskip('torch')
+    if not torch.cuda.is_available():
+        pytest.skip('needs an MI355X')
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    from make_apply_golden import CHARACTER
+    from chd_amd import apply_results as ar
+    from chd_amd import pipeline
+    from chd_amd import skeleton_io as sk
+    from chd_amd.ik_backproject import IkBackProject
+    from chd_amd.phys_optim import PhysOptim, default_config
+    g = np.load(os.path.join(os.path.dirname(GOLD), 'apply_golden.npz'))
+    bvh = str(tmp_path / 'in.bvh')
+    open(bvh, 'wb').write(g['bvh_text'].tobytes())
+    floor = (np.array([0.0, 0.0, 1.0]), np.array([0.0, 0.0, 0.0]))
+    outs = [str(tmp_path / ('c%d.bvh' % k)) for k in range(4)]
+    clips = [pipeline.Clip(bvh=bvh, floor=floor, contacts=g['prep_contacts'], out_bvh={'no_dynamics': o}) for o in outs]
+    phys = PhysOptim(device=0, config=default_config(max_iter=[60] * 6))
+    try:
+        res = pipeline.run_clips(clips, ar.Character(**CHARACTER), phys, IkBackProject(device=0))
+    finally:
+        phys.close()
+    for r, o in zip(res, outs):
+        assert r.phys.stage_status[0] == 0 and r.written == [o]
+        assert sk.load_bvh(o)[0].n_frames == 14
+    assert open(outs[0]).read() == open(outs[3]).read()              # identical clips, identical files
