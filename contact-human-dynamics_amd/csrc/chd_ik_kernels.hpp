@@ -174,9 +174,11 @@ IK_DEV void ik_step_frame(const IkSeq& s, const int f, const IkParams& P, const 
   //         es[3j+a] x (p_target - p_j) if j is a strict ancestor of the target; column of translation unknown (j, a): es[3J+3j+a]
   //         if j is an ancestor or the target itself.  One 3 x 3 block of G per pair of targets (lower triangle of blocks).
   const double lam = P.damping * (1.0 / (1.0 + 0.001));
-  IK_FOR(idx, T * T) {
-    const int t1 = idx / T, t2 = idx % T;
-    if (t2 > t1) continue;
+  IK_FOR(idx, T * (T + 1) / 2) {                                // (t1, t2 <= t1): one pass of the workgroup for T <= 15
+    int t1 = (int)((std::sqrt(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
+    while (t1 * (t1 + 1) / 2 > idx) --t1;
+    while ((t1 + 1) * (t1 + 2) / 2 <= idx) ++t1;
+    const int t2 = idx - t1 * (t1 + 1) / 2;
     const double* p1 = L.pg + 3 * tj[t1]; const double* p2 = L.pg + 3 * tj[t2];
     double g[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     // joints above both targets, from the per-target joint masks
