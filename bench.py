@@ -80,9 +80,19 @@ def contact_net_rate(device, n_videos=128, frames=FRAMES, reps=20):
             y = model(x)
         sync(); t_fwd = (time.perf_counter() - t0) / reps
     nfr = n_videos * frames
-    return {'fps': nfr / t_fwd, 'fps_end_to_end': nfr / t_all, 'unit': 'frames/s', 'videos': n_videos, 'frames': frames,
-            'windows': int(x.shape[0]), 'dtype': 'f32', 'device': str(device),
-            'note': 'fps: forward pass, windows resident on the device; fps_end_to_end: NumPy pre-processing + upload + forward + vote merge'}
+    out = {'fps': nfr / t_fwd, 'fps_end_to_end': nfr / t_all, 'unit': 'frames/s', 'videos': n_videos, 'frames': frames,
+           'windows': int(x.shape[0]), 'dtype': 'f32', 'device': str(device),
+           'note': 'fps: forward pass, windows resident on the device; fps_end_to_end: NumPy pre-processing + upload + forward + vote merge; '
+                   'fps_end_to_end_device_ops: the same with gap interpolation, windowing and vote merge as tensor ops on the device'}
+    try:                                                                          # device-side pre/post-processing
+        cn.detect_contacts_device(vids[:2], model, device)
+        t0 = time.perf_counter(); labels_d, _ = cn.detect_contacts_device(vids, model, device); sync(); t_dev = time.perf_counter() - t0
+        out['fps_end_to_end_device_ops'] = nfr / t_dev
+        out['device_ops_labels_equal'] = bool(all(np.array_equal(a, b) for a, b in zip(labels, labels_d)))
+    except Exception as exc:
+        out['fps_end_to_end_device_ops'] = None
+        out['device_ops_error'] = '%s: %s' % (type(exc).__name__, exc)
+    return out
 
 
 def main():

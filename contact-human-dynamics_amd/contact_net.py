@@ -163,6 +163,90 @@ def vote_merge(pred, window_size=WINDOW_SIZE, pred_size=PRED_SIZE):
 
 
 # ---------------------------------------------------------------------------------------------
+# the same pre- / post-processing as tensor ops on the device: V videos at once, float64 like the
+# reference's NumPy code and operation by operation in its order, so the windows are bit-identical to `make_windows`
+# ---------------------------------------------------------------------------------------------
+def fill_low_confidence_device(op, thresh=CONF_THRESH):
+    """`fill_low_confidence` for a V x F x J x 3 float64 tensor.  Neighbouring confident frames come from index scans
+    (cummax / cummin over frame numbers: integers, exact); the reference's accumulated interpolation weight
+    (`cur += step` once per frame of a gap) is reproduced by a loop over the position inside the gap -- as long as the
+    longest gap, elementwise over all videos and joints -- because a parallel prefix sum would round differently."""
+    V, F, J = op.shape[0], op.shape[1], op.shape[2]
+    xy, conf = op[..., :2], op[..., 2]
+    good = ~(conf < thresh)
+    t = torch.arange(F, device=op.device).view(1, F, 1).expand(V, F, J)
+    prev = torch.cummax(torch.where(good, t, torch.full_like(t, -1)), dim=1).values
+    nxt = torch.flip(torch.cummin(torch.flip(torch.where(good, t, torch.full_like(t, F)), dims=[1]), dim=1).values, dims=[1])
+    bad = ~good
+    has_prev, has_next = prev >= 0, nxt < F
+    a = torch.gather(xy, 1, prev.clamp(min=0).unsqueeze(-1).expand(V, F, J, 2))          # value at the previous confident frame
+    b = torch.gather(xy, 1, nxt.clamp(max=F - 1).unsqueeze(-1).expand(V, F, J, 2))       # ... at the next one
+    inside = bad & has_prev & has_next
+    r = torch.where(inside, t - prev, torch.zeros_like(t))                                 # 1, 2, ... inside a gap
+    step = 1.0 / torch.where(inside, nxt - prev, torch.ones_like(t)).to(torch.float64)
+    cur = step.clone()
+    w = torch.where(r == 1, cur, torch.zeros_like(cur))
+    for q in range(2, int(r.max().item()) + 1):
+        cur = cur + step
+        w = torch.where(r == q, cur, w)
+    w = w.unsqueeze(-1)
+    interp = (1.0 - w) * a + w * b
+    new_xy = torch.where(inside.unsqueeze(-1), interp, xy)
+    new_xy = torch.where((bad & ~has_prev & has_next).unsqueeze(-1), b, new_xy)           # gap at the start: copy the first confident frame
+    new_xy = torch.where((bad & has_prev & ~has_next).unsqueeze(-1), a, new_xy)           # gap at the end: copy the last one
+    return torch.cat([new_xy, conf.unsqueeze(-1)], dim=-1)
+
+
+def make_windows_device(op, dimensions=(1920, 1080), window_size=WINDOW_SIZE):
+    """V x F x 25 x 3 float64 tensor of raw detections -> V x (F - window_size + 1) x window_size x 13 x 3 float32, the
+    values `make_windows` produces for every video."""
+    op = op.to(torch.float64).clone()
+    op[..., :2] *= float(TRAIN_DIM[0]) / dimensions[0]
+    op = fill_low_confidence_device(op)
+    op[..., :2] /= TRAIN_NORMALIZATION
+    if op.shape[1] - 2 * (window_size // 2) <= 0:
+        raise ValueError('video shorter than one window')
+    win = op.unfold(1, window_size, 1).permute(0, 1, 4, 2, 3).contiguous()               # V x nwin x W x 25 x 3
+    mid = window_size // 2
+    root = win[:, :, mid, OP_ROOT_JOINT, :2].clone()
+    win[..., :2] -= root[:, :, None, None, :]
+    win[:, :, mid, OP_ROOT_JOINT, :2] = root
+    return win[:, :, :, OP_LOWER_JOINTS, :].to(torch.float32)
+
+
+def vote_merge_device(pred, window_size=WINDOW_SIZE, pred_size=PRED_SIZE):
+    """V x B x pred_size x 4 boolean window predictions -> V x F x 4 int64 labels (`vote_merge` per video; integer sums)."""
+    V, B = pred.shape[0], pred.shape[1]
+    n = B + 2 * (pred_size // 2)
+    votes = torch.zeros((V, n, 4), dtype=torch.int64, device=pred.device)
+    for k in range(pred_size):
+        votes[:, k:k + B] += pred[:, :, k, :].to(torch.int64)
+    thresh = torch.full((n,), -(-(pred_size + 1) // 2), dtype=torch.int64)            # votes >= (pred_size + 1) / 2 for integer votes
+    for off in range(pred_size - 1):
+        thresh[off] = (off // 2) + 1
+        thresh[-1 - off] = (off // 2) + 1
+    labels = (votes >= thresh.to(pred.device).view(1, n, 1)).to(torch.int64)
+    pad = (window_size - pred_size) // 2
+    return torch.cat([labels[:, :1].expand(V, pad, 4), labels, labels[:, -1:].expand(V, pad, 4)], dim=1)
+
+
+@torch.no_grad()
+def detect_contacts_device(videos, model, device, dimensions=(1920, 1080)):
+    """`detect_contacts` with the pre- and post-processing on the device: the raw detections are uploaded once (padded
+    to the longest video as there), labels come back.  Same labels, bit for bit."""
+    model = model.to(device).eval()
+    fmax = max(v.shape[0] for v in videos)
+    raw = np.stack([np.concatenate([np.asarray(v, dtype=np.float64), np.repeat(np.asarray(v, dtype=np.float64)[-1:], fmax - v.shape[0], axis=0)], axis=0)
+                    for v in videos], axis=0)
+    x = make_windows_device(torch.from_numpy(raw).to(device), dimensions)
+    V, B = x.shape[0], x.shape[1]
+    logits = model(x.view(V * B, *x.shape[2:]))
+    margin = float(logits.abs().min().item())
+    labels = vote_merge_device(OpenPoseModel.prediction(logits).view(V, B, *logits.shape[1:])).cpu().numpy()
+    return [labels[k, :v.shape[0]] for k, v in enumerate(videos)], margin
+
+
+# ---------------------------------------------------------------------------------------------
 # inference
 # ---------------------------------------------------------------------------------------------
 def select_device(prefer_gpu=True):

@@ -20,6 +20,7 @@ def test_contact_net_rate_fields():
     r = b.contact_net_rate(torch.device('cpu'), n_videos=3, frames=40, reps=2)
     assert r['unit'] == 'frames/s' and r['fps'] > 0 and r['fps_end_to_end'] > 0
     assert r['windows'] == 3 * (40 - 8) and r['dtype'] == 'f32' and r['videos'] == 3 and r['frames'] == 40
+    assert r['fps_end_to_end_device_ops'] > 0 and r['device_ops_labels_equal'] is True
 
 
 def test_defaults():

@@ -1,7 +1,8 @@
 #!/bin/bash
 # First GPU call of a round (run through gpurun from the repo root; ~6-8 minutes of box time):
 #   1. the hot path's GPU tests and smoke()            -> gpurun_out/start/pytest_gpu.log, smoke.log
-#   2. the IK back-projection row's first GPU run      -> pytest_gpu_next.log, ik_bench.log (+ kernel trace)
+#   2. the rows not yet run on a GPU (IK back-projection, in-memory pipeline, device-side contact pre-processing)
+#                                                      -> pytest_gpu_next.log, ik_bench.log (+ kernel trace)
 #   3. bench.py at its default depth, then with 16 launches in flight (only works while the kernel's scratch stays
 #      <= 4288 B/lane; the wrapper falls back by itself if the runtime refuses)
 # Every step runs under its own timeout so that a hang cannot eat the budget; nothing here reads /root/reference.
