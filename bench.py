@@ -122,10 +122,17 @@ def main():
                    '--warmup', str(args.warmup), '--batch', str(args.batch), '--pipeline', str(depth)]
             if args.no_cpu_baseline:
                 cmd.append('--no-cpu-baseline')
-            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            try:
+                r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+            except subprocess.TimeoutExpired as exc:                       # a hung worker: keep what it had already printed
+                so = exc.stdout.decode() if isinstance(exc.stdout, bytes) else (exc.stdout or '')
+                se = exc.stderr.decode() if isinstance(exc.stderr, bytes) else (exc.stderr or '')
+                r = subprocess.CompletedProcess(cmd, -9, so, 'timed out after 1500 s; ' + se)
             lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
-            if r.returncode == 0 and lines:
+            if lines:                                   # a complete measurement line exists (a later side metric may have failed)
                 print(lines[-1], flush=True)
+                if r.returncode != 0:
+                    sys.stderr.write('bench.py: worker exited with %d after the measurement: %s\n' % (r.returncode, r.stderr[-400:]))
                 return
             sys.stderr.write('bench.py: worker with %d steps in flight failed (exit %d): %s\n' % (depth, r.returncode, r.stderr[-400:]))
             if depth == 1:
@@ -251,9 +258,12 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         if world == 1 and not args.no_cpu_baseline:
+            # the side metric runs after the physics line is safely out: the wrapper keeps the LAST line, so a failure
+            # here (even one that kills the process) cannot cost the physics measurement
+            print(json.dumps(out), flush=True)
             try:
                 out['contact_net'] = contact_net_rate(torch.device('cuda', local))
-            except Exception as exc:                                               # never lose the physics line over the side metric
+            except Exception as exc:
                 out['contact_net'] = {'error': '%s: %s' % (type(exc).__name__, exc)}
         print(json.dumps(out), flush=True)
     for bt in batches:
