@@ -279,15 +279,16 @@ def detect_contacts(videos, model, device, dimensions=(1920, 1080)):
     return out, margin
 
 
-def run_on_directory(data_root, weights_path, out_root=None, dimensions=(1920, 1080), device=None):
+def run_on_directory(data_root, weights_path, out_root=None, dimensions=(1920, 1080), device=None, device_ops=False):
     """Host interface of ``scripts/run_detect_contacts.py``: every sub-directory of ``data_root`` with an
-    ``openpose_result`` folder gets a ``foot_contacts.npy``."""
+    ``openpose_result`` folder gets a ``foot_contacts.npy``.  ``device_ops``: gap interpolation, windowing and vote merge as
+    tensor ops on the device (`detect_contacts_device`; same labels) instead of NumPy on the host."""
     device = device or select_device()
     model = OpenPoseModel()
     model.load_state_dict(torch.load(weights_path, map_location='cpu'))
     names = sorted(d for d in os.listdir(data_root) if os.path.isdir(os.path.join(data_root, d, 'openpose_result')))
     videos = [load_keypoint_dir(os.path.join(data_root, n, 'openpose_result')) for n in names]
-    labels, _ = detect_contacts(videos, model, device, dimensions)
+    labels, _ = (detect_contacts_device if device_ops else detect_contacts)(videos, model, device, dimensions)
     for n, lab in zip(names, labels):
         dst = os.path.join(out_root or data_root, n)
         os.makedirs(dst, exist_ok=True)

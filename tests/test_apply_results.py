@@ -164,3 +164,31 @@ def test_batch_driver_writes_one_bvh_per_video(gold, tmp_path, character):
     assert len(tasks) == 2 and open(outs[0]).read() == open(outs[1]).read()
     m, names, _ = sk.load_bvh(outs[0])
     assert m.n_joints == 20 and m.n_frames == e - s
+
+
+def test_bvh_round_trip_on_random_trees(tmp_path):
+    """Writer -> reader on random joint trees (any branching, leaves anywhere in depth-first order): hierarchy exact, offsets
+    and root translations to the '%f' digits, rotations to 1e-6."""
+    rng = np.random.default_rng(42)
+    for case in range(8):
+        J = int(rng.integers(1, 24))
+        parents = [-1]
+        for j in range(1, J):                                   # depth-first order: the parent is the previous joint or one of its ancestors
+            cand = [j - 1]
+            while parents[cand[-1]] >= 0:
+                cand.append(parents[cand[-1]])
+            parents.append(int(rng.choice(cand)))
+        F = int(rng.integers(1, 6))
+        offsets = np.round(rng.normal(size=(J, 3)) * 20, 4); offsets[0] = 0
+        eul = rng.uniform(-80, 80, size=(F, J, 3))              # away from the +-90 degree singularity of the middle angle
+        pos = np.repeat(offsets[None], F, axis=0); pos[:, 0] = np.round(rng.normal(size=(F, 3)) * 50, 4)
+        m = sk.Motion(sk.quat_from_euler(np.radians(eul), order='zyx', world=False), pos, np.tile([1.0, 0, 0, 0], (J, 1)), offsets, np.array(parents))
+        names = ['j%d' % k for k in range(J)]
+        p = str(tmp_path / ('t%d.bvh' % case))
+        sk.save_bvh(p, m, names, frametime=0.04)
+        back, names2, ft = sk.load_bvh(p)
+        assert names2 == names and list(back.parents) == parents and abs(ft - 0.04) < 1e-9
+        assert np.abs(back.offsets - offsets).max() < 1e-6 and np.abs(back.positions[:, 0] - pos[:, 0]).max() < 1e-6
+        assert np.array_equal(back.positions[:, 1:], np.repeat(back.offsets[None, 1:], F, axis=0))
+        assert _same_rotation(back.rotations, m.rotations, 1e-6)
+        assert np.abs(sk.positions_global(back) - sk.positions_global(m)).max() < 1e-3

@@ -140,3 +140,36 @@ def test_device_preprocessing_on_gpu():
     a, _ = cn.detect_contacts(vids, model, dev)
     b, _ = cn.detect_contacts_device(vids, model, dev)
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_directory_interface_json_in_npy_out(tmp_path):
+    """run_detect_contacts (scripts/run_detect_contacts.py): OpenPose JSON directories in, foot_contacts.npy (F x 4 ints,
+    [l_heel, l_toe, r_heel, r_toe]) out; frames without a detected person are all-zero detections
+    (openpose_utils.py:60-63); host and device-op pre-processing write the same labels."""
+    import json
+    from chd_amd import run_detect_contacts as cli
+    vids = {'clipA': cn.synthetic_keypoints(3, F=30), 'clipB': cn.synthetic_keypoints(4, F=45)}
+    for name, kp in vids.items():
+        d = tmp_path / 'data' / name / 'openpose_result'
+        os.makedirs(d)
+        for f in range(kp.shape[0]):
+            people = [] if (name == 'clipA' and f in (4, 5)) else [{'pose_keypoints_2d': [float(x) for x in kp[f].reshape(-1)]}]
+            json.dump({'version': 1.3, 'people': people}, open(d / ('%s_%012d_keypoints.json' % (name, f)), 'w'))
+        open(tmp_path / 'data' / name / 'not_a_frame.txt', 'w').write('x')
+    os.makedirs(tmp_path / 'data' / 'no_openpose_here')
+    torch.manual_seed(0)
+    model = cn.randomize_batchnorm_stats(cn.OpenPoseModel(), seed=0)
+    w = str(tmp_path / 'op_only_weights.pth')
+    torch.save(model.state_dict(), w)
+    assert cli.main(['--data', str(tmp_path / 'data'), '--weights', w]) == 0
+    first = {n: np.load(tmp_path / 'data' / n / 'foot_contacts.npy') for n in vids}
+    assert cli.main(['--data', str(tmp_path / 'data'), '--weights', w, '--device-ops']) == 0
+    kpA = vids['clipA'].copy(); kpA[4:6] = 0.0
+    want, _ = cn.detect_contacts([kpA, vids['clipB']], model, torch.device('cpu'))
+    for (n, kp), ref in zip(vids.items(), want):
+        got = np.load(tmp_path / 'data' / n / 'foot_contacts.npy')
+        assert got.shape == (kp.shape[0], 4) and got.dtype == np.int64 and set(np.unique(got)) <= {0, 1}
+        assert np.array_equal(got, first[n])
+        if cn.select_device().type == 'cpu':
+            assert np.array_equal(got, ref)
+    assert not os.path.exists(tmp_path / 'data' / 'no_openpose_here' / 'foot_contacts.npy')
