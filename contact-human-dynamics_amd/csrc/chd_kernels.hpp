@@ -77,6 +77,15 @@ namespace chd {
 #define CHD_DELTA_W0 1e-4
 #define CHD_DELTA_W_MIN 1e-9
 #define CHD_DELTA_W_MAX 1e8
+// Inertia handling, OFF in round 1's validated build (the preprocessed source is unchanged by this block).  When a no-pivot
+// LDL^T meets a pivot of unexpected sign it substitutes +-1e-10 and carries on; the step computed from that modified
+// matrix is almost always rejected by the line search, but in ~2 % of sequences it is accepted, and then the kernel
+// and the oracle -- whose garbage differs -- part ways (found with the host emulation, sequence seed 31).
+// With 1, such a factorisation counts as a failed attempt (dw x 10), as IPOPT's inertia correction does.  The oracle
+// has the same switch (IpmOptions::inertia_retry); tests/test_host_emu.py checks the pair in lockstep.
+#ifndef CHD_INERTIA_RETRY
+#define CHD_INERTIA_RETRY 0
+#endif
 #define CHD_DELTA_C 1e-9
 #define CHD_CONSTR_VIOL_TOL 1e-4
 #define CHD_MAX_BACKTRACK 3
@@ -2558,6 +2567,10 @@ CHD_NOINLINE CHD_DEV void solve_stage(Ctx& c, StageResult& res) {
       PAR_FOR(i, m) diag[pos_row[i]] = -D[i];
       CHD_SYNC();
       kfactor(c, diag, sign); ++n_factor;
+#if CHD_INERTIA_RETRY
+      // a pivot of unexpected sign was replaced (wrong inertia): more damping instead of a step from the modified matrix
+      if (block_sum(c, CHD_TID == 0 ? (double)c.n_bad_pivots : 0.0) > 0.0) { dw *= 10.0; if (dw > CHD_DELTA_W_MAX) break; continue; }
+#endif
       ksolve(c, rhs, sol, diag, 1);
       PAR_FOR(j, n) dx[j] = sol[pos_var[j]];
       PAR_FOR(i, m) dlam[i] = sol[pos_row[i]];

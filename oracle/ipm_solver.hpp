@@ -43,6 +43,7 @@ struct IpmOptions {
   bool use_soc = true;
   int max_attempts = 12;
   bool verbose = false;
+  bool inertia_retry = false;   // a factorisation that had to replace a pivot counts as a failed attempt (see chd_kernels.hpp, CHD_INERTIA_RETRY)
 };
 
 struct IpmResult {
@@ -388,6 +389,7 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
         K.add(pos_row[i], pos_row[i], -D[i]);
       }
       K.factor(); ++res.n_factor;
+      if (opt.inertia_retry && K.n_bad_pivots > 0) { dw *= 10.0; if (dw > opt.delta_w_max) break; continue; }
       K.solve(rhs.data(), sol.data(), 1);      // one step of iterative refinement
       for (int j = 0; j < n; ++j) dx[j] = sol[pos_var[j]];
       for (int i = 0; i < m; ++i) dlam[i] = sol[pos_row[i]];

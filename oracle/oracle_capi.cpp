@@ -6,9 +6,10 @@
 
 using namespace orc;
 
-static int g_verbose = 0;
+static int g_verbose = 0, g_inertia_retry = 0;
 extern "C" {
 void orc_set_verbose(int v) { g_verbose = v; }
+void orc_set_inertia_retry(int v) { g_inertia_retry = v; }
 
 struct orc_seq_in {
   int F;
@@ -122,6 +123,7 @@ int orc_solve_stage(void* h, int stage, int max_iter, double* stats /*8*/) {
   opt.max_iter = max_iter > 0 ? max_iter : p->cfg.max_iter[stage];
   opt.ref_tol = p->cfg.tol;
   opt.verbose = g_verbose != 0;
+  opt.inertia_retry = g_inertia_retry != 0;
   IpmResult r = ipm_solve(*p, opt);
   if (stats) {
     stats[0] = r.iters; stats[1] = r.kkt_error; stats[2] = r.constr_viol; stats[3] = r.objective;

@@ -16,12 +16,17 @@ from chd_amd.phys_capi import ChdConfig, ChdSeqIn, PD, default_config, seq_to_c 
 _LIB = None
 
 
+# CHD_EMU_VARIANT=inertia builds / loads the emulation with -DCHD_INERTIA_RETRY=1 (chd_kernels.hpp); one variant per process
+_VARIANT = os.environ.get('CHD_EMU_VARIANT', '')
+
+
 def build(force=False):
-    so = os.path.join(_HERE, 'libchd_emu.so')
+    so = os.path.join(_HERE, 'libchd_emu%s.so' % ('_' + _VARIANT if _VARIANT else ''))
     csrc = os.path.join(_ROOT, 'contact-human-dynamics_amd', 'csrc')
     srcs = [os.path.join(_HERE, 'emu.cpp')] + [os.path.join(csrc, f) for f in ('chd_kernels.hpp', 'chd_model.hpp', 'chd_device.hpp')]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-Wno-unused-variable', '-o', so, srcs[0]])
+        flags = ['-DCHD_INERTIA_RETRY=1'] if _VARIANT == 'inertia' else []
+        subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-Wno-unused-variable'] + flags + ['-o', so, srcs[0]])
     return so
 
 

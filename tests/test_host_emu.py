@@ -14,6 +14,7 @@ from chd_amd.synth import make_walk
 from common import oracle_run, rel_max, snapshot_errors
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'host_emu'))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope='module')
@@ -136,3 +137,48 @@ def test_kkt_structure_tables(emu):
     e.solve(0, 4)
     stats = e.results()['stats'] if isinstance(e.results(), dict) else None
     assert stats is None or all(int(s[0]) in (0, -1, -2) for s in stats)
+
+
+def test_inertia_retry_switch_keeps_kernel_and_oracle_in_lockstep():
+    """A sequence on which the default build and the oracle part ways in the duration stage (seed 31: at its second
+    iteration the factorisation meets a pivot of unexpected sign, replaces it, and the oracle's line search accepts the
+    resulting step while the kernel source's -- NaN -- is rejected).  With the inertia switch on in both (kernel source
+    compiled with -DCHD_INERTIA_RETRY=1, IpmOptions::inertia_retry), such a factorisation is a failed attempt and the two
+    stay in lockstep to 1e-8 again.  The switch is off in round 1's GPU-validated build."""
+    import subprocess
+    code = r"""
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests')); sys.path.insert(0, os.path.join(%r, 'tests', 'host_emu'))
+import chd_amd
+from chd_amd.phys_capi import default_config
+from chd_amd.synth import make_walk
+from chd_amd.io_formats import Solution
+from common import oracle_run, snapshot_errors
+from oracle import oracle as O
+import emu
+emu.build()
+O.lib().orc_set_inertia_retry(int(os.environ.get('CHD_EMU_VARIANT', '') == 'inertia'))
+caps = [300] * 6
+seq = make_walk(seed=31, F=90, randomize=True)
+e = emu.EmuProblem(seq, default_config(max_iter=caps))
+e.solve(0, 4)
+stats, snaps = e.results()
+ostats, osnaps = oracle_run(seq, caps)
+same = all(int(stats[st, 0]) == ostats[st][0] and int(stats[st, 1]) == ostats[st][1] for st in range(5))
+worst = 0.0
+for k in range(3):
+    s = snaps[k]
+    sol = Solution(dt=seq.dt, num_frames=s['num_frames'], base_lin=s['base_lin'], base_ang_deg=s['base_ang_deg'], ee_pos=s['ee_pos'], ee_force=s['ee_force'], contact=s['contact'])
+    err = snapshot_errors(sol, osnaps[k])
+    worst = max(worst, err['base_lin'], err['base_ang_deg'], err['ee_pos'], err['ee_force'])
+print('RESULT', int(same), '%%.3e' %% worst, [int(stats[st, 1]) for st in range(5)])
+""" % (ROOT, ROOT, ROOT)
+    out = {}
+    for variant in ('', 'inertia'):
+        env = dict(os.environ, CHD_EMU_VARIANT=variant)
+        r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=900)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith('RESULT')]
+        assert line, r.stderr[-800:]
+        out[variant] = line[0].split()
+    assert out['inertia'][1] == '1' and float(out['inertia'][2]) < 1e-8, out          # lockstep with the switch
+    assert out[''][1] == '0' or float(out[''][2]) < 1e-8, out                            # documents the default build's behaviour on this sequence
