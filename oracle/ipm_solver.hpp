@@ -43,7 +43,7 @@ struct IpmOptions {
   bool use_soc = true;
   int max_attempts = 12;
   bool verbose = false;
-  bool inertia_retry = false;   // a factorisation that had to replace a pivot counts as a failed attempt (see chd_kernels.hpp, CHD_INERTIA_RETRY)
+  bool inertia_retry = true;    // a factorisation that had to replace a pivot counts as a failed attempt (see chd_kernels.hpp, CHD_INERTIA_RETRY)
 };
 
 struct IpmResult {

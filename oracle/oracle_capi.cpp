@@ -6,7 +6,7 @@
 
 using namespace orc;
 
-static int g_verbose = 0, g_inertia_retry = 0;
+static int g_verbose = 0, g_inertia_retry = 1;
 extern "C" {
 void orc_set_verbose(int v) { g_verbose = v; }
 void orc_set_inertia_retry(int v) { g_inertia_retry = v; }

@@ -16,7 +16,7 @@ from chd_amd.phys_capi import ChdConfig, ChdSeqIn, PD, default_config, seq_to_c 
 _LIB = None
 
 
-# CHD_EMU_VARIANT=inertia builds / loads the emulation with -DCHD_INERTIA_RETRY=1 (chd_kernels.hpp); one variant per process
+# CHD_EMU_VARIANT=noinertia builds / loads the emulation with -DCHD_INERTIA_RETRY=0 (the round-1 GPU build's behaviour, chd_kernels.hpp); one variant per process
 _VARIANT = os.environ.get('CHD_EMU_VARIANT', '')
 
 
@@ -25,7 +25,7 @@ def build(force=False):
     csrc = os.path.join(_ROOT, 'contact-human-dynamics_amd', 'csrc')
     srcs = [os.path.join(_HERE, 'emu.cpp')] + [os.path.join(csrc, f) for f in ('chd_kernels.hpp', 'chd_model.hpp', 'chd_device.hpp')]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        flags = ['-DCHD_INERTIA_RETRY=1'] if _VARIANT == 'inertia' else []
+        flags = ['-DCHD_INERTIA_RETRY=0'] if _VARIANT == 'noinertia' else []
         subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-Wno-unused-variable'] + flags + ['-o', so, srcs[0]])
     return so
 

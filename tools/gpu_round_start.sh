@@ -6,8 +6,8 @@
 #   3. bench.py at its default depth, then with 16 launches in flight (only works while the kernel's scratch stays
 #      <= 4288 B/lane; the wrapper falls back by itself if the runtime refuses)
 # Every step runs under its own timeout so that a hang cannot eat the budget; nothing here reads /root/reference.
-# Round 2: after this script, rebuild with -DCHD_INERTIA_RETRY=1 (+ orc_set_inertia_retry(1) in tests/common.py), re-run
-# pytest -m gpu and tests/tools/gpu_long.py with seed 31 added, regenerate tests/golden/phys_golden.npz, then make it the default.
+# Round 2: the inertia retry (CHD_INERTIA_RETRY) went in after round 1's last GPU run -- step 1 below is its
+# first GPU validation; add seeds 31, 73, 77, 105, 107, 113 (tilts as in profiles/r01_parity_cpu_emulation.md) to gpu_long.py.
 set -x
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/start
