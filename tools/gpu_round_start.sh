@@ -14,6 +14,7 @@ OUT=$R/gpurun_out/start
 mkdir -p $OUT
 cd $R
 timeout 900 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
+timeout 600 python tests/tools/gpu_parity_holes.py > $OUT/parity_holes.log 2>&1; tail -12 $OUT/parity_holes.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log
 timeout 300 python -m pytest tests -x -q -m gpu_next > $OUT/pytest_gpu_next.log 2>&1; tail -5 $OUT/pytest_gpu_next.log
 timeout 300 python tests/tools/ik_bench.py 128 90 > $OUT/ik_bench.log 2>&1; tail -3 $OUT/ik_bench.log
