@@ -26,5 +26,5 @@ for (seed, tilt), sq, r in zip(CASES, seqs, res):
     worst = max(worst, w if seed != 92 else 0.0)
     print('seed %3d tilt %.0f: gpu %s oracle %s equal %s max rel-L2 %.2e' % (seed, tilt, list(zip(r.stage_status, r.stage_iters))[:len(ostats)],
                                                                               [(a, b) for a, b, *_ in ostats], same, w))
-print('worst (without seed 92) %.2e; bad pivots reported by the batch: %s' % (worst, stats.get('phase_ms') is not None))
+print('worst (without seed 92) %.2e; %d IPM iterations, kernel %.0f ms' % (worst, stats['total_iters'], stats['kernel_ms'][0]))
 assert worst < 1e-3
