@@ -2636,8 +2636,10 @@ CHD_NOINLINE CHD_DEV void solve_stage(Ctx& c, StageResult& res) {
             double v = st[i];
             if (!(fl[i] & RF_EQ)) {
               v = st[i] + sol2[pos_row[i]] / Sig[i];
-              if ((fl[i] & RF_L) && v - l[i] < (1 - tau) * (s[i] - l[i])) inside = 0.0;
-              if ((fl[i] & RF_U) && u[i] - v < (1 - tau) * (u[i] - s[i])) inside = 0.0;
+              // (1 - 1e-8): a slack that limited the step (alpha = a_pr) sits exactly on this boundary and the correction leaves it
+              // there to rounding, which made the test a coin flip between implementations (seed 219)
+              if ((fl[i] & RF_L) && v - l[i] < (1 - 1e-8) * (1 - tau) * (s[i] - l[i])) inside = 0.0;
+              if ((fl[i] & RF_U) && u[i] - v < (1 - 1e-8) * (1 - tau) * (u[i] - s[i])) inside = 0.0;
             }
             ss2[i] = v;
           }

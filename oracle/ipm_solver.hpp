@@ -440,8 +440,9 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
             ss2[i] = st[i];
             if (eq[i]) continue;
             ss2[i] = st[i] + sol2[pos_row[i]] / Sigma[i];
-            if (hasL[i] && ss2[i] - l[i] < (1 - tau) * (s[i] - l[i])) inside = false;
-            if (hasU[i] && u[i] - ss2[i] < (1 - tau) * (u[i] - s[i])) inside = false;
+            // (1 - 1e-8): see the same test in chd_kernels.hpp (a slack that limited the step sits exactly on this boundary)
+            if (hasL[i] && ss2[i] - l[i] < (1 - 1e-8) * (1 - tau) * (s[i] - l[i])) inside = false;
+            if (hasU[i] && u[i] - ss2[i] < (1 - 1e-8) * (1 - tau) * (u[i] - s[i])) inside = false;
           }
           if (inside) {
             double fs = 0;

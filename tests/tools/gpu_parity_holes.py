@@ -11,7 +11,7 @@ from chd_amd.phys_optim import PhysOptim, default_config  # noqa: E402
 from chd_amd.synth import make_walk  # noqa: E402
 from common import oracle_run, snapshot_errors  # noqa: E402  (the oracle is the checker)
 
-CASES = [(31, 0.0), (73, 5.0), (77, 2.0), (105, 3.0), (106, 3.0), (107, 3.0), (113, 3.0), (92, 0.0), (9, 0.0), (30, 0.0)]
+CASES = [(31, 0.0), (73, 5.0), (77, 2.0), (105, 3.0), (106, 3.0), (107, 3.0), (113, 3.0), (92, 0.0), (9, 0.0), (30, 0.0), (237, 8.0)]      # (219 is a 60-frame case: see profiles/r01_parity_cpu_emulation.md)
 caps = [300] * 6
 seqs = [make_walk(seed=s, F=90, randomize=True, tilt_deg=t) for s, t in CASES]
 solver = PhysOptim(0, default_config(max_iter=caps))
