@@ -6,8 +6,9 @@
 #   3. bench.py at its default depth, then with 16 launches in flight (only works while the kernel's scratch stays
 #      <= 4288 B/lane; the wrapper falls back by itself if the runtime refuses)
 # Every step runs under its own timeout so that a hang cannot eat the budget; nothing here reads /root/reference.
-# Round 2: the inertia retry (CHD_INERTIA_RETRY) went in after round 1's last GPU run -- step 1 below is its
-# first GPU validation; add seeds 31, 73, 77, 105, 107, 113 (tilts as in profiles/r01_parity_cpu_emulation.md) to gpu_long.py.
+# Round 2: the inertia retry (CHD_INERTIA_RETRY) and the 1e-8 margin in the correction step's boundary test
+# went in after round 1's last GPU run -- step 1 below is their first GPU validation (-DCHD_INERTIA_RETRY=0 + reverting the margin
+# gives the measured round-1 kernel); add seeds 31, 73, 77, 105, 107, 113 (tilts as in profiles/r01_parity_cpu_emulation.md) to gpu_long.py.
 set -x
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/start
