@@ -20,7 +20,6 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')
 timeout 300 python -m pytest tests -x -q -m gpu_next > $OUT/pytest_gpu_next.log 2>&1; tail -5 $OUT/pytest_gpu_next.log
 timeout 300 python tests/tools/ik_bench.py 128 90 > $OUT/ik_bench.log 2>&1; tail -3 $OUT/ik_bench.log
 timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -c 1500 $OUT/bench_default.json; tail -3 $OUT/bench_default.err
-GPU_MAX_HW_QUEUES=16 timeout 600 python bench.py --pipeline 16 --steps 32 --no-cpu-baseline > $OUT/bench_16.json 2> $OUT/bench_16.err; tail -c 1500 $OUT/bench_16.json; tail -3 $OUT/bench_16.err
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/ik_trace -o ik -- python $R/tests/tools/ik_bench.py 128 90 > $OUT/ik_trace.log 2>&1
 for f in $(find $OUT/ik_trace -name "*kernel_stats*"); do head -4 $f; done
