@@ -3,11 +3,14 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one full staged solve (stages 1.1, 1.2, 2.1, 2.2, 3 and the stage-4 fallback where
-stage 3 fails; phys_optim.cpp:544-749, reference iteration caps) of one batch of 128 synthetic
-90-frame sequences per GPU (BASELINE.json configs[1]; seeds rank*128 .. rank*128+127), with the
-inputs and the structure tables already resident in HBM.  N > 1: one process per GPU (launched by
-torch.distributed.run), sequences are independent so there is no data-path collective; weak scaling.
+One "step" = one full staged solve (stages 1.1, 1.2, 2.1, 2.2, 3 and the stage-4 fallback where stage 3 fails;
+phys_optim.cpp:544-749, reference iteration caps and tolerance, no stall guard) of one batch of 128 synthetic 90-frame
+sequences (BASELINE.json configs[1]).  The K steps of the timed region are K DIFFERENT batches -- seeds
+rank*K*128 .. (rank+1)*K*128 - 1, a one-GPU slice of configs[2] -- handed to the library in one call: inputs and
+structure tables are resident in HBM when the clock starts, and ONE persistent launch (one resident workgroup per
+compute unit taking sequences from a queue) drains them; one handle, one stream, no replicated batches.
+N > 1: one process per GPU (launched by torch.distributed.run), sequences are independent, so there is no data-path
+collective; weak scaling.
 """
 import argparse
 import json
@@ -18,17 +21,30 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# One HIP stream per step in flight; the runtime multiplexes streams onto this many hardware queues (its default of 4
-# would cap the number of concurrently running launches at 4).  Must be set before the HIP runtime initialises.
-# Every queue gets its own scratch arena sized for the whole device: queues x scratch-bytes-per-lane of the kernel is
-# bounded (measured on MI355X: 16 queues x 4288 B/lane works, 16 x 4400 and 24 x 4288 abort with
-# HSA_STATUS_ERROR_OUT_OF_RESOURCES), hence 12 and not 16 for the present kernel (4400 B/lane).
-DEFAULT_IN_FLIGHT = 12
-os.environ.setdefault('GPU_MAX_HW_QUEUES', str(DEFAULT_IN_FLIGHT))
 
 BATCH = 128
 FRAMES = 90
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector = matrix peak (AMD spec)
+CAPS = [7000, 7000, 7000, 2500, 2000, 7000]
+
+
+def _gen(args):
+    import chd_amd  # noqa: F401
+    from chd_amd.synth import make_walk
+    seed0, n = args
+    return [make_walk(seed=seed0 + i, F=FRAMES, randomize=True) for i in range(n)]
+
+
+def make_sequences(seed0, n, workers):
+    """Seeds seed0 .. seed0 + n - 1 (synth.make_walk is a Python loop over frames: spread over a few processes)."""
+    if workers <= 1 or n < 64:
+        return _gen((seed0, n))
+    chunk = 32
+    parts = [(seed0 + a, min(chunk, n - a)) for a in range(0, n, chunk)]
+    with mp.get_context('fork').Pool(workers) as pool:          # (forked before the HIP runtime is initialised)
+        out = pool.map(_gen, parts)
+    return [s for p in out for s in p]
 
 
 def _cpu_worker(seed):
@@ -39,12 +55,13 @@ def _cpu_worker(seed):
     from common import oracle_run
     seq = make_walk(seed=seed, F=FRAMES, randomize=True)
     t0 = time.time()
-    stats, _ = oracle_run(seq, [7000, 7000, 7000, 2500, 2000, 7000])
+    stats, _ = oracle_run(seq, CAPS)
     return time.time() - t0, sum(s[1] for s in stats)
 
 
 def cpu_baseline(max_workers=8):
-    """Bounded sample of the same workload on the host cores: the first C sequences, one per core."""
+    """Bounded sample of the same workload on the host cores: the first C sequences one per core (all-core rate), whose
+    individual solve times also give the one-core rate."""
     from oracle import oracle
     oracle.build()
     cores = max(1, min(max_workers, os.cpu_count() or 1))
@@ -52,9 +69,53 @@ def cpu_baseline(max_workers=8):
     with mp.get_context('spawn').Pool(cores) as pool:
         res = pool.map(_cpu_worker, list(range(cores)))
     wall = time.time() - t0
-    return {'value': cores / wall, 'unit': 'sequences/s', 'cores': cores, 'kind': 'port',
-            'sample': 'first %d sequences of the workload (seeds 0..%d), one oracle process per core, %d IPM iterations, %.1f s wall'
-                      % (cores, cores - 1, sum(r[1] for r in res), wall)}
+    one_core = len(res) / sum(r[0] for r in res)
+    return {'value': cores / wall, 'unit': 'sequences/s', 'cores': cores, 'kind': 'port', 'value_one_core': one_core,
+            'sample': 'first %d sequences of the workload (seeds 0..%d), one oracle process per core, %d IPM iterations, %.1f s wall; '
+                      'value_one_core = sequences / sum of the per-sequence solve times' % (cores, cores - 1, sum(r[1] for r in res), wall),
+            'note': 'the oracle is this repo\'s dense single-threaded restatement of the same algorithm, not IPOPT(MA57): the reference binary cannot be built here'}
+
+
+def parity_block(results, seqs_first_seed):
+    """HIP results of the bench workload against the committed oracle results (tests/golden/bench_parity_golden.npz, made by
+    tests/golden/make_bench_parity_golden.py with the same caps / tolerance): computed outside the timed region."""
+    import numpy as np
+    path = os.path.join(ROOT, 'tests', 'golden', 'bench_parity_golden.npz')
+    if not os.path.exists(path) or seqs_first_seed != 0:
+        return None
+    g = np.load(path)
+    worst = 0.0; worst_failed = 0.0; n = 0; n_status = 0; n_iters = 0; n_contact = 0; failed = []; above = []
+    for seed in range(min(BATCH, len(results))):
+        key = 's%d_F%d_t000' % (seed, FRAMES)
+        if key + '_status' not in g.files:
+            continue
+        r = results[seed]
+        gs = list(g[key + '_status']); gi = list(g[key + '_iters'])
+        n += 1
+        st_eq = list(r.stage_status[:len(gs)]) == gs
+        n_status += st_eq; n_iters += st_eq and list(r.stage_iters[:len(gi)]) == gi
+        err = 0.0; c_ok = True
+        for k in range(3):
+            sn = r.snapshots[k]
+            for name, val in (('base_lin', sn.base_lin), ('base_ang_deg', sn.base_ang_deg), ('ee_pos', sn.ee_pos), ('ee_force', sn.ee_force)):
+                ref = g['%s_snap%d_%s' % (key, k, name)]
+                if ref.shape != np.asarray(val).shape:
+                    err = float('inf'); continue
+                nr = float(np.linalg.norm(ref))
+                if nr > 0:
+                    err = max(err, float(np.linalg.norm(np.asarray(val) - ref)) / nr)
+            c_ok = c_ok and np.array_equal(np.asarray(sn.contact), g['%s_snap%d_contact' % (key, k)])
+        n_contact += c_ok
+        if any(s != 0 for s in gs):          # a stage failed in the oracle: the iterates end on the merit function's noise floor
+            failed.append(seed); worst_failed = max(worst_failed, err)
+        else:
+            worst = max(worst, err)
+        if err > 1e-3:
+            above.append(seed)
+    return {'against': 'CPU oracle (tests/golden/bench_parity_golden.npz), not IPOPT: the reference binary cannot be built here',
+            'sequences_compared': n, 'worst_rel_l2': worst, 'stage_status_equal': n_status, 'stage_iterations_equal': n_iters,
+            'contact_flags_equal': n_contact, 'sequences_above_1e-3': above,
+            'oracle_stage_failures': failed, 'worst_rel_l2_on_those': worst_failed}
 
 
 def contact_net_rate(device, n_videos=128, frames=FRAMES, reps=20):
@@ -77,7 +138,7 @@ def contact_net_rate(device, n_videos=128, frames=FRAMES, reps=20):
         model(x); sync()
         t0 = time.perf_counter()
         for _ in range(reps):
-            y = model(x)
+            model(x)
         sync(); t_fwd = (time.perf_counter() - t0) / reps
     nfr = n_videos * frames
     out = {'fps': nfr / t_fwd, 'fps_end_to_end': nfr / t_all, 'unit': 'frames/s', 'videos': n_videos, 'frames': frames,
@@ -98,56 +159,32 @@ def contact_net_rate(device, n_videos=128, frames=FRAMES, reps=20):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=2 * DEFAULT_IN_FLIGHT)       # two full rounds of the steps in flight
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=12)
+    ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--batch', type=int, default=BATCH, help=argparse.SUPPRESS)
-    ap.add_argument('--pipeline', type=int, default=DEFAULT_IN_FLIGHT,
-                    help='steps in flight at once, each on its own HIP stream (1 = strictly one batch after the other)')
+    ap.add_argument('--stall-window', type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument('--max-workgroups', type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument('--threads', type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument('--lds-kb', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--no-cpu-baseline', action='store_true', help=argparse.SUPPRESS)
-    ap.add_argument('--worker', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--no-side-metrics', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--worker', action='store_true', help=argparse.SUPPRESS)        # (accepted for old command lines; no effect)
     args = ap.parse_args()
 
-    # Single-GPU runs are measured in a child process: if the HIP runtime aborts while creating the queues / scratch of
-    # the requested number of launches in flight (it does not return an error, it kills the process), the measurement
-    # is repeated with half as many instead of producing no line at all.  (Ranks started by torch.distributed.run are
-    # the workers themselves.)
-    if not args.worker and int(os.environ.get('WORLD_SIZE', '1')) == 1:
-        import subprocess
-        depth = max(1, args.pipeline)
-        while True:
-            env = dict(os.environ)
-            if int(env.get('GPU_MAX_HW_QUEUES', '4')) > depth or depth < DEFAULT_IN_FLIGHT:
-                env['GPU_MAX_HW_QUEUES'] = str(max(4, depth))
-            cmd = [sys.executable, os.path.abspath(__file__), '--worker', '--gpus', str(args.gpus), '--steps', str(args.steps),
-                   '--warmup', str(args.warmup), '--batch', str(args.batch), '--pipeline', str(depth)]
-            if args.no_cpu_baseline:
-                cmd.append('--no-cpu-baseline')
-            try:
-                r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
-            except subprocess.TimeoutExpired as exc:                       # a hung worker: keep what it had already printed
-                so = exc.stdout.decode() if isinstance(exc.stdout, bytes) else (exc.stdout or '')
-                se = exc.stderr.decode() if isinstance(exc.stderr, bytes) else (exc.stderr or '')
-                r = subprocess.CompletedProcess(cmd, -9, so, 'timed out after 1500 s; ' + se)
-            lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
-            if lines:                                   # a complete measurement line exists (a later side metric may have failed)
-                print(lines[-1], flush=True)
-                if r.returncode != 0:
-                    sys.stderr.write('bench.py: worker exited with %d after the measurement: %s\n' % (r.returncode, r.stderr[-400:]))
-                return
-            sys.stderr.write('bench.py: worker with %d steps in flight failed (exit %d): %s\n' % (depth, r.returncode, r.stderr[-400:]))
-            if depth == 1:
-                raise SystemExit(1)
-            depth = max(1, depth // 2)
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    B = args.batch
+    steps = max(1, args.steps)
+    workers = max(1, min(8, (os.cpu_count() or 1) // max(1, world)))
+    seed0 = rank * steps * B
+    seqs = make_sequences(seed0, steps * B, workers)                      # before the HIP runtime exists in this process (fork)
 
     import torch
     import torch.distributed as dist
     import chd_amd  # noqa: F401
     from chd_amd.phys_optim import PhysOptim, default_config
-    from chd_amd.synth import make_batch
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the physics stage has no CPU path')
     torch.cuda.set_device(local)
@@ -160,67 +197,40 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    B = args.batch
-    seqs = make_batch(B, F=FRAMES, seed0=rank * B)
-    # A step is one full staged solve of one batch.  With --pipeline D > 1, D steps are in flight at once: each has its
-    # own solver handle (own HIP stream) and its own device-resident copy of the batch, and is driven by its own host
-    # thread (the C call releases the GIL).  128 workgroups occupy half of the 256 CUs and a launch lasts as long as its
-    # slowest sequence (several times the mean), so many launches must be in flight to keep every CU busy.
-    depth = max(1, min(args.pipeline, max(1, args.steps)))
-    solvers = [PhysOptim(device=local, config=default_config()) for _ in range(depth)]      # reference iteration caps and tol
-    batches = [sv.upload(seqs) for sv in solvers]                                            # inputs + tables -> HBM (not timed)
-    batch, solver = batches[0], solvers[0]
-
-    from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(max_workers=depth)
-
-    def run_steps(n):
-        out = []
-        if depth == 1:
-            for _ in range(n):
-                out.append(batches[0].solve())
-            return out
-        # slot i handles steps i, i + depth, ...: the slots run concurrently
-        def slot(i):
-            return [batches[i].solve() for _ in range(i, n, depth)]
-        for part in pool.map(slot, range(depth)):
-            out.extend(part)
-        return out
-
-    run_steps(args.warmup)
+    cfg = default_config(stall_window=args.stall_window, max_workgroups=args.max_workgroups, threads_per_sequence=args.threads, lds_kilobytes=args.lds_kb)   # reference caps and tol
+    solver = PhysOptim(device=local, config=cfg)
+    batch = solver.upload(seqs)                                           # inputs + tables -> HBM (not timed)
+    if args.warmup > 0:                                                   # W untimed steps: the first W batches
+        wb = solver.upload(seqs[:min(len(seqs), args.warmup * B)])
+        wb.solve(); wb.free()
     barrier()
     t0 = time.perf_counter()
-    stats = run_steps(args.steps)                                        # returns when every step is solved
+    st = batch.solve()                                                    # the K steps: returns when the queue is drained
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = 0.0; alg_bytes = 0.0; iters = 0; nfact = 0; nfall = 0; launches = 0; max_seq_ms = 0.0
-    for st in stats:
-        kernel_ms += st['kernel_ms'][0] + st['kernel_ms'][1]
-        launches += 1 + (1 if st['kernel_ms'][1] > 0 else 0)
-        alg_bytes += st['alg_bytes']; iters += st['total_iters']; nfact += st['total_factorizations']; nfall += st['n_fallback']
-        max_seq_ms = max(max_seq_ms, st['max_seq_ms'])
+    kernel_ms = st['kernel_ms'][0] + st['kernel_ms'][1]
+    alg_bytes = st['alg_bytes']; iters = st['total_iters']; nfact = st['total_factorizations']
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        agg = torch.tensor([float(iters)], dtype=torch.float64, device='cuda')
+        agg = torch.tensor([float(iters), float(alg_bytes)], dtype=torch.float64, device='cuda')
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-        tot_iters_all = float(agg.item())
+        tot_iters_all, alg_bytes_all = float(agg[0].item()), float(agg[1].item())
     else:
-        tot_iters_all = float(iters)
+        tot_iters_all, alg_bytes_all = float(iters), float(alg_bytes)
 
     res = batch.fetch()
     n_ok = sum(1 for r in res if r.dynamics_succeed and r.durations_succeed)
     sizes = res[0].sizes
 
     if rank == 0:
-        total_seqs = world * B * args.steps
-        # algorithmic bytes of rank 0's launches / average launch duration (HIP events); with overlapping launches the
-        # per-launch rate is what the roofline of the kernel is compared with
-        ach = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        import numpy as np
+        total_seqs = world * B * steps
+        # sum of algorithmic bytes (bytes_iter(seq) x iterations, all ranks) / wall time of the timed region
+        ach = alg_bytes_all / elapsed / 1e9
         # fp64 work of the factorisations / substitutions / products (band N_b, half-width w, border b; multiply-add = 2),
-        # from the mean problem size of the batch -- a secondary view: the trailing update of the factorisation runs on
-        # the fp64 matrix cores
+        # from the mean problem size -- a secondary view: the trailing update of the factorisation runs on the fp64 matrix cores
         Nb_ = sum(r.sizes['kkt_dim'] - r.sizes['border'] for r in res) / len(res)
         w_ = sum(r.sizes['halfband'] for r in res) / len(res)
         b_ = sum(r.sizes['border'] for r in res) / len(res)
@@ -228,48 +238,56 @@ def main():
         fl_solve = 4 * (Nb_ * w_ + Nb_ * b_) + 2 * b_ * b_
         fl_mv = 2 * (Nb_ * (2 * w_ + 1) + 2 * Nb_ * b_ + b_ * b_)
         flops = nfact * (fl_fact + 2 * fl_solve + fl_mv) + iters * fl_mv
-        traffic = None
+        traffic = None; traffic_note = 'not measured for this build'
         tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get('hbm_bytes_per_launch')
+                tj = json.load(open(tfile))
+                traffic = tj.get('hbm_bytes_per_step')
+                traffic_note = tj.get('note', '')
             except Exception:
                 traffic = None
+        it_seq = np.array([r.total_iters for r in res], dtype=np.float64)
         out = {
             'metric': 'physics-optimized sequences/sec (90-frame)', 'value': total_seqs / elapsed, 'unit': 'sequences/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+            'n_gpus': world, 'steps': steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'batch of %d synthetic Mixamo-like %d-frame walks per GPU (BASELINE configs[1]), staged NLP solve, '
-                                   'reference iteration caps 7000/7000/7000/2500/2000/7000, tol 1e-3' % (B, FRAMES),
-                       'sequences_per_gpu': B, 'frames': FRAMES, 'parallelism': 'independent sequences, 1 workgroup each; %d process(es); %d step(s) in flight per GPU on separate HIP streams' % (world, depth),
+            'config': {'workload': '%d batches (steps) of %d synthetic Mixamo-like %d-frame walks per GPU (BASELINE configs[1]; seeds rank*%d .. : a slice of configs[2]), '
+                                   'staged NLP solve, reference iteration caps 7000/7000/7000/2500/2000/7000, tol 1e-3, stall guard %s'
+                                   % (steps, B, FRAMES, steps * B, 'off' if args.stall_window <= 0 else 'window %d' % args.stall_window),
+                       'sequences_per_gpu': B * steps, 'frames': FRAMES,
+                       'parallelism': 'independent sequences; %d process(es); per GPU one persistent launch of %d resident workgroups (1 per CU) draining a queue; one handle, one stream'
+                                      % (world, st['n_workgroups']),
                        'kkt_dim': sizes['kkt_dim'], 'halfband': sizes['halfband'], 'border': sizes['border'], 'nnz_jac': sizes['nnz_jac'],
-                       'ipm_iterations_per_sequence': tot_iters_all / (world * B * args.steps),
-                       'factorizations_rank0': nfact, 'stage4_fallbacks_rank0': nfall, 'converged_rank0': '%d/%d' % (n_ok, B),
-                       'slowest_sequence_ms': max_seq_ms},
-            'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
-                         'traffic': traffic, 'kernel': 'chd_solve_kernel', 'launches': launches,
-                         'avg_launch_ms': kernel_ms / max(1, launches),
-                         'algorithmic_bytes_per_launch': alg_bytes / max(1, launches),
-                         'launches_in_flight': depth,
-                         'achieved_all_launches': alg_bytes / elapsed / 1e9,        # rank 0: bytes of every launch / wall time of the timed region
-                         'fp64': {'achieved': flops / elapsed / 1e12, 'peak': 78.6, 'unit': 'TFLOP/s', 'frac': flops / elapsed / 1e12 / 78.6,
-                                  'note': 'rank 0; band LDL^T + substitutions + products; MI355X fp64 vector = matrix peak 78.6 TFLOP/s (AMD spec; not in MI355X_MICROARCH.md)'}},
+                       'ipm_iterations_per_sequence': tot_iters_all / total_seqs,
+                       'ipm_iterations_rank0': {'p50': float(np.percentile(it_seq, 50)), 'p90': float(np.percentile(it_seq, 90)), 'max': float(it_seq.max())},
+                       'factorizations_rank0': nfact, 'stage4_fallbacks_rank0': st['n_fallback'], 'stall_guard_hits_rank0': st['n_stalled'],
+                       'converged_rank0': '%d/%d' % (n_ok, len(res)),
+                       'slowest_sequence_ms': st['max_seq_ms'], 'mean_sequence_ms': st['phase_ms'][5] / max(1, len(res))},
+            'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS * world, 'unit': 'GB/s', 'frac': ach / (HBM_PEAK_GBS * world),
+                         'definition': 'sum over sequences of SURVEY 8(d) bytes_iter x IPM iterations / wall time of the timed region / (8 TB/s x GPUs)',
+                         'algorithmic_bytes_per_step': alg_bytes_all / steps / world, 'algorithmic_bytes_per_iteration': alg_bytes / max(1, iters),
+                         'traffic': traffic, 'traffic_note': traffic_note, 'kernel': 'chd_solve_kernel',
+                         'launches': 1 + (1 if st['kernel_ms'][1] > 0 else 0), 'kernel_ms_rank0': kernel_ms,
+                         'kernel_busy_fraction': st['phase_ms'][5] / max(1e-9, st['n_workgroups'] * kernel_ms),
+                         'fp64': {'achieved': flops / elapsed / 1e12, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': flops / elapsed / 1e12 / FP64_PEAK_TFLOPS,
+                                  'note': 'rank 0, by formula: band LDL^T + substitutions + products at the mean problem size; MFMA counters: profiles/'}},
         }
+        if world == 1 and not args.no_side_metrics:
+            try:
+                out['parity'] = parity_block(res, seed0)
+            except Exception as exc:
+                out['parity'] = {'error': '%s: %s' % (type(exc).__name__, exc)}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
-        if world == 1 and not args.no_cpu_baseline:
-            # the side metric runs after the physics line is safely out: the wrapper keeps the LAST line, so a failure
-            # here (even one that kills the process) cannot cost the physics measurement
-            print(json.dumps(out), flush=True)
+        if world == 1 and not args.no_side_metrics:
             try:
                 out['contact_net'] = contact_net_rate(torch.device('cuda', local))
             except Exception as exc:
                 out['contact_net'] = {'error': '%s: %s' % (type(exc).__name__, exc)}
         print(json.dumps(out), flush=True)
-    for bt in batches:
-        bt.free()
-    for sv in solvers:
-        sv.close()
+    batch.free()
+    solver.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -92,7 +92,6 @@ namespace chd {
 #define CHD_CONSTR_VIOL_TOL 1e-4
 #define CHD_MAX_BACKTRACK 3
 #define CHD_MAX_ATTEMPTS 12
-#define CHD_STALL_WINDOW 150
 #define CHD_G 9.80665
 #define CHD_MU_FRICTION 0.5
 #define CHD_INF 1e19
@@ -108,9 +107,20 @@ enum { VK_RHS = 0, VK_SOL, VK_RHS2, VK_SOL2, VK_T1, VK_T2, VK_DIAG, VK_Y, VK_HIS
 // row flags
 enum { RF_EQ = 1, RF_L = 2, RF_U = 4 };
 
+// The sequence descriptor and the solver context are workgroup-uniform: both live in LDS (one copy per workgroup, filled
+// when the workgroup takes a sequence from the queue) and are addressed through local-address-space pointers, so a
+// field access is a ds_read -- a generic `const SeqDesc*` compiles to flat_load, a context on the stack to scratch
+// traffic in every noinline phase.
+#ifdef CHD_HOST_EMU
+typedef const SeqDesc* QP;
+typedef const StageDesc* SDP;
+#else
+typedef const __attribute__((address_space(3))) SeqDesc* QP;
+typedef const __attribute__((address_space(3))) StageDesc* SDP;
+#endif
 struct Ctx {
-  const SeqDesc* q;
-  const StageDesc* S;
+  QP q;
+  SDP S;
   LdsD* lds;            // workgroup scratch (LDS on the device)
   int lds_cap;          // doubles available in lds
   int n, m, N, Nb, bc, w, W2, LD;
@@ -120,17 +130,21 @@ struct Ctx {
   GI* rcnt;             // [k]: the border rows [0, rcnt[k]) are the ones that can reach band column k (working copy)
   double sf;            // objective scaling
   double tol;           // IPOPT tol of the stage (phys_optim.cpp:578)
-  int err;              // sticky error flag (band overflow), uniform across the workgroup after a sync
-  int n_bad_pivots;
+  int stall_window;     // 0 = no stall guard (chd_config.stall_window)
+  int err;              // sticky error flag (band overflow): any thread may set it, read after a barrier
+  int n_bad_pivots;     // thread 0 counts
   long long tacc[24];    // cycles per phase (thread 0): 0 eval full, 1 eval values, 2 factor, 3 solve, 4 matvec, 5 total
 };
 #ifdef CHD_HOST_EMU
+typedef Ctx LCtx;
 #define CHD_CLOCK() 0LL
 #else
+typedef __attribute__((address_space(3))) Ctx LCtx;
 #define CHD_CLOCK() ((long long)wall_clock64())
 #endif
+#define TACC(c, k, v) do { if (CHD_TID == 0) (c).tacc[k] += (v); } while (0)
 #define TIC() const long long tic_ = CHD_CLOCK()
-#define TOC(c, k) (c).tacc[k] += CHD_CLOCK() - tic_
+#define TOC(c, k) TACC(c, k, CHD_CLOCK() - tic_)
 
 #define VN(c, k) ((c).q->wd + (c).q->o_vec_n + (long long)(k) * (c).q->max_n)
 #define VM(c, k) ((c).q->wd + (c).q->o_vec_m + (long long)(k) * (c).q->max_m)
@@ -141,12 +155,12 @@ struct Ctx {
 // in the same order)
 // ------------------------------------------------------------------------------------------
 #ifdef CHD_HOST_EMU
-CHD_DEV double block_sum(Ctx&, double v) { return v; }
-CHD_DEV double block_max(Ctx&, double v) { return v; }
-CHD_DEV double block_min(Ctx&, double v) { return v; }
+CHD_DEV double block_sum(LCtx&, double v) { return v; }
+CHD_DEV double block_max(LCtx&, double v) { return v; }
+CHD_DEV double block_min(LCtx&, double v) { return v; }
 CHD_DEV double group_sum(double v) { return v; }
 #else
-CHD_DEV double block_sum(Ctx& c, double v) {
+CHD_DEV double block_sum(LCtx& c, double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) c.lds[threadIdx.x >> 6] = v;
@@ -155,7 +169,7 @@ CHD_DEV double block_sum(Ctx& c, double v) {
   for (int k = 0; k < nw; ++k) t += c.lds[k];
   return t;
 }
-CHD_DEV double block_max(Ctx& c, double v) {
+CHD_DEV double block_max(LCtx& c, double v) {
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o));
   __syncthreads();
   if ((threadIdx.x & 63) == 0) c.lds[threadIdx.x >> 6] = v;
@@ -164,7 +178,7 @@ CHD_DEV double block_max(Ctx& c, double v) {
   for (int k = 1; k < nw; ++k) t = fmax(t, c.lds[k]);
   return t;
 }
-CHD_DEV double block_min(Ctx& c, double v) { return -block_max(c, -v); }
+CHD_DEV double block_min(LCtx& c, double v) { return -block_max(c, -v); }
 CHD_DEV double group_sum(double v) {
   v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
   return v;
@@ -197,8 +211,8 @@ CHD_DEV int seg_lookup(CP cum_end, int n, double t) {    // first i with cum_end
   return lo;
 }
 
-CHD_DEV void hermite_eval(const SeqDesc* q, int s, int id, double tl, PE& e) {
-  const SplineDesc& sp = q->sp[s];
+CHD_DEV void hermite_eval(QP q, int s, int id, double tl, PE& e) {
+  const auto& sp = q->sp[s];
   const double T = q->wd[q->o_poly_dur + sp.poly_off + id];
   e.poly = id; e.tl = tl; e.T = T;
   const double t = tl, t2 = t * t, t3 = t2 * t, iT = 1.0 / T, iT2 = iT * iT, iT3 = iT2 * iT;
@@ -217,16 +231,16 @@ CHD_DEV void hermite_eval(const SeqDesc* q, int s, int id, double tl, PE& e) {
   }
 }
 
-CHD_DEV void spline_eval(const SeqDesc* q, int s, double tg, PE& e) {
-  const SplineDesc& sp = q->sp[s];
+CHD_DEV void spline_eval(QP q, int s, double tg, PE& e) {
+  const auto& sp = q->sp[s];
   const GD* pend = q->wd + q->o_pend + sp.poly_off;
   const int id = seg_lookup(pend, sp.n_polys, tg);
   hermite_eval(q, s, id, tg - (id > 0 ? pend[id - 1] : 0.0), e);
 }
 
 // d p(t) / d T_poly for the active polynomial (CubicHermitePolynomial::GetDerivativeOfPosWrtDuration)
-CHD_DEV void dpos_dT(const SeqDesc* q, int s, const PE& e, double* out) {
-  const SplineDesc& sp = q->sp[s];
+CHD_DEV void dpos_dT(QP q, int s, const PE& e, double* out) {
+  const auto& sp = q->sp[s];
   const GD* nv = q->wd + q->o_node + sp.node_off + e.poly * 6;
   const double t = e.tl, t2 = t * t, t3 = t2 * t, T = e.T, iT = 1.0 / T, iT2 = iT * iT, iT3 = iT2 * iT, iT4 = iT2 * iT2;
   for (int k = 0; k < 3; ++k) {
@@ -237,7 +251,7 @@ CHD_DEV void dpos_dT(const SeqDesc* q, int s, const PE& e, double* out) {
 }
 
 // phase of end-effector e at time t, and whether it is the last one
-CHD_DEV int phase_lookup(const SeqDesc* q, int e, double t) {
+CHD_DEV int phase_lookup(QP q, int e, double t) {
   return seg_lookup(q->wd + q->o_phend + q->phase_off[e], q->n_phase[e], t);
 }
 
@@ -245,8 +259,8 @@ CHD_DEV int phase_lookup(const SeqDesc* q, int e, double t) {
 // PhaseDurations::GetJacobianOfPos).  Returns cur phase; dj_k[d] for k < cur is `early[d]`,
 // for k == cur (when not last) is `own[d]`; zero beyond.
 struct DurJac { int cur, last, nvar; double own[3], early[3]; };
-CHD_DEV void dur_jac(const SeqDesc* q, int s, double t, const PE& e, DurJac& dj) {
-  const SplineDesc& sp = q->sp[s];
+CHD_DEV void dur_jac(QP q, int s, double t, const PE& e, DurJac& dj) {
+  const auto& sp = q->sp[s];
   const int ee = sp.ee;
   const GI* pi = q->ci + q->o_pinfo + (sp.poly_off + e.poly) * 4;
   double dT[3];
@@ -273,8 +287,8 @@ CHD_DEV void dur_jac(const SeqDesc* q, int s, double t, const PE& e, DurJac& dj)
 // (the reference only needs first derivatives because IPOPT runs with an L-BFGS Hessian, phys_optim.cpp:572;
 //  this solver uses the exact duration block of the Lagrangian Hessian instead — DESIGN.md)
 struct DurJac2 { int cur, last, nvar; double Ge[3], Gc[3], Qee[3], Qec[3], Qcc[3]; };
-CHD_DEV void dur_jac2(const SeqDesc* q, int s, double t, const PE& e, DurJac2& dj) {
-  const SplineDesc& sp = q->sp[s];
+CHD_DEV void dur_jac2(QP q, int s, double t, const PE& e, DurJac2& dj) {
+  const auto& sp = q->sp[s];
   const int ee = sp.ee;
   const GI* pi = q->ci + q->o_pinfo + (sp.poly_off + e.poly) * 4;
   const GD* nv = q->wd + q->o_node + sp.node_off + e.poly * 6;
@@ -299,7 +313,7 @@ CHD_DEV void dur_jac2(const SeqDesc* q, int s, double t, const PE& e, DurJac2& d
   }
 }
 CHD_DEV double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
-CHD_DEV void d2_store(const SeqDesc* q, int ee, int slot, int cur, double see, double sec, double scc) {
+CHD_DEV void d2_store(QP q, int ee, int slot, int cur, double see, double sec, double scc) {
   GD* t = q->wd + q->o_d2tab + ((long long)ee * q->d2_slots + slot) * D2_STRIDE;
   t[0] = cur; t[1] = see; t[2] = sec; t[3] = scc;
 }
@@ -429,14 +443,14 @@ CHD_DEV void env_max(GI* p, int v) { if (v > *p) *p = v; }
 CHD_DEV void env_min(GI* p, int v) { __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 CHD_DEV void env_max(GI* p, int v) { __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #endif
-CHD_DEV void env_cover(Ctx& c, const int hi, const int lo) {
+CHD_DEV void env_cover(LCtx& c, const int hi, const int lo) {
   const int first = c.env[2 * hi];
   if (lo >= first) return;
   env_min(c.env + 2 * hi, lo);
   if (hi < c.Nb) for (int k = lo; k < first && k < hi; ++k) env_max(c.env + 2 * k + 1, hi);
   else for (int k = lo; k < first && k < c.Nb; ++k) env_max(c.rcnt + k, hi - c.Nb + 1);      // border row hi - Nb now reaches columns lo ..
 }
-CHD_DEV void kadd(Ctx& c, int p, int qq, double val) {
+CHD_DEV void kadd(LCtx& c, int p, int qq, double val) {
   if (p < c.Nb && qq < c.Nb) {
     int dlt = qq - p;
     if (dlt > c.w || dlt < -c.w) { c.err = 1; return; }
@@ -455,7 +469,7 @@ CHD_DEV void kadd(Ctx& c, int p, int qq, double val) {
 }
 // the (up to two: both triangles are stored) locations of the KKT entry (p, qq); same checks as kadd
 struct KSlot { GD* a; GD* b; };
-CHD_DEV KSlot kslot(Ctx& c, int p, int qq) {
+CHD_DEV KSlot kslot(LCtx& c, int p, int qq) {
   KSlot sl; sl.a = nullptr; sl.b = nullptr;
   if (p < c.Nb && qq < c.Nb) {
     const int dlt = qq - p;
@@ -475,7 +489,7 @@ CHD_DEV KSlot kslot(Ctx& c, int p, int qq) {
 // N distinct KKT entries (p[i], q[i]) += val[i] (entries with p[i] < 0 are skipped): look-ups, loads and stores of all
 // of them are issued together
 template <int N>
-CHD_DEV void kadd_batch(Ctx& c, const int* p, const int* qq, const double* val) {
+CHD_DEV void kadd_batch(LCtx& c, const int* p, const int* qq, const double* val) {
   KSlot sl[N]; double oa[N], ob[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) { sl[i].a = nullptr; sl[i].b = nullptr; if (p[i] >= 0) sl[i] = kslot(c, p[i], qq[i]); }
@@ -484,7 +498,7 @@ CHD_DEV void kadd_batch(Ctx& c, const int* p, const int* qq, const double* val) 
 #pragma unroll
   for (int i = 0; i < N; ++i) { if (sl[i].a) *sl[i].a = oa[i] + val[i]; if (sl[i].b) *sl[i].b = ob[i] + val[i]; }
 }
-CHD_DEV double kget(const Ctx& c, int p, int qq) {
+CHD_DEV double kget(const LCtx& c, int p, int qq) {
   if (p < c.Nb && qq < c.Nb) {
     int dlt = qq - p;
     if (dlt > c.w || dlt < -c.w) return 0.0;
@@ -494,7 +508,7 @@ CHD_DEV double kget(const Ctx& c, int p, int qq) {
   return c.K0x[(long long)(hi - c.Nb) * c.LD + lo];
 }
 
-CHD_DEV void kzero(Ctx& c) {
+CHD_DEV void kzero(LCtx& c) {
   const long long nx_ = (long long)c.bc * c.LD;
   // band rows: only the envelope [efirst_i, clast_i] (what the mat-vec and the factor copy read; kadd widens it first
   // if an entry ever lands outside), one wavefront per row
@@ -518,7 +532,7 @@ CHD_DEV void kzero(Ctx& c) {
 }
 // start of a stage: the border blocks are reused with a new layout, and their structurally-zero left parts are
 // neither cleared nor copied again afterwards
-CHD_DEV void kreset(Ctx& c) {
+CHD_DEV void kreset(LCtx& c) {
   PAR_FOR(i, 2 * c.N) c.env[i] = c.q->ci[c.S->o_env + i];
   PAR_FOR(i, c.Nb) c.rcnt[i] = c.q->ci[c.S->o_rcnt + i];
   const long long nx_ = (long long)c.bc * c.LD;
@@ -572,7 +586,7 @@ CHD_DEV double dot_column(AP col, const long long ld, BP b, int r, const int ren
 // y = K0 x (+ diag .* x)
 // `only` (optional): rows whose entry is <= 0 are skipped (their y is left untouched)
 template <class XP>
-CHD_DEV void kmatvec_impl(Ctx& c, XP x, GD* y, const GD* diag, const GI* only) {
+CHD_DEV void kmatvec_impl(LCtx& c, XP x, GD* y, const GD* diag, const GI* only) {
   const int Nb = c.Nb, w = c.w, W2 = c.W2, LD = c.LD, bc = c.bc;
   {
     // 8 lanes per band row (an envelope holds ~100-200 entries: 16 requests in flight per lane), 64 rows per pass
@@ -608,7 +622,7 @@ CHD_DEV void kmatvec_impl(Ctx& c, XP x, GD* y, const GD* diag, const GI* only) {
   }
   CHD_SYNC();
 }
-CHD_NOINLINE CHD_DEV void kmatvec(Ctx& c, const GD* x, GD* y, const GD* diag, const GI* only) {
+CHD_NOINLINE CHD_DEV void kmatvec(LCtx& c, const GD* x, GD* y, const GD* diag, const GI* only) {
   TIC();
   if (c.N <= c.lds_cap - LDS_RED) {          // x is read 2 w + 1 times: keep it in LDS
     LdsD* xs = c.lds + LDS_RED;
@@ -620,7 +634,7 @@ CHD_NOINLINE CHD_DEV void kmatvec(Ctx& c, const GD* x, GD* y, const GD* diag, co
 }
 
 // ---- factorisation: K0 + diag -> L D L^T in Kf (no pivoting; expected pivot sign from `sign`) ----
-CHD_DEV double pivot_fix(Ctx& c, double d, int sg) {
+CHD_DEV double pivot_fix(LCtx& c, double d, int sg) {
   if (!(d * sg > 1e-14)) { d = sg * 1e-10; if (CHD_TID == 0) c.n_bad_pivots++; }
   return d;
 }
@@ -646,7 +660,7 @@ CHD_DEV double pivot_fix(Ctx& c, double d, int sg) {
 //      wavefronts are still busy with the previous panel's trailing update (look-ahead).
 #ifdef CHD_HOST_EMU
 template <int NB>
-CHD_DEV void diag_block_g(Ctx& c, const GI* sign, LdsD* dv, LdsD* DL, const int c0, const int jb) {
+CHD_DEV void diag_block_g(LCtx& c, const GI* sign, LdsD* dv, LdsD* DL, const int c0, const int jb) {
   const int W1 = c.w + 1, w = c.w;
   double A[NB][NB];
   for (int a = 0; a < NB; ++a)
@@ -678,7 +692,7 @@ CHD_DEV double rcp_f64(double d) {
 // only L(j, j-1) and the pivot travel by v_readlane (whose result takes tens of cycles to reach the VALU -- the
 // right-looking form needed 31 - j of them per column and took ~11 us per block).
 template <int NB>
-CHD_DEV void diag_block_g(Ctx& c, const GI* sign, LdsD* dv, LdsD* DL, const int c0, const int jb) {
+CHD_DEV void diag_block_g(LCtx& c, const GI* sign, LdsD* dv, LdsD* DL, const int c0, const int jb) {
   if (threadIdx.x < 64) {
     const int W1 = c.w + 1, w = c.w;
     const int a = threadIdx.x;
@@ -724,13 +738,13 @@ CHD_DEV void diag_block_g(Ctx& c, const GI* sign, LdsD* dv, LdsD* DL, const int 
 // ---- active rows of a panel's window (sorted): u in [0, wr) whose first coupled column (efirst of a band row i0 + u,
 //      bfirst of a border row u - nbelow) is <= last_col
 #ifdef CHD_HOST_EMU
-CHD_DEV void build_active_rows(Ctx& c, int* act, int* nact, int wr, int nbelow, int i0, int last_col) {
+CHD_DEV void build_active_rows(LCtx& c, int* act, int* nact, int wr, int nbelow, int i0, int last_col) {
   int n = 0;
   for (int u = 0; u < wr; ++u) if (c.env[2 * (u >= nbelow ? c.Nb + u - nbelow : i0 + u)] <= last_col) act[n++] = u;
   *nact = n;
 }
 #else
-CHD_DEV void build_active_rows(Ctx& c, int* act_, int* nact_, int wr, int nbelow, int i0, int last_col) {
+CHD_DEV void build_active_rows(LCtx& c, int* act_, int* nact_, int wr, int nbelow, int i0, int last_col) {
   if (threadIdx.x >= 64 && threadIdx.x < 128) {       // one wavefront (the second): ballot + prefix count keeps the list sorted
     LdsI* act = (LdsI*)act_; LdsI* nact = (LdsI*)nact_;
     const int ln = threadIdx.x - 64;
@@ -763,7 +777,7 @@ CHD_DEV void build_active_rows(Ctx& c, int* act_, int* nact_, int wr, int nbelow
 // window rows/cols u = 0..wr-1 live at PT rows NB+u; u < nbelow are band rows i0+u, the rest border rows
 #ifdef CHD_HOST_EMU
 template <int NB>
-CHD_DEV void trailing_update(Ctx& c, const LdsD* dv, const LdsD* PT, const int ldp, const int wr, const int nbelow, const int i0, const int* act, const int nact, const bool) {
+CHD_DEV void trailing_update(LCtx& c, const LdsD* dv, const LdsD* PT, const int ldp, const int wr, const int nbelow, const int i0, const int* act, const int nact, const bool) {
   const int W1 = c.w + 1, w = c.w, LD = c.LD, Nb = c.Nb;
   for (int tr = 0; tr < nact; ++tr)
     for (int tc = 0; tc <= tr; ++tc) {
@@ -783,7 +797,7 @@ typedef double chd_f64x4 __attribute__((ext_vector_type(4)));
 // `split`: the first wavefront only takes the three tiles that cover the next panel's diagonal block (it goes on to
 // factor that block), the other wavefronts share the rest; otherwise all wavefronts share all tiles
 template <int NB>
-CHD_DEV void trailing_update(Ctx& c, const LdsD* dv, const LdsD* PT, const int ldp, const int wr, const int nbelow, const int i0, const int* act_, const int nact, const bool split) {
+CHD_DEV void trailing_update(LCtx& c, const LdsD* dv, const LdsD* PT, const int ldp, const int wr, const int nbelow, const int i0, const int* act_, const int nact, const bool split) {
   const int W1 = c.w + 1, w = c.w, LD = c.LD, Nb = c.Nb;
   const LdsI* act = (const LdsI*)act_;
   const int wave = threadIdx.x >> 6, nwv = blockDim.x >> 6, lane = threadIdx.x & 63;
@@ -849,7 +863,7 @@ CHD_DEV void trailing_update(Ctx& c, const LdsD* dv, const LdsD* PT, const int l
 #endif
 
 template <int NB>
-CHD_NOINLINE CHD_DEV void trailing_phase(Ctx& c, const GI* sign, const LdsD* dv, const LdsD* PT, const int ldp, const int wr, const int nbelow, const int i0,
+CHD_NOINLINE CHD_DEV void trailing_phase(LCtx& c, const GI* sign, const LdsD* dv, const LdsD* PT, const int ldp, const int wr, const int nbelow, const int i0,
                                          const int* act, const int nact, const bool more, LdsD* dv_n, LdsD* DL_n, const int c0n, const int jbn) {
   trailing_update<NB>(c, dv, PT, ldp, wr, nbelow, i0, act, nact, more);
   if (more) {
@@ -876,7 +890,7 @@ struct Panel {
 // part 1: the active rows below the diagonal block (which was factored straight from HBM during the previous panel's
 // trailing update).  Rows that are not active keep whatever an earlier panel left in the LDS panel: nothing reads them.
 template <int NB>
-CHD_NOINLINE CHD_DEV void panel_load(Ctx& c, const Panel P, const int part) {
+CHD_NOINLINE CHD_DEV void panel_load(LCtx& c, const Panel P, const int part) {
   const int W1 = c.w + 1, w = c.w, LD = c.LD;
   const int c0 = P.c0, jb = P.jb, nbelow = P.nbelow, pr = P.pr, ldp = P.ldp;
   LdsD* PT = P.PT;
@@ -911,7 +925,7 @@ CHD_NOINLINE CHD_DEV void panel_load(Ctx& c, const Panel P, const int part) {
 //      before the multiply-adds of column k, so the LDS latency is paid once, not once per column (the first version
 //      waited ~100 cycles per read pair: 9 us per panel for 2 us of arithmetic).
 template <int NB>
-CHD_DEV void panel_rows(Ctx& c, const Panel P, const int nact) {
+CHD_DEV void panel_rows(LCtx& c, const Panel P, const int nact) {
   const int ldp = P.ldp;
   LdsD* PT = P.PT; const LdsD* DL = P.DL; const LdsD* dv = P.dv; const LdsI* act = (const LdsI*)P.act;
   PAR_FOR(t2, nact) {           // compacted: inactive rows are never read
@@ -938,7 +952,7 @@ CHD_DEV void panel_rows(Ctx& c, const Panel P, const int nact) {
 // ---- write the panel back (8 consecutive columns of one row per task): the diagonal block rows and the active rows.
 //      Entries left of a row's envelope are exact zeros (as is what the storage holds there): only the band limit is checked.
 template <int NB>
-CHD_NOINLINE CHD_DEV void panel_store(Ctx& c, const Panel P, const int nact) {
+CHD_NOINLINE CHD_DEV void panel_store(LCtx& c, const Panel P, const int nact) {
   const int W1 = c.w + 1, w = c.w, LD = c.LD;
   const int c0 = P.c0, jb = P.jb, nbelow = P.nbelow, ldp = P.ldp;
   const LdsD* PT = P.PT; const LdsD* dv = P.dv; const LdsD* DL = P.DL;
@@ -969,7 +983,7 @@ CHD_NOINLINE CHD_DEV void panel_store(Ctx& c, const Panel P, const int nact) {
 }
 
 template <int NB>
-CHD_DEV void panel_geometry(Ctx& c, Panel& P, const int c0, const int ldp) {
+CHD_DEV void panel_geometry(LCtx& c, Panel& P, const int c0, const int ldp) {
   const int Nb = c.Nb, w = c.w, bc = c.bc;
   P.c0 = c0; P.jb = Nb - c0 < NB ? Nb - c0 : NB;
   const int nbr = (Nb - c0 < P.jb + w) ? Nb - c0 : P.jb + w;     // band rows touched by this panel
@@ -977,7 +991,7 @@ CHD_DEV void panel_geometry(Ctx& c, Panel& P, const int c0, const int ldp) {
   P.pr = NB + P.nbelow + bc; P.ldp = ldp;
 }
 template <int NB>
-CHD_DEV void kfactor_band(Ctx& c, const GI* sign, LdsD* dv, LdsD* DL, LdsD* dv2, LdsD* DL2, LdsD* PT, const int ldp) {
+CHD_DEV void kfactor_band(LCtx& c, const GI* sign, LdsD* dv, LdsD* DL, LdsD* dv2, LdsD* DL2, LdsD* PT, const int ldp) {
   const int Nb = c.Nb, w = c.w, bc = c.bc;
   // look-ahead: the diagonal block of panel J + 1 is factored by the first wavefront during panel J's trailing update
   // (after it has applied the three tiles of that update which touch the block), into the other (dv, DL) pair; the
@@ -999,12 +1013,12 @@ CHD_DEV void kfactor_band(Ctx& c, const GI* sign, LdsD* dv, LdsD* DL, LdsD* dv2,
     const int nact = *(const LdsI*)P.nact_p;
     panel_load<NB>(c, P, 1);
     CHD_SYNC();
-    c.tacc[8] += CHD_CLOCK() - tp_; tp_ = CHD_CLOCK();
+    TACC(c, 8, CHD_CLOCK() - tp_); tp_ = CHD_CLOCK();
     panel_rows<NB>(c, P, nact);
     CHD_SYNC();
-    c.tacc[9] += CHD_CLOCK() - tp_; tp_ = CHD_CLOCK();
+    TACC(c, 9, CHD_CLOCK() - tp_); tp_ = CHD_CLOCK();
     panel_store<NB>(c, P, nact);               // stores of the panel columns; the update below touches other columns
-    c.tacc[10] += CHD_CLOCK() - tp_; tp_ = CHD_CLOCK();
+    TACC(c, 10, CHD_CLOCK() - tp_); tp_ = CHD_CLOCK();
     // ---- trailing update of the window (+ the next diagonal block and the next list of active rows)
     const int c0n = c0 + NB;
     const bool more = c0n < Nb;
@@ -1015,7 +1029,7 @@ CHD_DEV void kfactor_band(Ctx& c, const GI* sign, LdsD* dv, LdsD* DL, LdsD* dv2,
     }
     trailing_phase<NB>(c, sign, dv, PT, ldp, P.pr - NB, P.nbelow, c0 + P.jb, P.act, nact, more, dv2, DL2, c0n, Nb - c0n < NB ? Nb - c0n : NB);
     CHD_SYNC();
-    c.tacc[11] += CHD_CLOCK() - tp_;
+    TACC(c, 11, CHD_CLOCK() - tp_);
     LdsD* t_ = dv; dv = dv2; dv2 = t_; t_ = DL; DL = DL2; DL2 = t_;
     int* ti_ = actA; actA = actB; actB = ti_;
   }
@@ -1025,7 +1039,7 @@ CHD_DEV void kfactor_band(Ctx& c, const GI* sign, LdsD* dv, LdsD* DL, LdsD* dv2,
 // The columns stay unscaled (L D) while the elimination runs -- later columns never touch them -- and are divided
 // by their pivots in one pass at the end: one workgroup barrier per column instead of three.
 template <class P>
-CHD_DEV void dense_ldlt(Ctx& c, P Sp, const int ld, const int n, const GI* sign) {
+CHD_DEV void dense_ldlt(LCtx& c, P Sp, const int ld, const int n, const GI* sign) {
   int sg_next = n > 0 ? sign[0] : 1;
   for (int j = 0; j < n; ++j) {
     const int sg = sg_next;
@@ -1043,7 +1057,7 @@ CHD_DEV void dense_ldlt(Ctx& c, P Sp, const int ld, const int n, const GI* sign)
   CHD_SYNC();
 }
 
-CHD_NOINLINE CHD_DEV void kfactor(Ctx& c, const GD* diag, const GI* sign) {
+CHD_NOINLINE CHD_DEV void kfactor(LCtx& c, const GD* diag, const GI* sign) {
   TIC();
   const int Nb = c.Nb, w = c.w, W2 = c.W2, W1 = c.w + 1, LD = c.LD, bc = c.bc;
   if (CHD_TID == 0) c.n_bad_pivots = 0;
@@ -1106,7 +1120,7 @@ CHD_NOINLINE CHD_DEV void kfactor(Ctx& c, const GD* diag, const GI* sign) {
     for (; k < LD; k += CHD_WAVE_SZ) dst[k] = src[k] + (k == Nb + r ? diag[Nb + r] : 0.0);
   }
   CHD_SYNC();
-  c.tacc[6] += CHD_CLOCK() - tic_;
+  TACC(c, 6, CHD_CLOCK() - tic_);
   // panel width from the LDS budget
   LdsD* dv = c.lds + LDS_RED;            // pivots of the current panel (<= 32) and their reciprocals
   LdsD* DL = dv + 64;                    // dense copy of the panel's unit-lower diagonal block
@@ -1137,7 +1151,7 @@ CHD_NOINLINE CHD_DEV void kfactor(Ctx& c, const GD* diag, const GI* sign) {
       dense_ldlt(c, c.Kfx + Nb, LD, bc, sign + Nb);
     }
   }
-  c.tacc[12] += CHD_CLOCK() - td_;
+  TACC(c, 12, CHD_CLOCK() - td_);
   TOC(c, 2);
 }
 
@@ -1146,7 +1160,7 @@ CHD_NOINLINE CHD_DEV void kfactor(Ctx& c, const GD* diag, const GI* sign) {
 #define CHD_TILE_LD 65
 #ifdef CHD_HOST_EMU
 template <class YP>
-CHD_DEV void tri_forward(Ctx& c, YP y, int c0, int jb, const LdsD*) {
+CHD_DEV void tri_forward(LCtx& c, YP y, int c0, int jb, const LdsD*) {
   const int W1 = c.w + 1, w = c.w;
   for (int i = 1; i < jb; ++i) {
     double s = y[c0 + i];
@@ -1155,7 +1169,7 @@ CHD_DEV void tri_forward(Ctx& c, YP y, int c0, int jb, const LdsD*) {
   }
 }
 template <class YP>
-CHD_DEV void tri_backward(Ctx& c, YP y, int c0, int jb, const LdsD*) {
+CHD_DEV void tri_backward(LCtx& c, YP y, int c0, int jb, const LdsD*) {
   const int W1 = c.w + 1, w = c.w;
   for (int i = jb - 2; i >= 0; --i) {
     double s = y[c0 + i];
@@ -1167,7 +1181,7 @@ CHD_DEV void tri_backward(Ctx& c, YP y, int c0, int jb, const LdsD*) {
 // lane i owns row c0+i of the 64x64 diagonal block; its entries are fetched up front (independent loads) so that
 // the dependent chain below runs out of registers
 template <class YP>
-CHD_NOINLINE CHD_DEV void tri_forward(Ctx& c, YP y, int c0, int jb, const LdsD* tile) {
+CHD_NOINLINE CHD_DEV void tri_forward(LCtx& c, YP y, int c0, int jb, const LdsD* tile) {
   if (threadIdx.x < 64) {
     const int W1 = c.w + 1, w = c.w, i = threadIdx.x;
     const bool act = i < jb;
@@ -1190,7 +1204,7 @@ CHD_NOINLINE CHD_DEV void tri_forward(Ctx& c, YP y, int c0, int jb, const LdsD* 
   }
 }
 template <class YP>
-CHD_NOINLINE CHD_DEV void tri_backward(Ctx& c, YP y, int c0, int jb, const LdsD* tile) {
+CHD_NOINLINE CHD_DEV void tri_backward(LCtx& c, YP y, int c0, int jb, const LdsD* tile) {
   if (threadIdx.x < 64) {
     const int W1 = c.w + 1, w = c.w, i = threadIdx.x;
     const bool act = i < jb;
@@ -1214,7 +1228,7 @@ CHD_NOINLINE CHD_DEV void tri_backward(Ctx& c, YP y, int c0, int jb, const LdsD*
 #endif
 
 // strictly-lower part of the diagonal block of `Kf` starting at c0 -> LDS tile (coalesced along the rows)
-CHD_DEV void load_diag_tile(Ctx& c, LdsD* tile, int c0, int jb) {
+CHD_DEV void load_diag_tile(LCtx& c, LdsD* tile, int c0, int jb) {
   const int W1 = c.w + 1, w = c.w;
   PAR_FOR(t, CHD_SOLVE_NB * 8) {            // 8 tasks per row, 8 consecutive entries each, loads issued together
     const int a = t >> 3, j0 = (t & 7) << 3;
@@ -1239,7 +1253,7 @@ CHD_DEV void load_diag_tile(Ctx& c, LdsD* tile, int c0, int jb) {
 #endif
 // y[i] -= sum_{k in [kbeg, kend)} L(i, k) y[k] for the rows i = r0 .. r0 + nr - 1 (clipped to each row's envelope)
 template <class YP>
-CHD_DEV void fwd_rows_dot(Ctx& c, YP y, const int r0, const int nr, const int kbeg, const int kend, const int wv0, const int nwv) {
+CHD_DEV void fwd_rows_dot(LCtx& c, YP y, const int r0, const int nr, const int kbeg, const int kend, const int wv0, const int nwv) {
   const int W1 = c.w + 1, w = c.w;
   const int gpw = CHD_WAVE_SZ / CHD_GL;                    // lane groups per wavefront
   if (CHD_WAVE_ID < wv0 || CHD_WAVE_ID >= wv0 + nwv) return;
@@ -1255,7 +1269,7 @@ CHD_DEV void fwd_rows_dot(Ctx& c, YP y, const int r0, const int nr, const int kb
 // y[k] -= sum_a L(c0 + a, k) y[c0 + a] for the columns k in [kbeg, kend), rows of the block at c0:
 // two half-waves per 32 columns (rows a < 32 and a >= 32 of the block), combined with one xor-32 shuffle
 template <class YP>
-CHD_DEV void bwd_cols_scatter(Ctx& c, YP y, const int c0, const int jb, const int kbeg, const int kend, const int wv0, const int nwv) {
+CHD_DEV void bwd_cols_scatter(LCtx& c, YP y, const int c0, const int jb, const int kbeg, const int kend, const int wv0, const int nwv) {
   const int W1 = c.w + 1, w = c.w;
   if (CHD_WAVE_ID < wv0 || CHD_WAVE_ID >= wv0 + nwv) return;
   const int ncol = kend - kbeg, cpw = CHD_WAVE_SZ / CHD_PAIR;
@@ -1278,7 +1292,7 @@ CHD_DEV void bwd_cols_scatter(Ctx& c, YP y, const int c0, const int jb, const in
 // The 64x64 triangular blocks are a one-wavefront dependent chain; the other wavefronts spend that time on the part
 // of the next block's update that does not need the chain's result.
 template <class YP, class SP>
-CHD_DEV void ksolve_impl(Ctx& c, const GD* rhs, GD* x, YP y, SP Sp, const int lds_, const bool stage_s, LdsD* tile) {
+CHD_DEV void ksolve_impl(LCtx& c, const GD* rhs, GD* x, YP y, SP Sp, const int lds_, const bool stage_s, LdsD* tile) {
   const int Nb = c.Nb, w = c.w, W1 = c.w + 1, LD = c.LD, bc = c.bc, N = c.N;
   PAR_FOR(i, N) y[i] = rhs[i];
   if (stage_s) PAR_FOR(idx, bc * bc) { const int r = idx / bc, k = idx % bc; Sp[idx] = c.Kfx[(long long)r * LD + Nb + k]; }
@@ -1296,13 +1310,13 @@ CHD_DEV void ksolve_impl(Ctx& c, const GD* rhs, GD* x, YP y, SP Sp, const int ld
     tri_forward(c, y, c0, jb, tile);                                                  // first wavefront
     if (jb1 > 0 && c0 > 0) fwd_rows_dot(c, y, c1, jb1, 0, c0, CHD_REST_W0, CHD_REST_NW);     // the others: columns left of this block
     CHD_SYNC();
-    c.tacc[16] += CHD_CLOCK() - ts_; ts_ = CHD_CLOCK();
+    TACC(c, 16, CHD_CLOCK() - ts_); ts_ = CHD_CLOCK();
     if (jb1 > 0) {
       fwd_rows_dot(c, y, c1, jb1, c0, c1, 0, CHD_NWAVES);                             // columns of the block just solved
       if (tile) load_diag_tile(c, tile, c1, jb1);
     }
     CHD_SYNC();
-    c.tacc[17] += CHD_CLOCK() - ts_;
+    TACC(c, 17, CHD_CLOCK() - ts_);
   }
   ts_ = CHD_CLOCK();
   // forward, border rows: band part of L_border
@@ -1338,7 +1352,7 @@ CHD_DEV void ksolve_impl(Ctx& c, const GD* rhs, GD* x, YP y, SP Sp, const int ld
   }
   if (tile) load_diag_tile(c, tile, (nblk - 1) * nb, Nb - (nblk - 1) * nb);
   CHD_SYNC();
-  c.tacc[18] += CHD_CLOCK() - ts_;
+  TACC(c, 18, CHD_CLOCK() - ts_);
   // backward, band
   tri_backward(c, y, (nblk - 1) * nb, Nb - (nblk - 1) * nb, tile);
   CHD_SYNC();
@@ -1350,11 +1364,11 @@ CHD_DEV void ksolve_impl(Ctx& c, const GD* rhs, GD* x, YP y, SP Sp, const int ld
     bwd_cols_scatter(c, y, c0, jb, k0 > cp ? k0 : cp, c0, 0, CHD_NWAVES);             // into the previous block
     if (tile) load_diag_tile(c, tile, cp, nb);
     CHD_SYNC();
-    c.tacc[19] += CHD_CLOCK() - ts_; ts_ = CHD_CLOCK();
+    TACC(c, 19, CHD_CLOCK() - ts_); ts_ = CHD_CLOCK();
     tri_backward(c, y, cp, nb, tile);                                                 // first wavefront
     if (k0 < cp) bwd_cols_scatter(c, y, c0, jb, k0, cp, CHD_REST_W0, CHD_REST_NW);    // the others: columns further left
     CHD_SYNC();
-    c.tacc[20] += CHD_CLOCK() - ts_;
+    TACC(c, 20, CHD_CLOCK() - ts_);
   }
   PAR_FOR(i, N) x[i] = y[i];
   CHD_SYNC();
@@ -1400,7 +1414,7 @@ CHD_DEV void tri_chain_bwd(LdsD* y, const LdsD* tile, const int c0, const int jb
   }
   if (act) y[c0 + i] = yi;
 }
-CHD_DEV void ksolve_fast(Ctx& c, const GD* rhs, GD* x, LdsD* y, LdsD* Sp, LdsD* tile) {
+CHD_DEV void ksolve_fast(LCtx& c, const GD* rhs, GD* x, LdsD* y, LdsD* Sp, LdsD* tile) {
   const int Nb = c.Nb, w = c.w, W1 = c.w + 1, LD = c.LD, bc = c.bc, N = c.N;
   const int nb = CHD_SOLVE_NB, nblk = (Nb + nb - 1) / nb;
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
@@ -1547,7 +1561,7 @@ CHD_DEV void ksolve_fast(Ctx& c, const GD* rhs, GD* x, LdsD* y, LdsD* Sp, LdsD* 
   }
   CHD_WRITE_TILE();
   CHD_SYNC();
-  c.tacc[18] += CHD_CLOCK() - ts_;
+  TACC(c, 18, CHD_CLOCK() - ts_);
   // backward, band
   CHD_LOAD_TILE(nblk - 2);
   if (wv == 0) tri_chain_bwd(y, tile, (nblk - 1) * nb, Nb - (nblk - 1) * nb);
@@ -1569,7 +1583,7 @@ CHD_DEV void ksolve_fast(Ctx& c, const GD* rhs, GD* x, LdsD* y, LdsD* Sp, LdsD* 
   }
   PAR_FOR(i, N) x[i] = y[i];
   CHD_SYNC();
-  c.tacc[16] += t16_; c.tacc[17] += t17_; c.tacc[19] += t19_; c.tacc[20] += t20_;
+  TACC(c, 16, t16_); TACC(c, 17, t17_); TACC(c, 19, t19_); TACC(c, 20, t20_);
 #undef CHD_LOAD_TILE
 #undef CHD_WRITE_TILE
 #undef CHD_LOAD_FAR
@@ -1583,7 +1597,7 @@ CHD_DEV void ksolve_fast(Ctx& c, const GD* rhs, GD* x, LdsD* y, LdsD* Sp, LdsD* 
 }
 #endif
 
-CHD_NOINLINE CHD_DEV void ksolve_once(Ctx& c, const GD* rhs, GD* x) {
+CHD_NOINLINE CHD_DEV void ksolve_once(LCtx& c, const GD* rhs, GD* x) {
   TIC();
   const int N = c.N, bc = c.bc, Npad = (N + 1) & ~1;
   const int room = c.lds_cap - LDS_RED;
@@ -1605,7 +1619,7 @@ CHD_NOINLINE CHD_DEV void ksolve_once(Ctx& c, const GD* rhs, GD* x) {
   TOC(c, 3);
 }
 
-CHD_DEV void ksolve(Ctx& c, const GD* rhs, GD* x, const GD* diag, int refine) {
+CHD_DEV void ksolve(LCtx& c, const GD* rhs, GD* x, const GD* diag, int refine) {
   ksolve_once(c, rhs, x);
   GD* t1 = VK(c, VK_T1); GD* t2 = VK(c, VK_T2);
   for (int it = 0; it < refine; ++it) {
@@ -1621,12 +1635,12 @@ CHD_DEV void ksolve(Ctx& c, const GD* rhs, GD* x, const GD* diag, int refine) {
 // ------------------------------------------------------------------------------------------
 // NLP state <-> x
 // ------------------------------------------------------------------------------------------
-CHD_DEV void refresh_durations(const SeqDesc* q) {     // polynomial durations + cumulative times from the phase durations
+CHD_DEV void refresh_durations(QP q) {     // polynomial durations + cumulative times from the phase durations
   GD* wd = q->wd;
   PAR_FOR(idx, q->tot_polys) {
     int s = 0;
     while (s + 1 < N_SPLINES && idx >= q->sp[s + 1].poly_off) ++s;
-    const SplineDesc& sp = q->sp[s];
+    const auto& sp = q->sp[s];
     if (sp.phase_based) {
       const GI* pi = q->ci + q->o_pinfo + idx * 4;
       wd[q->o_poly_dur + idx] = wd[q->o_phase_dur + q->phase_off[sp.ee] + pi[0]] / pi[2];
@@ -1635,7 +1649,7 @@ CHD_DEV void refresh_durations(const SeqDesc* q) {     // polynomial durations +
   CHD_SYNC();
   PAR_FOR(s, N_SPLINES + N_EE) {
     if (s < N_SPLINES) {
-      const SplineDesc& sp = q->sp[s];
+      const auto& sp = q->sp[s];
       double t = 0;
       for (int p = 0; p < sp.n_polys; ++p) { t += wd[q->o_poly_dur + sp.poly_off + p]; wd[q->o_pend + sp.poly_off + p] = t; }
       wd[q->o_ttot + s] = t;
@@ -1648,8 +1662,8 @@ CHD_DEV void refresh_durations(const SeqDesc* q) {     // polynomial durations +
   CHD_SYNC();
 }
 
-CHD_DEV void state_from_x(Ctx& c, const GD* x) {
-  const SeqDesc* q = c.q;
+CHD_DEV void state_from_x(LCtx& c, const GD* x) {
+  QP q = c.q;
   PAR_FOR(k, q->tot_entries) {
     const int v = q->ci[q->o_varof + k];
     if (v >= 0) {
@@ -1671,8 +1685,8 @@ CHD_DEV void state_from_x(Ctx& c, const GD* x) {
   if (c.S->opt_dur) refresh_durations(q);
 }
 
-CHD_DEV void x_from_state(Ctx& c, GD* x) {
-  const SeqDesc* q = c.q;
+CHD_DEV void x_from_state(LCtx& c, GD* x) {
+  QP q = c.q;
   PAR_FOR(k, q->tot_entries) {
     const int v = q->ci[q->o_varof + k];
     if (v >= 0) {
@@ -1691,7 +1705,7 @@ CHD_DEV void x_from_state(Ctx& c, GD* x) {
 // Constraint rows
 // ------------------------------------------------------------------------------------------
 struct RowW {           // where one row's Jacobian entries go
-  Ctx* c; int pr; double sc; bool on;
+  LCtx* c; int pr; double sc; bool on;
 };
 // The (up to) 12 Jacobian entries of one row w.r.t. the four Hermite coefficients x three dimensions of the active
 // polynomial.  They are distinct KKT entries (after folding the two nodes of a stance pair, which share a variable), so
@@ -1699,9 +1713,9 @@ struct RowW {           // where one row's Jacobian entries go
 // trip per call instead of one (dependent) per entry.
 CHD_DEV void row_nodes(const RowW& r, int s, const PE& e, int which, const double coef[3], int dimmask) {
   if (!r.on) return;
-  Ctx& c = *r.c;
-  const SeqDesc* q = c.q;
-  const SplineDesc& sp = q->sp[s];
+  LCtx& c = *r.c;
+  QP q = c.q;
+  const auto& sp = q->sp[s];
   const GI* vo = q->ci + q->o_varof + sp.node_off + e.poly * 6;
   int v[12]; double val[12];
 #pragma unroll
@@ -1727,7 +1741,7 @@ CHD_DEV void row_nodes(const RowW& r, int s, const PE& e, int which, const doubl
 }
 CHD_DEV void row_durs(const RowW& r, int s, double t, const PE& e, const double coef[3]) {
   if (!r.on || !r.c->S->opt_dur) return;
-  const SeqDesc* q = r.c->q;
+  QP q = r.c->q;
   DurJac dj;
   dur_jac(q, s, t, e, dj);
   const int ee = q->sp[s].ee;
@@ -1736,7 +1750,7 @@ CHD_DEV void row_durs(const RowW& r, int s, double t, const PE& e, const double 
   const double vo = coef[0] * dj.own[0] + coef[1] * dj.own[1] + coef[2] * dj.own[2];
   // entries (row, T_k) for k < cur (value ve) and k == cur (value vo, unless it is the dependent last duration):
   // distinct KKT entries, eight at a time with their look-ups / loads / stores issued together
-  Ctx& c = *r.c;
+  LCtx& c = *r.c;
   const int n_early = dj.cur < dj.nvar ? dj.cur : dj.nvar;
   const int n_ent = n_early + (dj.last ? 0 : 1);
   for (int k0 = 0; k0 < n_ent; k0 += 8) {
@@ -1756,7 +1770,7 @@ CHD_DEV void row_durs(const RowW& r, int s, double t, const PE& e, const double 
   }
 }
 
-CHD_DEV int frame_index(const SeqDesc* q, double t) {       // humanoid_rigid_body_dynamics.cpp:81-87, leg_length_constraint.cpp:40-42
+CHD_DEV int frame_index(QP q, double t) {       // humanoid_rigid_body_dynamics.cpp:81-87, leg_length_constraint.cpp:40-42
   int idx = (int)((t / q->T) * q->F);
   if (idx >= q->F) idx = q->F - 1;
   if (idx < 0) idx = 0;
@@ -1770,8 +1784,8 @@ CHD_DEV int frame_index(const SeqDesc* q, double t) {       // humanoid_rigid_bo
 //   units 4-15: end-effector e = (unit - 4) / 3, rows i = (unit - 4) % 3 (force nodes, position nodes, durations;
 //               the unit with i = 0 also stores the second-order duration terms of e)
 // Every unit evaluates only the splines it needs.
-CHD_DEV void dyn_unit(Ctx& c, const int ti, const int unit, const bool D2, GD* cout_, const GD* lam, const GD* sc) {
-  const SeqDesc* q = c.q; const StageDesc* S = c.S;
+CHD_DEV void dyn_unit(LCtx& c, const int ti, const int unit, const bool D2, GD* cout_, const GD* lam, const GD* sc) {
+  QP q = c.q; SDP S = c.S;
   const GI* tk = q->ci + S->o_task + 4 * ti;
   const int B = tk[2], row0 = tk[3];
   const double t = q->cd[S->o_task_t + ti];
@@ -1856,8 +1870,8 @@ CHD_DEV void dyn_unit(Ctx& c, const int ti, const int unit, const bool D2, GD* c
   }
 }
 
-CHD_NOINLINE CHD_DEV void eval_rows(Ctx& c, int mode, GD* cout_, const GD* lam) {
-  const SeqDesc* q = c.q; const StageDesc* S = c.S;
+CHD_NOINLINE CHD_DEV void eval_rows(LCtx& c, int mode, GD* cout_, const GD* lam) {
+  QP q = c.q; SDP S = c.S;
   const GD* sc = VM(c, VM_SC);
   const bool J = mode == EV_FULL;
   const bool D2 = J && S->opt_dur && lam != nullptr;      // exact duration block of the Lagrangian Hessian
@@ -1883,7 +1897,7 @@ CHD_NOINLINE CHD_DEV void eval_rows(Ctx& c, int mode, GD* cout_, const GD* lam) 
         }
       } break;
       case T_TERRAIN: {      // TOWR TerrainConstraint: z - h(x, y)
-        const SplineDesc& sp = q->sp[2 + A];
+        const auto& sp = q->sp[2 + A];
         const GD* nv = q->wd + q->o_node + sp.node_off + B * 6;
         const double h = (-q->normal[1] * (nv[1] - q->point[1]) - q->normal[0] * (nv[0] - q->point[0])) / q->normal[2] + q->point[2];   // ground_plane.cpp:18-27
         cout_[row0] = sc[row0] * (nv[2] - h);
@@ -1946,7 +1960,7 @@ CHD_NOINLINE CHD_DEV void eval_rows(Ctx& c, int mode, GD* cout_, const GD* lam) 
       } break;
       case T_DYN: break;     // dyn_unit above
       case T_FORCE: {        // TOWR ForceConstraint: normal force range + friction pyramid
-        const SplineDesc& sp = q->sp[6 + A];
+        const auto& sp = q->sp[6 + A];
         const GD* nv = q->wd + q->o_node + sp.node_off + B * 6;
         const GI* vo = q->ci + q->o_varof + sp.node_off + B * 6;
         for (int r5 = 0; r5 < 5; ++r5) {
@@ -1967,12 +1981,13 @@ CHD_NOINLINE CHD_DEV void eval_rows(Ctx& c, int mode, GD* cout_, const GD* lam) 
         if (J) {
           RowW r{&c, c.pos_row[row0], sc[row0], true};
           const int mask = (q->normal[0] != 0.0 ? 1 : 0) | (q->normal[1] != 0.0 ? 2 : 0) | (q->normal[2] != 0.0 ? 4 : 0);
-          row_nodes(r, 2 + A, pm, 0, q->normal, mask);
-          row_durs(r, 2 + A, t, pm, q->normal);
+          const double nrm[3] = {q->normal[0], q->normal[1], q->normal[2]};
+          row_nodes(r, 2 + A, pm, 0, nrm, mask);
+          row_durs(r, 2 + A, t, pm, nrm);
           if (D2) {
             DurJac2 dj; dur_jac2(q, 2 + A, t, pm, dj);
             const double ls = lam[row0] * sc[row0];
-            d2_store(q, A, slot_height + B, dj.cur, ls * dot3(q->normal, dj.Qee), ls * dot3(q->normal, dj.Qec), ls * dot3(q->normal, dj.Qcc));
+            d2_store(q, A, slot_height + B, dj.cur, ls * dot3(nrm, dj.Qee), ls * dot3(nrm, dj.Qec), ls * dot3(nrm, dj.Qcc));
           }
         }
       } break;
@@ -1994,10 +2009,10 @@ CHD_NOINLINE CHD_DEV void eval_rows(Ctx& c, int mode, GD* cout_, const GD* lam) 
 // ------------------------------------------------------------------------------------------
 // Cost terms: sum 1/2 w r^2 with gradient and Gauss-Newton Hessian
 // ------------------------------------------------------------------------------------------
-CHD_DEV const GD* scache(const SeqDesc* q, int s, int i) { return q->wd + q->o_scache + ((long long)s * (q->F + 2) + i) * SC_STRIDE; }
+CHD_DEV const GD* scache(QP q, int s, int i) { return q->wd + q->o_scache + ((long long)s * (q->F + 2) + i) * SC_STRIDE; }
 
-CHD_NOINLINE CHD_DEV void fill_sample_cache(Ctx& c, const bool with_dur) {       // with_dur: also the duration derivatives (full evaluations only)
-  const SeqDesc* q = c.q;
+CHD_NOINLINE CHD_DEV void fill_sample_cache(LCtx& c, const bool with_dur) {       // with_dur: also the duration derivatives (full evaluations only)
+  QP q = c.q;
   const int F1 = q->F + 1;
   PAR_FOR(idx, 6 * F1) {
     const int s = idx / F1, i = idx % F1;
@@ -2031,15 +2046,15 @@ CHD_DEV double cache_djac(SP sc_, int dim, int k) {
 }
 
 // number of smoothing residuals of spline s: loop `for (t = 0; t < T_s - dt; t += dt)` (vel_smooth_cost.cpp:41)
-CHD_DEV int n_smooth(const SeqDesc* q, int s) {
+CHD_DEV int n_smooth(QP q, int s) {
   const double lim = q->wd[q->o_ttot + s] - q->dt - 1e-9;   // the last sample sits exactly on the limit: tolerance, not rounding, decides
   int n = q->F;
   while (n > 0 && !(q->cd[q->o_tcost + n - 1] < lim)) --n;
   return n;
 }
 
-CHD_NOINLINE CHD_DEV double eval_cost_value(Ctx& c) {
-  const SeqDesc* q = c.q; const StageDesc* S = c.S;
+CHD_NOINLINE CHD_DEV double eval_cost_value(LCtx& c) {
+  QP q = c.q; SDP S = c.S;
   const int F = q->F;
   double part = 0.0;
   PAR_FOR(idx, 6 * F) {
@@ -2075,8 +2090,8 @@ CHD_DEV void supp_add_sample(Supp& sp, const double* sc_, int which, double sign
     for (int dq = 0; dq < 2; ++dq) { sp.node[sp.n] = poly + side; sp.dq[sp.n] = dq; sp.g[sp.n] = sign * wv[side * 2 + dq]; ++sp.n; }
 }
 
-CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, GD* g, const GD* lam) {
-  const SeqDesc* q = c.q; const StageDesc* S = c.S;
+CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(LCtx& c, GD* g, const GD* lam) {
+  QP q = c.q; SDP S = c.S;
   const int F = q->F;
   GI* first = q->wi + q->o_first;
   const int fstride = q->max_polys + 2;
@@ -2102,8 +2117,8 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, GD* g, const GD* lam) {
   int tot_nodes = 0;
   for (int s = 0; s < 6; ++s) tot_nodes += q->sp[s].n_nodes;
   const int reach = gap + 2, ncol = (reach + 1) * 2;
-  auto second_of_pair = [&](const SplineDesc& sp, const GI* pinfo, int n) { return sp.phase_based && n > 0 && pinfo[(n - 1) * 4 + 3] != 0; };
-  auto group_end = [&](const SplineDesc& sp, const GI* pinfo, int n) { return (sp.phase_based && n < sp.n_polys && pinfo[n * 4 + 3]) ? n + 1 : n; };
+  auto second_of_pair = [&](const auto& sp, const GI* pinfo, int n) { return sp.phase_based && n > 0 && pinfo[(n - 1) * 4 + 3] != 0; };
+  auto group_end = [&](const auto& sp, const GI* pinfo, int n) { return (sp.phase_based && n < sp.n_polys && pinfo[n * 4 + 3]) ? n + 1 : n; };
   // weight of the coefficient (nodes n..nh, derivative dq) in the position (which = 0) / velocity (1) of a sample
   auto wgt = [](auto a, int which, int n, int nh, int dq) {
     const int p = (int)a[SC_POLY];
@@ -2119,7 +2134,7 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, GD* g, const GD* lam) {
       const int dq1 = row % 2, back = col / 2, dq2 = col % 2;
       int n1 = row / 2, s = 0;
       while (n1 >= q->sp[s].n_nodes) { n1 -= q->sp[s].n_nodes; ++s; }
-      const SplineDesc& sp = q->sp[s];
+      const auto& sp = q->sp[s];
       const GI* pinfo = q->ci + q->o_pinfo + sp.poly_off * 4;
       const GI* vo = q->ci + q->o_varof + sp.node_off;
       const int n2 = n1 - back;
@@ -2162,7 +2177,7 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, GD* g, const GD* lam) {
       const int dim = idx % 3, row = idx / 3, dq1 = row % 2;
       int n1 = row / 2, s = 0;
       while (n1 >= q->sp[s].n_nodes) { n1 -= q->sp[s].n_nodes; ++s; }
-      const SplineDesc& sp = q->sp[s];
+      const auto& sp = q->sp[s];
       const GI* pinfo = q->ci + q->o_pinfo + sp.poly_off * 4;
       const GI* vo = q->ci + q->o_varof + sp.node_off;
       const int v1 = vo[n1 * 6 + dq1 * 3 + dim];
@@ -2200,7 +2215,7 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, GD* g, const GD* lam) {
     node_terms(lds_sample);
   } else node_terms(hbm_sample);
   CHD_SYNC();
-  c.tacc[13] += CHD_CLOCK() - tg_; tg_ = CHD_CLOCK();
+  TACC(c, 13, CHD_CLOCK() - tg_); tg_ = CHD_CLOCK();
   // ---- duration variables (stage 3 only)
   if (S->opt_dur && lam) {
     // residual-weighted curvature of the cost terms, one table slot per data sample:
@@ -2244,7 +2259,7 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, GD* g, const GD* lam) {
     }
   }
   CHD_SYNC();
-  c.tacc[14] += CHD_CLOCK() - tg_; tg_ = CHD_CLOCK();
+  TACC(c, 14, CHD_CLOCK() - tg_); tg_ = CHD_CLOCK();
   if (S->opt_dur) {
     auto dur_terms = [&](auto sample) {
     int tot = 0;
@@ -2253,7 +2268,7 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, GD* g, const GD* lam) {
       int idx = idx0, e = 0;
       while (idx >= (q->n_phase[e] - 1) * (q->n_phase[e] - 1)) { idx -= (q->n_phase[e] - 1) * (q->n_phase[e] - 1); ++e; }
       const int s = 2 + e;
-      const SplineDesc& sp = q->sp[s];
+      const auto& sp = q->sp[s];
       const int ntar = q->n_phase[e] - 1;
       const int k = idx / ntar, tar = sp.n_var + idx % ntar;
       const int Pk = c.pos_var[S->dur_off[e] + k];
@@ -2303,7 +2318,7 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, GD* g, const GD* lam) {
       int tar = idx0, e = 0;
       while (tar >= q->sp[2 + e].n_var) { tar -= q->sp[2 + e].n_var; ++e; }
       const int s = 2 + e;
-      const SplineDesc& sp = q->sp[s];
+      const auto& sp = q->sp[s];
       const int nv = q->n_phase[e] - 1;
       const double wdat = S->w_data[2], wvel = S->w_vel[2];
       const int nsm = n_smooth(q, s);
@@ -2361,12 +2376,12 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(Ctx& c, GD* g, const GD* lam) {
     if (in_lds) dur_terms(lds_sample); else dur_terms(hbm_sample);
   }
   CHD_SYNC();
-  c.tacc[15] += CHD_CLOCK() - tg_;
+  TACC(c, 15, CHD_CLOCK() - tg_);
 }
 
 // Full evaluation at x.  Returns the (scaled) objective; fills c_out (scaled rows), and in
 // EV_FULL mode the scaled gradient g and the unfactored KKT matrix K0 = [sf H, (sc J)^T; sc J, 0].
-CHD_DEV double eval_nlp(Ctx& c, const GD* x, int mode, GD* c_out, GD* g, const GD* lam = nullptr) {
+CHD_DEV double eval_nlp(LCtx& c, const GD* x, int mode, GD* c_out, GD* g, const GD* lam = nullptr) {
   TIC();
   state_from_x(c, x);
   if (mode == EV_FULL) {
@@ -2377,16 +2392,16 @@ CHD_DEV double eval_nlp(Ctx& c, const GD* x, int mode, GD* c_out, GD* g, const G
     }
   }
   fill_sample_cache(c, mode == EV_FULL);      // ends with a sync (also orders kzero before the kadd's below)
-  if (mode == EV_FULL) c.tacc[21] += CHD_CLOCK() - tic_;
+  if (mode == EV_FULL) TACC(c, 21, CHD_CLOCK() - tic_);
   long long te_ = CHD_CLOCK();
   eval_rows(c, mode, c_out, lam);
   const double f = c.sf * eval_cost_value(c);
   if (mode == EV_FULL) {
     CHD_SYNC();
-    c.tacc[22] += CHD_CLOCK() - te_; te_ = CHD_CLOCK();
+    TACC(c, 22, CHD_CLOCK() - te_); te_ = CHD_CLOCK();
     eval_cost_grad_hess(c, g, lam);
     c.err = block_max(c, (double)c.err) > 0.5 ? 1 : 0;     // a band overflow seen by any thread
-    c.tacc[23] += CHD_CLOCK() - te_;
+    TACC(c, 23, CHD_CLOCK() - te_);
   }
   CHD_SYNC();
   TOC(c, mode == EV_FULL ? 0 : 1);
@@ -2398,9 +2413,9 @@ CHD_DEV double eval_nlp(Ctx& c, const GD* x, int mode, GD* c_out, GD* g, const G
 // algorithm: primal-dual log-barrier on the slack formulation, Gauss-Newton Hessian with
 // Levenberg damping, l1 merit line search with second-order correction).
 // ------------------------------------------------------------------------------------------
-struct StageResult { int status, iters, n_factor; double kkt, viol, obj, mu; };
+struct StageResult { int status, iters, n_factor, stalled; double kkt, viol, obj, mu; };
 
-CHD_DEV double compl_error(Ctx& c, double mu) {
+CHD_DEV double compl_error(LCtx& c, double mu) {
   const GI* fl = c.q->wi + c.q->o_flags;
   const GD* s = VM(c, VM_S), *l = VM(c, VM_L), *u = VM(c, VM_U), *zL = VM(c, VM_ZL), *zU = VM(c, VM_ZU);
   double e = 0;
@@ -2411,7 +2426,7 @@ CHD_DEV double compl_error(Ctx& c, double mu) {
   return block_max(c, e);
 }
 
-CHD_DEV double barrier_val(Ctx& c, const GD* ss, double mu) {
+CHD_DEV double barrier_val(LCtx& c, const GD* ss, double mu) {
   const GI* fl = c.q->wi + c.q->o_flags;
   const GD* l = VM(c, VM_L), *u = VM(c, VM_U);
   double b = 0;
@@ -2422,15 +2437,15 @@ CHD_DEV double barrier_val(Ctx& c, const GD* ss, double mu) {
   return block_sum(c, b);
 }
 
-CHD_DEV void residual(Ctx& c, const GD* cc, const GD* ss, GD* r) {
+CHD_DEV void residual(LCtx& c, const GD* cc, const GD* ss, GD* r) {
   const GI* fl = c.q->wi + c.q->o_flags;
   const GD* l = VM(c, VM_L);
   PAR_FOR(i, c.m) r[i] = (fl[i] & RF_EQ) ? cc[i] - l[i] : cc[i] - ss[i];
   CHD_SYNC();
 }
 
-CHD_NOINLINE CHD_DEV void solve_stage(Ctx& c, StageResult& res) {
-  const SeqDesc* q = c.q; const StageDesc* S = c.S;
+CHD_NOINLINE CHD_DEV void solve_stage(LCtx& c, StageResult& res) {
+  QP q = c.q; SDP S = c.S;
   const int n = c.n, m = c.m, N = c.N;
   GD* x = VN(c, VN_X), *g = VN(c, VN_G), *dualx = VN(c, VN_DUALX), *dx = VN(c, VN_DX), *xt = VN(c, VN_XT), *xs = VN(c, VN_XS);
   GD* cc = VM(c, VM_C), *s = VM(c, VM_S), *zL = VM(c, VM_ZL), *zU = VM(c, VM_ZU), *lam = VM(c, VM_LAM), *l = VM(c, VM_L), *u = VM(c, VM_U),
@@ -2503,7 +2518,7 @@ CHD_NOINLINE CHD_DEV void solve_stage(Ctx& c, StageResult& res) {
   const double kappa_eps = 10.0, kappa_mu = 0.2, theta_mu = 1.5, smax = 100.0;
   const double tol_ = c.tol;
 
-  int status = -1, it = 0, n_factor = 0;
+  int status = -1, it = 0, n_factor = 0, stalled_out = 0;
   double E0 = 0, e_d = 0, e_p = 0, e_pu = 0;
   for (it = 0; it < S->max_iter; ++it) {
     // ---- optimality error (IPOPT eq. (5)/(6))
@@ -2529,14 +2544,16 @@ CHD_NOINLINE CHD_DEV void solve_stage(Ctx& c, StageResult& res) {
     e_d = d1 / s_d;
     E0 = fmax(e_d, fmax(e_p, compl_error(c, 0.0) / s_c));
     if (E0 <= tol_ && e_pu <= CHD_CONSTR_VIOL_TOL) { status = 0; break; }
-    // stall guard: no factor-2 reduction of the optimality error over the last CHD_STALL_WINDOW iterations -> status -2
-    // instead of running to the iteration cap (stage 3 then takes the reference's stage-4 fallback, phys_optim.cpp:714)
-    {
+    // stall guard (chd_config.stall_window, 0 = off): no factor-2 reduction of the optimality error over the last `window`
+    // iterations -> status -2 instead of running to the iteration cap (stage 3 then takes the reference's stage-4
+    // fallback, phys_optim.cpp:714).  Not an IPOPT rule: the per-stage statistics report it (RS_AUX2 = 1).
+    if (c.stall_window > 0) {
       GD* hist = VK(c, VK_HIST);
-      const int slot = it % CHD_STALL_WINDOW;
-      const bool stalled = it >= CHD_STALL_WINDOW && E0 > 0.5 * hist[slot];
+      const int win = c.stall_window < q->max_N ? c.stall_window : q->max_N;
+      const int slot = it % win;
+      const bool stalled = it >= win && E0 > 0.5 * hist[slot];
       CHD_SYNC();
-      if (stalled) { status = -2; break; }
+      if (stalled) { status = -2; stalled_out = 1; break; }
       if (CHD_TID == 0) hist[slot] = E0;
       CHD_SYNC();
     }
@@ -2681,13 +2698,13 @@ CHD_NOINLINE CHD_DEV void solve_stage(Ctx& c, StageResult& res) {
   double cv = 0;
   PAR_FOR(i, m) { const double v = cc[i] / sc[i]; cv = fmax(cv, fmax(cl[i] - v, v - cu[i])); }
   cv = block_max(c, cv);
-  res.status = c.err ? -3 : status; res.iters = it; res.n_factor = n_factor; res.kkt = E0; res.viol = fmax(cv, 0.0); res.obj = f / c.sf; res.mu = mu;
+  res.status = c.err ? -3 : status; res.iters = it; res.n_factor = n_factor; res.kkt = E0; res.viol = fmax(cv, 0.0); res.obj = f / c.sf; res.mu = mu; res.stalled = stalled_out;
 }
 
 // ------------------------------------------------------------------------------------------
 // SaveSolution (phys_optim.cpp:63-143): resample the splines at the data rate
 // ------------------------------------------------------------------------------------------
-CHD_NOINLINE CHD_DEV void sample_solution(const SeqDesc* q, int snap) {
+CHD_NOINLINE CHD_DEV void sample_solution(QP q, int snap) {
   const int cap = q->cap;
   GD* od = q->out_d + N_STAGES * RS_STRIDE + (long long)snap * 10 * cap * 3;
   GI* oi = q->out_i;
@@ -2720,21 +2737,24 @@ CHD_NOINLINE CHD_DEV void sample_solution(const SeqDesc* q, int snap) {
 // ------------------------------------------------------------------------------------------
 // One sequence, stages stage_first..stage_last (the whole of main() after the readers)
 // ------------------------------------------------------------------------------------------
-CHD_DEV void bind_stage(Ctx& c, const SeqDesc* q, int stage) {
-  c.q = q; c.S = &q->st[stage];
-  c.n = c.S->n; c.m = c.S->m; c.N = c.n + c.m; c.Nb = c.S->Nb; c.bc = c.S->bc; c.w = c.S->w;
-  c.W2 = 2 * c.w + 1; c.LD = c.N;
-  c.K0b = q->wd + q->o_K0b; c.K0x = q->wd + q->o_K0x; c.Kfb = q->wd + q->o_Kfb; c.Kfx = q->wd + q->o_Kfx;
-  c.pos_var = q->ci + c.S->o_pos_var; c.pos_row = q->ci + c.S->o_pos_row; c.env = q->wi + q->o_envw; c.rcnt = q->wi + q->o_rcntw;
-  c.sf = 1.0; c.err = 0; c.n_bad_pivots = 0;
+CHD_DEV void bind_stage(LCtx& c, QP q, int stage) {
+  if (CHD_TID == 0) {          // the context is shared by the workgroup
+    c.q = q; c.S = &q->st[stage];
+    c.n = c.S->n; c.m = c.S->m; c.N = c.n + c.m; c.Nb = c.S->Nb; c.bc = c.S->bc; c.w = c.S->w;
+    c.W2 = 2 * c.w + 1; c.LD = c.N;
+    c.K0b = q->wd + q->o_K0b; c.K0x = q->wd + q->o_K0x; c.Kfb = q->wd + q->o_Kfb; c.Kfx = q->wd + q->o_Kfx;
+    c.pos_var = q->ci + c.S->o_pos_var; c.pos_row = q->ci + c.S->o_pos_row; c.env = q->wi + q->o_envw; c.rcnt = q->wi + q->o_rcntw;
+    c.sf = 1.0; c.err = 0; c.n_bad_pivots = 0;
+  }
+  CHD_SYNC();
 }
 
-CHD_DEV void init_state(const SeqDesc* q) {
+CHD_DEV void init_state(QP q) {
   PAR_FOR(k, q->tot_entries) q->wd[q->o_node + k] = q->cd[q->o_node0 + k];
   PAR_FOR(k, q->tot_phases) q->wd[q->o_phase_dur + k] = q->cd[q->o_phase_dur_in + k];
   // base splines: fixed 0.1 s polynomials (parameters.cpp:109-125)
   for (int b = 0; b < 2; ++b) {
-    const SplineDesc& sp = q->sp[b];
+    const auto& sp = q->sp[b];
     PAR_FOR(p, sp.n_polys) {
       double left = q->T;
       for (int k = 0; k < p; ++k) left -= 0.1;
@@ -2745,28 +2765,56 @@ CHD_DEV void init_state(const SeqDesc* q) {
   refresh_durations(q);
 }
 
-CHD_DEV void run_sequence(const SeqDesc* q, LdsD* lds, int lds_cap, double tol, int stage_first, int stage_last) {
-  Ctx c;
-  c.lds = lds; c.lds_cap = lds_cap;
-  for (int k = 0; k < 24; ++k) c.tacc[k] = 0;
+// The workspace belongs to the workgroup, not to the sequence: what a later launch needs of a sequence's state (the
+// stage-4 fallback starts from the node values and durations stage 3 left, phys_optim.cpp:714-749) is kept with the
+// sequence's results.
+CHD_DEV GD* saved_state(QP q) { return q->out_d + out_d_state_off(q->cap); }
+CHD_DEV void save_state(QP q) {
+  GD* st = saved_state(q);
+  PAR_FOR(k, q->tot_entries) st[k] = q->wd[q->o_node + k];
+  PAR_FOR(k, q->tot_phases) st[q->tot_entries + k] = q->wd[q->o_phase_dur + k];
+  CHD_SYNC();
+}
+CHD_DEV void load_state(QP q) {
+  const GD* st = saved_state(q);
+  PAR_FOR(k, q->tot_entries) q->wd[q->o_node + k] = st[k];
+  PAR_FOR(k, q->tot_phases) q->wd[q->o_phase_dur + k] = st[q->tot_entries + k];
+  CHD_SYNC();
+  refresh_durations(q);
+}
+
+CHD_DEV void reset_context(LCtx& c, LdsD* lds, int lds_cap, double tol, int stall_window) {
+  if (CHD_TID == 0) {
+    c.lds = lds; c.lds_cap = lds_cap; c.tol = tol; c.stall_window = stall_window;
+    for (int k = 0; k < 24; ++k) c.tacc[k] = 0;
+  }
+  CHD_SYNC();
+}
+
+CHD_DEV void run_sequence(QP q, LCtx& c, LdsD* lds, int lds_cap, double tol, int stall_window, int stage_first, int stage_last) {
+  reset_context(c, lds, lds_cap, tol, stall_window);
   const long long t_begin = CHD_CLOCK();
-  if (stage_first == 0) init_state(q);
-  else refresh_durations(q);
+  // the workgroup's workspace still holds the previous sequence: everything below the KKT storage (state, solver
+  // vectors, tables) starts from zero; the KKT storage is cleared stage by stage (kreset)
+  for (long long i = CHD_TID; i < q->o_K0b; i += CHD_NT) q->wd[i] = 0.0;
+  CHD_SYNC();
+  init_state(q);
+  if (stage_first != 0) load_state(q);
   for (int stage = stage_first; stage <= stage_last; ++stage) {
     GD* rs = q->out_d + stage * RS_STRIDE;
     if (!q->st[stage].valid) { if (CHD_TID == 0) { rs[RS_STATUS] = -3; rs[RS_ITERS] = 0; } continue; }
     bind_stage(c, q, stage);
     kreset(c);
-    c.tol = tol;
     StageResult r;
     solve_stage(c, r);
     if (CHD_TID == 0) {
       rs[RS_STATUS] = r.status; rs[RS_ITERS] = r.iters; rs[RS_KKT] = r.kkt; rs[RS_VIOL] = r.viol; rs[RS_OBJ] = r.obj;
-      rs[RS_MU] = r.mu; rs[RS_NFACT] = r.n_factor; rs[RS_AUX] = c.n_bad_pivots;
+      rs[RS_MU] = r.mu; rs[RS_NFACT] = r.n_factor; rs[RS_AUX] = r.stalled;
     }
     if (stage == 1) sample_solution(q, 0);       // sol_out_no_dynamics.txt  (phys_optim.cpp:603)
     if (stage == 3) sample_solution(q, 1);       // sol_out_dynamics.txt     (:661)
     if (stage == 4 || stage == 5) sample_solution(q, 2);   // sol_out_durations.txt (:757)
+    if (stage == 4) save_state(q);
     CHD_SYNC();
   }
   if (CHD_TID == 0) {      // phase timers (100 MHz wall clock ticks), accumulated over launches
@@ -2774,23 +2822,24 @@ CHD_DEV void run_sequence(const SeqDesc* q, LdsD* lds, int lds_cap, double tol, 
     GD* tm = q->out_d + N_STAGES * RS_STRIDE + 3LL * 10 * q->cap * 3;
     for (int k = 0; k < 24; ++k) tm[k] += (double)c.tacc[k];
   }
+  CHD_SYNC();
 }
 
-// Debug entry: evaluate stage `stage` at the state currently in the workspace (or at x if given in VN_XT).
-CHD_DEV void debug_eval(const SeqDesc* q, int stage, int use_x, LdsD* lds, int lds_cap, double* f_out, int use_lam = 0) {
-  Ctx c;
-  c.lds = lds; c.lds_cap = lds_cap;
-  for (int k = 0; k < 24; ++k) c.tacc[k] = 0;
+// Debug entry: evaluate stage `stage` at the initial state (or at xin), with the exact duration block for the multipliers lamin if given.
+CHD_DEV void debug_eval(QP q, LCtx& c, int stage, int use_x, LdsD* lds, int lds_cap, const GD* xin, const GD* lamin, double* f_out) {
+  reset_context(c, lds, lds_cap, 1e-3, 0);
+  for (long long i = CHD_TID; i < q->o_K0b; i += CHD_NT) q->wd[i] = 0.0;
+  CHD_SYNC();
   init_state(q);
   bind_stage(c, q, stage);
   kreset(c);
-  c.tol = 1e-3;
   GD* x = VN(c, VN_X);
-  if (use_x) { PAR_FOR(j, c.n) x[j] = VN(c, VN_XT)[j]; CHD_SYNC(); state_from_x(c, x); }
+  if (use_x) { PAR_FOR(j, c.n) x[j] = xin[j]; CHD_SYNC(); state_from_x(c, x); }
   x_from_state(c, x);
   PAR_FOR(i, c.m) VM(c, VM_SC)[i] = 1.0;
+  if (lamin) PAR_FOR(i, c.m) VM(c, VM_LAM)[i] = lamin[i];
   CHD_SYNC();
-  const double f = eval_nlp(c, x, EV_FULL, VM(c, VM_C), VN(c, VN_G), use_lam ? VM(c, VM_LAM) : nullptr);
+  const double f = eval_nlp(c, x, EV_FULL, VM(c, VM_C), VN(c, VN_G), lamin ? VM(c, VM_LAM) : nullptr);
   if (CHD_TID == 0) { f_out[0] = f; f_out[1] = c.err; }
   CHD_SYNC();
 }

@@ -107,6 +107,9 @@ class SeqModel {
     double T = 0;
     for (int k = 0; k < in.n_phases[0]; ++k) T += in.durations[0][k];   // total time from the L-toe schedule (phys_optim.cpp:420-423)
     d.T = T;
+    // SaveSolution writes int((T + 1e-5) / dt) + 1 samples (phys_optim.cpp:71-84); prepare_input makes T = (F - 1) dt
+    // (towr_utils.py:440).  A schedule longer than the frame count implies does not fit the caller's F + 4 arrays.
+    if ((int)((T + 1e-5) / in.dt) + 1 > F + 3) throw std::runtime_error("contact_info: the contact schedule is longer than nframes x dt");
     for (int e = 0; e < 4; ++e) {   // parameters.cpp:150 asserts all schedules share the total time
       double s = 0; for (double v : phase_in[e]) s += v;
       if (std::fabs(s - T) > 1e-6) throw std::runtime_error("contact_info: phase durations of the four end-effectors do not sum to the same total time");

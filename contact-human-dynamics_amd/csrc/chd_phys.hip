@@ -5,6 +5,7 @@
 // There is no CPU solve path in this library: without a HIP device chd_phys_create fails.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -21,16 +22,55 @@ using namespace chd;
 
 #define CHD_MAX_THREADS 512
 
-__global__ __launch_bounds__(CHD_MAX_THREADS) void chd_solve_kernel(const SeqDesc* descs, const int* index, int lds_doubles, double tol,
-                                                                    int stage_first, int stage_last) {
-  extern __shared__ double lds[];
-  const SeqDesc* q = descs + (index ? index[blockIdx.x] : (int)blockIdx.x);
-  run_sequence(q, (LdsD*)lds, lds_doubles, tol, stage_first, stage_last);
+// A launch is persistent: `grid` resident workgroups (one per compute unit: a workgroup needs the whole LDS) take sequence
+// after sequence from a queue (`order[0 .. n_items)`, next index = atomic counter) until it is drained.  A workgroup owns
+// a workspace (KKT storage, solver vectors: ~30 MB at 90 frames) for the lifetime of the handle; a sequence owns only its
+// inputs, structure tables and results.  The descriptor of the sequence being solved and the solver context sit in LDS.
+static_assert(sizeof(SeqDesc) % 8 == 0, "SeqDesc is copied word by word");
+static_assert(sizeof(SeqDesc) + sizeof(Ctx) + 64 <= 4096, "static LDS of the solver kernel must fit the 4 KB left beside the dynamic part");
+
+__device__ inline QP take_sequence(SeqDesc* s_desc, int* s_item, const SeqDesc* descs, const int* order, int n_items, int* counter,
+                                   double* wd_pool, long long wd_stride, int* wi_pool, long long wi_stride) {
+  __syncthreads();                                  // everybody is done with the previous descriptor
+  if (threadIdx.x == 0) *s_item = atomicAdd(counter, 1);
+  __syncthreads();
+  const int item = *s_item;
+  if (item >= n_items) return nullptr;
+  const int* src = (const int*)(descs + order[item]);
+  LdsI* dst = (LdsI*)s_desc;
+  for (int i = threadIdx.x; i < (int)(sizeof(SeqDesc) / 4); i += blockDim.x) dst[i] = src[i];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s_desc->wd = (GD*)(wd_pool + (long long)blockIdx.x * wd_stride);
+    s_desc->wi = (GI*)(wi_pool + (long long)blockIdx.x * wi_stride);
+  }
+  __syncthreads();
+  return (QP)s_desc;
 }
 
-__global__ __launch_bounds__(CHD_MAX_THREADS) void chd_debug_eval_kernel(const SeqDesc* descs, int seq, int stage, int use_x, int lds_doubles, double* f_out) {
+__global__ __launch_bounds__(CHD_MAX_THREADS) void chd_solve_kernel(const SeqDesc* descs, const int* order, int n_items, int* counter,
+                                                                    double* wd_pool, long long wd_stride, int* wi_pool, long long wi_stride,
+                                                                    int lds_doubles, double tol, int stall_window, int stage_first, int stage_last) {
   extern __shared__ double lds[];
-  debug_eval(descs + seq, stage, use_x, (LdsD*)lds, lds_doubles, f_out);
+  __shared__ SeqDesc s_desc;
+  __shared__ Ctx s_ctx;
+  __shared__ int s_item;
+  for (;;) {
+    QP q = take_sequence(&s_desc, &s_item, descs, order, n_items, counter, wd_pool, wd_stride, wi_pool, wi_stride);
+    if (!q) break;
+    run_sequence(q, *(LCtx*)&s_ctx, (LdsD*)lds, lds_doubles, tol, stall_window, stage_first, stage_last);
+  }
+}
+
+__global__ __launch_bounds__(CHD_MAX_THREADS) void chd_debug_eval_kernel(const SeqDesc* descs, const int* order, int* counter, double* wd_pool, int* wi_pool,
+                                                                         int stage, const double* xin, int lds_doubles, double* f_out) {
+  extern __shared__ double lds[];
+  __shared__ SeqDesc s_desc;
+  __shared__ Ctx s_ctx;
+  __shared__ int s_item;
+  QP q = take_sequence(&s_desc, &s_item, descs, order, 1, counter, wd_pool, 0, wi_pool, 0);
+  if (!q) return;
+  debug_eval(q, *(LCtx*)&s_ctx, stage, xin != nullptr, (LdsD*)lds, lds_doubles, (const GD*)xin, (const GD*)nullptr, f_out);
 }
 
 struct chd_handle {
@@ -40,20 +80,29 @@ struct chd_handle {
   std::string err;
   int lds_bytes = 0;
   int threads = CHD_MAX_THREADS;
+  int n_wg = 0;                        // resident workgroups of a launch
+  // workgroup workspaces (grow-only) and the queue counter
+  double* d_wd = nullptr; int* d_wi = nullptr; int* d_counter = nullptr;
+  long long wd_stride = 0, wi_stride = 0;
 };
 
 struct chd_batch {
   int B = 0;
   std::vector<SeqModel> models;
   std::vector<SeqDesc> descs;            // host copy with DEVICE pointers
-  std::vector<long long> off_cd, off_ci, off_wd, off_wi, off_od, off_oi;
-  long long tot_cd = 0, tot_ci = 0, tot_wd = 0, tot_wi = 0, tot_od = 0, tot_oi = 0;
-  double *d_cd = nullptr, *d_wd = nullptr, *d_od = nullptr, *d_f = nullptr;
-  int *d_ci = nullptr, *d_wi = nullptr, *d_oi = nullptr, *d_index = nullptr;
+  std::vector<char> ok;                  // 0: rejected at set-up (build_err), never queued
+  std::vector<std::string> build_err;
+  std::vector<int> order;                // queue order of the solvable sequences (longest first)
+  std::vector<long long> off_cd, off_ci;
+  long long tot_cd = 0, tot_ci = 0, od_stride = 0, oi_stride = 0;      // results: one fixed-size slot per sequence (strided copies of the statistics)
+  long long wd_need = 0, wi_need = 0;
+  double *d_cd = nullptr, *d_od = nullptr, *d_f = nullptr, *d_x = nullptr;
+  int *d_ci = nullptr, *d_oi = nullptr, *d_order = nullptr;
+  long long x_cap = 0;
   SeqDesc* d_descs = nullptr;
   std::vector<double> h_od;
   std::vector<int> h_oi;
-  bool solved = false;
+  bool solved = false, fetched = false;
   chd_batch_stats stats{};
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
@@ -72,7 +121,10 @@ void chd_config_default(chd_config* c) {
   for (int i = 0; i < CHD_N_STAGES; ++i) c->max_iter[i] = mi[i];
   c->tol = 1e-3;                                                                                   // :578
   c->threads_per_sequence = 0;
-  for (int i = 0; i < 7; ++i) c->reserved[i] = 0;
+  c->stall_window = 0;
+  c->max_workgroups = 0;
+  c->lds_kilobytes = 0;
+  for (int i = 0; i < 4; ++i) c->reserved[i] = 0;
 }
 
 int chd_phys_create(const chd_config* cfg, int device_id, chd_handle** out) {
@@ -93,30 +145,56 @@ int chd_phys_create(const chd_config* cfg, int device_id, chd_handle** out) {
   size_t lds = prop.maxSharedMemoryPerMultiProcessor;
   if (lds > 160 * 1024) lds = 160 * 1024;
   if (lds < 64 * 1024) lds = 64 * 1024;
-  h->lds_bytes = (int)lds - 4096;     // leave room for the compiler's own static LDS
+  h->lds_bytes = (int)lds - 4096;     // the 4 KB hold the kernel's static LDS: sequence descriptor + solver context
+  if (h->cfg.lds_kilobytes > 0 && h->cfg.lds_kilobytes * 1024 < h->lds_bytes) h->lds_bytes = std::max(32, h->cfg.lds_kilobytes) * 1024;
   hipFuncSetAttribute((const void*)chd_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
   hipFuncSetAttribute((const void*)chd_debug_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
   int t = h->cfg.threads_per_sequence > 0 ? h->cfg.threads_per_sequence : CHD_MAX_THREADS;
   if (t > CHD_MAX_THREADS) t = CHD_MAX_THREADS;
   if (t < 64) t = 64;
   h->threads = (t / 64) * 64;
+  h->n_wg = h->cfg.max_workgroups > 0 ? h->cfg.max_workgroups : prop.multiProcessorCount;
+  if (h->n_wg < 1) h->n_wg = 1;
+  if (hipMalloc((void**)&h->d_counter, 64) != hipSuccess) { (void)hipStreamDestroy(h->stream); delete h; return -6; }
   *out = h;
   return 0;
 }
 
 void chd_phys_destroy(chd_handle* h) {
   if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipFree(h->d_wd); (void)hipFree(h->d_wi); (void)hipFree(h->d_counter);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
 
 const char* chd_phys_last_error(const chd_handle* h) { return h ? h->err.c_str() : "null handle"; }
 
+// workspaces for `n_wg` resident workgroups of at least (wd_need, wi_need) elements each
+static int ensure_workspace(chd_handle* h, long long wd_need, long long wi_need) {
+  if (h->d_wd && wd_need <= h->wd_stride && wi_need <= h->wi_stride) return 0;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  (void)hipFree(h->d_wd); (void)hipFree(h->d_wi);
+  h->d_wd = nullptr; h->d_wi = nullptr;
+  auto al = [](long long v) { return (v + 63) & ~63LL; };
+  h->wd_stride = std::max(h->wd_stride, al(wd_need)); h->wi_stride = std::max(h->wi_stride, al(wi_need));
+  hipError_t e = hipMalloc((void**)&h->d_wd, (size_t)h->wd_stride * 8 * h->n_wg);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_wi, (size_t)h->wi_stride * 4 * h->n_wg);
+  if (e != hipSuccess) {
+    (void)hipFree(h->d_wd); h->d_wd = nullptr; h->wd_stride = h->wi_stride = 0;
+    return fail(h, std::string("workspace allocation (") + std::to_string((h->wd_stride * 8 + h->wi_stride * 4) * h->n_wg >> 20) + " MiB): " + hipGetErrorString(e));
+  }
+  // (no clearing needed for correctness: a workgroup zeroes / initialises what it reads, sequence by sequence and stage by stage)
+  HIP_TRY(h, hipMemsetAsync(h->d_wd, 0, (size_t)h->wd_stride * 8 * h->n_wg, h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->d_wi, 0, (size_t)h->wi_stride * 4 * h->n_wg, h->stream));
+  return 0;
+}
+
 void chd_batch_free(chd_handle* h, chd_batch* b) {
   if (!b) return;
   if (h) (void)hipSetDevice(h->device);
-  (void)hipFree(b->d_cd); (void)hipFree(b->d_ci); (void)hipFree(b->d_wd); (void)hipFree(b->d_wi); (void)hipFree(b->d_od); (void)hipFree(b->d_oi);
-  (void)hipFree(b->d_descs); (void)hipFree(b->d_index); (void)hipFree(b->d_f);
+  (void)hipFree(b->d_cd); (void)hipFree(b->d_ci); (void)hipFree(b->d_od); (void)hipFree(b->d_oi);
+  (void)hipFree(b->d_descs); (void)hipFree(b->d_order); (void)hipFree(b->d_f); (void)hipFree(b->d_x);
   for (int k = 0; k < 4; ++k) if (b->ev[k]) (void)hipEventDestroy(b->ev[k]);
   delete b;
 }
@@ -128,8 +206,10 @@ int chd_batch_upload(chd_handle* h, int B, const chd_seq_in* in, chd_batch** out
   chd_batch* b = new chd_batch();
   b->B = B;
   b->models.resize(B);
-  // ---- structure tables on the host, in parallel
-  std::vector<std::string> errs(B);
+  b->ok.assign(B, 1); b->build_err.assign(B, std::string());
+  // ---- structure tables on the host, in parallel.  A sequence whose set-up fails (too short, inconsistent contact
+  // schedule, degenerate floor normal ...) is rejected on its own -- the reference runs one process per video, so a bad
+  // video only loses itself (run_phys_mocap.py:159-174) -- and the rest of the batch is solved.
   {
     unsigned nt = std::thread::hardware_concurrency();
     if (nt == 0) nt = 4;
@@ -139,45 +219,47 @@ int chd_batch_upload(chd_handle* h, int B, const chd_seq_in* in, chd_batch** out
     for (unsigned t = 0; t < nt; ++t)
       pool.emplace_back([&, t]() {
         for (int i = t; i < B; i += nt) {
-          try { b->models[i].build(in[i], h->cfg); } catch (const std::exception& e) { errs[i] = e.what(); }
+          try { b->models[i].build(in[i], h->cfg); }
+          catch (const std::exception& e) { b->ok[i] = 0; b->build_err[i] = e.what(); }
+          catch (...) { b->ok[i] = 0; b->build_err[i] = "set-up failed"; }
         }
       });
     for (auto& th : pool) th.join();
   }
-  for (int i = 0; i < B; ++i)
-    if (!errs[i].empty()) { std::string m = "sequence " + std::to_string(i) + ": " + errs[i]; chd_batch_free(h, b); return fail(h, m); }
+  for (int i = 0; i < B; ++i) if (b->ok[i]) b->order.push_back(i);
+  if (b->order.empty()) { std::string m = "no solvable sequence in the batch (sequence 0: " + b->build_err[0] + ")"; chd_batch_free(h, b); return fail(h, m); }
+  for (int i = 0; i < B; ++i) if (!b->ok[i]) h->err = "sequence " + std::to_string(i) + " rejected: " + b->build_err[i];
+  // longest sequences first (cost ~ frames x iterations: the queue's tail is made of the short ones)
+  std::stable_sort(b->order.begin(), b->order.end(), [&](int a, int c2) { return b->models[a].d.F > b->models[c2].d.F; });
   // ---- pool layout
   auto al = [](long long v) { return (v + 31) & ~31LL; };
-  b->off_cd.resize(B); b->off_ci.resize(B); b->off_wd.resize(B); b->off_wi.resize(B); b->off_od.resize(B); b->off_oi.resize(B);
+  b->off_cd.assign(B, 0); b->off_ci.assign(B, 0);
   for (int i = 0; i < B; ++i) {
+    if (!b->ok[i]) continue;
     SeqModel& M = b->models[i];
     b->off_cd[i] = b->tot_cd; b->tot_cd += al((long long)M.cd.size());
     b->off_ci[i] = b->tot_ci; b->tot_ci += al((long long)M.ci.size());
-    b->off_wd[i] = b->tot_wd; b->tot_wd += al(M.wd_size);
-    b->off_wi[i] = b->tot_wi; b->tot_wi += al(M.wi_size);
-    b->off_od[i] = b->tot_od; b->tot_od += al(out_d_size(M.d.cap));
-    b->off_oi[i] = b->tot_oi; b->tot_oi += al(out_i_size(M.d.cap));
+    b->wd_need = std::max(b->wd_need, M.wd_size); b->wi_need = std::max(b->wi_need, M.wi_size);
+    b->od_stride = std::max(b->od_stride, al(out_d_size(M.d.cap, M.d.tot_entries + M.d.tot_phases)));
+    b->oi_stride = std::max(b->oi_stride, al(out_i_size(M.d.cap)));
   }
   auto bail = [&](const char* what, hipError_t e) { std::string m = std::string(what) + ": " + hipGetErrorString(e); chd_batch_free(h, b); return fail(h, m); };
   hipError_t e;
   if ((e = hipMalloc((void**)&b->d_cd, b->tot_cd * 8)) != hipSuccess) return bail("hipMalloc cd", e);
   if ((e = hipMalloc((void**)&b->d_ci, b->tot_ci * 4)) != hipSuccess) return bail("hipMalloc ci", e);
-  if ((e = hipMalloc((void**)&b->d_wd, b->tot_wd * 8)) != hipSuccess) return bail("hipMalloc wd", e);
-  if ((e = hipMalloc((void**)&b->d_wi, b->tot_wi * 4)) != hipSuccess) return bail("hipMalloc wi", e);
-  if ((e = hipMalloc((void**)&b->d_od, b->tot_od * 8)) != hipSuccess) return bail("hipMalloc od", e);
-  if ((e = hipMalloc((void**)&b->d_oi, b->tot_oi * 4)) != hipSuccess) return bail("hipMalloc oi", e);
+  if ((e = hipMalloc((void**)&b->d_od, b->od_stride * 8 * B)) != hipSuccess) return bail("hipMalloc od", e);
+  if ((e = hipMalloc((void**)&b->d_oi, b->oi_stride * 4 * B)) != hipSuccess) return bail("hipMalloc oi", e);
   if ((e = hipMalloc((void**)&b->d_descs, sizeof(SeqDesc) * B)) != hipSuccess) return bail("hipMalloc descs", e);
-  if ((e = hipMalloc((void**)&b->d_index, sizeof(int) * B)) != hipSuccess) return bail("hipMalloc index", e);
+  if ((e = hipMalloc((void**)&b->d_order, sizeof(int) * B)) != hipSuccess) return bail("hipMalloc order", e);
   if ((e = hipMalloc((void**)&b->d_f, 64)) != hipSuccess) return bail("hipMalloc f", e);
-  if ((e = hipMemsetAsync(b->d_wd, 0, b->tot_wd * 8, h->stream)) != hipSuccess) return bail("memset wd", e);
-  if ((e = hipMemsetAsync(b->d_wi, 0, b->tot_wi * 4, h->stream)) != hipSuccess) return bail("memset wi", e);
-  if ((e = hipMemsetAsync(b->d_od, 0, b->tot_od * 8, h->stream)) != hipSuccess) return bail("memset od", e);
-  if ((e = hipMemsetAsync(b->d_oi, 0, b->tot_oi * 4, h->stream)) != hipSuccess) return bail("memset oi", e);
+  if ((e = hipMemsetAsync(b->d_od, 0, b->od_stride * 8 * B, h->stream)) != hipSuccess) return bail("memset od", e);
+  if ((e = hipMemsetAsync(b->d_oi, 0, b->oi_stride * 4 * B, h->stream)) != hipSuccess) return bail("memset oi", e);
   // ---- stage pools through one staging buffer each
   {
     std::vector<double> hcd(b->tot_cd, 0.0);
     std::vector<int> hci(b->tot_ci, 0);
     for (int i = 0; i < B; ++i) {
+      if (!b->ok[i]) continue;
       std::copy(b->models[i].cd.begin(), b->models[i].cd.end(), hcd.begin() + b->off_cd[i]);
       std::copy(b->models[i].ci.begin(), b->models[i].ci.end(), hci.begin() + b->off_ci[i]);
     }
@@ -188,57 +270,68 @@ int chd_batch_upload(chd_handle* h, int B, const chd_seq_in* in, chd_batch** out
   for (int i = 0; i < B; ++i) {
     SeqDesc dd = b->models[i].d;
     dd.cd = (const GD*)(b->d_cd + b->off_cd[i]); dd.ci = (const GI*)(b->d_ci + b->off_ci[i]);
-    dd.wd = (GD*)(b->d_wd + b->off_wd[i]); dd.wi = (GI*)(b->d_wi + b->off_wi[i]);
-    dd.out_d = (GD*)(b->d_od + b->off_od[i]); dd.out_i = (GI*)(b->d_oi + b->off_oi[i]);
+    dd.wd = nullptr; dd.wi = nullptr;            // the workgroup that takes the sequence fills in its own workspace
+    dd.out_d = (GD*)(b->d_od + b->od_stride * i); dd.out_i = (GI*)(b->d_oi + b->oi_stride * i);
     b->descs[i] = dd;
   }
   if ((e = hipMemcpy(b->d_descs, b->descs.data(), sizeof(SeqDesc) * B, hipMemcpyHostToDevice)) != hipSuccess) return bail("copy descs", e);
   for (int k = 0; k < 4; ++k) if ((e = hipEventCreate(&b->ev[k])) != hipSuccess) return bail("hipEventCreate", e);
+  if (ensure_workspace(h, b->wd_need, b->wi_need) != 0) { std::string m = h->err; chd_batch_free(h, b); return fail(h, m); }
   if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return bail("sync", e);
   *out = b;
   return 0;
 }
 
-static int fetch_raw(chd_handle* h, chd_batch* b) {
-  b->h_od.resize(b->tot_od); b->h_oi.resize(b->tot_oi);
-  HIP_TRY(h, hipMemcpy(b->h_od.data(), b->d_od, b->tot_od * 8, hipMemcpyDeviceToHost));
-  HIP_TRY(h, hipMemcpy(b->h_oi.data(), b->d_oi, b->tot_oi * 4, hipMemcpyDeviceToHost));
+// one persistent launch over `items` (indices into the batch)
+static int launch_queue(chd_handle* h, chd_batch* b, const std::vector<int>& items, int stage_first, int stage_last, hipEvent_t e0, hipEvent_t e1) {
+  HIP_TRY(h, hipMemcpyAsync(b->d_order, items.data(), items.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->d_counter, 0, sizeof(int), h->stream));
+  const unsigned grid = (unsigned)std::min<size_t>(items.size(), (size_t)h->n_wg);
+  HIP_TRY(h, hipEventRecord(e0, h->stream));
+  hipLaunchKernelGGL(chd_solve_kernel, dim3(grid), dim3(h->threads), h->lds_bytes, h->stream, b->d_descs, (const int*)b->d_order, (int)items.size(),
+                     h->d_counter, h->d_wd, h->wd_stride, h->d_wi, h->wi_stride, h->lds_bytes / 8, h->cfg.tol, h->cfg.stall_window, stage_first, stage_last);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipEventRecord(e1, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// per-sequence statistics block (stages + phase timers are fetched with two strided copies)
+static int fetch_stats(chd_handle* h, chd_batch* b, std::vector<double>& st) {
+  const size_t w = (size_t)N_STAGES * RS_STRIDE;
+  st.resize(w * b->B);
+  HIP_TRY(h, hipMemcpy2D(st.data(), w * 8, b->d_od, (size_t)b->od_stride * 8, w * 8, (size_t)b->B, hipMemcpyDeviceToHost));
   return 0;
 }
 
 int chd_batch_solve(chd_handle* h, chd_batch* b) {
   if (!h || !b) return fail(h, "chd_batch_solve: bad arguments");
   HIP_TRY(h, hipSetDevice(h->device));
-  const int lds_doubles = h->lds_bytes / 8;
+  if (ensure_workspace(h, b->wd_need, b->wi_need) != 0) return -1;
   b->stats = chd_batch_stats{};
-  HIP_TRY(h, hipMemsetAsync(b->d_od, 0, b->tot_od * 8, h->stream));
+  b->fetched = false;
+  HIP_TRY(h, hipMemsetAsync(b->d_od, 0, b->od_stride * 8 * b->B, h->stream));
   // ---- launch 1: stages 1.1, 1.2, 2.1, 2.2, 3 for every sequence
-  HIP_TRY(h, hipEventRecord(b->ev[0], h->stream));
-  hipLaunchKernelGGL(chd_solve_kernel, dim3(b->B), dim3(h->threads), h->lds_bytes, h->stream, b->d_descs, (const int*)nullptr, lds_doubles,
-                     h->cfg.tol, 0, 4);
-  HIP_TRY(h, hipGetLastError());
-  HIP_TRY(h, hipEventRecord(b->ev[1], h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (launch_queue(h, b, b->order, 0, 4, b->ev[0], b->ev[1]) != 0) return -1;
   float ms = 0;
   HIP_TRY(h, hipEventElapsedTime(&ms, b->ev[0], b->ev[1]));
   b->stats.kernel_ms[0] = ms;
   // ---- which sequences need the stage-4 fallback (phys_optim.cpp:714)
   auto t0 = std::chrono::steady_clock::now();
-  std::vector<double> st((size_t)N_STAGES * RS_STRIDE);
+  std::vector<double> st;
+  if (fetch_stats(h, b, st) != 0) return -1;
+  const size_t sw = (size_t)N_STAGES * RS_STRIDE;
   std::vector<int> idx;
-  for (int i = 0; i < b->B; ++i) {
-    HIP_TRY(h, hipMemcpy(st.data(), b->d_od + b->off_od[i], st.size() * 8, hipMemcpyDeviceToHost));
-    if ((int)st[4 * RS_STRIDE + RS_STATUS] != 0) idx.push_back(i);
-  }
+  for (int i : b->order) if ((int)st[sw * i + 4 * RS_STRIDE + RS_STATUS] != 0) idx.push_back(i);
+  std::sort(idx.begin(), idx.end());
   b->stats.n_fallback = (int)idx.size();
   if (!idx.empty()) {
-    // durations left by stage 3 -> rebuild the tables of the fallback stage on the host
-    std::vector<char> ok(idx.size(), 1);
+    // durations left by stage 3 (kept with the sequence's results) -> rebuild the tables of the fallback stage on the host
     std::vector<std::vector<double>> ph(idx.size());
     for (size_t k = 0; k < idx.size(); ++k) {
       const SeqModel& M = b->models[idx[k]];
       ph[k].resize(M.d.tot_phases);
-      HIP_TRY(h, hipMemcpy(ph[k].data(), b->d_wd + b->off_wd[idx[k]] + M.d.o_phase_dur, ph[k].size() * 8, hipMemcpyDeviceToHost));
+      HIP_TRY(h, hipMemcpy(ph[k].data(), b->d_od + b->od_stride * idx[k] + out_d_state_off(M.d.cap) + M.d.tot_entries, ph[k].size() * 8, hipMemcpyDeviceToHost));
     }
     unsigned nt = std::thread::hardware_concurrency();
     if (nt == 0) nt = 4;
@@ -262,42 +355,52 @@ int chd_batch_solve(chd_handle* h, chd_batch* b) {
       b->descs[i].st[5] = S;
       if (S.valid) {
         // the stage's regions are contiguous in the pools: [o_pos_var, o_env + 2*(n + m_cap)) and [o_cl, o_task_t + task_cap)
-        const long long i0 = S.o_pos_var, i1 = S.o_env + 2LL * (S.n + M.stage_m_cap[5]);
+        const long long i0 = S.o_pos_var, i1 = S.o_rcnt + (S.n + M.stage_m_cap[5]);
         const long long d0 = S.o_cl, d1 = S.o_task_t + (long long)M.stage_task_cap[5];
         HIP_TRY(h, hipMemcpy(b->d_ci + b->off_ci[i] + i0, M.ci.data() + i0, (i1 - i0) * 4, hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(b->d_cd + b->off_cd[i] + d0, M.cd.data() + d0, (d1 - d0) * 8, hipMemcpyHostToDevice));
       }
       HIP_TRY(h, hipMemcpy(b->d_descs + i, &b->descs[i], sizeof(SeqDesc), hipMemcpyHostToDevice));
     }
-    HIP_TRY(h, hipMemcpy(b->d_index, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
     b->stats.host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    HIP_TRY(h, hipEventRecord(b->ev[2], h->stream));
-    hipLaunchKernelGGL(chd_solve_kernel, dim3((unsigned)idx.size()), dim3(h->threads), h->lds_bytes, h->stream, b->d_descs, (const int*)b->d_index,
-                       lds_doubles, h->cfg.tol, 5, 5);
-    HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipEventRecord(b->ev[3], h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (launch_queue(h, b, idx, 5, 5, b->ev[2], b->ev[3]) != 0) return -1;
     HIP_TRY(h, hipEventElapsedTime(&ms, b->ev[2], b->ev[3]));
     b->stats.kernel_ms[1] = ms;
+    if (fetch_stats(h, b, st) != 0) return -1;
   } else {
     b->stats.host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
   b->solved = true;
   // ---- accounting
-  if (fetch_raw(h, b) != 0) return -1;
-  for (int i = 0; i < b->B; ++i) {
-    const double* s = b->h_od.data() + b->off_od[i];
+  std::vector<double> tm((size_t)24 * b->B);
+  {
+    // the timers sit behind the snapshots, whose size depends on the sequence: equal capacities (the usual case) take one strided copy
+    bool same = true;
+    for (int i : b->order) same = same && b->models[i].d.cap == b->models[b->order[0]].d.cap;
+    if (same) {
+      const long long off = N_STAGES * RS_STRIDE + 3LL * 10 * b->models[b->order[0]].d.cap * 3;
+      HIP_TRY(h, hipMemcpy2D(tm.data(), 24 * 8, b->d_od + off, (size_t)b->od_stride * 8, 24 * 8, (size_t)b->B, hipMemcpyDeviceToHost));
+    } else {
+      for (int i : b->order)
+        HIP_TRY(h, hipMemcpy(tm.data() + 24 * (size_t)i, b->d_od + b->od_stride * i + N_STAGES * RS_STRIDE + 3LL * 10 * b->models[i].d.cap * 3, 24 * 8, hipMemcpyDeviceToHost));
+    }
+  }
+  for (int i : b->order) {
+    const double* s = st.data() + sw * i;
     for (int stg = 0; stg < N_STAGES; ++stg) {
       if (stg == 5 && (int)s[4 * RS_STRIDE + RS_STATUS] == 0) continue;
       const double it = s[stg * RS_STRIDE + RS_ITERS];
       b->stats.total_iters += (long long)it;
       b->stats.total_factorizations += (long long)s[stg * RS_STRIDE + RS_NFACT];
       b->stats.alg_bytes += it * b->models[i].alg_bytes_iter[stg];
+      if ((int)s[stg * RS_STRIDE + RS_AUX] != 0) b->stats.n_stalled += 1;
     }
-    const double* tm = s + N_STAGES * RS_STRIDE + 3LL * 10 * b->models[i].d.cap * 3;     // 100 MHz ticks
-    for (int k = 0; k < 24; ++k) b->stats.phase_ms[k] += tm[k] * 1e-5;
-    if (tm[5] * 1e-5 > b->stats.max_seq_ms) b->stats.max_seq_ms = tm[5] * 1e-5;
+    const double* t = tm.data() + 24 * (size_t)i;     // 100 MHz ticks
+    for (int k = 0; k < 24; ++k) b->stats.phase_ms[k] += t[k] * 1e-5;
+    if (t[5] * 1e-5 > b->stats.max_seq_ms) b->stats.max_seq_ms = t[5] * 1e-5;
   }
+  b->stats.n_rejected = b->B - (int)b->order.size();
+  b->stats.n_workgroups = (int)std::min<size_t>(b->order.size(), (size_t)h->n_wg);
   return 0;
 }
 
@@ -311,19 +414,32 @@ int chd_batch_fetch(chd_handle* h, chd_batch* b, chd_seq_out* out) {
   if (!h || !b || !out) return fail(h, "chd_batch_fetch: bad arguments");
   if (!b->solved) return fail(h, "chd_batch_fetch: batch not solved");
   HIP_TRY(h, hipSetDevice(h->device));
-  if (b->h_od.empty() && fetch_raw(h, b) != 0) return -1;
+  if (!b->fetched) {
+    b->h_od.resize((size_t)b->od_stride * b->B); b->h_oi.resize((size_t)b->oi_stride * b->B);
+    HIP_TRY(h, hipMemcpy(b->h_od.data(), b->d_od, b->h_od.size() * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(b->h_oi.data(), b->d_oi, b->h_oi.size() * 4, hipMemcpyDeviceToHost));
+    b->fetched = true;
+  }
   for (int i = 0; i < b->B; ++i) {
+    chd_seq_out& o = out[i];
+    if (!b->ok[i]) {                 // rejected at set-up: nothing was solved
+      for (int s = 0; s < N_STAGES; ++s) { o.stage_status[s] = -4; o.stage_iters[s] = 0; o.stage_stalled[s] = 0; o.stage_kkt_error[s] = o.stage_constr_viol[s] = o.stage_objective[s] = 0.0; }
+      o.dynamics_succeed = 0; o.durations_succeed = 0;
+      o.n_vars = o.n_rows = o.kkt_dim = o.kkt_halfband = o.kkt_border = 0; o.nnz_jac = 0;
+      for (int s = 0; s < CHD_N_SNAPSHOTS; ++s) { o.snap[s].n_samples = 0; o.snap[s].num_frames_header = 0; }
+      continue;
+    }
     const SeqModel& M = b->models[i];
     const int cap = M.d.cap;
-    const double* od = b->h_od.data() + b->off_od[i];
-    const int* oi = b->h_oi.data() + b->off_oi[i];
-    chd_seq_out& o = out[i];
+    const double* od = b->h_od.data() + b->od_stride * i;
+    const int* oi = b->h_oi.data() + b->oi_stride * i;
     const bool fb = (int)od[4 * RS_STRIDE + RS_STATUS] != 0;
     for (int s = 0; s < N_STAGES; ++s) {
       const double* r = od + s * RS_STRIDE;
       const bool ran = (s < 5) || fb;
       o.stage_status[s] = ran ? (int)r[RS_STATUS] : 9;
       o.stage_iters[s] = ran ? (int)r[RS_ITERS] : 0;
+      o.stage_stalled[s] = ran ? (int)r[RS_AUX] : 0;
       o.stage_kkt_error[s] = ran ? r[RS_KKT] : 0.0;
       o.stage_constr_viol[s] = ran ? r[RS_VIOL] : 0.0;
       o.stage_objective[s] = ran ? r[RS_OBJ] : 0.0;
@@ -365,13 +481,14 @@ int chd_phys_solve_dirs(chd_handle* h, int B, const char* const* in_dirs, const 
   if (!h || B <= 0 || !in_dirs || !out_dirs || !nframes) return fail(h, "chd_phys_solve_dirs: bad arguments");
   std::vector<io::SeqFiles> files(B);
   std::vector<int> good;
+  std::string first_err;
   for (int i = 0; i < B; ++i) {
     std::string err;
     const bool ok = io::read_inputs(in_dirs[i], nframes[i], files[i], err);
     if (status) status[i] = ok ? 0 : -1;
-    if (ok) good.push_back(i); else h->err = std::string(in_dirs[i]) + ": " + err;
+    if (ok) good.push_back(i); else if (first_err.empty()) first_err = std::string(in_dirs[i]) + ": " + err;
   }
-  if (good.empty()) return fail(h, "chd_phys_solve_dirs: no readable input directory (" + h->err + ")");
+  if (good.empty()) return fail(h, "chd_phys_solve_dirs: no readable input directory (" + first_err + ")");
   std::vector<chd_seq_in> in(good.size());
   std::vector<chd_seq_out> out(good.size());
   std::vector<io::SnapStore> store(good.size());
@@ -379,12 +496,16 @@ int chd_phys_solve_dirs(chd_handle* h, int B, const char* const* in_dirs, const 
     files[good[k]].fill(in[k]);
     store[k].bind(out[k], nframes[good[k]] + 4);
   }
+  h->err.clear();
   int rc = chd_phys_solve_batch(h, (int)good.size(), in.data(), out.data());
   if (rc != 0) return rc;
+  if (first_err.empty()) first_err = h->err;           // a sequence rejected at set-up (the rest was solved)
   for (size_t k = 0; k < good.size(); ++k) {
+    if (out[k].stage_status[0] == -4) { if (status) status[good[k]] = -3; continue; }      // rejected at set-up: no output files, as when the reference's child process dies
     std::string err;
-    if (!io::write_outputs(out_dirs[good[k]], files[good[k]].dt, out[k], err)) { if (status) status[good[k]] = -2; h->err = err; }
+    if (!io::write_outputs(out_dirs[good[k]], files[good[k]].dt, out[k], err)) { if (status) status[good[k]] = -2; if (first_err.empty()) first_err = err; }
   }
+  h->err = first_err;
   return 0;
 }
 
@@ -397,20 +518,27 @@ int chd_debug_sizes(chd_handle* h, chd_batch* b, int seq, int stage, int* n, int
 
 int chd_debug_eval(chd_handle* h, chd_batch* b, int seq, int stage, const double* x, double* x_out, double* f, double* grad, double* cvals,
                    double* J, double* H) {
-  if (!h || !b || seq < 0 || seq >= b->B || stage < 0 || stage >= N_STAGES) return fail(h, "chd_debug_eval: bad arguments");
+  if (!h || !b || seq < 0 || seq >= b->B || stage < 0 || stage >= N_STAGES || !b->ok[seq]) return fail(h, "chd_debug_eval: bad arguments");
   HIP_TRY(h, hipSetDevice(h->device));
+  if (ensure_workspace(h, b->wd_need, b->wi_need) != 0) return -1;
   const SeqModel& M = b->models[seq];
   const SeqDesc& dd = b->descs[seq];
   const StageDesc& S = M.d.st[stage];
   const int n = S.n, m = S.m;
-  double* wd = b->d_wd + b->off_wd[seq];
-  if (x) HIP_TRY(h, hipMemcpy(wd + dd.o_vec_n + (long long)VN_XT * dd.max_n, x, n * 8, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(chd_debug_eval_kernel, dim3(1), dim3(h->threads), h->lds_bytes, h->stream, b->d_descs, seq, stage, x ? 1 : 0, h->lds_bytes / 8, b->d_f);
+  if (x) {
+    if (b->x_cap < n) { (void)hipFree(b->d_x); b->d_x = nullptr; HIP_TRY(h, hipMalloc((void**)&b->d_x, (size_t)dd.max_n * 8)); b->x_cap = dd.max_n; }
+    HIP_TRY(h, hipMemcpy(b->d_x, x, n * 8, hipMemcpyHostToDevice));
+  }
+  HIP_TRY(h, hipMemcpyAsync(b->d_order, &seq, sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->d_counter, 0, sizeof(int), h->stream));
+  hipLaunchKernelGGL(chd_debug_eval_kernel, dim3(1), dim3(h->threads), h->lds_bytes, h->stream, b->d_descs, (const int*)b->d_order, h->d_counter, h->d_wd, h->d_wi,
+                     stage, x ? (const double*)b->d_x : (const double*)nullptr, h->lds_bytes / 8, b->d_f);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   double fo[2];
   HIP_TRY(h, hipMemcpy(fo, b->d_f, 16, hipMemcpyDeviceToHost));
   if (f) *f = fo[0];
+  const double* wd = h->d_wd;          // workgroup 0's workspace
   if (x_out) HIP_TRY(h, hipMemcpy(x_out, wd + dd.o_vec_n + (long long)VN_X * dd.max_n, n * 8, hipMemcpyDeviceToHost));
   if (grad) HIP_TRY(h, hipMemcpy(grad, wd + dd.o_vec_n + (long long)VN_G * dd.max_n, n * 8, hipMemcpyDeviceToHost));
   if (cvals) HIP_TRY(h, hipMemcpy(cvals, wd + dd.o_vec_m + (long long)VM_C * dd.max_m, m * 8, hipMemcpyDeviceToHost));

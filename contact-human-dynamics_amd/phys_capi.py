@@ -11,7 +11,8 @@ N_SNAPSHOTS = 3
 class ChdConfig(C.Structure):
     _fields_ = [('w_com_lin', C.c_double), ('w_com_ang', C.c_double), ('w_ee', C.c_double),
                 ('w_smooth', C.c_double), ('w_dur', C.c_double), ('max_iter', C.c_int * N_STAGES),
-                ('tol', C.c_double), ('threads_per_sequence', C.c_int), ('reserved', C.c_int * 7)]
+                ('tol', C.c_double), ('threads_per_sequence', C.c_int), ('stall_window', C.c_int), ('max_workgroups', C.c_int),
+                ('lds_kilobytes', C.c_int), ('reserved', C.c_int * 4)]
 
 
 class ChdSeqIn(C.Structure):
@@ -30,7 +31,7 @@ class ChdSnapshot(C.Structure):
 
 class ChdSeqOut(C.Structure):
     _fields_ = [('snap', ChdSnapshot * N_SNAPSHOTS), ('stage_status', C.c_int * N_STAGES),
-                ('stage_iters', C.c_int * N_STAGES), ('stage_kkt_error', C.c_double * N_STAGES),
+                ('stage_iters', C.c_int * N_STAGES), ('stage_stalled', C.c_int * N_STAGES), ('stage_kkt_error', C.c_double * N_STAGES),
                 ('stage_constr_viol', C.c_double * N_STAGES), ('stage_objective', C.c_double * N_STAGES),
                 ('dynamics_succeed', C.c_int), ('durations_succeed', C.c_int),
                 ('n_vars', C.c_int), ('n_rows', C.c_int), ('kkt_dim', C.c_int), ('kkt_halfband', C.c_int),
@@ -40,7 +41,8 @@ class ChdSeqOut(C.Structure):
 class ChdBatchStats(C.Structure):
     _fields_ = [('kernel_ms', C.c_double * 2), ('host_ms', C.c_double), ('total_iters', C.c_longlong),
                 ('total_factorizations', C.c_longlong), ('alg_bytes', C.c_double), ('n_fallback', C.c_int),
-                ('phase_ms', C.c_double * 24), ('max_seq_ms', C.c_double)]
+                ('phase_ms', C.c_double * 24), ('max_seq_ms', C.c_double), ('n_stalled', C.c_int), ('n_rejected', C.c_int),
+                ('n_workgroups', C.c_int)]
 
 
 def default_config(**kw):
@@ -51,6 +53,9 @@ def default_config(**kw):
         c.max_iter[i] = v
     c.tol = 1e-3
     c.threads_per_sequence = 0
+    c.stall_window = 0          # no stall guard: a stage runs to its iteration cap like IPOPT would
+    c.max_workgroups = 0
+    c.lds_kilobytes = 0
     for k, v in kw.items():
         if k == 'max_iter':
             for i, it in enumerate(v):

@@ -88,6 +88,8 @@ class SeqResult:
                                            ee_pos=ep[:, :ns].copy(), ee_force=ef[:, :ns].copy(), contact=ct[:, :ns].astype(np.int64)))
         self.stage_status = [out.stage_status[i] for i in range(N_STAGES)]
         self.stage_iters = [out.stage_iters[i] for i in range(N_STAGES)]
+        self.stage_stalled = [out.stage_stalled[i] for i in range(N_STAGES)]
+        self.rejected = self.stage_status[0] == -4       # refused at set-up (inconsistent inputs): nothing was solved
         self.stage_kkt_error = [out.stage_kkt_error[i] for i in range(N_STAGES)]
         self.stage_constr_viol = [out.stage_constr_viol[i] for i in range(N_STAGES)]
         self.stage_objective = [out.stage_objective[i] for i in range(N_STAGES)]
@@ -119,7 +121,8 @@ class Batch:
         self.solver._check(self.solver.L.chd_batch_get_stats(self.solver.h, self.h, C.byref(st)), 'chd_batch_get_stats')
         return dict(kernel_ms=[st.kernel_ms[0], st.kernel_ms[1]], host_ms=st.host_ms, total_iters=st.total_iters,
                     total_factorizations=st.total_factorizations, alg_bytes=st.alg_bytes, n_fallback=st.n_fallback,
-                    phase_ms=[st.phase_ms[i] for i in range(24)], max_seq_ms=st.max_seq_ms)
+                    phase_ms=[st.phase_ms[i] for i in range(24)], max_seq_ms=st.max_seq_ms, n_stalled=st.n_stalled,
+                    n_rejected=st.n_rejected, n_workgroups=st.n_workgroups)
 
     def fetch(self):
         B = len(self.seqs)

@@ -6,7 +6,9 @@
  *                     '--w_com_lin', ..., '--w_com_ang', ..., '--w_ee', ..., '--w_smooth', ..., '--w_dur', ...])
  * (reference: scripts/run_phys_mocap.py:159-174; flags: towr_phys_optim/phys_optim.cpp:23-31),
  * by an in-process, batched call: many independent sequences are solved by one
- * persistent HIP kernel launch (one workgroup per sequence) on one gfx950 device.
+ * persistent HIP kernel launch on one gfx950 device (one resident workgroup per compute
+ * unit; the workgroups take sequences from a queue until the batch is drained, so a batch
+ * may hold thousands of sequences of mixed length).
  *
  * Conventions: plain C, every function returns 0 on success and <0 on error (the
  * message is available through chd_phys_last_error), no exception crosses the boundary,
@@ -38,7 +40,13 @@ typedef struct chd_config {
   int max_iter[CHD_N_STAGES];   /* 7000, 7000, 7000, 2500, 2000, 7000 */
   double tol;              /* IPOPT "tol", 1e-3 (phys_optim.cpp:578) */
   int threads_per_sequence;     /* workgroup size of the solver kernel; 0 = default (512) */
-  int reserved[7];
+  int stall_window;             /* > 0: a stage whose optimality error has not halved within this many iterations ends with
+                                   status -2 (stage 3 then takes the stage-4 fallback) instead of running to max_iter; the hit
+                                   is reported in chd_seq_out.stage_stalled.  0 (default) = off: IPOPT has no such rule */
+  int max_workgroups;           /* resident workgroups of the solver launch; 0 = one per compute unit */
+  int lds_kilobytes;            /* dynamic LDS per workgroup; 0 = all of a compute unit's (156 KB): tuning knob for two smaller
+                                   workgroups per compute unit (with threads_per_sequence 256 and max_workgroups 2 x CUs) */
+  int reserved[4];
 } chd_config;
 
 /* One sequence = the content of phys_optim_in_<char>/{skel,motion,terrain,contact}_info.txt
@@ -80,8 +88,10 @@ typedef struct chd_snapshot {
 
 typedef struct chd_seq_out {
   chd_snapshot snap[CHD_N_SNAPSHOTS];
-  int stage_status[CHD_N_STAGES];   /* 0 solved, 1 acceptable, -1 max-iter, -2 numerical failure, -3 internal (band overflow), 9 not run */
+  int stage_status[CHD_N_STAGES];   /* 0 solved, 1 acceptable, -1 max-iter, -2 numerical failure, -3 internal (band overflow), 9 not run;
+                                       all stages -4: the sequence was rejected at set-up (see build_error) and not solved */
   int stage_iters[CHD_N_STAGES];
+  int stage_stalled[CHD_N_STAGES];  /* 1 = the stage was ended by the stall guard (chd_config.stall_window) */
   double stage_kkt_error[CHD_N_STAGES];
   double stage_constr_viol[CHD_N_STAGES];
   double stage_objective[CHD_N_STAGES];
@@ -105,7 +115,10 @@ const char* chd_phys_last_error(const chd_handle* h);   /* owned by the handle; 
 /* Split interface (what the benchmark times is chd_batch_solve alone: inputs are resident
  * in HBM when it starts).
  *   upload : builds the per-sequence NLP structure tables on the host and copies inputs +
- *            tables to the device;
+ *            tables to the device.  A sequence whose set-up fails (fewer than 8 frames, contact
+ *            schedules of different total time, degenerate floor normal ...) is rejected on its
+ *            own: the call still succeeds if at least one sequence is solvable, the rejected ones
+ *            come back from fetch with stage_status -4 (chd_phys_last_error names the last one);
  *   solve  : runs stages 1.1 .. 3 (+4 where stage 3 failed) for every sequence on the device;
  *   fetch  : copies the three snapshots and the per-stage statistics back. */
 int chd_batch_upload(chd_handle* h, int B, const chd_seq_in* in, chd_batch** out);
@@ -127,6 +140,9 @@ typedef struct chd_batch_stats {
                                   2 factorisation, 3 substitution, 4 KKT mat-vec, 5 whole sequence,
                                   6-12 factorisation sub-phases (copy, panel load, diagonal block, row solves, write-back, trailing update, border) */
   double max_seq_ms;           /* slowest single sequence (in-kernel wall clock) */
+  int n_stalled;               /* stages ended by the stall guard (0 unless chd_config.stall_window > 0) */
+  int n_rejected;              /* sequences rejected at set-up (not solved; stage_status -4) */
+  int n_workgroups;            /* resident workgroups of the main launch */
 } chd_batch_stats;
 int chd_batch_get_stats(chd_handle* h, chd_batch* b, chd_batch_stats* out);
 
@@ -136,7 +152,9 @@ int chd_phys_solve_batch(chd_handle* h, int B, const chd_seq_in* in, chd_seq_out
 /* Drop-in for B invocations of ./phys_optim: reads the four input files of every in_dirs[i],
  * solves the batch, writes sol_out_no_dynamics.txt, sol_out_dynamics.txt, sol_out_durations.txt
  * and success_log.txt into out_dirs[i] (which must exist, as for the reference,
- * phys_optim.cpp:23).  status[i] (optional) = 0 ok, <0 I/O error for that directory. */
+ * phys_optim.cpp:23).  status[i] (optional) = 0 ok, -1 unreadable inputs, -2 outputs not writable, -3 rejected at
+ * set-up (inconsistent inputs; nothing written -- the reference's child process would have died on that video alone).
+ * The return value is 0 as long as one directory could be solved. */
 int chd_phys_solve_dirs(chd_handle* h, int B, const char* const* in_dirs, const char* const* out_dirs,
                         const int* nframes, int* status);
 

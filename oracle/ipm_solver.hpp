@@ -12,7 +12,7 @@
 //   * termination on IPOPT's scaled optimality error E_0 <= tol (tol = 1e-3 is
 //     the reference's option, phys_optim.cpp:578),
 //   * symmetric indefinite (quasi-definite) KKT solve  [H+dw*Dw  J^T; J  -D].
-//   * a stall guard (optimality error not halved within 150 iterations => status -2).
+//   * an optional stall guard (IpmOptions::stall_window; optimality error not halved within that many iterations => status -2).
 // Deliberate differences from IPOPT (the reference binary cannot be run here, so
 // its iterates are not reproducible anyway; SURVEY.md §7 "Hard parts"):
 //   * Hessian: Gauss-Newton Hessian of the sum-of-squares objective, plus the exact duration-duration
@@ -43,6 +43,7 @@ struct IpmOptions {
   bool use_soc = true;
   int max_attempts = 12;
   bool verbose = false;
+  int stall_window = 0;         // > 0: stall guard (chd_config.stall_window); 0 = off, as IPOPT has no such rule
   bool inertia_retry = true;    // a factorisation that had to replace a pivot counts as a failed attempt (see chd_kernels.hpp, CHD_INERTIA_RETRY)
 };
 
@@ -50,7 +51,7 @@ struct IpmResult {
   int status = -2;
   int iters = 0;
   double kkt_error = 0, constr_viol = 0, objective = 0, mu = 0;
-  int n_factor = 0, N = 0, bandwidth = 0;
+  int n_factor = 0, N = 0, bandwidth = 0, stalled = 0;
 };
 
 // -----------------------------------------------------------------------------
@@ -343,11 +344,12 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
     if (opt.verbose) { int wi = 0; double wv = 0; for (int i = 0; i < m; ++i) { double v = std::fabs(eq[i] ? c[i] - l[i] : c[i] - s[i]); if (v > wv) { wv = v; wi = i; } } std::printf("[worst row %d fam %d eq %d c=%.4e s=%.4e l=%.3e u=%.3e lam=%.3e] ", wi, P.row_family[wi], (int)eq[wi], c[wi], s[wi], l[wi], u[wi], lam[wi]); }
     if (opt.verbose) std::printf("%4d f=%.6e E0=%.2e (d %.1e p %.1e pu %.1e c %.1e) mu=%.1e nu=%.1e dw=%.1e | last a=%.2e nls=%d att=%d soc=%d\n", it, f / sf, E0, e_d, e_p, e_p_unscaled, e_c, mu, nu, dw, last_alpha, last_nls, last_att, (int)last_soc);
     if (E0 <= tol && e_p_unscaled <= opt.constr_viol_tol) { status = 0; break; }
-    // stall guard: no factor-2 reduction of the optimality error over the last 150 iterations -> give up (status -2,
-    // "numerical failure") instead of running to the iteration cap; stage 3 then takes the reference's stage-4 fallback
-    {
-      const int W = 150;
-      if (it >= W && E0 > 0.5 * e0_hist[it % W]) { status = -2; break; }
+    // stall guard (optional, chd_config.stall_window): no factor-2 reduction of the optimality error over the last W iterations
+    // -> give up (status -2) instead of running to the iteration cap; stage 3 then takes the reference's stage-4 fallback
+    if (opt.stall_window > 0) {
+      const int W = std::min(opt.stall_window, N);
+      if ((int)e0_hist.size() < W) e0_hist.assign(W, 0.0);
+      if (it >= W && E0 > 0.5 * e0_hist[it % W]) { status = -2; res.stalled = 1; break; }
       e0_hist[it % W] = E0;
     }
     while (true) {

@@ -6,10 +6,11 @@
 
 using namespace orc;
 
-static int g_verbose = 0, g_inertia_retry = 1;
+static int g_verbose = 0, g_inertia_retry = 1, g_stall_window = 0;
 extern "C" {
 void orc_set_verbose(int v) { g_verbose = v; }
 void orc_set_inertia_retry(int v) { g_inertia_retry = v; }
+void orc_set_stall_window(int v) { g_stall_window = v; }
 
 struct orc_seq_in {
   int F;
@@ -124,6 +125,7 @@ int orc_solve_stage(void* h, int stage, int max_iter, double* stats /*8*/) {
   opt.ref_tol = p->cfg.tol;
   opt.verbose = g_verbose != 0;
   opt.inertia_retry = g_inertia_retry != 0;
+  opt.stall_window = g_stall_window;
   IpmResult r = ipm_solve(*p, opt);
   if (stats) {
     stats[0] = r.iters; stats[1] = r.kkt_error; stats[2] = r.constr_viol; stats[3] = r.objective;

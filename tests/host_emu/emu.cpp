@@ -15,6 +15,7 @@ struct Emu {
   chd_config cfg;
   std::vector<double> wd, out_d, lds;
   std::vector<int> wi, out_i;
+  Ctx ctx;
   void bind() {
     M.d.cd = M.cd.data(); M.d.ci = M.ci.data(); M.d.wd = wd.data(); M.d.wi = wi.data();
     M.d.out_d = out_d.data(); M.d.out_i = out_i.data();
@@ -28,7 +29,7 @@ void* emu_create(const chd_seq_in* in, const chd_config* cfg) {
     e->cfg = *cfg;
     e->M.build(*in, *cfg);
     e->wd.assign(e->M.wd_size, 0.0); e->wi.assign(e->M.wi_size, 0);
-    e->out_d.assign(out_d_size(e->M.d.cap), 0.0); e->out_i.assign(out_i_size(e->M.d.cap), 0);
+    e->out_d.assign(out_d_size(e->M.d.cap, e->M.d.tot_entries + e->M.d.tot_phases), 0.0); e->out_i.assign(out_i_size(e->M.d.cap), 0);
     e->lds.assign(1 << 20, 0.0);
     e->bind();
     return e.release();
@@ -55,10 +56,8 @@ int emu_eval_lam(void* h, int stage, const double* x, const double* lam, double*
   Emu* e = (Emu*)h; e->bind();
   const StageDesc& S = e->M.d.st[stage];
   Ctx c; c.q = &e->M.d;
-  if (x) for (int j = 0; j < S.n; ++j) VN(c, VN_XT)[j] = x[j];
-  if (lam) for (int i = 0; i < S.m; ++i) VM(c, VM_LAM)[i] = lam[i];
   double fo[2];
-  debug_eval(&e->M.d, stage, x != nullptr, e->lds.data(), (int)e->lds.size(), fo, lam != nullptr);
+  debug_eval(&e->M.d, e->ctx, stage, x != nullptr, e->lds.data(), (int)e->lds.size(), (double*)x, (double*)lam, fo);
   if (f) *f = fo[0];
   if (x_out) for (int j = 0; j < S.n; ++j) x_out[j] = VN(c, VN_X)[j];
   if (grad) for (int j = 0; j < S.n; ++j) grad[j] = VN(c, VN_G)[j];
@@ -70,7 +69,7 @@ int emu_eval_lam(void* h, int stage, const double* x, const double* lam, double*
 int emu_linsolve(void* h, int stage, double dw, double dval, const double* b, double* x, int refine) {
   Emu* e = (Emu*)h; e->bind();
   double fo[2];
-  debug_eval(&e->M.d, stage, 0, e->lds.data(), (int)e->lds.size(), fo);
+  debug_eval(&e->M.d, e->ctx, stage, 0, e->lds.data(), (int)e->lds.size(), nullptr, nullptr, fo);
   Ctx c; c.lds = e->lds.data(); c.lds_cap = 18432;
   bind_stage(c, &e->M.d, stage);
   double* diag = VK(c, VK_DIAG); int* sign = e->M.d.wi + e->M.d.o_sign;
@@ -91,22 +90,22 @@ int emu_linsolve(void* h, int stage, double dw, double dval, const double* b, do
 }
 int emu_solve(void* h, int stage_first, int stage_last, int lds_doubles) {
   Emu* e = (Emu*)h; e->bind();
-  run_sequence(&e->M.d, e->lds.data(), lds_doubles > 0 ? lds_doubles : 18432, e->cfg.tol, stage_first, stage_last);
+  run_sequence(&e->M.d, e->ctx, e->lds.data(), lds_doubles > 0 ? lds_doubles : 18432, e->cfg.tol, e->cfg.stall_window, stage_first, stage_last);
   return 0;
 }
 // stage-4 fallback: rebuild the tables of stage index 5 with the durations stage 3 left
 int emu_rebuild_fallback(void* h) {
   Emu* e = (Emu*)h; e->bind();
   std::vector<double> cur[4];
-  for (int k = 0; k < 4; ++k) cur[k].assign(e->wd.data() + e->M.d.o_phase_dur + e->M.d.phase_off[k],
-                                            e->wd.data() + e->M.d.o_phase_dur + e->M.d.phase_off[k] + e->M.d.n_phase[k]);
+  const double* ph = e->out_d.data() + out_d_state_off(e->M.d.cap) + e->M.d.tot_entries;      // the durations stage 3 left (save_state)
+  for (int k = 0; k < 4; ++k) cur[k].assign(ph + e->M.d.phase_off[k], ph + e->M.d.phase_off[k] + e->M.d.n_phase[k]);
   e->M.build_stage(5, e->cfg, cur, false);
   e->bind();
   return e->M.d.st[5].valid;
 }
 void emu_get_out(void* h, double* od, int* oi) {
   Emu* e = (Emu*)h;
-  std::copy(e->out_d.begin(), e->out_d.end(), od);
+  std::copy(e->out_d.begin(), e->out_d.begin() + out_d_state_off(e->M.d.cap), od);      // statistics, snapshots, timers (not the saved state)
   std::copy(e->out_i.begin(), e->out_i.end(), oi);
 }
 }
@@ -115,7 +114,7 @@ void emu_get_out(void* h, double* od, int* oi) {
 extern "C" void emu_envelope(void* h, int stage, double* out) {
   Emu* e = (Emu*)h; e->bind();
   double fo[2];
-  debug_eval(&e->M.d, stage, 0, e->lds.data(), (int)e->lds.size(), fo);
+  debug_eval(&e->M.d, e->ctx, stage, 0, e->lds.data(), (int)e->lds.size(), nullptr, nullptr, fo);
   Ctx c; c.lds = e->lds.data(); c.lds_cap = (int)e->lds.size();
   bind_stage(c, &e->M.d, stage);
   long long env = 0, band = 0;
@@ -137,7 +136,7 @@ extern "C" void emu_envelope(void* h, int stage, double* out) {
 extern "C" void emu_border_first(void* h, int stage, double* out, int* first_out) {
   Emu* e = (Emu*)h; e->bind();
   double fo[2];
-  debug_eval(&e->M.d, stage, 0, e->lds.data(), (int)e->lds.size(), fo);
+  debug_eval(&e->M.d, e->ctx, stage, 0, e->lds.data(), (int)e->lds.size(), nullptr, nullptr, fo);
   Ctx c; c.lds = e->lds.data(); c.lds_cap = (int)e->lds.size();
   bind_stage(c, &e->M.d, stage);
   double acc = 0;
@@ -155,7 +154,7 @@ extern "C" void emu_border_first(void* h, int stage, double* out, int* first_out
 extern "C" void emu_nact_stats(void* h, int stage, double* out) {
   Emu* e = (Emu*)h; e->bind();
   double fo[2];
-  debug_eval(&e->M.d, stage, 0, e->lds.data(), (int)e->lds.size(), fo);
+  debug_eval(&e->M.d, e->ctx, stage, 0, e->lds.data(), (int)e->lds.size(), nullptr, nullptr, fo);
   Ctx c; c.lds = e->lds.data(); c.lds_cap = (int)e->lds.size();
   bind_stage(c, &e->M.d, stage);
   double sa = 0, sb = 0, sx = 0, st = 0; int np = 0;

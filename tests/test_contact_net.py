@@ -125,10 +125,10 @@ def test_device_preprocessing_is_bit_identical_to_numpy():
     assert all(np.array_equal(x, y) and x.shape == (v.shape[0], 4) for x, y, v in zip(a, b, vids))
 
 
-@pytest.mark.gpu_next
+@pytest.mark.gpu
 def test_device_preprocessing_on_gpu():
-    """The tensor-op pre- / post-processing on the HIP device: same windows and labels as the NumPy path (not yet run on
-    an MI355X: added after round 1's GPU budget was spent, hence `gpu_next`)."""
+    """The tensor-op pre- / post-processing on the HIP device: same windows and labels as the NumPy path (first run on an
+    MI355X at the start of round 2: profiles/r02a_round_start)."""
     if not torch.cuda.is_available():
         pytest.skip('needs an MI355X')
     dev = torch.device('cuda:0')

@@ -131,3 +131,56 @@ def test_file_interface_round_trip(solver, tmp_path):
         assert np.array_equal(sol.contact, mem[0].snapshots[k].contact)
     log = open(os.path.join(dout, 'success_log.txt')).read().split()
     assert log[0] == 'dynamics' and log[2] == 'durations' and log[1] in '01' and log[3] in '01'
+
+
+REF_CAPS = [7000, 7000, 7000, 2500, 2000, 7000]
+
+
+def test_bench_workload_matches_oracle():
+    """The BASELINE workload itself (bench.py's first batch: seeds 0..127, 90 frames, reference iteration caps) and 32
+    tilted-floor sequences, one persistent launch, against the committed oracle results
+    (tests/golden/bench_parity_golden.npz, made by tests/golden/make_bench_parity_golden.py): every sequence whose
+    stages all converge in the oracle -> identical stage statuses and iteration counts, contact flags bit-exact,
+    trajectories and forces within 1e-3 relative L2 (measured: ~1e-12).  A sequence on which a stage fails in the oracle
+    (its iterates stop on the noise floor of the merit function, where two implementations need not take the same
+    path) must fail in the same stage and stay within 1e-2."""
+    import os
+    import sys
+    from chd_amd.phys_optim import PhysOptim, default_config
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import make_bench_parity_golden as mk
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'bench_parity_golden.npz'))
+    cases = [c for c in mk.FLAT + mk.TILTED if mk.case_key(*c) + '_status' in g.files]
+    assert len(cases) >= 160
+    seqs = [mk.make_case(*c) for c in cases]
+    s = PhysOptim(device=0, config=default_config(max_iter=REF_CAPS))
+    res, st = s.solve(seqs)
+    s.close()
+    assert st['n_rejected'] == 0 and st['n_stalled'] == 0
+    worst = 0.0; n_failed = 0
+    for c, r in zip(cases, res):
+        key = mk.case_key(*c)
+        gs = list(g[key + '_status']); gi = list(g[key + '_iters'])
+        ok = all(v == 0 for v in gs)
+        err = 0.0
+        for k in range(3):
+            sn = r.snapshots[k]
+            for name, val in (('base_lin', sn.base_lin), ('base_ang_deg', sn.base_ang_deg), ('ee_pos', sn.ee_pos), ('ee_force', sn.ee_force)):
+                ref = g['%s_snap%d_%s' % (key, k, name)]
+                assert ref.shape == np.asarray(val).shape, (key, k, name)
+                nr = np.linalg.norm(ref)
+                if nr > 0:
+                    err = max(err, float(np.linalg.norm(np.asarray(val) - ref) / nr))
+            if ok or k < 2:
+                assert np.array_equal(np.asarray(sn.contact), g['%s_snap%d_contact' % (key, k)]), (key, k)
+        if ok:
+            assert list(r.stage_status[:len(gs)]) == gs and list(r.stage_iters[:len(gi)]) == gi, (key, r.stage_status, r.stage_iters, gs, gi)
+            assert err < 1e-3, (key, err)
+            worst = max(worst, err)
+        else:
+            n_failed += 1
+            first_bad = next(i for i, v in enumerate(gs) if v != 0)
+            assert r.stage_status[first_bad] == gs[first_bad] and list(r.stage_status[:first_bad]) == gs[:first_bad], (key, r.stage_status, gs)
+            assert err < 1e-2, (key, err)
+    print('bench workload parity: %d sequences, worst rel-L2 %.2e on the %d converging ones' % (len(cases), worst, len(cases) - n_failed))
+    assert n_failed <= 2

@@ -1,6 +1,5 @@
 """GPU parity of the IK back-projection step through its C ABI: libchd_ik.so on an MI355X against
-the vectors produced by the reference solver.  NOT YET RUN ON A GPU (round 1's GPU budget went to the physics path):
-marked `gpu_next`, i.e. outside `-m gpu` and outside `-m "not gpu"`'s expectations -- it skips without a GPU."""
+the vectors produced by the reference solver (first run on an MI355X at the start of round 2: profiles/r02a_round_start)."""
 import os
 
 import numpy as np
@@ -9,7 +8,7 @@ import pytest
 import chd_amd  # noqa: F401
 from oracle import ik_oracle as ik
 
-pytestmark = pytest.mark.gpu_next
+pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ik_golden.npz')
 
 
