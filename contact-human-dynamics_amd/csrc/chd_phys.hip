@@ -29,13 +29,15 @@ using namespace chd;
 static_assert(sizeof(SeqDesc) % 8 == 0, "SeqDesc is copied word by word");
 static_assert(sizeof(SeqDesc) + sizeof(Ctx) + 64 <= 4096, "static LDS of the solver kernel must fit the 4 KB left beside the dynamic part");
 
-__device__ inline QP take_sequence(SeqDesc* s_desc, int* s_item, const SeqDesc* descs, const int* order, int n_items, int* counter,
+// (returns false when the queue is empty.  Not a pointer: the descriptor sits at LDS address 0, which is what a null
+// local-address-space pointer compares equal to.)
+__device__ inline bool take_sequence(SeqDesc* s_desc, int* s_item, const SeqDesc* descs, const int* order, int n_items, int* counter,
                                    double* wd_pool, long long wd_stride, int* wi_pool, long long wi_stride) {
   __syncthreads();                                  // everybody is done with the previous descriptor
   if (threadIdx.x == 0) *s_item = atomicAdd(counter, 1);
   __syncthreads();
   const int item = *s_item;
-  if (item >= n_items) return nullptr;
+  if (item >= n_items) return false;
   const int* src = (const int*)(descs + order[item]);
   LdsI* dst = (LdsI*)s_desc;
   for (int i = threadIdx.x; i < (int)(sizeof(SeqDesc) / 4); i += blockDim.x) dst[i] = src[i];
@@ -45,7 +47,7 @@ __device__ inline QP take_sequence(SeqDesc* s_desc, int* s_item, const SeqDesc* 
     s_desc->wi = (GI*)(wi_pool + (long long)blockIdx.x * wi_stride);
   }
   __syncthreads();
-  return (QP)s_desc;
+  return true;
 }
 
 __global__ __launch_bounds__(CHD_MAX_THREADS) void chd_solve_kernel(const SeqDesc* descs, const int* order, int n_items, int* counter,
@@ -56,9 +58,8 @@ __global__ __launch_bounds__(CHD_MAX_THREADS) void chd_solve_kernel(const SeqDes
   __shared__ Ctx s_ctx;
   __shared__ int s_item;
   for (;;) {
-    QP q = take_sequence(&s_desc, &s_item, descs, order, n_items, counter, wd_pool, wd_stride, wi_pool, wi_stride);
-    if (!q) break;
-    run_sequence(q, *(LCtx*)&s_ctx, (LdsD*)lds, lds_doubles, tol, stall_window, stage_first, stage_last);
+    if (!take_sequence(&s_desc, &s_item, descs, order, n_items, counter, wd_pool, wd_stride, wi_pool, wi_stride)) break;
+    run_sequence((QP)&s_desc, *(LCtx*)&s_ctx, (LdsD*)lds, lds_doubles, tol, stall_window, stage_first, stage_last);
   }
 }
 
@@ -68,9 +69,8 @@ __global__ __launch_bounds__(CHD_MAX_THREADS) void chd_debug_eval_kernel(const S
   __shared__ SeqDesc s_desc;
   __shared__ Ctx s_ctx;
   __shared__ int s_item;
-  QP q = take_sequence(&s_desc, &s_item, descs, order, 1, counter, wd_pool, 0, wi_pool, 0);
-  if (!q) return;
-  debug_eval(q, *(LCtx*)&s_ctx, stage, xin != nullptr, (LdsD*)lds, lds_doubles, (const GD*)xin, (const GD*)nullptr, f_out);
+  if (!take_sequence(&s_desc, &s_item, descs, order, 1, counter, wd_pool, 0, wi_pool, 0)) return;
+  debug_eval((QP)&s_desc, *(LCtx*)&s_ctx, stage, xin != nullptr, (LdsD*)lds, lds_doubles, (const GD*)xin, (const GD*)nullptr, f_out);
 }
 
 struct chd_handle {
