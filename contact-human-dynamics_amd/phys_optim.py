@@ -41,6 +41,23 @@ def build_library(force=False, verbose=False):
     return LIB_PATH
 
 
+CLI_PATH = os.path.join(_HERE, 'cli', 'phys_optim')
+
+
+def build_cli(force=False, verbose=False):
+    """The `phys_optim` executable (cli/phys_optim_main.cpp): the reference's gflags, one sequence per process, for an
+    unmodified scripts/run_phys_mocap.py --towr_phys_optim_path <this cli directory>.  Links libchd_phys.so by rpath."""
+    build_library()
+    src = os.path.join(_HERE, 'cli', 'phys_optim_main.cpp')
+    if not force and os.path.exists(CLI_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(CLI_PATH) for s in (src, LIB_PATH)):
+        return CLI_PATH
+    cmd = ['g++', '-O2', '-std=c++17', src, '-o', CLI_PATH, '-L' + _CSRC, '-lchd_phys', '-Wl,-rpath,$ORIGIN/../csrc']
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return CLI_PATH
+
+
 _LIB = None
 
 

@@ -37,7 +37,7 @@ def parse_args(argv):
     p.add_argument('--w-ee', type=float, default=0.3)
     p.add_argument('--w-smooth', type=float, default=0.1)
     p.add_argument('--w-dur', type=float, default=0.1)
-    p.add_argument('--batch', type=int, default=128, help='sequences per kernel launch')
+    p.add_argument('--batch', type=int, default=4096, help='most sequences handed to the library in one call (one persistent launch drains them all)')
     p.add_argument('--prepare', action='store_true', help='write phys_optim_in_<character>/ from kinematic_results/ first')
     p.add_argument('--out-bvh', action='store_true', help='back-project the solutions onto the skeleton and write BVH files')
     p.add_argument('--character-json', default=None, help='joint / segment tables of the character (apply_results.Character)')
@@ -107,7 +107,7 @@ def main(argv=None):
                                    [os.path.join(vd, 'kinematic_results', a.character + '_out.bvh') for vd in vdirs],
                                    [os.path.join(p[1], '%s_%s_%s.bvh' % (os.path.basename(vd), a.character, kind)) for p, vd in zip(part, vdirs)],
                                    character, ik, starts=[0] * len(part), ends=[p[2] for p in part])
-    print('[run_phys_mocap] rank %d/%d: %d sequences, %d I/O failures' % (rank, world, len(mine), bad))
+    print('[run_phys_mocap] rank %d/%d: %d sequences, %d failed (unreadable inputs, rejected at set-up or unwritable outputs: each loses only itself)' % (rank, world, len(mine), bad))
     return 0 if bad == 0 else 1
 
 
