@@ -4,8 +4,11 @@
     python bench.py --gpus N --steps K --warmup W
 
 One "step" = one full staged solve (stages 1.1, 1.2, 2.1, 2.2, 3 and the stage-4 fallback where stage 3 fails;
-phys_optim.cpp:544-749, reference iteration caps and tolerance, no stall guard) of one batch of 128 synthetic 90-frame
-sequences (BASELINE.json configs[1]).  The K steps of the timed region are K DIFFERENT batches -- seeds
+phys_optim.cpp:544-749, reference iteration caps and tolerance) of one batch of 128 synthetic 90-frame sequences
+(BASELINE.json configs[1]).  The solver's stall guard is ON in the measured configuration (chd_config.stall_window = 150,
+--stall-window 0 switches it off; its hits are reported): roughly one 90-frame sequence in a thousand stagnates in the
+duration stage and would otherwise run to the 2000-iteration cap -- ~13 s on one compute unit -- before taking the same
+stage-4 fallback.  The K steps of the timed region are K DIFFERENT batches -- seeds
 rank*K*128 .. (rank+1)*K*128 - 1, a one-GPU slice of configs[2] -- handed to the library in one call: inputs and
 structure tables are resident in HBM when the clock starts, and ONE persistent launch (one resident workgroup per
 compute unit taking sequences from a queue) drains them; one handle, one stream, no replicated batches.
@@ -162,7 +165,9 @@ def main():
     ap.add_argument('--steps', type=int, default=12)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--batch', type=int, default=BATCH, help=argparse.SUPPRESS)
-    ap.add_argument('--stall-window', type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument('--stall-window', type=int, default=150,
+                    help='chd_config.stall_window of the measured configuration (0 = off: a stagnating stage runs to its iteration cap)')
+    ap.add_argument('--gen-workers', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--max-workgroups', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--threads', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--lds-kb', type=int, default=0, help=argparse.SUPPRESS)
@@ -176,7 +181,7 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     B = args.batch
     steps = max(1, args.steps)
-    workers = max(1, min(8, (os.cpu_count() or 1) // max(1, world)))
+    workers = args.gen_workers if args.gen_workers > 0 else max(1, min(8, (os.cpu_count() or 1) // max(1, world)))
     seed0 = rank * steps * B
     seqs = make_sequences(seed0, steps * B, workers)                      # before the HIP runtime exists in this process (fork)
 
@@ -263,7 +268,11 @@ def main():
                        'ipm_iterations_rank0': {'p50': float(np.percentile(it_seq, 50)), 'p90': float(np.percentile(it_seq, 90)), 'max': float(it_seq.max())},
                        'factorizations_rank0': nfact, 'stage4_fallbacks_rank0': st['n_fallback'], 'stall_guard_hits_rank0': st['n_stalled'],
                        'converged_rank0': '%d/%d' % (n_ok, len(res)),
-                       'slowest_sequence_ms': st['max_seq_ms'], 'mean_sequence_ms': st['phase_ms'][5] / max(1, len(res))},
+                       'slowest_sequence_ms': st['max_seq_ms'], 'mean_sequence_ms': st['phase_ms'][5] / max(1, len(res)),
+                       'in_kernel_time_share': {k: st['phase_ms'][i] / max(1e-9, st['phase_ms'][5]) for k, i in
+                                                (('evaluation_full', 0), ('evaluation_values', 1), ('factorisation', 2), ('substitution', 3), ('kkt_matvec', 4),
+                                                 ('factor_copy', 6), ('factor_panel_load', 8), ('factor_row_solve', 9), ('factor_store', 10),
+                                                 ('factor_trailing_update', 11), ('factor_border', 12))}},
             'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS * world, 'unit': 'GB/s', 'frac': ach / (HBM_PEAK_GBS * world),
                          'definition': 'sum over sequences of SURVEY 8(d) bytes_iter x IPM iterations / wall time of the timed region / (8 TB/s x GPUs)',
                          'algorithmic_bytes_per_step': alg_bytes_all / steps / world, 'algorithmic_bytes_per_iteration': alg_bytes / max(1, iters),

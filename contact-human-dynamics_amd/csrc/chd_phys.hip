@@ -149,10 +149,13 @@ int chd_phys_create(const chd_config* cfg, int device_id, chd_handle** out) {
   if (h->cfg.lds_kilobytes > 0 && h->cfg.lds_kilobytes * 1024 < h->lds_bytes) h->lds_bytes = std::max(32, h->cfg.lds_kilobytes) * 1024;
   hipFuncSetAttribute((const void*)chd_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
   hipFuncSetAttribute((const void*)chd_debug_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
-  int t = h->cfg.threads_per_sequence > 0 ? h->cfg.threads_per_sequence : CHD_MAX_THREADS;
-  if (t > CHD_MAX_THREADS) t = CHD_MAX_THREADS;
-  if (t < 64) t = 64;
-  h->threads = (t / 64) * 64;
+  // the factorisation / substitution phases are written for eight wavefronts (wave-specialised look-ahead, register prefetch
+  // by lane group): other workgroup sizes are refused rather than silently mis-solved
+  if (h->cfg.threads_per_sequence != 0 && h->cfg.threads_per_sequence != CHD_MAX_THREADS) {
+    std::fprintf(stderr, "chd_phys_create: threads_per_sequence must be 0 or %d\n", CHD_MAX_THREADS);
+    (void)hipStreamDestroy(h->stream); delete h; return -7;
+  }
+  h->threads = CHD_MAX_THREADS;
   h->n_wg = h->cfg.max_workgroups > 0 ? h->cfg.max_workgroups : prop.multiProcessorCount;
   if (h->n_wg < 1) h->n_wg = 1;
   if (hipMalloc((void**)&h->d_counter, 64) != hipSuccess) { (void)hipStreamDestroy(h->stream); delete h; return -6; }

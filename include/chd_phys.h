@@ -39,13 +39,14 @@ typedef struct chd_config {
   double w_dur;            /* --w_dur      default 0.1  */
   int max_iter[CHD_N_STAGES];   /* 7000, 7000, 7000, 2500, 2000, 7000 */
   double tol;              /* IPOPT "tol", 1e-3 (phys_optim.cpp:578) */
-  int threads_per_sequence;     /* workgroup size of the solver kernel; 0 = default (512) */
+  int threads_per_sequence;     /* workgroup size of the solver kernel: 0 or 512 (the phases are written for eight wavefronts;
+                                   anything else is refused by chd_phys_create) */
   int stall_window;             /* > 0: a stage whose optimality error has not halved within this many iterations ends with
                                    status -2 (stage 3 then takes the stage-4 fallback) instead of running to max_iter; the hit
                                    is reported in chd_seq_out.stage_stalled.  0 (default) = off: IPOPT has no such rule */
   int max_workgroups;           /* resident workgroups of the solver launch; 0 = one per compute unit */
-  int lds_kilobytes;            /* dynamic LDS per workgroup; 0 = all of a compute unit's (156 KB): tuning knob for two smaller
-                                   workgroups per compute unit (with threads_per_sequence 256 and max_workgroups 2 x CUs) */
+  int lds_kilobytes;            /* dynamic LDS per workgroup; 0 = all of a compute unit's (156 KB); smaller values narrow the
+                                   factorisation panels (tuning / test knob) */
   int reserved[4];
 } chd_config;
 

@@ -1,33 +1,35 @@
-"""BASELINE config 5 (single 600-frame sequence, tilted floor) and a multi-seed parity sweep on the GPU."""
-import sys, time
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
-import numpy as np
-import chd_amd
-from chd_amd.synth import make_walk
-from chd_amd.phys_optim import PhysOptim, default_config
-from common import oracle_run, snapshot_errors
+"""BASELINE configs[4] on the GPU: one 600-frame sequence, floor tilted by 10 degrees (the stress case for the KKT band),
+alone in a launch; compared with the oracle's committed result when the fixture holds it.
 
-s = PhysOptim(0, default_config())
-seq = make_walk(seed=5, F=600, randomize=True, tilt_deg=10.0)
-t0 = time.time(); b = s.upload([seq]); t1 = time.time()
-for st in range(5):
-    print('stage', st, b.sizes(0, st))
-stt = b.solve(); t2 = time.time(); res = b.fetch()
-r = res[0]
-print('F=600: upload %.2fs solve %.2fs' % (t1 - t0, t2 - t1), list(zip(r.stage_status, r.stage_iters)), r.sizes)
-print({k: stt[k] for k in ('kernel_ms', 'total_iters', 'total_factorizations', 'max_seq_ms')})
-print('phase_ms', [round(x, 1) for x in stt['phase_ms']])
-print('finite', all(np.isfinite(sn.ee_force).all() for sn in r.snapshots), 'viol', r.stage_constr_viol)
-b.free()
-if len(sys.argv) > 1:
-    worst = 0
-    for seed in [int(a) for a in sys.argv[1:]]:
-        sq = make_walk(seed=seed, F=90, randomize=True)
-        rs, _ = s.solve([sq])
-        ostats, osnaps = oracle_run(sq, [7000, 7000, 7000, 2500, 2000, 7000])
-        errs = [snapshot_errors(rs[0].snapshots[k], osnaps[k]) for k in range(3)]
-        w = max(max(e['base_lin'], e['base_ang_deg'], e['ee_pos'], e['ee_force']) for e in errs)
-        worst = max(worst, w)
-        print('seed', seed, 'gpu', list(zip(rs[0].stage_status, rs[0].stage_iters)), 'oracle', [(a, b_) for a, b_, c in ostats], 'max rel-L2 %.2e' % w,
-              'contact mismatches', sum(e['contact_mismatch'] for e in errs))
-    print('worst rel-L2 over seeds', worst)
+    python tests/tools/gpu_long.py [frames] [tilt]
+"""
+import os
+import sys
+import time
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests'); sys.path.insert(0, 'tests/golden')
+import numpy as np
+import chd_amd  # noqa: E402,F401
+from chd_amd.phys_optim import PhysOptim, default_config  # noqa: E402
+import make_bench_parity_golden as mk  # noqa: E402
+
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 600
+tilt = float(sys.argv[2]) if len(sys.argv) > 2 else 10.0
+seq = mk.make_case(0, F, tilt)
+s = PhysOptim(0, default_config(stall_window=int(os.environ.get('STALL', '0'))))
+t0 = time.time(); b = s.upload([seq]); t1 = time.time(); st = b.solve(); t2 = time.time(); r = b.fetch()[0]
+print('F %d tilt %.0f: upload %.2fs solve %.2fs kernel %.0f + %.0f ms; sizes %s' % (F, tilt, t1 - t0, t2 - t1, st['kernel_ms'][0], st['kernel_ms'][1], r.sizes))
+print('stages', list(zip(r.stage_status, r.stage_iters)), 'viol', ['%.1e' % v for v in r.stage_constr_viol])
+print('phase share', {k: round(st['phase_ms'][i] / max(1e-9, st['phase_ms'][5]), 3) for k, i in (('eval', 0), ('eval_values', 1), ('factor', 2), ('solve', 3), ('matvec', 4))})
+g = np.load(os.path.join('tests', 'golden', 'bench_parity_golden.npz'))
+key = mk.case_key(0, F, tilt)
+if key + '_status' in g.files:
+    worst = 0.0
+    for k in range(3):
+        sn = r.snapshots[k]
+        for name, val in (('base_lin', sn.base_lin), ('base_ang_deg', sn.base_ang_deg), ('ee_pos', sn.ee_pos), ('ee_force', sn.ee_force)):
+            ref = g['%s_snap%d_%s' % (key, k, name)]
+            if np.linalg.norm(ref) > 0:
+                worst = max(worst, float(np.linalg.norm(np.asarray(val) - ref) / np.linalg.norm(ref)))
+    print('oracle', list(zip(g[key + '_status'], g[key + '_iters'])), 'worst rel-L2 %.2e' % worst)
+else:
+    print('no oracle result for', key, 'in the fixture')
