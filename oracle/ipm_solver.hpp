@@ -43,6 +43,12 @@ struct IpmOptions {
   bool use_soc = true;
   int max_attempts = 12;
   bool verbose = false;
+  // IPOPT-like mode, ORACLE ONLY -- never the shipped algorithm: limited-memory BFGS(6) Hessian of the Lagrangian
+  // (phys_optim.cpp:572 hessian_approximation = limited-memory) folded into the KKT solve by the Sherman-Morrison-Woodbury formula,
+  // IPOPT's mu_init = 0.1 on every stage.  Used by tests/tools/ipopt_like_distance.py to measure how far a solver of IPOPT's family lands
+  // from the shipped Gauss-Newton algorithm at the same tolerance.
+  bool lbfgs = false;
+  int lbfgs_history = 6;
   int stall_window = 0;         // > 0: stall guard (chd_config.stall_window); 0 = off, as IPOPT has no such rule
   bool inertia_retry = true;    // a factorisation that had to replace a pivot counts as a failed attempt (see chd_kernels.hpp, CHD_INERTIA_RETRY)
 };
@@ -286,7 +292,7 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
   res.N = N;
 
   // ---- slack / multiplier initialisation ------------------------------------
-  double mu = (P.stage == 0) ? opt.mu_init_cold : opt.mu_init_warm;
+  double mu = (P.stage == 0 || opt.lbfgs) ? opt.mu_init_cold : opt.mu_init_warm;
   std::vector<double> s(m, 0.0), zL(m, 0.0), zU(m, 0.0), lam(m, 0.0);
   for (int i = 0; i < m; ++i) {
     if (eq[i]) continue;
@@ -336,6 +342,10 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
   std::vector<double> Sigma(m), rs(m), D(m), rhs(N), sol(N), dx(n), dlam(m), ds(m), dzL(m), dzU(m);
   std::vector<double> xt(n), st(m), ct(m), rt(m), Hdx(n), rhs2(N), sol2(N), xs(n), ss2(m), lraw(m);
   int status = -1, it = 0;
+  // limited-memory BFGS state (IPOPT-like mode): pairs (s, y) in the scaled variables, sigma = s^T y / s^T s of the newest pair
+  std::vector<std::vector<double>> lb_S, lb_Y;
+  double lb_sigma = 1.0;
+  std::vector<double> lb_xold, lb_Jold, lb_gold;
   std::vector<double> e0_hist(150, 0.0);
   double last_alpha = 0; int last_nls = 0, last_att = 0; bool last_soc = false;
   for (it = 0; it < opt.max_iter; ++it) {
@@ -373,13 +383,16 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
     for (int i = 0; i < m; ++i) rhs[pos_row[i]] = eq[i] ? -r[i] : -(r[i] + rs[i] / Sigma[i]);
     // bandwidth of the current pattern
     int w = 0;
-    for (int a = 0; a < n; ++a) { if (pos_var[a] >= Nb) continue; const double* Hr = &H[(size_t)a * n]; for (int b2 = 0; b2 < a; ++b2) if (Hr[b2] != 0.0 && pos_var[b2] < Nb) w = std::max(w, std::abs(pos_var[a] - pos_var[b2])); }
+    if (!opt.lbfgs) for (int a = 0; a < n; ++a) { if (pos_var[a] >= Nb) continue; const double* Hr = &H[(size_t)a * n]; for (int b2 = 0; b2 < a; ++b2) if (Hr[b2] != 0.0 && pos_var[b2] < Nb) w = std::max(w, std::abs(pos_var[a] - pos_var[b2])); }
     for (int i = 0; i < m; ++i) { if (pos_row[i] >= Nb) continue; const double* Jr = &J[(size_t)i * n]; for (int j = 0; j < n; ++j) if (Jr[j] != 0.0 && pos_var[j] < Nb) w = std::max(w, std::abs(pos_row[i] - pos_var[j])); }
     res.bandwidth = std::max(res.bandwidth, w);
 
     bool ok = false, used_soc = false; double alpha = 0, a_du = 1.0; int nls = 0, attempt = 0;
     for (attempt = 0; attempt < opt.max_attempts; ++attempt) {
       K.resize(Nb, bcount, w);
+      if (opt.lbfgs) {
+        for (int a = 0; a < n; ++a) K.add(pos_var[a], pos_var[a], lb_sigma + dw * Dw[a]);      // B = sigma I - W M^-1 W^T: the low-rank part enters through kkt_solve
+      } else
       for (int a = 0; a < n; ++a) {
         const double* Hr = &H[(size_t)a * n];
         for (int b2 = 0; b2 < a; ++b2) if (Hr[b2] != 0.0) K.add(pos_var[a], pos_var[b2], Hr[b2]);
@@ -392,7 +405,53 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
       }
       K.factor(); ++res.n_factor;
       if (opt.inertia_retry && K.n_bad_pivots > 0) { dw *= 10.0; if (dw > opt.delta_w_max) break; continue; }
-      K.solve(rhs.data(), sol.data(), 1);      // one step of iterative refinement
+      const int lk = opt.lbfgs ? (int)lb_S.size() : 0;
+      std::vector<double> lbZ, lbC;          // Z = K_sigma^-1 What (N x 2k, column major), C = M - What^T Z (2k x 2k)
+      if (lk > 0) {
+        const int k2 = 2 * lk;
+        lbZ.assign((size_t)N * k2, 0.0);
+        std::vector<double> col(N);
+        for (int c2 = 0; c2 < k2; ++c2) {
+          std::fill(col.begin(), col.end(), 0.0);
+          const std::vector<double>& v = c2 < lk ? lb_S[c2] : lb_Y[c2 - lk];
+          for (int j = 0; j < n; ++j) col[pos_var[j]] = (c2 < lk ? lb_sigma : 1.0) * v[j];
+          K.solve(col.data(), &lbZ[(size_t)c2 * N], 1);
+        }
+        lbC.assign((size_t)k2 * k2, 0.0);
+        auto Wd = [&](int c2, int j) { return (c2 < lk ? lb_sigma * lb_S[c2][j] : lb_Y[c2 - lk][j]); };
+        for (int a = 0; a < lk; ++a)
+          for (int b2 = 0; b2 < lk; ++b2) {
+            double ss = 0, sy = 0;
+            for (int j = 0; j < n; ++j) { ss += lb_S[a][j] * lb_S[b2][j]; sy += lb_S[a][j] * lb_Y[b2][j]; }
+            lbC[(size_t)a * k2 + b2] = lb_sigma * ss;                               // sigma S^T S
+            if (a > b2) { lbC[(size_t)a * k2 + lk + b2] = sy; lbC[(size_t)(lk + b2) * k2 + a] = sy; }      // L (strictly lower) and L^T
+            if (a == b2) lbC[(size_t)(lk + a) * k2 + lk + a] = -sy;                 // -D
+          }
+        for (int a = 0; a < k2; ++a)
+          for (int b2 = 0; b2 < k2; ++b2) {
+            double acc = 0;
+            for (int j = 0; j < n; ++j) acc += Wd(a, j) * lbZ[(size_t)b2 * N + pos_var[j]];
+            lbC[(size_t)a * k2 + b2] -= acc;
+          }
+      }
+      auto kkt_solve = [&](const double* r_, double* z_) {
+        K.solve(r_, z_, 1);      // one step of iterative refinement
+        if (lk == 0) return;
+        const int k2 = 2 * lk;
+        std::vector<double> t(k2), A(lbC);
+        for (int a = 0; a < k2; ++a) { double acc = 0; for (int j = 0; j < n; ++j) acc += (a < lk ? lb_sigma * lb_S[a][j] : lb_Y[a - lk][j]) * z_[pos_var[j]]; t[a] = acc; }
+        // dense solve A t = t (Gaussian elimination with partial pivoting; 2k <= 12)
+        for (int c2 = 0; c2 < k2; ++c2) {
+          int piv = c2; for (int r2 = c2 + 1; r2 < k2; ++r2) if (std::fabs(A[(size_t)r2 * k2 + c2]) > std::fabs(A[(size_t)piv * k2 + c2])) piv = r2;
+          if (piv != c2) { for (int q = 0; q < k2; ++q) std::swap(A[(size_t)c2 * k2 + q], A[(size_t)piv * k2 + q]); std::swap(t[c2], t[piv]); }
+          const double d = A[(size_t)c2 * k2 + c2];
+          if (d == 0.0) continue;
+          for (int r2 = c2 + 1; r2 < k2; ++r2) { const double f2 = A[(size_t)r2 * k2 + c2] / d; if (f2 == 0.0) continue; for (int q = c2; q < k2; ++q) A[(size_t)r2 * k2 + q] -= f2 * A[(size_t)c2 * k2 + q]; t[r2] -= f2 * t[c2]; }
+        }
+        for (int c2 = k2 - 1; c2 >= 0; --c2) { double acc = t[c2]; for (int q = c2 + 1; q < k2; ++q) acc -= A[(size_t)c2 * k2 + q] * t[q]; const double d = A[(size_t)c2 * k2 + c2]; t[c2] = d != 0.0 ? acc / d : 0.0; }
+        for (int a = 0; a < k2; ++a) { const double ta = t[a]; const double* Zc = &lbZ[(size_t)a * N]; for (int i = 0; i < N; ++i) z_[i] += Zc[i] * ta; }
+      };
+      kkt_solve(rhs.data(), sol.data());
       for (int j = 0; j < n; ++j) dx[j] = sol[pos_var[j]];
       for (int i = 0; i < m; ++i) dlam[i] = sol[pos_row[i]];
       double a_pr = 1.0; a_du = 1.0;
@@ -435,7 +494,7 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
           // residual at the trial point; avoids the Maratos effect of the l1 merit function.
           for (int j = 0; j < n; ++j) rhs2[pos_var[j]] = 0.0;
           for (int i = 0; i < m; ++i) rhs2[pos_row[i]] = -rt[i];
-          K.solve(rhs2.data(), sol2.data(), 1);
+          kkt_solve(rhs2.data(), sol2.data());
           bool inside = true;
           for (int j = 0; j < n; ++j) xs[j] = xt[j] + sol2[pos_var[j]];
           for (int i = 0; i < m; ++i) {
@@ -466,6 +525,7 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
     if (attempt == 0 && nls == 0) dw = std::max(opt.delta_w_min, dw / 2.0);
     else if (nls >= 1) dw *= 4.0;
     last_alpha = alpha; last_nls = nls; last_att = attempt; last_soc = used_soc;
+    if (opt.lbfgs) lb_xold = x;
     if (used_soc) { for (int j = 0; j < n; ++j) x[j] = xs[j]; } else { for (int j = 0; j < n; ++j) x[j] += alpha * dx[j]; }
     for (int i = 0; i < m; ++i) {
       if (used_soc) s[i] = ss2[i]; else s[i] += alpha * ds[i];
@@ -477,9 +537,23 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
     }
     // multipliers of the unscaled rows for the exact duration block of the Lagrangian Hessian (nlp_model.hpp)
     for (int i = 0; i < m; ++i) lraw[i] = lam[i] * sc[i] / sf;
-    P.eval(x.data(), &fraw, graw.data(), craw.data(), J.data(), H.data(), lraw.data());
+    if (opt.lbfgs) { lb_Jold = J; lb_gold = g; }          // (scaled values of the point just left; lb_xold was taken before the step)
+    P.eval(x.data(), &fraw, graw.data(), craw.data(), J.data(), opt.lbfgs ? nullptr : H.data(), opt.lbfgs ? nullptr : lraw.data());
     apply_scaling(true);
     f = sf * fraw;
+    if (opt.lbfgs) {
+      // y = grad_x L(x+, lam+) - grad_x L(x, lam+)   (IPOPT's limited-memory update uses the new multipliers for both)
+      std::vector<double> sv(n), yv(n);
+      for (int j = 0; j < n; ++j) { sv[j] = x[j] - lb_xold[j]; yv[j] = g[j] - lb_gold[j]; }
+      for (int i = 0; i < m; ++i) { const double li = lam[i]; if (li == 0.0) continue; const double* Jn = &J[(size_t)i * n]; const double* Jo = &lb_Jold[(size_t)i * n]; for (int j = 0; j < n; ++j) yv[j] += (Jn[j] - Jo[j]) * li; }
+      double sy = 0, ss = 0, yy = 0;
+      for (int j = 0; j < n; ++j) { sy += sv[j] * yv[j]; ss += sv[j] * sv[j]; yy += yv[j] * yv[j]; }
+      if (sy > 1.4901161193847656e-08 * std::sqrt(ss) * std::sqrt(yy) && ss > 0) {      // skip the update unless s^T y > sqrt(eps) |s| |y|
+        lb_S.push_back(sv); lb_Y.push_back(yv);
+        if ((int)lb_S.size() > opt.lbfgs_history) { lb_S.erase(lb_S.begin()); lb_Y.erase(lb_Y.begin()); }
+        lb_sigma = std::min(1e8, std::max(1e-8, sy / ss));
+      }
+    }
   }
   P.set_x(x.data());
   res.status = status; res.iters = it; res.kkt_error = errors(0.0); res.objective = f / sf; res.mu = mu;

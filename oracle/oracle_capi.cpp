@@ -6,11 +6,12 @@
 
 using namespace orc;
 
-static int g_verbose = 0, g_inertia_retry = 1, g_stall_window = 0;
+static int g_verbose = 0, g_inertia_retry = 1, g_stall_window = 0, g_lbfgs = 0;
 extern "C" {
 void orc_set_verbose(int v) { g_verbose = v; }
 void orc_set_inertia_retry(int v) { g_inertia_retry = v; }
 void orc_set_stall_window(int v) { g_stall_window = v; }
+void orc_set_ipopt_like(int v) { g_lbfgs = v; }      // L-BFGS(6) + mu_init 0.1 on every stage: see IpmOptions::lbfgs (oracle-only study mode)
 
 struct orc_seq_in {
   int F;
@@ -126,6 +127,7 @@ int orc_solve_stage(void* h, int stage, int max_iter, double* stats /*8*/) {
   opt.verbose = g_verbose != 0;
   opt.inertia_retry = g_inertia_retry != 0;
   opt.stall_window = g_stall_window;
+  opt.lbfgs = g_lbfgs != 0;
   IpmResult r = ipm_solve(*p, opt);
   if (stats) {
     stats[0] = r.iters; stats[1] = r.kkt_error; stats[2] = r.constr_viol; stats[3] = r.objective;
