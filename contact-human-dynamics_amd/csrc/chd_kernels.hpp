@@ -1711,18 +1711,20 @@ struct RowW {           // where one row's Jacobian entries go
 // polynomial.  They are distinct KKT entries (after folding the two nodes of a stance pair, which share a variable), so
 // their read-modify-writes are issued together: all index look-ups, then all loads, then all stores -- one HBM round
 // trip per call instead of one (dependent) per entry.
-CHD_DEV void row_nodes(const RowW& r, int s, const PE& e, int which, const double coef[3], int dimmask) {
-  if (!r.on) return;
-  LCtx& c = *r.c;
+// (its own function, arguments by value: inlined at its ~25 call sites the twelve-entry bodies made the row phases 70 k
+//  instructions long -- more than the instruction cache -- and kept the spline samples they read in scratch memory)
+CHD_NOINLINE CHD_DEV void row_nodes_nv(LCtx& c, const int pr, const double sc, const int s, const int poly, const double w0, const double w1, const double w2, const double w3,
+                                       const double c0, const double c1, const double c2, const int dimmask) {
   QP q = c.q;
   const auto& sp = q->sp[s];
-  const GI* vo = q->ci + q->o_varof + sp.node_off + e.poly * 6;
+  const GI* vo = q->ci + q->o_varof + sp.node_off + poly * 6;
   int v[12]; double val[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) {
     const int side = i / 6, dq = (i % 6) / 3, k = i % 3;
+    const double wk = side == 0 ? (dq == 0 ? w0 : w1) : (dq == 0 ? w2 : w3);
     v[i] = ((dimmask >> k) & 1) ? vo[i] : -1;
-    val[i] = r.sc * coef[k] * e.w[which][side * 2 + dq];
+    val[i] = sc * (k == 0 ? c0 : k == 1 ? c1 : c2) * wk;
   }
 #pragma unroll
   for (int i = 0; i < 6; ++i)
@@ -1732,12 +1734,16 @@ CHD_DEV void row_nodes(const RowW& r, int s, const PE& e, int which, const doubl
   for (int i = 0; i < 12; ++i) pv[i] = c.pos_var[sp.var_off + (v[i] >= 0 ? v[i] : 0)];
   KSlot sl[12];
 #pragma unroll
-  for (int i = 0; i < 12; ++i) { sl[i].a = nullptr; sl[i].b = nullptr; if (v[i] >= 0) sl[i] = kslot(c, r.pr, pv[i]); }
+  for (int i = 0; i < 12; ++i) { sl[i].a = nullptr; sl[i].b = nullptr; if (v[i] >= 0) sl[i] = kslot(c, pr, pv[i]); }
   double oa[12], ob[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) { oa[i] = *(sl[i].a ? sl[i].a : c.K0b); ob[i] = *(sl[i].b ? sl[i].b : c.K0b); }
 #pragma unroll
   for (int i = 0; i < 12; ++i) { if (sl[i].a) *sl[i].a = oa[i] + val[i]; if (sl[i].b) *sl[i].b = ob[i] + val[i]; }
+}
+CHD_DEV void row_nodes(const RowW& r, int s, const PE& e, int which, const double coef[3], int dimmask) {
+  if (!r.on) return;
+  row_nodes_nv(*r.c, r.pr, r.sc, s, e.poly, e.w[which][0], e.w[which][1], e.w[which][2], e.w[which][3], coef[0], coef[1], coef[2], dimmask);
 }
 CHD_DEV void row_durs(const RowW& r, int s, double t, const PE& e, const double coef[3]) {
   if (!r.on || !r.c->S->opt_dur) return;
