@@ -1,0 +1,75 @@
+"""BASELINE configs[3] end to end on one GPU, SUBSTITUTED: the real videos need OpenPose / MTC and their
+weights, none of which exist offline, so the chain starts from synthetic OpenPose-like JSON files and a seeded
+random-weight contact network:
+
+    openpose_result/*.json --run_detect_contacts (ROCm, device ops)--> foot_contacts.npy
+        --run_phys_mocap --prepare--> phys_optim_in_<char>/ --libchd_phys.so--> sol_out_*.txt
+        --run_phys_mocap --out-bvh (libchd_ik.so)--> <video>_<char>_*.bvh
+
+with the reference's directory layout (scripts/run_detect_contacts.py:52-58, scripts/run_phys_mocap.py:97-201).  Every
+stage's numerics is pinned elsewhere; this checks that the stages accept each other's output on the device, that the
+labels equal the CPU labels bit for bit, and that both drivers run unmodified on a directory tree."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import chd_amd  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_openpose_json_to_bvh_on_one_gpu(tmp_path):
+    import torch
+    sys.path.insert(0, os.path.join(HERE, 'golden'))
+    from make_apply_golden import CHARACTER
+    from chd_amd import contact_net as cn
+    from chd_amd import io_formats as iof
+    from chd_amd import run_detect_contacts, run_phys_mocap
+    from chd_amd import skeleton_io as sk
+    g = np.load(os.path.join(HERE, 'golden', 'apply_golden.npz'))
+    F = 14                                                            # the fixture clip's length
+    root = tmp_path / 'data'
+    vids = ['dance_a', 'dance_b', 'dance_c']
+    for k, v in enumerate(vids):
+        op = root / v / 'openpose_result'; kin = root / v / 'kinematic_results'
+        os.makedirs(op); os.makedirs(kin)
+        kp = cn.synthetic_keypoints(k, F=F)
+        for i in range(F):                                            # OpenPose's per-frame JSON (openpose_utils.py:48-76)
+            json.dump({'version': 1.3, 'people': [{'pose_keypoints_2d': [float(x) for x in kp[i].reshape(-1)]}]},
+                      open(op / ('%s_%012d_keypoints.json' % (v, i)), 'w'))
+        open(kin / 'synth_out.bvh', 'wb').write(g['bvh_text'].tobytes())
+        open(kin / 'floor_out.txt', 'wb').write(g['prep_floor_text'].tobytes())
+    torch.manual_seed(0)
+    model = cn.randomize_batchnorm_stats(cn.OpenPoseModel(), seed=0)
+    weights = str(tmp_path / 'op_only_weights.pth')
+    torch.save(model.state_dict(), weights)
+    # ---- contact detection on the GPU (run_detect_contacts.py:52-58)
+    assert run_detect_contacts.main(['--data', str(root), '--weights', weights, '--device-ops']) == 0
+    cpu_labels, _ = cn.detect_contacts([cn.load_keypoint_dir(str(root / v / 'openpose_result')) for v in vids], model.eval(), torch.device('cpu'))
+    for v, lab in zip(vids, cpu_labels):
+        got = np.load(str(root / v / 'foot_contacts.npy'))
+        assert got.shape == (F, 4) and np.array_equal(got, lab)       # bit-exact labels, GPU device ops vs CPU NumPy path
+        # the physics stage reads kinematic_results/foot_contacts.npy (run_phys_mocap.py:146: the kinematic optimisation's refined
+        # contacts, a stage outside this path -- here the network's own)
+        np.save(str(root / v / 'kinematic_results' / 'foot_contacts.npy'), got)
+    # ---- prepare_input -> physics -> back-projection (run_phys_mocap.py:137-201)
+    cj = str(tmp_path / 'character.json')
+    json.dump(CHARACTER, open(cj, 'w'))
+    rc = run_phys_mocap.main(['--data', str(root), '--character', 'synth', '--prepare', '--out-bvh', '--character-json', cj])
+    assert rc == 0
+    for v in vids:
+        out = root / v / 'phys_optim_out_synth'
+        files = sorted(os.listdir(out))
+        assert {'sol_out_no_dynamics.txt', 'sol_out_dynamics.txt', 'sol_out_durations.txt', 'success_log.txt'} <= set(files)
+        sol = iof.load_results(str(out / 'sol_out_no_dynamics.txt'))
+        assert sol.num_frames == F and np.isfinite(sol.base_lin).all() and np.isfinite(sol.ee_pos).all()
+        bvh = str(out / ('%s_synth_no_dynamics.bvh' % v))
+        assert os.path.exists(bvh)
+        m, names, _ = sk.load_bvh(bvh)
+        assert m.n_frames == F and m.n_joints == 20 and names[0] == 'Hips'
+        log = open(str(out / 'success_log.txt')).read().split()
+        assert log[0] == 'dynamics' and log[1] in '01' and log[2] == 'durations' and log[3] in '01'
