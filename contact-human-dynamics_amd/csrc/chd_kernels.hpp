@@ -92,6 +92,9 @@ namespace chd {
 #define CHD_CONSTR_VIOL_TOL 1e-4
 #define CHD_MAX_BACKTRACK 3
 #define CHD_MAX_ATTEMPTS 12
+#ifndef CHD_TRAIL_TP
+#define CHD_TRAIL_TP 4      // independent 16x16 tiles per wavefront pass of the trailing update
+#endif
 #define CHD_G 9.80665
 #define CHD_MU_FRICTION 0.5
 #define CHD_INF 1e19
@@ -818,7 +821,7 @@ CHD_DEV void trailing_update(LCtx& c, const LdsD* dv, const LdsD* PT, const int 
   };
   // TP independent tiles per pass: the old window values of all of them are requested before the MFMA
   // chains start (memory-level parallelism), and the chains interleave on the matrix pipe
-  constexpr int TP = 4;
+  constexpr int TP = CHD_TRAIL_TP;
   const int t_first = !split ? wave : wave == 0 ? 0 : 3 + (wave - 1);
   const int t_stride = !split ? nwv : wave == 0 ? 1 : nwv - 1;                 // between the TP tiles of one pass
   const int t_limit = (split && wave == 0) ? (ntri < 3 ? ntri : 3) : ntri;

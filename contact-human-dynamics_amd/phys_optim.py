@@ -18,7 +18,7 @@ from .phys_capi import (ChdBatchStats, ChdConfig, ChdSeqIn, ChdSeqOut, N_SNAPSHO
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, 'csrc')
-LIB_PATH = os.path.join(_CSRC, 'libchd_phys.so')
+LIB_PATH = os.environ.get('CHD_PHYS_LIB') or os.path.join(_CSRC, 'libchd_phys.so')      # (override: kernel experiments with variant builds)
 SOURCES = ['chd_phys.hip', 'chd_kernels.hpp', 'chd_model.hpp', 'chd_device.hpp', 'chd_io.hpp']
 SNAPSHOT_FILES = ('sol_out_no_dynamics.txt', 'sol_out_dynamics.txt', 'sol_out_durations.txt')
 

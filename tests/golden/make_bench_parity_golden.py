@@ -45,6 +45,8 @@ def make_case(seed, F, tilt):
 
 def _work(case):
     from common import oracle_run
+    from oracle.oracle import lib
+    lib().orc_set_stall_window(int(os.environ.get('CHD_FIXTURE_STALL_WINDOW', '0')))      # (study runs only: the committed fixture is made with the guard off)
     seed, F, tilt = case
     t0 = time.time()
     stats, snaps = oracle_run(make_case(seed, F, tilt), CAPS)
