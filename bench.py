@@ -269,6 +269,7 @@ def main():
                        'factorizations_rank0': nfact, 'stage4_fallbacks_rank0': st['n_fallback'], 'stall_guard_hits_rank0': st['n_stalled'],
                        'converged_rank0': '%d/%d' % (n_ok, len(res)),
                        'slowest_sequence_ms': st['max_seq_ms'], 'mean_sequence_ms': st['phase_ms'][5] / max(1, len(res)),
+                       'in_kernel_phase_ms_per_sequence': [round(v / max(1, len(res)), 3) for v in st['phase_ms']],
                        'in_kernel_time_share': {k: st['phase_ms'][i] / max(1e-9, st['phase_ms'][5]) for k, i in
                                                 (('evaluation_full', 0), ('evaluation_values', 1), ('factorisation', 2), ('substitution', 3), ('kkt_matvec', 4),
                                                  ('factor_copy', 6), ('factor_panel_load', 8), ('factor_row_solve', 9), ('factor_store', 10),
