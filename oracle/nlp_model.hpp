@@ -9,8 +9,10 @@
 //
 // PARITY UNPINNED: the reference has no golden vectors and its own binary
 // cannot be built here (TOWR fork, ifopt, IPOPT/MA57, Eigen, gflags absent), so
-// this restatement is validated by finite-difference Jacobian checks, physical
-// invariants and an independent SciPy solve, not against reference outputs.
+// this restatement is validated by finite-difference Jacobian checks
+// (tests/test_oracle.py), physical invariants, and for its solver by an
+// independent SciPy KKT check + SLSQP solve (tests/test_oracle_second_opinion.py),
+// not against reference outputs.
 //
 // Every function cites the reference file:line it follows.  Pieces that live
 // in the absent TOWR fork / ifopt restate the published upstream algorithm

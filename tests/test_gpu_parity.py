@@ -184,3 +184,40 @@ def test_bench_workload_matches_oracle():
             assert err < 1e-2, (key, err)
     print('bench workload parity: %d sequences, worst rel-L2 %.2e on the %d converging ones' % (len(cases), worst, len(cases) - n_failed))
     assert n_failed <= 2
+
+
+def test_bad_sequence_loses_only_itself(tmp_path):
+    """The reference runs one process per video, so a video with inconsistent inputs only loses itself
+    (run_phys_mocap.py:159-174).  Same here: a batch with a too-short sequence and one whose contact schedules do not sum to
+    the same total time (parameters.cpp:150) solves the good ones; the bad ones come back rejected (stage_status -4 in
+    memory, status -3 and no output files through the directory interface), and the good results are bit-identical to a
+    batch without them."""
+    import copy
+    import os
+    from chd_amd import io_formats as iof
+    from chd_amd.phys_optim import PhysOptim, default_config
+    good = [make_walk(seed=s, F=40, randomize=True) for s in (2, 3)]
+    short = make_walk(seed=4, F=6, randomize=True)
+    skew = copy.deepcopy(good[0]); skew.durations = [list(d) for d in skew.durations]; skew.durations[1][0] += 0.05
+    s = PhysOptim(device=0, config=default_config(max_iter=CAP))
+    ref, _ = s.solve(good)
+    res, st = s.solve([short, good[0], skew, good[1]])
+    assert st['n_rejected'] == 2
+    assert res[0].rejected and res[2].rejected and res[0].stage_status == [-4] * 6 and res[0].snapshots[0].base_lin.shape[0] == 0
+    for a, b in ((res[1], ref[0]), (res[3], ref[1])):
+        assert not a.rejected and a.stage_status == b.stage_status and a.stage_iters == b.stage_iters
+        for k in range(3):
+            assert np.array_equal(a.snapshots[k].base_lin, b.snapshots[k].base_lin) and np.array_equal(a.snapshots[k].ee_force, b.snapshots[k].ee_force)
+    # directory interface
+    dirs = []
+    for i, q in enumerate([good[0], skew, good[1]]):
+        din = str(tmp_path / ('in%d' % i)); dout = str(tmp_path / ('out%d' % i))
+        iof.write_inputs(q, din); os.makedirs(dout)
+        dirs.append((din, dout, q.F))
+    missing = str(tmp_path / 'nowhere')
+    stt = s.solve_dirs([d[0] for d in dirs] + [missing], [d[1] for d in dirs] + [str(tmp_path / 'out0')], [d[2] for d in dirs] + [40])
+    assert stt == [0, -3, 0, -1] and 'rejected' in s.last_error() or 'nowhere' in s.last_error()
+    assert len(os.listdir(dirs[0][1])) == 4 and len(os.listdir(dirs[1][1])) == 0 and len(os.listdir(dirs[2][1])) == 4
+    with pytest.raises(Exception):
+        s.solve([short])                       # nothing solvable: the call itself fails
+    s.close()
