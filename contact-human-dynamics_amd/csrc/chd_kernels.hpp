@@ -352,11 +352,20 @@ CHD_DEV void cross3(const double a[3], const double b[3], double o[3]) {
 CHD_DEV void matvec3(const double A[3][3], const double v[3], double o[3]) {
   for (int i = 0; i < 3; ++i) o[i] = A[i][0] * v[0] + A[i][1] * v[1] + A[i][2] * v[2];
 }
+// selections by a run-time row number i in {0, 1, 2}: compare-and-select keeps small vectors in registers (indexing a
+// local array with i puts it in scratch memory)
+CHD_DEV double pick3(const double a, const double b, const double cc, const int i) { return i == 0 ? a : (i == 1 ? b : cc); }
+// coefficients on u of (v x u)_i
+CHD_DEV void cross_row(const double v[3], const int i, double o[3]) {
+  o[0] = i == 0 ? 0.0 : (i == 1 ? v[2] : -v[1]);
+  o[1] = i == 0 ? -v[2] : (i == 1 ? 0.0 : v[0]);
+  o[2] = i == 0 ? v[1] : (i == 1 ? -v[0] : 0.0);
+}
 
 // Angular part of the centroidal dynamics (humanoid_rigid_body_dynamics.cpp:89-115):
 //   ang = I_w wd + w x (I_w w),  I_w = R I_b R^T,  w = M(e) e',  wd = Md(e,e') e' + M(e) e''.
 // Outputs ang[3] and its partials d0 (wrt e), d1 (wrt e'), d2 (wrt e''): dX[i][k] = d ang_i / d (.)_k.
-CHD_NOINLINE CHD_DEV void angular_term(const double e[3], const double ed[3], const double edd[3], const double Ib[3][3], int want_jac,
+CHD_DEV void angular_term(const double e[3], const double ed[3], const double edd[3], const double Ib[3][3], int want_jac,
                           double ang[3], double d0[3][3], double d1[3][3], double d2[3][3]) {
   double R[3][3], dR[3][3][3];
   rot_and_derivs(e, R, dR);
@@ -1826,16 +1835,19 @@ CHD_DEV void dyn_unit(LCtx& c, const int ti, const int unit, const bool D2, GD* 
     const int i = unit - 1;
     RowW ra{&c, c.pos_row[row0 + i], sc[row0 + i], true};
     RowW rl{&c, c.pos_row[row0 + 3 + i], sc[row0 + 3 + i], true};
-    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
-    // (v x u)_i = v_{i1} u_{i2} - v_{i2} u_{i1}  ->  coefficients on u: [i2] = v_{i1}, [i1] = -v_{i2}
-    double cf[3] = {0, 0, 0};
-    cf[i2] -= fsum[i1]; cf[i1] += fsum[i2];           // -sum_e (f_e x dc)_i
+    // (v x u)_i = v_{i1} u_{i2} - v_{i2} u_{i1}  ->  coefficients on u: [i2] = v_{i1}, [i1] = -v_{i2}   (cross_row)
+    double cr_[3];
+    cross_row(fsum, i, cr_);
+    const double cf[3] = {-cr_[0], -cr_[1], -cr_[2]};           // -sum_e (f_e x dc)_i
     row_nodes(ra, 0, pl, 0, cf, 7 & ~(1 << i));
-    double cm[3] = {0, 0, 0}; cm[i] = q->mass;
+    const double cm[3] = {i == 0 ? q->mass : 0.0, i == 1 ? q->mass : 0.0, i == 2 ? q->mass : 0.0};
     row_nodes(rl, 0, pl, 2, cm, 1 << i);
-    row_nodes(ra, 1, pa, 0, d0[i], 7);
-    row_nodes(ra, 1, pa, 1, d1[i], 7);
-    row_nodes(ra, 1, pa, 2, d2[i], 7);
+    const double d0i[3] = {pick3(d0[0][0], d0[1][0], d0[2][0], i), pick3(d0[0][1], d0[1][1], d0[2][1], i), pick3(d0[0][2], d0[1][2], d0[2][2], i)};
+    const double d1i[3] = {pick3(d1[0][0], d1[1][0], d1[2][0], i), pick3(d1[0][1], d1[1][1], d1[2][1], i), pick3(d1[0][2], d1[1][2], d1[2][2], i)};
+    const double d2i[3] = {pick3(d2[0][0], d2[1][0], d2[2][0], i), pick3(d2[0][1], d2[1][1], d2[2][1], i), pick3(d2[0][2], d2[1][2], d2[2][2], i)};
+    row_nodes(ra, 1, pa, 0, d0i, 7);
+    row_nodes(ra, 1, pa, 1, d1i, 7);
+    row_nodes(ra, 1, pa, 2, d2i, 7);
     return;
   }
   const int e = (unit - 4) / 3, i = (unit - 4) % 3;
@@ -1845,11 +1857,10 @@ CHD_DEV void dyn_unit(LCtx& c, const int ti, const int unit, const bool D2, GD* 
   {
     RowW ra{&c, c.pos_row[row0 + i], sc[row0 + i], true};
     RowW rl{&c, c.pos_row[row0 + 3 + i], sc[row0 + 3 + i], true};
-    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
-    double xr[3] = {0, 0, 0}, xf[3] = {0, 0, 0}, ml[3] = {0, 0, 0};
-    xr[i2] = rr[i1]; xr[i1] = -rr[i2];              // +(r x df)_i
-    xf[i2] = pfe.p[i1]; xf[i1] = -pfe.p[i2];        // +(f x dp)_i
-    ml[i] = -1.0;
+    double xr[3], xf[3];
+    cross_row(rr, i, xr);                           // +(r x df)_i
+    cross_row(pfe.p, i, xf);                        // +(f x dp)_i
+    const double ml[3] = {i == 0 ? -1.0 : 0.0, i == 1 ? -1.0 : 0.0, i == 2 ? -1.0 : 0.0};
     row_nodes(ra, 6 + e, pfe, 0, xr, 7 & ~(1 << i));
     row_nodes(rl, 6 + e, pfe, 0, ml, 1 << i);
     row_nodes(ra, 2 + e, pme, 0, xf, 7 & ~(1 << i));
