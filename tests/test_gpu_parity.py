@@ -221,3 +221,36 @@ def test_bad_sequence_loses_only_itself(tmp_path):
     with pytest.raises(Exception):
         s.solve([short])                       # nothing solvable: the call itself fails
     s.close()
+
+
+def test_long_sequence_matches_oracle():
+    """BASELINE configs[4]: one 600-frame sequence on a floor tilted by 10 degrees (KKT dimension 13 592, border 700), reference
+    caps, alone in a launch, against the oracle's committed result (an hour of CPU: make_bench_parity_golden.py --long)."""
+    import os
+    import sys
+    from chd_amd.phys_optim import PhysOptim, default_config
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import make_bench_parity_golden as mk
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'bench_parity_golden.npz'))
+    case = mk.LONG[0]
+    key = mk.case_key(*case)
+    if key + '_status' not in g.files:
+        pytest.skip('fixture made without --long')
+    s = PhysOptim(device=0, config=default_config(max_iter=REF_CAPS))
+    res, st = s.solve([mk.make_case(*case)])
+    s.close()
+    r = res[0]
+    gs = list(g[key + '_status']); gi = list(g[key + '_iters'])
+    assert list(r.stage_status[:len(gs)]) == gs and list(r.stage_iters[:len(gi)]) == gi
+    assert r.sizes['kkt_dim'] > 13000
+    worst = 0.0
+    for k in range(3):
+        sn = r.snapshots[k]
+        for name, val in (('base_lin', sn.base_lin), ('base_ang_deg', sn.base_ang_deg), ('ee_pos', sn.ee_pos), ('ee_force', sn.ee_force)):
+            ref = g['%s_snap%d_%s' % (key, k, name)]
+            assert ref.shape == np.asarray(val).shape
+            if np.linalg.norm(ref) > 0:
+                worst = max(worst, float(np.linalg.norm(np.asarray(val) - ref) / np.linalg.norm(ref)))
+        assert np.array_equal(np.asarray(sn.contact), g['%s_snap%d_contact' % (key, k)])
+    print('600-frame sequence: worst rel-L2 %.2e, kernel %.0f ms' % (worst, st['kernel_ms'][0]))
+    assert worst < 1e-3
