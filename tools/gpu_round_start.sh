@@ -1,25 +1,24 @@
 #!/bin/bash
-# First GPU call of a round (run through gpurun from the repo root; ~6-8 minutes of box time):
-#   1. the hot path's GPU tests and smoke()            -> gpurun_out/start/pytest_gpu.log, smoke.log
-#   2. the rows not yet run on a GPU (IK back-projection, in-memory pipeline, device-side contact pre-processing)
-#                                                      -> pytest_gpu_next.log, ik_bench.log (+ kernel trace)
-#   3. bench.py at its default depth, then with 16 launches in flight (only works while the kernel's scratch stays
-#      <= 4288 B/lane; the wrapper falls back by itself if the runtime refuses)
-# Every step runs under its own timeout so that a hang cannot eat the budget; nothing here reads /root/reference.
-# Round 2: the inertia retry (CHD_INERTIA_RETRY) and the 1e-8 margin in the correction step's boundary test
-# went in after round 1's last GPU run -- step 1 below is their first GPU validation (-DCHD_INERTIA_RETRY=0 + reverting the margin
-# gives the measured round-1 kernel); add seeds 31, 73, 77, 105, 107, 113 (tilts as in profiles/r01_parity_cpu_emulation.md) to gpu_long.py.
+# First GPU call of a round (run through gpurun from the repo root; ~2 minutes of box time):
+#   1. pytest -m gpu (16 tests: bench-workload parity against the committed oracle fixture, 600-frame parity, slot independence,
+#      rejection, file interface, CLI, IK, contact-net device ops, OpenPose-JSON -> BVH) and smoke()
+#   2. bench.py as the driver runs it (--steps 20 --warmup 5)              -> bench_driver.json
+#   3. rocprofv3 kernel trace + PMC passes (HBM-side bytes, fp64 MFMA, wave states) on short runs; --gen-workers 1 keeps
+#      bench.py from forking under the profiler
+# Every step runs under its own timeout; nothing here reads /root/reference.
 set -x
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/start
 mkdir -p $OUT
 cd $R
-timeout 900 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
-timeout 600 python tests/tools/gpu_parity_holes.py > $OUT/parity_holes.log 2>&1; tail -12 $OUT/parity_holes.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log
-timeout 300 python -m pytest tests -x -q -m gpu_next > $OUT/pytest_gpu_next.log 2>&1; tail -5 $OUT/pytest_gpu_next.log
-timeout 300 python tests/tools/ik_bench.py 128 90 > $OUT/ik_bench.log 2>&1; tail -3 $OUT/ik_bench.log
-timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -c 1500 $OUT/bench_default.json; tail -3 $OUT/bench_default.err
+timeout 400 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
+timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/bench_driver.err; tail -c 1500 $OUT/bench_driver.json; tail -3 $OUT/bench_driver.err
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/ik_trace -o ik -- python $R/tests/tools/ik_bench.py 128 90 > $OUT/ik_trace.log 2>&1
-for f in $(find $OUT/ik_trace -name "*kernel_stats*"); do head -4 $f; done
+P="python $R/bench.py --gen-workers 1 --no-cpu-baseline --no-side-metrics"
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $P --steps 4 > $OUT/trace_bench.json 2> $OUT/trace.err; head -4 $OUT/trace/trace_kernel_stats.csv
+timeout 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- $P --steps 1 --warmup 0 > $OUT/fetch_bench.json 2> $OUT/fetch.err
+timeout 150 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o write -- $P --steps 1 --warmup 0 > $OUT/write_bench.json 2> $OUT/write.err
+timeout 150 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAVE_CYCLES --output-format csv -d $OUT/pmc_mfma -o mfma -- $P --steps 2 --warmup 0 > $OUT/mfma_bench.json 2> $OUT/mfma.err
+timeout 150 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM --output-format csv -d $OUT/pmc_sq -o sq -- $P --steps 2 --warmup 0 > $OUT/sq_bench.json 2> $OUT/sq.err
+find $OUT -name "*counter_collection.csv" | head
