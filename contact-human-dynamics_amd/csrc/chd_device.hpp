@@ -57,6 +57,7 @@ struct StageDesc {
   int dyn_first, n_dyn;     // the dynamics samples are a contiguous run of tasks (a lane group works on each)
   int nnz_jac;
   int valid;
+  int heel_row0;            // first row of the heel-distance family (rows heel_row0 + pair * n_trom + sample), -1 if the stage has none
   double w_data[3], w_vel[3], w_acc[3], w_dur;
   // offsets into ci
   int o_pos_var, o_pos_row, o_task;     // task: 4 ints (type, a, b, row0)
@@ -71,6 +72,10 @@ enum { SC_WP = 0, SC_WV = 4, SC_P = 8, SC_V = 11, SC_DXDT = 14, SC_POLY = 17, SC
        SC_QEE = 20, SC_QEC = 23, SC_QCC = 26, SC_STRIDE = 30 };
 // second-order duration tables (stage 3): per end-effector one slot per row sample; 4 doubles = (cur phase, S_ee, S_ec, S_cc)
 enum { D2_STRIDE = 4, X2_STRIDE = 6 };
+// cache of the ee-motion splines at the range-of-motion sample times (exact curvature of the heel-distance rows): per (end-effector,
+// sample) the four position weights at SC_WP, the row's scaled multiplier at RC_MU and the polynomial at SC_POLY (same offsets as the
+// cost-sample cache, so the same weight look-up serves both)
+enum { RC_MU = 4, RC_STRIDE = 18 };
 
 struct SeqDesc {
   const GD* cd;       // constant doubles
@@ -98,7 +103,7 @@ struct SeqDesc {
   // wd offsets — state
   int o_node, o_poly_dur, o_pend, o_phase_dur, o_phend, o_ttot;
   // wd offsets — solver vectors (n-, m- and N-sized), see chd_kernels.hpp
-  int o_vec_n, o_vec_m, o_vec_N, o_scache, o_d2tab, o_x2tab, d2_slots;
+  int o_vec_n, o_vec_m, o_vec_N, o_scache, o_d2tab, o_x2tab, d2_slots, o_rcache;
   int max_n, max_m, max_N;
   // wd offsets — KKT storage
   int o_K0b, o_K0x, o_Kfb, o_Kfx;      // full band, border rows (unfactored); lower band, border rows (factor)

@@ -92,6 +92,9 @@ namespace chd {
 #define CHD_CONSTR_VIOL_TOL 1e-4
 #define CHD_MAX_BACKTRACK 3
 #define CHD_MAX_ATTEMPTS 12
+#ifndef CHD_ABORT_BAD_FACTOR
+#define CHD_ABORT_BAD_FACTOR 1
+#endif
 #ifndef CHD_TRAIL_TP
 #define CHD_TRAIL_TP 4      // independent 16x16 tiles per wavefront pass of the trailing update
 #endif
@@ -485,7 +488,8 @@ CHD_DEV KSlot kslot(LCtx& c, int p, int qq) {
   KSlot sl; sl.a = nullptr; sl.b = nullptr;
   if (p < c.Nb && qq < c.Nb) {
     const int dlt = qq - p;
-    if (dlt > c.w || dlt < -c.w) { c.err = 1; return sl; }
+    if (dlt > c.w || dlt < -c.w) {
+      c.err = 1; return sl; }
     const int hi_ = dlt < 0 ? p : qq, lo_ = dlt < 0 ? qq : p;
     if (lo_ < c.env[2 * hi_]) env_cover(c, hi_, lo_);
     sl.a = c.K0b + (long long)p * c.W2 + (dlt + c.w);
@@ -1018,6 +1022,12 @@ CHD_DEV void kfactor_band(LCtx& c, const GI* sign, LdsD* dv, LdsD* DL, LdsD* dv2
   diag_block_g<NB>(c, sign, dv, DL, 0, Nb < NB ? Nb : NB);
   CHD_SYNC();
   for (int c0 = 0; c0 < Nb; c0 += NB) {
+#if CHD_INERTIA_RETRY && CHD_ABORT_BAD_FACTOR
+    // A diagonal block met a pivot of unexpected sign: the factorisation is going to be discarded (inertia retry), so it stops
+    // here -- before the block's columns (multipliers of order 1e10 after the pivot was replaced) are stored and can overflow into
+    // NaNs that would stay in the factor storage outside the envelope.  (The count lives in the LDS context: uniform after the barrier.)
+    if (c.n_bad_pivots > 0) return;
+#endif
     Panel P; panel_geometry<NB>(c, P, c0, ldp);
     P.dv = dv; P.DL = DL; P.PT = PT;
     P.act = actA; P.nact_p = actA + lsz - 2;
@@ -1150,7 +1160,7 @@ CHD_NOINLINE CHD_DEV void kfactor(LCtx& c, const GD* diag, const GI* sign) {
   else kfactor_band<8>(c, sign, dv, DL, dv2, DL2, PT, ldp);
   // ---- dense L D L^T of the border Schur complement (rows/cols Nb..N-1)
   const long long td_ = CHD_CLOCK();
-  if (bc > 0) {
+  if (bc > 0 && !(CHD_INERTIA_RETRY && CHD_ABORT_BAD_FACTOR && c.n_bad_pivots > 0)) {
     LdsD* SL = c.lds + LDS_RED;
     const bool in_lds = (long long)bc * bc <= c.lds_cap - LDS_RED;
     if (in_lds) {
@@ -2110,6 +2120,29 @@ CHD_DEV void supp_add_sample(Supp& sp, const double* sc_, int which, double sign
     for (int dq = 0; dq < 2; ++dq) { sp.node[sp.n] = poly + side; sp.dq[sp.n] = dq; sp.g[sp.n] = sign * wv[side * 2 + dq]; ++sp.n; }
 }
 
+// Exact curvature of the heel-distance rows (ee_dist_constraint.cpp:29-94): c = 1/2 |p_toe(t) - p_heel(t)|^2 is quadratic in the
+// node values, and its multipliers reach 10^2 .. 10^3, so lam * grad^2 c is a large part of the Lagrangian Hessian that the
+// Gauss-Newton model lacks (without it the optimality error hovers just above tol for 100+ iterations on the slow
+// sequences).  grad^2 c = sum_dim g g^T with g = Hermite weights of the toe polynomial (+) and of the heel polynomial (-) at
+// the sample.  This cache holds, per (end-effector, range-of-motion sample): the four position weights, the polynomial and
+// the row's multiplier times its scaling; the entries are then gathered owner-computes like the cost terms.
+CHD_DEV const GD* rcache(QP q, int ee, int k) { return q->wd + q->o_rcache + ((long long)ee * q->n_trom + k) * RC_STRIDE; }
+CHD_DEV void fill_rom_cache(LCtx& c, const GD* lam) {
+  QP q = c.q; SDP S = c.S;
+  const GD* sc = VM(c, VM_SC);
+  PAR_FOR(idx, 4 * q->n_trom) {
+    const int ee = idx / q->n_trom, k = idx % q->n_trom;
+    PE e;
+    spline_eval(q, 2 + ee, q->cd[q->o_trom + k], e);
+    GD* r = q->wd + q->o_rcache + (long long)idx * RC_STRIDE;
+    for (int j = 0; j < 4; ++j) r[SC_WP + j] = e.w[0][j];
+    const int row = S->heel_row0 + (ee % 2) * q->n_trom + k;          // pairs (0, 2) and (1, 3): nlp_formulation.cpp:249-257
+    r[RC_MU] = lam[row] * sc[row];
+    r[SC_POLY] = e.poly;
+  }
+  CHD_SYNC();
+}
+
 CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(LCtx& c, GD* g, const GD* lam) {
   QP q = c.q; SDP S = c.S;
   const int F = q->F;
@@ -2128,6 +2161,8 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(LCtx& c, GD* g, const GD* lam) {
     if (i > 0 && pi - pp > gap) gap = pi - pp;
   }
   gap = (int)block_max(c, (double)gap);       // (ends with a barrier)
+  const bool HC = lam != nullptr && S->heel_row0 >= 0;      // exact curvature of the heel-distance rows
+  if (HC) fill_rom_cache(c, lam);
   long long tg_ = CHD_CLOCK();
   // ---- node variables.  Every cost residual is linear in the node values for fixed durations,
   //   r = sum_v G(v) x_v + const, with G the Hermite weights of the sample(s) the residual touches, so the
@@ -2180,14 +2215,22 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(LCtx& c, GD* g, const GD* lam) {
           if (wvel >= 0) acc += wvel * (wgt(b, 0, n1, h1, dq1) - wgt(a, 0, n1, h1, dq1)) * (wgt(b, 0, n2, h2, dq2) - wgt(a, 0, n2, h2, dq2));
           if (wacc >= 0) acc += wacc * (wgt(b, 1, n1, h1, dq1) - wgt(a, 1, n1, h1, dq1)) * (wgt(b, 1, n2, h2, dq2) - wgt(a, 1, n2, h2, dq2));
         }
-      if (acc == 0.0) continue;
+      double acch = 0.0;                   // + sum over the range-of-motion samples in these polynomials of lam sc w w (heel-distance rows)
+      if (HC && s >= 2)
+        for (int k = 0; k < q->n_trom; ++k) {
+          const GD* a = rcache(q, s - 2, k);
+          const int p = (int)a[SC_POLY];
+          if (p < pa || p > pb) continue;
+          acch += a[RC_MU] * wgt(a, 0, n1, h1, dq1) * wgt(a, 0, n2, h2, dq2);
+        }
+      if (acc == 0.0 && acch == 0.0) continue;
       {
         int pp[3], qv[3]; double vv[3];
 #pragma unroll
         for (int dim = 0; dim < 3; ++dim) {
           const int v1 = vo[n1 * 6 + dq1 * 3 + dim], v2 = vo[n2 * 6 + dq2 * 3 + dim];
           const bool on = v1 >= 0 && v2 >= 0;
-          pp[dim] = on ? c.pos_var[sp.var_off + v1] : -1; qv[dim] = on ? c.pos_var[sp.var_off + v2] : 0; vv[dim] = c.sf * acc;
+          pp[dim] = on ? c.pos_var[sp.var_off + v1] : -1; qv[dim] = on ? c.pos_var[sp.var_off + v2] : 0; vv[dim] = c.sf * acc + acch;
         }
         kadd_batch<3>(c, pp, qv, vv);      // the three dimensions are three different entries
       }
@@ -2234,6 +2277,43 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(LCtx& c, GD* g, const GD* lam) {
     CHD_SYNC();
     node_terms(lds_sample);
   } else node_terms(hbm_sample);
+  if (HC) {
+    // toe x heel blocks of the heel-distance curvature: one thread per (pair, toe coefficient, heel coefficient); the entry is
+    // - sum over the samples of lam sc w_toe w_heel, the same for the three dimensions
+    const int nA0 = q->sp[2].n_nodes, nB0 = q->sp[4].n_nodes, nA1 = q->sp[3].n_nodes, nB1 = q->sp[5].n_nodes;
+    const int cnt0 = 4 * nA0 * nB0, cnt1 = 4 * nA1 * nB1;
+    PAR_FOR(idx0, cnt0 + cnt1) {
+      const int pr = idx0 < cnt0 ? 0 : 1;
+      const int idx = pr ? idx0 - cnt0 : idx0;
+      const int nB_ = pr ? nB1 : nB0;
+      const int dq1 = idx & 1, dq2 = (idx >> 1) & 1, n1 = (idx >> 2) / nB_, n2 = (idx >> 2) % nB_;
+      const auto& sa = q->sp[2 + pr]; const auto& sb = q->sp[4 + pr];
+      const GI* pia = q->ci + q->o_pinfo + sa.poly_off * 4; const GI* pib = q->ci + q->o_pinfo + sb.poly_off * 4;
+      if (second_of_pair(sa, pia, n1) || second_of_pair(sb, pib, n2)) continue;
+      const GI* voa = q->ci + q->o_varof + sa.node_off; const GI* vob = q->ci + q->o_varof + sb.node_off;
+      bool any = false;
+      for (int dim = 0; dim < 3; ++dim) any = any || (voa[n1 * 6 + dq1 * 3 + dim] >= 0 && vob[n2 * 6 + dq2 * 3 + dim] >= 0);
+      if (!any) continue;
+      const int h1 = group_end(sa, pia, n1), h2 = group_end(sb, pib, n2);
+      double acc = 0.0;
+      for (int k = 0; k < q->n_trom; ++k) {
+        const GD* a = rcache(q, pr, k);
+        const int p = (int)a[SC_POLY];
+        if (p + 1 < n1 || p > h1) continue;                 // the toe polynomial of this sample does not touch the coefficient
+        const GD* b = rcache(q, 2 + pr, k);
+        acc -= a[RC_MU] * wgt(a, 0, n1, h1, dq1) * wgt(b, 0, n2, h2, dq2);
+      }
+      if (acc == 0.0) continue;
+      int pp[3], qv[3]; double vv[3];
+#pragma unroll
+      for (int dim = 0; dim < 3; ++dim) {
+        const int v1 = voa[n1 * 6 + dq1 * 3 + dim], v2 = vob[n2 * 6 + dq2 * 3 + dim];
+        const bool on = v1 >= 0 && v2 >= 0;
+        pp[dim] = on ? c.pos_var[sa.var_off + v1] : -1; qv[dim] = on ? c.pos_var[sb.var_off + v2] : 0; vv[dim] = acc;
+      }
+      kadd_batch<3>(c, pp, qv, vv);
+    }
+  }
   CHD_SYNC();
   TACC(c, 13, CHD_CLOCK() - tg_); tg_ = CHD_CLOCK();
   // ---- duration variables (stage 3 only)

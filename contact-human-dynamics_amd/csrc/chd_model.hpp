@@ -415,6 +415,7 @@ class SeqModel {
           at_time(0, trom_[k], all, r); at_time(1, trom_[k], all, r); at_time(2 + e, trom_[k], all, r);
           dur_at(e, trom_[k], r);
         }
+    S.heel_row0 = (S.families & FAM_HEELDIST) ? (int)cl.size() : -1;
     if (S.families & FAM_HEELDIST)     // EEDistConstraint (ee_dist_constraint.cpp:29-94), pairs (0,2), (1,3)
       for (int pr = 0; pr < 2; ++pr)
         for (int k = 0; k < d.n_trom; ++k) {
@@ -569,6 +570,12 @@ class SeqModel {
         }
       }
     }
+    if (S.heel_row0 >= 0)      // exact curvature of the heel-distance rows: the row's variables couple with each other -- with the
+      for (int i = S.heel_row0; i < S.heel_row0 + 2 * d.n_trom; ++i) {      // slack polynomials of stage 3 they can lie on both sides of the row
+        int lo = 1 << 30, hi = -1;
+        for (int v : sup_wide[i]) if (v < d.n_nodesvars && pos_var[v] < Nb) { lo = std::min(lo, pos_var[v]); hi = std::max(hi, pos_var[v]); }
+        if (hi >= 0) w = std::max(w, hi - lo);
+      }
     // ---- envelope of the banded part: efirst[p] / elast[p] = smallest / largest band position coupled to p.
     // L D L^T without pivoting keeps its fill inside this envelope, so the substitution, the mat-vec and the panel
     // row solves only visit [efirst[p], p] (and by symmetry up to elast[p]).
@@ -605,7 +612,14 @@ class SeqModel {
           }
         }
       }
+      if (S.heel_row0 >= 0)              // exact curvature of the heel-distance rows: a row's toe and heel variables couple with each other
+        for (int i = S.heel_row0; i < S.heel_row0 + 2 * d.n_trom; ++i) {
+          pos.clear();
+          for (int v : sup_wide[i]) if (v < d.n_nodesvars) pos.push_back(pos_var[v]);
+          couple(pos);
+        }
     }
+    for (int p = 0; p < Nb; ++p) w = std::max(w, std::max(p - efirst[p], elast[p] - p));      // (safety net: no envelope wider than the band)
     // ---- first band position coupled to each border position (Nb = none): left of it the border row of the KKT matrix
     // and of its factor is structurally zero, so the row joins the factorisation only from that panel on
     std::vector<int> bfirst(bc, Nb);
@@ -635,6 +649,12 @@ class SeqModel {
           }
         }
       }
+      if (S.heel_row0 >= 0)              // (same couplings seen from the border: a stance position of one contact point and the other point's variables)
+        for (int i = S.heel_row0; i < S.heel_row0 + 2 * d.n_trom; ++i) {
+          int lob = Nb;
+          for (int v : sup_wide[i]) if (v < d.n_nodesvars && pos_var[v] < Nb) lob = std::min(lob, pos_var[v]);
+          for (int v : sup_wide[i]) if (v < d.n_nodesvars) reach(pos_var[v], lob < Nb ? lob : -1);
+        }
       if (S.opt_dur)      // a duration moves every later sample of its end-effector: couples with all node values from its phase on
         for (int e = 0; e < N_EE; ++e) {
           const HostSpline& h = hs[2 + e];
@@ -730,6 +750,7 @@ class SeqModel {
     d.d2_slots = 2 * d.n_tdyn + 2 * d.n_trom + d.F + 2;      // DYN, HEIGHT, ROM, HEELDIST, cost samples
     d.o_d2tab = take(4LL * d.d2_slots * D2_STRIDE);
     d.o_x2tab = take(2LL * d.n_trom * X2_STRIDE);
+    d.o_rcache = take(4LL * d.n_trom * RC_STRIDE);
     const long long Nb_cap = N_cap, W2 = 2LL * w_cap + 1, LD = N_cap;
     d.sz_K0b = Nb_cap * W2; d.sz_K0x = (long long)bc_cap * LD;
     d.sz_Kfb = Nb_cap * (w_cap + 1); d.sz_Kfx = (long long)bc_cap * LD;

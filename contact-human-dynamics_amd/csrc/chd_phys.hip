@@ -440,7 +440,7 @@ int chd_batch_fetch(chd_handle* h, chd_batch* b, chd_seq_out* out) {
   for (int i = 0; i < b->B; ++i) {
     chd_seq_out& o = out[i];
     if (!b->ok[i]) {                 // rejected at set-up: nothing was solved
-      for (int s = 0; s < N_STAGES; ++s) { o.stage_status[s] = -4; o.stage_iters[s] = 0; o.stage_stalled[s] = 0; o.stage_kkt_error[s] = o.stage_constr_viol[s] = o.stage_objective[s] = 0.0; }
+      for (int s = 0; s < N_STAGES; ++s) { o.stage_status[s] = -4; o.stage_iters[s] = 0; o.stage_stalled[s] = 0; o.stage_factorizations[s] = 0; o.stage_kkt_error[s] = o.stage_constr_viol[s] = o.stage_objective[s] = 0.0; }
       o.dynamics_succeed = 0; o.durations_succeed = 0;
       o.n_vars = o.n_rows = o.kkt_dim = o.kkt_halfband = o.kkt_border = 0; o.nnz_jac = 0;
       for (int s = 0; s < CHD_N_SNAPSHOTS; ++s) { o.snap[s].n_samples = 0; o.snap[s].num_frames_header = 0; }
@@ -457,6 +457,7 @@ int chd_batch_fetch(chd_handle* h, chd_batch* b, chd_seq_out* out) {
       o.stage_status[s] = ran ? (int)r[RS_STATUS] : 9;
       o.stage_iters[s] = ran ? (int)r[RS_ITERS] : 0;
       o.stage_stalled[s] = ran ? (int)r[RS_AUX] : 0;
+      o.stage_factorizations[s] = ran ? (int)r[RS_NFACT] : 0;
       o.stage_kkt_error[s] = ran ? r[RS_KKT] : 0.0;
       o.stage_constr_viol[s] = ran ? r[RS_VIOL] : 0.0;
       o.stage_objective[s] = ran ? r[RS_OBJ] : 0.0;

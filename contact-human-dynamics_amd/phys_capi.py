@@ -31,7 +31,8 @@ class ChdSnapshot(C.Structure):
 
 class ChdSeqOut(C.Structure):
     _fields_ = [('snap', ChdSnapshot * N_SNAPSHOTS), ('stage_status', C.c_int * N_STAGES),
-                ('stage_iters', C.c_int * N_STAGES), ('stage_stalled', C.c_int * N_STAGES), ('stage_kkt_error', C.c_double * N_STAGES),
+                ('stage_iters', C.c_int * N_STAGES), ('stage_stalled', C.c_int * N_STAGES), ('stage_factorizations', C.c_int * N_STAGES),
+                ('stage_kkt_error', C.c_double * N_STAGES),
                 ('stage_constr_viol', C.c_double * N_STAGES), ('stage_objective', C.c_double * N_STAGES),
                 ('dynamics_succeed', C.c_int), ('durations_succeed', C.c_int),
                 ('n_vars', C.c_int), ('n_rows', C.c_int), ('kkt_dim', C.c_int), ('kkt_halfband', C.c_int),

@@ -106,6 +106,7 @@ class SeqResult:
         self.stage_status = [out.stage_status[i] for i in range(N_STAGES)]
         self.stage_iters = [out.stage_iters[i] for i in range(N_STAGES)]
         self.stage_stalled = [out.stage_stalled[i] for i in range(N_STAGES)]
+        self.stage_factorizations = [out.stage_factorizations[i] for i in range(N_STAGES)]
         self.rejected = self.stage_status[0] == -4       # refused at set-up (inconsistent inputs): nothing was solved
         self.stage_kkt_error = [out.stage_kkt_error[i] for i in range(N_STAGES)]
         self.stage_constr_viol = [out.stage_constr_viol[i] for i in range(N_STAGES)]

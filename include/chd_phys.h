@@ -93,6 +93,7 @@ typedef struct chd_seq_out {
                                        all stages -4: the sequence was rejected at set-up (see build_error) and not solved */
   int stage_iters[CHD_N_STAGES];
   int stage_stalled[CHD_N_STAGES];  /* 1 = the stage was ended by the stall guard (chd_config.stall_window) */
+  int stage_factorizations[CHD_N_STAGES];   /* KKT factorisations of the stage (>= iterations: inertia retries, rejected steps) */
   double stage_kkt_error[CHD_N_STAGES];
   double stage_constr_viol[CHD_N_STAGES];
   double stage_objective[CHD_N_STAGES];

@@ -539,35 +539,6 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
     for (int i = 0; i < m; ++i) lraw[i] = lam[i] * sc[i] / sf;
     if (opt.lbfgs) { lb_Jold = J; lb_gold = g; }          // (scaled values of the point just left; lb_xold was taken before the step)
     P.eval(x.data(), &fraw, graw.data(), craw.data(), J.data(), opt.lbfgs ? nullptr : H.data(), opt.lbfgs ? nullptr : lraw.data());
-    if (std::getenv("ORC_FD_LAGHESS") && !opt.lbfgs && P.stage >= 1 && P.stage <= (std::getenv("ORC_FD_MAXSTAGE") ? std::atoi(std::getenv("ORC_FD_MAXSTAGE")) : 3)) {
-      // EXPERIMENT (not committed): constraint curvature sum_i lam_i grad^2 c_i by finite differences of J^T lam
-      std::vector<double> lr(lraw);
-      if (const char* fm = std::getenv("ORC_FD_FAMS")) { const int mask = std::atoi(fm); for (int i = 0; i < m; ++i) if (!(P.row_family[i] & mask)) lr[i] = 0.0; }
-      const bool skip_ang = std::getenv("ORC_FD_SKIP_ANG") != nullptr;
-      const int a0 = P.sp[1].var_off, a1 = P.sp[1].var_off + P.sp[1].n_var;
-      std::vector<double> Jp((size_t)m * n), cp(m), xp(x), base(n, 0.0), col(n);
-      for (int i = 0; i < m; ++i) { if (lr[i] == 0.0) continue; const double* Jr = &J[(size_t)i * n]; for (int j = 0; j < n; ++j) base[j] += Jr[j] * lr[i]; }
-      std::vector<double> HL((size_t)n * n, 0.0);
-      const int nn = P.n_nodesvars;
-      for (int j = 0; j < nn; ++j) {
-        if (skip_ang && j >= a0 && j < a1) continue;
-        { bool used = false; for (int i = 0; i < m && !used; ++i) used = lr[i] != 0.0 && J[(size_t)i * n + j] != 0.0; if (!used) continue; }
-        const double h = 1e-6 * std::max(1.0, std::fabs(x[j]));
-        xp[j] = x[j] + h;
-        P.eval(xp.data(), nullptr, nullptr, cp.data(), Jp.data(), nullptr);
-        xp[j] = x[j];
-        std::fill(col.begin(), col.end(), 0.0);
-        for (int i = 0; i < m; ++i) { if (lr[i] == 0.0) continue; const double* Jr = &Jp[(size_t)i * n]; for (int k = 0; k < n; ++k) col[k] += Jr[k] * lr[i]; }
-        for (int k = 0; k < n; ++k) HL[(size_t)k * n + j] = (col[k] - base[k]) / h;
-      }
-      P.eval(x.data(), &fraw, graw.data(), craw.data(), J.data(), nullptr);      // restore the model's state
-      for (int a = 0; a < nn; ++a) for (int b2 = 0; b2 <= a; ++b2) {
-        if (skip_ang && ((a >= a0 && a < a1) || (b2 >= a0 && b2 < a1))) continue;
-        const double v = 0.5 * (HL[(size_t)a * n + b2] + HL[(size_t)b2 * n + a]);
-        if (std::fabs(v) < 1e-7) continue;
-        H[(size_t)a * n + b2] += v; if (a != b2) H[(size_t)b2 * n + a] += v;
-      }
-    }
     apply_scaling(true);
     f = sf * fraw;
     if (opt.lbfgs) {

@@ -876,6 +876,30 @@ class Problem {
             add_nodes(row, sp[2 + e2], pe2, kPos, md);
             add_durs(row, sp[2 + e1], t, pe, d);
             add_durs(row, sp[2 + e2], t, pe2, md);
+            if (H && lam) {
+              // exact node-node block of lam * grad^2 c for this row: c = 1/2 |p_toe - p_heel|^2 is quadratic in the node values
+              // (for fixed durations), grad^2 c = sum_dim g_dim g_dim^T with g_dim = d(p_toe - p_heel)[dim] / d(node variables).
+              // The Gauss-Newton model lacks it, and the multipliers of these equality rows reach 10^2..10^3: without the term
+              // the damping has to stand in for it and the optimality error hovers just above tol for 100+ iterations.
+              for (int dim = 0; dim < 3; ++dim) {
+                int gv[8]; double gw[8]; int ng = 0;
+                auto push = [&](const Spline& s, const PointEval& e, double sign) {
+                  for (int side = 0; side < 2; ++side)
+                    for (int deriv = 0; deriv < 2; ++deriv) {
+                      const int v = s.vi(e.poly + side, deriv, dim);
+                      if (v < 0) continue;
+                      const int gidx = s.var_off + v;
+                      const double w = sign * e.w[kPos][side * 2 + deriv];
+                      int at = -1;
+                      for (int q = 0; q < ng; ++q) if (gv[q] == gidx) at = q;      // a stance position is one variable for two nodes
+                      if (at >= 0) gw[at] += w; else { gv[ng] = gidx; gw[ng] = w; ++ng; }
+                    }
+                };
+                push(sp[2 + e1], pe, 1.0); push(sp[2 + e2], pe2, -1.0);
+                for (int a = 0; a < ng; ++a)
+                  for (int b2 = 0; b2 < ng; ++b2) H[(size_t)gv[a] * n + gv[b2]] += lam[row] * gw[a] * gw[b2];
+              }
+            }
             if (D2) {
               auto dot = [](const double* a, const double* b2) { return a[0] * b2[0] + a[1] * b2[1] + a[2] * b2[2]; };
               for (int k2 = 0; k2 < nvar_of(e1); ++k2)

@@ -101,3 +101,29 @@ def test_output_sampling_contract(oracle_lib):
     toe_l = np.asarray(seq.contacts[:, 1])          # foot_contacts.npy column 1 = l_toe; NLP ee 0 = L-toe
     # a frame exactly on a phase boundary belongs to the earlier phase (Spline::GetSegmentID): at most one flip per boundary
     assert np.abs(snaps[0]['contact'][0][:-1] - toe_l[:-1]).sum() <= len(seq.durations[0])
+
+
+def test_heel_distance_curvature_vs_finite_differences(oracle_lib):
+    """The exact node-node block lam * grad^2 c of the heel-distance rows (ee_dist_constraint.cpp:29-94; what the solver adds to its
+    Gauss-Newton Hessian): H(lam) - H(0) against central differences of J^T lam, multipliers on the heel rows only."""
+    from oracle.oracle import OracleProblem
+    seq = make_walk(seed=3, F=40, randomize=True, tilt_deg=4.0)
+    o = OracleProblem(seq)
+    o.set_stage(3)
+    rng = np.random.default_rng(2)
+    x = o.get_x() + 1e-2 * rng.normal(size=o.n)
+    fam = o.row_family()
+    lam = np.where(fam == 8, rng.normal(size=o.m) * 30.0, 0.0)
+    assert (fam == 8).sum() > 0
+    _, _, _, _, H1 = o.eval(x, jac=True, hess=True, lam=lam)
+    _, _, _, _, H0 = o.eval(x, jac=True, hess=True)
+    D = H1 - H0
+    assert np.abs(D - D.T).max() < 1e-12 and np.abs(D).max() > 1.0
+    cols = np.flatnonzero(np.abs(D).sum(axis=0) > 0)
+    cols = rng.choice(cols, size=min(40, cols.size), replace=False)
+    h = 1e-6
+    for j in cols:
+        xp = x.copy(); xm = x.copy(); xp[j] += h; xm[j] -= h
+        Jp = o.eval(xp)[3]; Jm = o.eval(xm)[3]
+        fd = (Jp - Jm).T @ lam / (2 * h)
+        assert np.abs(fd - D[:, j]).max() <= 1e-5 * max(1.0, np.abs(D[:, j]).max()), j
