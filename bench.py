@@ -87,13 +87,16 @@ def parity_block(results, seqs_first_seed):
     if not os.path.exists(path) or seqs_first_seed != 0:
         return None
     g = np.load(path)
-    worst = 0.0; worst_failed = 0.0; n = 0; n_status = 0; n_iters = 0; n_contact = 0; failed = []; above = []
+    worst = 0.0; worst_failed = 0.0; n = 0; n_status = 0; n_iters = 0; n_contact = 0; failed = []; above = []; guarded = []
     for seed in range(min(BATCH, len(results))):
         key = 's%d_F%d_t000' % (seed, FRAMES)
         if key + '_status' not in g.files:
             continue
         r = results[seed]
         gs = list(g[key + '_status']); gi = list(g[key + '_iters'])
+        if any(getattr(r, 'stage_stalled', [])):      # ended by the stall guard of the measured configuration: the fixture is made without the guard
+            guarded.append(seed)
+            continue
         n += 1
         st_eq = list(r.stage_status[:len(gs)]) == gs
         n_status += st_eq; n_iters += st_eq and list(r.stage_iters[:len(gi)]) == gi
@@ -117,7 +120,7 @@ def parity_block(results, seqs_first_seed):
             above.append(seed)
     return {'against': 'CPU oracle (tests/golden/bench_parity_golden.npz), not IPOPT: the reference binary cannot be built here',
             'sequences_compared': n, 'worst_rel_l2': worst, 'stage_status_equal': n_status, 'stage_iterations_equal': n_iters,
-            'contact_flags_equal': n_contact, 'sequences_above_1e-3': above,
+            'contact_flags_equal': n_contact, 'sequences_above_1e-3': above, 'not_compared_ended_by_stall_guard': guarded,
             'oracle_stage_failures': failed, 'worst_rel_l2_on_those': worst_failed}
 
 

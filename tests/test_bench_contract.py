@@ -61,7 +61,7 @@ def test_parity_block_on_fixture_values():
         key = 's%d_F90_t000' % seed
         r = Res(); r.snapshots = []
         st = list(g[key + '_status']); it = list(g[key + '_iters'])
-        r.stage_status = st + [9] * (6 - len(st)); r.stage_iters = it + [0] * (6 - len(it))
+        r.stage_status = st + [9] * (6 - len(st)); r.stage_iters = it + [0] * (6 - len(it)); r.stage_stalled = [0] * 6
         for k in range(3):
             sn = Snap()
             for name in ('base_lin', 'base_ang_deg', 'ee_pos', 'ee_force', 'contact'):
@@ -72,5 +72,6 @@ def test_parity_block_on_fixture_values():
     assert out['sequences_compared'] == 128 and out['worst_rel_l2'] == 0.0 and out['sequences_above_1e-3'] == []
     assert out['stage_status_equal'] == 128 and out['stage_iterations_equal'] == 128 and out['contact_flags_equal'] == 128
     res[3].snapshots[2].ee_force = res[3].snapshots[2].ee_force * (1 + 2e-3)
+    res[5].stage_stalled = [0, 0, 0, 0, 1, 0]
     out = b.parity_block(res, 0)
-    assert out['sequences_above_1e-3'] == [3]
+    assert out['sequences_above_1e-3'] == [3] and out['not_compared_ended_by_stall_guard'] == [5] and out['sequences_compared'] == 127
