@@ -157,7 +157,7 @@ extern "C" void emu_nact_stats(void* h, int stage, double* out) {
   debug_eval(&e->M.d, e->ctx, stage, 0, e->lds.data(), (int)e->lds.size(), nullptr, nullptr, fo);
   Ctx c; c.lds = e->lds.data(); c.lds_cap = (int)e->lds.size();
   bind_stage(c, &e->M.d, stage);
-  double sa = 0, sb = 0, sx = 0, st = 0; int np = 0;
+  double sa = 0, sb = 0, sx = 0, st = 0; int np = 0, mx = 0;
   for (int c0 = 0; c0 < c.Nb; c0 += 32) {
     const int jb = std::min(32, c.Nb - c0), last = c0 + jb - 1;
     const int nbr = std::min(c.Nb - c0, jb + c.w), nbelow = nbr - jb;
@@ -165,7 +165,7 @@ extern "C" void emu_nact_stats(void* h, int stage, double* out) {
     for (int u = 0; u < nbelow; ++u) if (c.env[2 * (c0 + jb + u)] <= last) ++nb_;
     for (int r = 0; r < c.bc; ++r) if (c.env[2 * (c.Nb + r)] <= last) ++nx_;
     const int nact = nb_ + nx_, nt = (nact + 15) / 16;
-    sa += nact; sb += nb_; sx += nx_; st += nt * (nt + 1) / 2; ++np;
+    sa += nact; sb += nb_; sx += nx_; st += nt * (nt + 1) / 2; ++np; mx = std::max(mx, nact + jb);
   }
-  out[0] = sa / np; out[1] = sb / np; out[2] = sx / np; out[3] = st / np; out[4] = np;
+  out[0] = sa / np; out[1] = sb / np; out[2] = sx / np; out[3] = st / np; out[4] = np; out[5] = mx;      // mx: largest front (panel rows + active rows)
 }
