@@ -67,7 +67,8 @@ int chd_ik_solve_batch(const chd_ik_config* cfg, int device, int B, const chd_ik
   IK_TRY(hipMemcpy(d_ip, bt.ipool.data(), sizeof(int) * bt.ipool.size(), hipMemcpyHostToDevice), "copy ints");
   IK_TRY(hipMemcpy(d_dp, bt.dpool.data(), sizeof(double) * bt.dpool.size(), hipMemcpyHostToDevice), "copy targets");
   IK_TRY(hipMemcpy(d_x0, bt.state.data(), sizeof(double) * nst, hipMemcpyHostToDevice), "copy state");
-  const size_t lds = sizeof(double) * (size_t)IkLds::doubles(bt.max_J, bt.max_T);      // 26 KB for J = 33, T = 13; 59 KB at the size limits
+  const size_t lds = sizeof(double) * (size_t)IkLds::doubles(bt.max_J, bt.max_T);      // 26 KB for J = 33, T = 13; 60 KB for the kinematic optimisation (J = 28, T = 25); 78 KB at the size limits
+  if (lds > 48 * 1024) IK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chd_ik_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   IK_TRY(hipEventCreate(&ev0), "hipEventCreate");
   if ((e = hipEventCreate(&ev1)) != hipSuccess) { (void)hipEventDestroy(ev0); release(); return fail("hipEventCreate", e); }

@@ -46,7 +46,7 @@
 
 namespace chd_ik {
 
-enum { MAXJ = 64, MAXT = 21, MAXR = 3 * MAXT };
+enum { MAXJ = 64, MAXT = 26, MAXR = 3 * MAXT };
 
 struct IkParams { int iterations, translate; double damping, smoothness, gamma; };
 

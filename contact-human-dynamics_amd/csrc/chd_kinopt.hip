@@ -1,0 +1,88 @@
+// chd_kinopt.hip -- C ABI of the kinematic optimisation's least-squares solves (include/chd_kinopt.h) on HIP / gfx950.
+// One workgroup of 512 threads per (video, stage) problem runs the whole trust-region solve (chd_kinopt_kernels.hpp);
+// the host packs the batch into three pools (constants, contacts, start points) and allocates one workspace per video.
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "chd_kinopt_host.hpp"
+
+using namespace chd_kin;
+
+namespace {
+thread_local std::string g_err;
+thread_local double g_kernel_ms = 0.0;
+int fail(const std::string& what, hipError_t e = hipSuccess) {
+  g_err = e == hipSuccess ? what : what + ": " + hipGetErrorString(e);
+  return 1;
+}
+}  // namespace
+
+__global__ void __launch_bounds__(512) chd_kin_solve_kernel(const KinSeq* seqs, KinParams P, const double* dpool, const int* ipool, double* work,
+                                                            double* state, double* stats) {
+  __shared__ double red[48];
+  __shared__ KinParams Ps;
+  if (threadIdx.x == 0) Ps = P;
+  __syncthreads();
+  KinCtx c;
+  const KinSeq* q = seqs + blockIdx.x;
+  kin_bind(c, q, &Ps, dpool, ipool, work, red);
+  kin_solve(c, state + q->o_x, stats + 8 * blockIdx.x);
+}
+
+extern "C" {
+
+const char* chd_kin_version(void) { return "chd_kinopt 0.1 (gfx950)"; }
+void chd_kin_config_default(chd_kin_config* cfg) { config_default(cfg); }
+const char* chd_kin_last_error(void) { return g_err.c_str(); }
+double chd_kin_last_kernel_ms(void) { return g_kernel_ms; }
+
+int chd_kin_solve_batch(const chd_kin_config* cfg, int device, int B, chd_kin_seq* in) {
+  if (!cfg || !in || B < 1) return fail("bad arguments");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail("no HIP device (this library has no CPU path)");
+  if (device < 0 || device >= ndev) return fail("device index out of range");
+  hipError_t e;
+  if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
+  KinBatch bt;
+  if (!bt.build(cfg, B, in)) return fail(bt.err);
+  KinSeq* d_seqs = nullptr; double *d_dp = nullptr, *d_work = nullptr, *d_state = nullptr, *d_stats = nullptr; int* d_ip = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  auto release = [&]() {
+    for (void* p : {(void*)d_seqs, (void*)d_dp, (void*)d_work, (void*)d_state, (void*)d_stats, (void*)d_ip}) (void)hipFree(p);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+  };
+#define KIN_TRY(call, what) if ((e = (call)) != hipSuccess) { release(); return fail(what, e); }
+  KIN_TRY(hipMalloc(&d_seqs, sizeof(KinSeq) * bt.seqs.size()), "hipMalloc descriptors");
+  KIN_TRY(hipMalloc(&d_dp, sizeof(double) * bt.dpool.size()), "hipMalloc constants");
+  KIN_TRY(hipMalloc(&d_ip, sizeof(int) * bt.ipool.size()), "hipMalloc contacts");
+  KIN_TRY(hipMalloc(&d_work, sizeof(double) * (size_t)bt.work_total), "hipMalloc workspace");
+  KIN_TRY(hipMalloc(&d_state, sizeof(double) * bt.state.size()), "hipMalloc state");
+  KIN_TRY(hipMalloc(&d_stats, sizeof(double) * 8 * (size_t)B), "hipMalloc statistics");
+  KIN_TRY(hipMemcpy(d_seqs, bt.seqs.data(), sizeof(KinSeq) * bt.seqs.size(), hipMemcpyHostToDevice), "copy descriptors");
+  KIN_TRY(hipMemcpy(d_dp, bt.dpool.data(), sizeof(double) * bt.dpool.size(), hipMemcpyHostToDevice), "copy constants");
+  KIN_TRY(hipMemcpy(d_ip, bt.ipool.data(), sizeof(int) * bt.ipool.size(), hipMemcpyHostToDevice), "copy contacts");
+  KIN_TRY(hipMemcpy(d_state, bt.state.data(), sizeof(double) * bt.state.size(), hipMemcpyHostToDevice), "copy start points");
+  KIN_TRY(hipMemset(d_stats, 0, sizeof(double) * 8 * (size_t)B), "clear statistics");
+  KIN_TRY(hipEventCreate(&ev0), "hipEventCreate");
+  KIN_TRY(hipEventCreate(&ev1), "hipEventCreate");
+  KIN_TRY(hipEventRecord(ev0, 0), "hipEventRecord");
+  hipLaunchKernelGGL(chd_kin_solve_kernel, dim3((unsigned)B), dim3(512), 0, 0, d_seqs, bt.P, d_dp, d_ip, d_work, d_state, d_stats);
+  KIN_TRY(hipGetLastError(), "launch");
+  KIN_TRY(hipEventRecord(ev1, 0), "hipEventRecord");
+  KIN_TRY(hipDeviceSynchronize(), "synchronize");
+  float ms = 0.0f;
+  KIN_TRY(hipEventElapsedTime(&ms, ev0, ev1), "hipEventElapsedTime");
+  std::vector<double> fin(bt.state.size()), stats(8 * (size_t)B);
+  KIN_TRY(hipMemcpy(fin.data(), d_state, sizeof(double) * fin.size(), hipMemcpyDeviceToHost), "copy solutions");
+  KIN_TRY(hipMemcpy(stats.data(), d_stats, sizeof(double) * stats.size(), hipMemcpyDeviceToHost), "copy statistics");
+#undef KIN_TRY
+  bt.scatter(fin.data(), stats.data(), in);
+  release();
+  g_kernel_ms = ms;
+  g_err.clear();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,259 @@
+"""Host side of the kinematic optimisation: the reference's ``optimize_trajectory``
+(src/optimize/optimize_trajectory.py:522-834) for a LIST of clips, with the two expensive steps on the GPU:
+
+* the IK initialisation (:605-617, ``JacobianInverseKinematicsCK(translate=False, iterations=200, smoothness=0, damping=7)``)
+  through ``libchd_ik.so`` (include/chd_ik.h) -- all clips in one call;
+* the two ``least_squares`` solves (:660-670, :779-789) through ``libchd_kinopt.so`` (include/chd_kinopt.h) -- one workgroup
+  per clip, all clips of a stage in one launch.  The reference assembles a dense Jacobian in Python loops (3.5 GB and minutes
+  per evaluation for 100 frames); the kernel never forms it.
+
+Host code (NumPy, negligible cost): bone lengths (``update_skeleton``, :485-520), weights and normalised 2D targets (:556-572),
+the Huber floor fit and contact relabelling (:713-767; the same optimisation problem scikit-learn's ``HuberRegressor`` solves,
+with SciPy's L-BFGS-B like it), the outputs (:791-834) and the three files ``kinematic_optimizer.py:184-219`` leaves for the
+physics stage: ``foot_contacts.npy``, ``floor_out.txt``, ``final_test.bvh``.
+
+There is no CPU path for the two GPU steps: without the libraries / a HIP device the constructor or the first call raises.
+The monocular-total-capture ingest in front of this (``totalcap_utils``) is not part of this row.
+
+Reproducibility: the reference's solves stop on SciPy's ``xtol`` after rejected steps of an inexact Jacobian, with LSMR at its
+iteration limit -- rounding-level differences (even SciPy's own, sparse vs dense Jacobian storage) move the result by 1e-4..1e-3;
+tests/test_kinopt_*.py state the tolerances.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import skeleton_io as sio
+from .ik_backproject import IkBackProject
+from .ik_capi import ChdIkConfig
+from .kinopt_capi import ChdKinConfig, NJ, NV, problems_to_c, results_of
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, 'csrc')
+LIB_PATH = os.path.join(_CSRC, 'libchd_kinopt.so')
+SOURCES = ['chd_kinopt.hip', 'chd_kinopt_kernels.hpp', 'chd_kinopt_host.hpp']
+EXPORTS = ['chd_kin_version', 'chd_kin_config_default', 'chd_kin_solve_batch', 'chd_kin_last_error', 'chd_kin_last_kernel_ms']
+
+# ---- SkeletonDefinitions.py:64-137 (combined skeleton: body-25 + three spine joints) --------------------------------------------
+ROOT_IDX = 8                                            # COMBINED_ROOT_IDX (data order)
+FEET_IDX = np.array([4, 5, 6, 10, 11, 12])             # COMBINED_FEET_IDX (skeleton order)
+SPINE_JOINTS = (13, 14, 15)                             # COMBINED_SKEL_SPINE_JOINTS
+FORWARD_MAPPING = np.array([8, 12, 13, 14, 21, 19, 20, 9, 10, 11, 24, 22, 23, 25, 26, 27, 1, 0, 16, 18, 15, 17, 5, 6, 7, 2, 3, 4])
+BACKWARD_MAPPING = np.argsort(FORWARD_MAPPING)
+PROJ_WEIGHTS = np.array([0.1, 0.1, 0.3, 0.1, 0.1, 0.3, 0.1, 0.1, 0.1, 1.0, 0.1, 0.1, 1.0] + [0.1] * 12 + [0.0] * 3)
+DATA_WEIGHTS = np.array([2.5] + [1.0] * 14 + [2.5] * 4 + [1.0] * 6 + [0.0] * 3)
+STAGE_WEIGHTS = ((1000.0, 0.1, 0.5, 0.3, 10.0, 0.0),    # :630-635  projection, velocity smoothness, acceleration smoothness, data, contact velocity, floor
+                 (1000.0, 0.1, 0.5, 0.3, 10.0, 10.0))   # :773-778
+
+
+def build_library(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU); in-tree so that the .so travels with the repo."""
+    srcs = [os.path.join(_CSRC, s) for s in SOURCES] + [os.path.join(_HERE, '..', 'include', 'chd_kinopt.h')]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
+        return LIB_PATH
+    cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', os.path.join(_CSRC, 'chd_kinopt.hip'), '-o', LIB_PATH]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def load_library():
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError('libchd_kinopt.so is not built (run __graft_entry__.build()); the kinematic optimisation has no CPU path')
+    lib = C.CDLL(LIB_PATH)
+    lib.chd_kin_version.restype = C.c_char_p
+    lib.chd_kin_last_error.restype = C.c_char_p
+    lib.chd_kin_last_kernel_ms.restype = C.c_double
+    return lib
+
+
+class KinSolver:
+    """``least_squares`` of optimize_trajectory.py:660 / :779 for a batch of problems on one GPU (include/chd_kinopt.h)."""
+
+    def __init__(self, device=0, parents=None, **overrides):
+        self.lib = load_library()
+        self.device = device
+        self.cfg = ChdKinConfig()
+        self.lib.chd_kin_config_default(C.byref(self.cfg))
+        if parents is not None:
+            self.cfg.parents = (C.c_int * NJ)(*[int(p) for p in parents])
+        for k, v in overrides.items():
+            setattr(self.cfg, k, v)
+
+    def solve(self, problems):
+        arr, keep, xs = problems_to_c(problems)
+        if self.lib.chd_kin_solve_batch(C.byref(self.cfg), self.device, len(problems), arr) != 0:
+            raise RuntimeError('chd_kin_solve_batch: ' + self.lib.chd_kin_last_error().decode())
+        return results_of(arr, xs)
+
+    def last_kernel_ms(self):
+        return float(self.lib.chd_kin_last_kernel_ms())
+
+
+# ---- host steps ------------------------------------------------------------------------------------------------------------------
+def update_skeleton(offsets, parents, targets):
+    """:485-520.  Bone length = median over the frames of the target bone (the three spine bones: a third of root -> Spine2,
+    'to avoid crunched spine from SMPL'); bone directions from the template; root offset zero."""
+    lengths = np.zeros(NJ)
+    for j in range(1, NJ):
+        if j in SPINE_JOINTS:
+            lengths[j] = np.median(np.linalg.norm(targets[:, SPINE_JOINTS[2]] - targets[:, 0], axis=1) / 3.0)
+        else:
+            lengths[j] = np.median(np.linalg.norm(targets[:, j] - targets[:, int(parents[j])], axis=1))
+    out = np.array(offsets, dtype=np.float64)
+    out[1:] = out[1:] / np.linalg.norm(out[1:], axis=1, keepdims=True) * lengths[1:, None]
+    out[0] = 0.0
+    return out
+
+
+def prepare_weights(poses2d, conf, cam_center, focal):
+    """:556-572: weights of the projection and data terms, 2D targets with focal length and camera centre removed."""
+    F = conf.shape[0]
+    proj_w = np.zeros((F, NJ)); data_w = np.zeros((F, NJ))
+    p2 = np.array(poses2d, dtype=np.float64)
+    proj_w[:, :25] = conf[:, :25] * PROJ_WEIGHTS[:25]
+    data_w[:, :25] = (1.0 + conf[:, :25]) * DATA_WEIGHTS[:25]
+    data_w[:, 25:] = (1.0 + 0.4) * DATA_WEIGHTS[25:]
+    p2[:, :25, 0] = (poses2d[:, :25, 0] - cam_center[0]) / focal[0]
+    p2[:, :25, 1] = (poses2d[:, :25, 1] - cam_center[1]) / focal[1]
+    return p2, proj_w, data_w
+
+
+def _huber_objective(w, X, y, epsilon, alpha):
+    """n sigma + sum_i sigma H_eps((y_i - x_i w - c) / sigma) + alpha |w|^2 and its gradient in (w, c, sigma): the problem
+    HuberRegressor(epsilon, alpha=1e-4) poses (Owen 2007), unit sample weights."""
+    p = X.shape[1]
+    sigma, c0, coef = w[-1], w[-2], w[:p]
+    r = y - X.dot(coef) - c0
+    out = np.abs(r) > epsilon * sigma
+    rin = r[~out]
+    sgn = np.where(r[out] < 0, -1.0, 1.0)
+    n_out = int(out.sum())
+    grad = np.empty(p + 2)
+    grad[:p] = -2.0 / sigma * X[~out].T.dot(rin) - 2.0 * epsilon * X[out].T.dot(sgn) + 2.0 * alpha * coef
+    grad[-2] = -2.0 * rin.sum() / sigma - 2.0 * epsilon * sgn.sum()
+    grad[-1] = len(y) - n_out * epsilon ** 2 - rin.dot(rin) / sigma ** 2
+    loss = len(y) * sigma + rin.dot(rin) / sigma + 2.0 * epsilon * np.abs(r[out]).sum() - sigma * n_out * epsilon ** 2 + alpha * coef.dot(coef)
+    return loss, grad
+
+
+def huber_fit(X, y, epsilon, alpha=1e-4, max_iter=100, tol=1e-5):
+    """linear_model.HuberRegressor(epsilon).fit(X, y) of :719-720 / :743-744 -> coef, intercept, scale, outlier mask."""
+    from scipy import optimize
+    p = X.shape[1]
+    w0 = np.zeros(p + 2); w0[-1] = 1.0
+    bounds = [(None, None)] * (p + 1) + [(np.finfo(np.float64).eps * 10, None)]
+    res = optimize.minimize(_huber_objective, w0, method='L-BFGS-B', jac=True, args=(X, y, epsilon, alpha), bounds=bounds,
+                            options={'maxiter': max_iter, 'gtol': tol, 'iprint': -1})
+    w = res.x
+    return w[:p], w[-2], w[-1], np.abs(y - X.dot(w[:p]) - w[-2]) > w[-1] * epsilon
+
+
+def fit_floor(feet_pos):
+    """:713-767.  y = a x + b z + c through the contact positions: the epsilon = 1.5 fit gives the plane (normal from three of
+    its points, point = the plane under the origin), the epsilon = 2.2 fit marks the labels to drop."""
+    X = feet_pos[:, [0, 2]]; y = feet_pos[:, 1]
+    coef, c0, _, _ = huber_fit(X, y, 1.5)
+    verts = np.array([[0.0, -1.0, 0.0], [0.0, -1.0, 100.0], [100.0, -1.0, 0.0]])
+    verts[:, 1] = verts[:, [0, 2]].dot(coef) + c0
+    normal = np.cross(verts[2] - verts[0], verts[1] - verts[2])
+    normal /= np.linalg.norm(normal)
+    return normal, verts[0].copy(), huber_fit(X, y, 2.2)[3]
+
+
+def _motion(x, offsets, parents):
+    """The animation of an unknown vector (:675-683): Euler angles -> rotations, root translation -> root position."""
+    F = x.shape[0]
+    rot = sio.quat_from_euler(x[:, 3:].reshape(F, NJ, 3), order='xyz', world=True)
+    pos = np.repeat(offsets[None], F, axis=0)
+    pos[:, 0] = x[:, :3]
+    return sio.Motion(rot, pos, np.tile([1.0, 0.0, 0.0, 0.0], (NJ, 1)), offsets.copy(), np.asarray(parents).copy())
+
+
+class KinematicOptimizer:
+    """``optimize_trajectory`` for a list of clips.  `ik` / `kin` default to the HIP libraries on `device`; tests inject the host
+    emulation of the same kernel sources."""
+
+    def __init__(self, device=0, ik=None, kin=None, parents=None):
+        self.parents = np.asarray(parents) if parents is not None else None
+        self.ik = ik if ik is not None else IkBackProject(device, ChdIkConfig.default(iterations=200, translate=0, damping=7.0, smoothness=0.0))
+        self.kin = kin if kin is not None else KinSolver(device, parents=parents)
+        self.timings = {}
+
+    def optimize(self, clips):
+        """clips: dicts with poses2D (F,28,2), joint_conf_2d (F,28), poses3D (F,28,3), root_pos (F,3), joint_angles (F,28,3),
+        offsets (28,3), parents (28,), ppx, ppy, camFocal (2,), velConstraints (F,28) and optionally plane_normal / plane_point --
+        the arguments of optimize_trajectory (:522-526).  Returns one dict per clip (see the end of this function)."""
+        prep = []
+        for cl in clips:
+            F = cl['poses2D'].shape[0]
+            if cl['poses2D'].shape[1] != cl['poses3D'].shape[1] or cl['poses3D'].shape[1] != NJ:
+                raise ValueError('2D and 3D data must have the %d joints of the combined skeleton' % NJ)       # :538-542
+            parents = np.asarray(cl['parents'])
+            if self.parents is not None and not np.array_equal(parents, self.parents):
+                raise ValueError('all clips of a KinematicOptimizer share one skeleton hierarchy')
+            targets = cl['poses3D'][:, FORWARD_MAPPING] + cl['root_pos'][:, None]                              # :546-549
+            offs = update_skeleton(cl['offsets'], parents, targets)
+            p2n, pw, dw = prepare_weights(cl['poses2D'], cl['joint_conf_2d'], (cl['ppx'], cl['ppy']), cl['camFocal'])
+            ang = np.linalg.norm(cl['joint_angles'], axis=2)                                                     # :589-594
+            rot0 = sio.quat_from_angle_axis(ang, -(cl['joint_angles'] / (ang + 1e-10)[..., None]))
+            pos = np.repeat(offs[None], F, axis=0); pos[:, 0] = cl['root_pos']
+            tj = np.array([j for j in range(NJ) if j not in SPINE_JOINTS], dtype=np.int32)                       # :605-609
+            given = cl.get('plane_normal') is not None and cl.get('plane_point') is not None
+            prep.append(dict(F=F, parents=parents, offs=offs, p2n=p2n, pw=pw, dw=dw, vel=np.array(cl['velConstraints']), given=given,
+                             floor_n=np.asarray(cl['plane_normal'], dtype=np.float64) if given else np.zeros(3),
+                             floor_p=np.asarray(cl['plane_point'], dtype=np.float64) if given else np.zeros(3),
+                             ik=dict(parents=parents, target_joints=tj, targets=np.swapaxes(targets[:, tj], 0, 1), rot=rot0, pos=pos)))
+        iks = self.ik.solve([p['ik'] for p in prep])                                                             # :611-617
+        for p, (rot, pos) in zip(prep, iks):
+            p['ik_rot'] = rot
+            p['x'] = np.concatenate([pos[:, 0], sio.quat_to_euler_xyz(rot).reshape(p['F'], -1)], axis=1).reshape(-1)      # :638-640
+
+        def problems(stage):
+            return [dict(offsets=p['offs'], pose3d=cl['poses3D'], root_trans=cl['root_pos'], pose2d_n=p['p2n'], proj_w=p['pw'], data_w=p['dw'],
+                         contact=p['vel'], floor_n=p['floor_n'], floor_p=p['floor_p'], weights=STAGE_WEIGHTS[stage], x0=p['x']) for p, cl in zip(prep, clips)]
+
+        stats = []
+        r1 = self.kin.solve(problems(0))                                                                         # :660-670
+        for p, r in zip(prep, r1):
+            p['x'] = r['x']
+            X = r['x'].reshape(p['F'], NV)
+            gp = sio.positions_global(_motion(X, p['offs'], p['parents']))                                       # :693-709
+            feet_contact = FORWARD_MAPPING[FEET_IDX]
+            fv = p['vel'][:, feet_contact]
+            feet_pos = gp[:, FEET_IDX][fv == 1]
+            if not p['given']:
+                p['floor_n'], p['floor_p'], outl = fit_floor(feet_pos)
+                fv = fv.copy()
+                fv[fv == 1] = np.where(outl, 0, 1)                                                               # :755-767 (row-major walk = the reference's loops)
+                p['vel'][:, feet_contact] = fv
+        r2 = self.kin.solve(problems(1))                                                                         # :779-789
+        out = []
+        for p, cl, a, b in zip(prep, clips, r1, r2):
+            X = b['x'].reshape(p['F'], NV)
+            motion = _motion(X, p['offs'], p['parents'])
+            new3d = sio.positions_global(motion)[:, BACKWARD_MAPPING]                                            # :809-813
+            proj = np.stack([cl['camFocal'][0] * new3d[..., 0] / new3d[..., 2] + cl['ppx'],
+                             cl['camFocal'][1] * new3d[..., 1] / new3d[..., 2] + cl['ppy']], axis=-1)            # :816-830
+            out.append(dict(motion=motion, pose3d=new3d, proj2d=proj, plane_normal=p['floor_n'], plane_point=p['floor_p'], velConstraints=p['vel'],
+                            ik_rot=p['ik_rot'], stages=[{k: v for k, v in s.items()} for s in (a, b)]))
+        return out
+
+
+def refined_contacts(vel):
+    """kinematic_optimizer.py:184-204: F x 4 [l_heel, l_toe, r_heel, r_toe] from the relabelled body-25 feet columns 19..24."""
+    f = np.asarray(vel)[:, 19:25]
+    return np.stack([f[:, 2], np.logical_or(f[:, 0], f[:, 1]), f[:, 5], np.logical_or(f[:, 3], f[:, 4])], axis=1).astype(int)
+
+
+def save_results(out_dir, result, names):
+    """The three files the physics stage reads from `kinematic_results/` (kinematic_optimizer.py:204-219, optimize_trajectory.py:807)."""
+    os.makedirs(out_dir, exist_ok=True)
+    np.save(os.path.join(out_dir, 'foot_contacts'), refined_contacts(result['velConstraints']))
+    n, p = result['plane_normal'], result['plane_point']
+    with open(os.path.join(out_dir, 'floor_out.txt'), 'w') as fh:
+        fh.write('%s %s %s\n%s %s %s' % tuple(str(float(v)) for v in (n[0], n[1], n[2], p[0], p[1], p[2])))
+    sio.save_bvh(os.path.join(out_dir, 'final_test.bvh'), result['motion'], names)

@@ -7,9 +7,9 @@
  * Quaternions.py:215-227, 401-420).  Plain pointers and sizes only; all arrays are caller-owned host buffers of IEEE
  * doubles / 32-bit ints.  Quaternions are (w, x, y, z).
  *
- * STATUS (end of round 1): built for gfx950 and checked against the reference-generated golden vectors through the
- * host emulation of the kernel source (tests/test_ik_emu.py); NOT yet run on an MI355X (the round's GPU budget was
- * spent on the physics path) -- the GPU parity test exists (tests/test_ik_gpu.py) but carries the marker `gpu_next`.
+ * Checked against vectors produced by the reference's own solver, on the MI355X (tests/test_ik_gpu.py) and through the host
+ * emulation of the kernel source (tests/test_ik_emu.py).  The same entry point serves the IK initialisation of the
+ * kinematic optimisation (translate = 0, iterations = 200, smoothness = 0; optimize_trajectory.py:611-617).
  */
 #ifndef CHD_IK_H
 #define CHD_IK_H
@@ -19,7 +19,8 @@ extern "C" {
 #endif
 
 #define CHD_IK_MAX_JOINTS 64      /* joints of a skeleton (the reference's characters have 25-31 + 2 added heels) */
-#define CHD_IK_MAX_TARGETS 21     /* targeted joints (apply_results: upper-body joints + 2 toes + 2 heels, towr_utils.py:826-840) */
+#define CHD_IK_MAX_TARGETS 26     /* targeted joints (apply_results: upper-body joints + 2 toes + 2 heels, towr_utils.py:826-840;
+                                     the kinematic optimisation's initialisation: 25 of the 28 combined-skeleton joints, optimize_trajectory.py:605-617) */
 
 typedef struct chd_ik_config {
   int iterations;        /* 30   (towr_utils.py:843) */

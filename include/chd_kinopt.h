@@ -1,0 +1,66 @@
+/* chd_kinopt.h -- C ABI of the kinematic optimisation's least-squares solves.
+ *
+ * Replaces, for a whole batch of videos at once, each of the two calls
+ *     cur_sol = least_squares(fun_anim_for_projection, init_sol, max_nfev=50, jac=jac_anim_for_projection_sparse,
+ *                             gtol=1e-12, bounds=[-inf, inf], tr_solver='lsmr', args=(skeleton, poses3D, root_pos, ...))
+ * of the reference's `optimize_trajectory` (src/optimize/optimize_trajectory.py:660-670 and :779-789; residual :324-483,
+ * Jacobian :51-322, skeleton tables src/optimize/SkeletonDefinitions.py:64-137; SciPy: trust-region-reflective without
+ * bounds, 2-D subspace + LSMR).  The steps around the two solves (bone lengths, weights, IK initialisation through
+ * chd_ik.h, Huber floor fit, contact relabelling, outputs) are host code: contact-human-dynamics_amd/kinematic_optimizer.py.
+ * Plain pointers and sizes only; all arrays are caller-owned host buffers of IEEE doubles / 32-bit ints.
+ * The skeleton is the reference's combined 28-joint skeleton (body-25 + three spine joints): "skeleton order" is the joint
+ * order of skeleton_fitting/combined_body_25.bvh, "data order" the order of the 2D / 3D estimates (body-25, then the spine).
+ */
+#ifndef CHD_KINOPT_H
+#define CHD_KINOPT_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CHD_KIN_JOINTS 28
+#define CHD_KIN_UNKNOWNS_PER_FRAME 87     /* root translation + 28 Euler triples (xyz, world order) */
+
+typedef struct chd_kin_config {
+  int max_nfev;            /* 50     (optimize_trajectory.py:661) */
+  double ftol, xtol, gtol; /* 1e-8, 1e-8 (SciPy defaults), 1e-12 (:664) */
+  double lsmr_atol, lsmr_btol, lsmr_conlim;   /* 1e-6, 1e-6, 1e8 (SciPy's lsmr defaults; least_squares passes no tr_options) */
+  int lsmr_maxiter;        /* 0 = min(rows, unknowns), SciPy's default */
+  int parents[CHD_KIN_JOINTS];   /* skeleton.parents (BVH order); parents[0] = -1, parents[j] < j */
+  int reserved[4];
+} chd_kin_config;
+
+/* One video, one solve: the `args` tuple of :667-670 after `optimize_trajectory`'s own preparation (:544-572). */
+typedef struct chd_kin_seq {
+  int n_frames;                /* F >= 3 */
+  const double* offsets;       /* 28 x 3: bone offsets of the fitted skeleton (update_skeleton, :485-520), skeleton order, root row zero */
+  const double* pose3d;        /* F x 28 x 3: poses3D, data order, root relative */
+  const double* root_trans;    /* F x 3: root_pos */
+  const double* pose2d_n;      /* F x 28 x 2: joints_2d_normalized (:568-569) */
+  const double* proj_w;        /* F x 28: proj_weights (:564, :571) */
+  const double* data_w;        /* F x 28: data_weights (:566, :572) */
+  const int* contact;          /* F x 28: velConstraints == 1, data order */
+  double floor_n[3], floor_p[3];   /* plane_normal, plane_point */
+  double w_proj, w_smooth_vel, w_smooth_acc, w_data, w_vel, w_floor;   /* :630-635 / :773-778 */
+  double* x;                   /* F x 87: init_sol in, cur_sol.x out */
+  double cost;                 /* out: cur_sol.cost */
+  int nfev, njev, status;      /* out: as scipy.optimize.OptimizeResult (status 0 max_nfev, 1 gtol, 2 ftol, 3 xtol, 4 both) */
+  int lsmr_iterations;         /* out: LSMR iterations summed over the solve */
+  double optimality;           /* out: infinity norm of the gradient at the solution */
+} chd_kin_seq;
+
+const char* chd_kin_version(void);
+void chd_kin_config_default(chd_kin_config* cfg);      /* the reference's values; parents of combined_body_25.bvh */
+
+/* Solves B (video, stage) problems on HIP device `device`, one workgroup each.  Returns 0 on success; non-zero with a
+ * message in chd_kin_last_error() (no device, bad sizes, allocation failure).  There is no CPU path. */
+int chd_kin_solve_batch(const chd_kin_config* cfg, int device, int B, chd_kin_seq* seqs);
+const char* chd_kin_last_error(void);
+
+/* Device time (HIP events around the launch) of the last successful call on this thread, in milliseconds. */
+double chd_kin_last_kernel_ms(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

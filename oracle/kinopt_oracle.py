@@ -321,7 +321,7 @@ def solve_trust_region_2d(B, g, Delta):
     return p[:, np.argmin(value)], False
 
 
-def trf_lsmr(fun, jac, x0, ftol=1e-8, xtol=1e-8, gtol=1e-12, max_nfev=50, trace=None):
+def trf_lsmr(fun, jac, x0, ftol=1e-8, xtol=1e-8, gtol=1e-12, max_nfev=50, trace=None, lsmr_maxiter=None):
     """least_squares(fun, x0, jac=jac, method='trf', tr_solver='lsmr', bounds=(-inf, inf), max_nfev=50, gtol=1e-12) as the
     reference calls it (:660-670, :779-789).  Returns (x, cost, nfev, njev, status)."""
     from scipy import sparse                                                          # (storage only: the Jacobian is ~2 % dense)
@@ -352,9 +352,9 @@ def trf_lsmr(fun, jac, x0, ftol=1e-8, xtol=1e-8, gtol=1e-12, max_nfev=50, trace=
         ts = np.asarray(ts)
         ag_value = np.min(ts * (a * ts + b))
         reg_term = -ag_value / Delta ** 2
-        gn, _, itn = lsmr(J.dot, J.T.dot, f, x.size, damp=reg_term ** 0.5)
+        gn, _, itn = lsmr(J.dot, J.T.dot, f, x.size, damp=reg_term ** 0.5, maxiter=lsmr_maxiter)      # (lsmr_maxiter: test knob; SciPy: min(m, n))
         if trace is not None:
-            trace.append(('lsmr', itn))
+            trace.append(('iter', cost, Delta, g_norm, reg_term ** 0.5, itn))
         S = np.vstack((g, gn)).T
         S, _ = np.linalg.qr(S, mode='reduced')
         JS = J.dot(S)
@@ -374,6 +374,8 @@ def trf_lsmr(fun, jac, x0, ftol=1e-8, xtol=1e-8, gtol=1e-12, max_nfev=50, trace=
                 continue
             cost_new = 0.5 * np.dot(f_new, f_new)
             actual_reduction = cost - cost_new
+            if trace is not None:
+                trace.append(('try', p_S.copy(), predicted_reduction, actual_reduction, B_S.copy(), g_S.copy()))
             if predicted_reduction > 0:
                 ratio = actual_reduction / predicted_reduction
             elif predicted_reduction == actual_reduction == 0:

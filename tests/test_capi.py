@@ -92,6 +92,44 @@ def test_ik_fails_loudly_without_gpu(ik_lib):
         IkBackProject(device=0).solve([case])
 
 
+# ---- kinematic optimisation library (include/chd_kinopt.h; next row) -------------------------------------------
+@pytest.fixture(scope='module')
+def kin_lib():
+    from chd_amd import kinematic_optimizer
+    kinematic_optimizer.build_library()
+    return C.CDLL(kinematic_optimizer.LIB_PATH)
+
+
+def test_kinopt_header_exports_and_struct_sizes_agree(kin_lib, tmp_path):
+    import subprocess
+    from chd_amd import kinematic_optimizer, kinopt_capi
+    src = open(os.path.join(ROOT, 'include', 'chd_kinopt.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    names = sorted(set(re.findall(r'\b(chd_kin_[a-z_]+)\s*\(', src)))
+    assert set(names) == set(kinematic_optimizer.EXPORTS)
+    for n in names:
+        assert hasattr(kin_lib, n), n
+    cfg = kinopt_capi.ChdKinConfig()
+    kin_lib.chd_kin_config_default(C.byref(cfg))
+    assert (cfg.max_nfev, cfg.ftol, cfg.xtol, cfg.gtol, cfg.lsmr_atol, cfg.lsmr_btol, cfg.lsmr_conlim, cfg.lsmr_maxiter) == (50, 1e-8, 1e-8, 1e-12, 1e-6, 1e-6, 1e8, 0)
+    assert list(cfg.parents) == [-1, 0, 1, 2, 3, 3, 3, 0, 7, 8, 9, 9, 9, 0, 13, 14, 15, 16, 16, 16, 16, 16, 15, 22, 23, 15, 25, 26]      # combined_body_25.bvh
+    csrc = tmp_path / 'k.c'
+    csrc.write_text('#include <stdio.h>\n#include "chd_kinopt.h"\nint main(void){printf("%zu %zu\\n", sizeof(chd_kin_config), sizeof(chd_kin_seq)); return 0;}\n')
+    exe = tmp_path / 'k'
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(csrc), '-o', str(exe)])
+    assert [int(v) for v in subprocess.check_output([str(exe)], text=True).split()] == [C.sizeof(kinopt_capi.ChdKinConfig), C.sizeof(kinopt_capi.ChdKinSeq)]
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU failure mode')
+def test_kinopt_fails_loudly_without_gpu(kin_lib):
+    from chd_amd.kinematic_optimizer import KinSolver, STAGE_WEIGHTS
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'kinopt_golden.npz'))
+    p = dict(offsets=g['c0_fit_offsets'], pose3d=g['c0_poses3D'], root_trans=g['c0_root_pos'], pose2d_n=g['c0_lsq0_pose2d_n'], proj_w=g['c0_lsq0_proj_w'],
+             data_w=g['c0_lsq0_data_w'], contact=g['c0_lsq0_vel'], floor_n=np.zeros(3), floor_p=np.zeros(3), weights=STAGE_WEIGHTS[0], x0=g['c0_lsq0_x0'])
+    with pytest.raises(RuntimeError):
+        KinSolver(device=0).solve([p])
+
+
 def test_struct_mirrors_match_the_header_sizes(lib, tmp_path):
     """sizeof of every struct of include/chd_phys.h as compiled by the C compiler == the ctypes mirror."""
     import subprocess

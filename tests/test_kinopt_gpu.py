@@ -1,0 +1,68 @@
+"""GPU parity of the kinematic optimisation through its C ABIs: libchd_kinopt.so (the two least-squares
+solves) and libchd_ik.so (the IK initialisation) on an MI355X -- against the oracle, the host emulation of the same kernel source
+and the vectors the reference's own functions produced (tests/golden/kinopt_golden.npz).  Tolerances: see tests/test_kinopt_emu.py."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import chd_amd  # noqa: F401
+from chd_amd import kinematic_optimizer as kopt
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, 'host_emu'))
+sys.path.insert(0, HERE)
+from test_kinopt_emu import clip_of, problem, rel      # noqa: E402
+GOLD = os.path.join(HERE, 'golden', 'kinopt_golden.npz')
+
+
+@pytest.fixture(scope='module')
+def gold():
+    torch = pytest.importorskip('torch')
+    if not torch.cuda.is_available():
+        pytest.skip('needs an MI355X')
+    return np.load(GOLD)
+
+
+def test_bounded_solve_in_lockstep_with_oracle_and_emulation(gold):
+    from oracle import kinopt_oracle as ko
+    import kin_emu
+    for ci, li, cut in [(0, 0, 3), (2, 1, 8)]:
+        p, q = problem(gold, ci, li)
+        k = 'c%d_' % ci
+        P = ko.Problem(p['offsets'], gold[k + 'skel_parents'], p['pose3d'], p['root_trans'], p['pose2d_n'], p['proj_w'], p['data_w'], p['contact'], p['floor_n'], p['floor_p'],
+                       kopt.STAGE_WEIGHTS[li])
+        x, cost, nfev, njev, status = ko.trf_lsmr(P.fun, P.jac, p['x0'], lsmr_maxiter=cut)
+        e = kin_emu.solve([p], kin_emu.default_config(lsmr_maxiter=cut))[0]
+        r = kopt.KinSolver(device=0, lsmr_maxiter=cut).solve([p])[0]
+        assert (r['nfev'], r['njev'], r['status']) == (nfev, njev, status) == (e['nfev'], e['njev'], e['status'])
+        assert rel(r['x'], x) < 1e-7 and rel(r['x'], e['x']) < 1e-7 and abs(r['cost'] - cost) < 1e-6 * cost
+
+
+def test_every_solve_of_the_fixture_matches_the_reference(gold):
+    ps = [problem(gold, ci, li) for ci in range(3) for li in range(2)]
+    solver = kopt.KinSolver(device=0)
+    res = solver.solve([p for p, _ in ps] * 3)                 # 18 workgroups; the three copies must agree bit for bit
+    for i, ((p, q), r) in enumerate(zip(ps, res)):
+        assert rel(r['x'], gold[q + 'x']) < 2e-3
+        assert abs(r['cost'] - float(gold[q + 'cost'])) < 0.06 * float(gold[q + 'cost'])
+        assert r['status'] == int(gold[q + 'status']) and abs(r['nfev'] - int(gold[q + 'nfev'])) <= 3
+        for rep in (1, 2):
+            assert np.array_equal(res[i + rep * len(ps)]['x'], r['x'])
+    assert solver.last_kernel_ms() > 0
+
+
+def test_whole_optimisation_on_gpu(gold, tmp_path):
+    g = gold
+    res = kopt.KinematicOptimizer(device=0).optimize([clip_of(g, ci) for ci in range(3)])
+    for ci, r in enumerate(res):
+        k = 'c%d_' % ci
+        s = np.sign((r['ik_rot'] * g[k + 'ik_rot']).sum(-1, keepdims=True))
+        assert rel(r['ik_rot'] * s, g[k + 'ik_rot']) < 1e-10
+        assert np.array_equal(r['velConstraints'], g[k + 'out_vel'])
+        assert np.abs(r['plane_normal'] - g[k + 'out_floor_n']).max() < 2e-2 and np.abs(r['plane_point'] - g[k + 'out_floor_p']).max() < 3.0
+        assert rel(r['pose3d'], g[k + 'out_pose3d']) < 5e-3 and rel(r['proj2d'], g[k + 'out_proj2d']) < 5e-3
+        kopt.save_results(str(tmp_path / ('clip%d' % ci)), r, ['j%d' % j for j in range(28)])
+        assert np.array_equal(np.load(str(tmp_path / ('clip%d' % ci) / 'foot_contacts.npy')), kopt.refined_contacts(g[k + 'out_vel']))
