@@ -68,7 +68,10 @@ int chd_kin_solve_batch(const chd_kin_config* cfg, int device, int B, chd_kin_se
   KIN_TRY(hipEventCreate(&ev0), "hipEventCreate");
   KIN_TRY(hipEventCreate(&ev1), "hipEventCreate");
   KIN_TRY(hipEventRecord(ev0, 0), "hipEventRecord");
-  hipLaunchKernelGGL(chd_kin_solve_kernel, dim3((unsigned)B), dim3(512), 0, 0, d_seqs, bt.P, d_dp, d_ip, d_work, d_state, d_stats);
+  // 512 threads: measured against 256 and 1024 (profiles/r02h_kinopt/sweep.md); results are bitwise reproducible for a fixed
+  // workgroup size (fixed reduction trees) and move at the solve's own sensitivity level when it changes
+  const int nthreads = cfg->reserved[0] == 256 ? 256 : 512;
+  hipLaunchKernelGGL(chd_kin_solve_kernel, dim3((unsigned)B), dim3((unsigned)nthreads), 0, 0, d_seqs, bt.P, d_dp, d_ip, d_work, d_state, d_stats);
   KIN_TRY(hipGetLastError(), "launch");
   KIN_TRY(hipEventRecord(ev1, 0), "hipEventRecord");
   KIN_TRY(hipDeviceSynchronize(), "synchronize");

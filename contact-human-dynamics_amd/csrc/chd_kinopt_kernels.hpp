@@ -105,10 +105,35 @@ struct KinCtx {
 };
 
 // ---- workgroup reductions (fixed tree: results do not depend on scheduling) -------------------------------------------------
+// A sum over a KO_FOR loop: every thread adds its own items in loop order, the per-thread sums are combined by a butterfly inside
+// each wavefront and then wavefront by wavefront.  The host emulation keeps 512 lane accumulators and combines them the same
+// way, so that its sums round like the 512-thread workgroup's (a single running sum over ~50 000 terms is 1000 times less
+// accurate, and LSMR's convergence over thousands of iterations feels that).
 #ifdef CHD_HOST_EMU
-KO_DEV void ko_sum3(KinCtx&, double& a, double& b, double& c) {}
+enum { KO_LANES = 512 };
+struct KoAcc {
+  double l[KO_LANES];
+  KoAcc() { for (int i = 0; i < KO_LANES; ++i) l[i] = 0.0; }
+  void add(long long i, double v) { l[i & (KO_LANES - 1)] += v; }
+  double total() const {
+    double s = 0.0;
+    for (int w0 = 0; w0 < KO_LANES; w0 += 64) {
+      double a[64], t[64];
+      for (int k = 0; k < 64; ++k) a[k] = l[w0 + k];
+      for (int o = 32; o > 0; o >>= 1) { for (int k = 0; k < 64; ++k) t[k] = a[k] + a[k ^ o]; for (int k = 0; k < 64; ++k) a[k] = t[k]; }
+      s += a[0];
+    }
+    return s;
+  }
+};
+KO_DEV void ko_total3(KinCtx&, const KoAcc& A, const KoAcc& B, const KoAcc& C, double& a, double& b, double& c) { a = A.total(); b = B.total(); c = C.total(); }
 #else
-KO_DEV void ko_sum3(KinCtx& c_, double& a, double& b, double& c) {
+struct KoAcc {
+  double s = 0.0;
+  __device__ void add(long long, double v) { s += v; }
+};
+KO_DEV void ko_total3(KinCtx& c_, const KoAcc& A, const KoAcc& B, const KoAcc& C, double& a, double& b, double& c) {
+  a = A.s; b = B.s; c = C.s;
   for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
   const int wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
   __syncthreads();
@@ -119,11 +144,11 @@ KO_DEV void ko_sum3(KinCtx& c_, double& a, double& b, double& c) {
   a = sa; b = sb; c = sc;
 }
 #endif
-KO_DEV double ko_sum(KinCtx& c, double a) { double b = 0, d = 0; ko_sum3(c, a, b, d); return a; }
+KO_DEV double ko_total(KinCtx& c, const KoAcc& A) { KoAcc z1, z2; double a, b, d; ko_total3(c, A, z1, z2, a, b, d); return a; }
 KO_DEV double ko_dot(KinCtx& c, const double* a, const double* b, long long n) {
-  double s = 0;
-  for (long long i = KO_TID; i < n; i += KO_NT) s += a[i] * b[i];
-  return ko_sum(c, s);
+  KoAcc s;
+  for (long long i = KO_TID; i < n; i += KO_NT) s.add(i, a[i] * b[i]);
+  return ko_total(c, s);
 }
 
 // ---- forward kinematics of one frame (Animation.py:294-323, 379-414; Quaternions.from_euler(order='xyz', world=True)) -------
@@ -235,7 +260,9 @@ KO_DEV void kin_linearise(KinCtx& c, const double* x) {
 }
 
 // ---- out = J v (:51-322 applied to a vector) -----------------------------------------------------------------------------------
-KO_DEV void kin_jv(KinCtx& c, const double* v, double* out) {
+// With `sumsq`: the fused form LSMR's bidiagonalisation needs, out <- scale * (J v) + keep * out in place and *sumsq = |out|^2
+// (every row has exactly one writer; saves writing J v, reading it back and a separate pass for the norm).
+KO_DEV void kin_jv(KinCtx& c, const double* v, double* out, const double scale = 1.0, const double keep = 0.0, double* sumsq = nullptr) {
   const int F = c.q->F;
   KO_FOR(idx, F * NJ) {                       // omega_j = sum_a v_{j,a} axis_{j,a}
     const int f = idx / NJ, j = idx % NJ;
@@ -262,34 +289,44 @@ KO_DEV void kin_jv(KinCtx& c, const double* v, double* out) {
   KO_SYNC();
   const double sv = c.q->w[1], sa = c.q->w[2], dw = c.q->w[3], vw = c.q->w[4], fw = c.q->w[5];
   const double* DY = c.w.DY;
+  const bool fused = sumsq != nullptr;
+  KoAcc acc;
+  long long cur = 0;                          // the loop index the running sum belongs to
+  auto put = [&](long long r, double val) {
+    if (fused) { val = scale * val + keep * out[r]; acc.add(cur, val * val); }
+    out[r] = val;
+  };
   KO_FOR(idx, F * NJ) {
     const int f = idx / NJ, jd = idx % NJ;
+    cur = idx;
     const double* dy = DY + 3 * (long long)idx;
     const double* d0 = DY + 3 * (long long)f * NJ;                  // data joint 0: where the reference puts the root's projection derivative
     const double* dr = DY + 3 * ((long long)f * NJ + ROOT);
     const double* C = c.w.C + 3 * (long long)idx;
     const double ex = jd == 0 ? dy[0] : d0[0] + dy[0], ey = jd == 0 ? dy[1] : d0[1] + dy[1], ez = jd == 0 ? dy[2] : d0[2] + dy[2];
-    out[2 * idx] = C[0] * ex + C[1] * ez;
-    out[2 * idx + 1] = C[0] * ey + C[2] * ez;
+    put(2 * idx, C[0] * ex + C[1] * ez);
+    put(2 * idx + 1, C[0] * ey + C[2] * ez);
     const bool ct = c.contact[idx] == 1;
     for (int k = 0; k < 3; ++k) {
       if (f < F - 1) {
-        out[c.o2 + 3 * idx + k] = sv * SMOOTH_W[jd] * SMOOTH_VEL[k] * (dy[k] - dy[3 * NJ + k]);
-        out[c.o5 + 3 * idx + k] = ct ? vw * ((dr[k] + dy[k]) - (dr[3 * NJ + k] + dy[3 * NJ + k])) : 0.0;
+        put(c.o2 + 3 * idx + k, sv * SMOOTH_W[jd] * SMOOTH_VEL[k] * (dy[k] - dy[3 * NJ + k]));
+        put(c.o5 + 3 * idx + k, ct ? vw * ((dr[k] + dy[k]) - (dr[3 * NJ + k] + dy[3 * NJ + k])) : 0.0);
       }
-      if (f < F - 2) out[c.o3 + 3 * idx + k] = sa * (dy[k] - 2.0 * dy[3 * NJ + k] + dy[6 * NJ + k]);
-      out[c.o4 + 3 * idx + k] = dw * c.data_w[idx] * dy[k];
+      if (f < F - 2) put(c.o3 + 3 * idx + k, sa * (dy[k] - 2.0 * dy[3 * NJ + k] + dy[6 * NJ + k]));
+      put(c.o4 + 3 * idx + k, dw * c.data_w[idx] * dy[k]);
     }
     double d = 0;
     for (int k = 0; k < 3; ++k) d += c.q->floor_n[k] * (dr[k] + dy[k]);
-    out[c.o6 + idx] = ct ? fw * d : 0.0;
+    put(c.o6 + idx, ct ? fw * d : 0.0);
   }
-  KO_FOR(idx, (F - 1) * NV) out[c.o7 + idx] = sv * KO_SMOOTH_EULER * (v[idx] - v[idx + NV]);
-  KO_SYNC();
+  KO_FOR(idx, (F - 1) * NV) { cur = idx; put(c.o7 + idx, sv * KO_SMOOTH_EULER * (v[idx] - v[idx + NV])); }
+  if (fused) *sumsq = ko_total(c, acc);      // (its barriers order the stores before the next phase)
+  else KO_SYNC();
 }
 
 // ---- out = J^T u ---------------------------------------------------------------------------------------------------------------
-KO_DEV void kin_jtu(KinCtx& c, const double* u, double* out) {
+// With `sumsq`: out <- scale * (J^T u) + keep * out in place and *sumsq = |out|^2 (one writer per unknown).
+KO_DEV void kin_jtu(KinCtx& c, const double* u, double* out, const double scale = 1.0, const double keep = 0.0, double* sumsq = nullptr) {
   const int F = c.q->F;
   const double sv = c.q->w[1], sa = c.q->w[2], dw = c.q->w[3], vw = c.q->w[4], fw = c.q->w[5];
   KO_FOR(idx, F * NJ) {                       // lambda of data joint jd of frame f
@@ -328,6 +365,8 @@ KO_DEV void kin_jtu(KinCtx& c, const double* u, double* out) {
     o[0] = lam[0]; o[1] = lam[1]; o[2] = lam[2];
   }
   KO_SYNC();
+  const bool fused = sumsq != nullptr;
+  KoAcc acc;
   KO_FOR(idx, F * NJ) {                       // (J^T u)_{j,a} = axis_{j,a} . sum over the strict descendants t of j of (p_t - p_j) x lambda_t
     const int f = idx / NJ, j = idx % NJ;
     const double* Pf = c.w.P + (long long)f * 84;
@@ -343,16 +382,21 @@ KO_DEV void kin_jtu(KinCtx& c, const double* u, double* out) {
     const double* e = c.w.E + (long long)f * 252 + 9 * j;
     double* o = out + (long long)f * NV;
     const double se = sv * KO_SMOOTH_EULER;
+    auto put = [&](int k, double val) {
+      if (fused) { val = scale * val + keep * o[k]; acc.add(idx, val * val); }
+      o[k] = val;
+    };
     auto euler = [&](int k) {                 // Euler-smoothness rows of unknown k of frame f
       double a = 0;
       if (f < F - 1) a += se * u[c.o7 + f * NV + k];
       if (f >= 1) a -= se * u[c.o7 + (f - 1) * NV + k];
       return a;
     };
-    for (int a = 0; a < 3; ++a) o[3 + 3 * j + a] = e[3 * a] * M[0] + e[3 * a + 1] * M[1] + e[3 * a + 2] * M[2] + euler(3 + 3 * j + a);
-    if (j == 0) for (int k = 0; k < 3; ++k) o[k] = L[3 * ROOT + k] + euler(k);
+    for (int a = 0; a < 3; ++a) put(3 + 3 * j + a, e[3 * a] * M[0] + e[3 * a + 1] * M[1] + e[3 * a + 2] * M[2] + euler(3 + 3 * j + a));
+    if (j == 0) for (int k = 0; k < 3; ++k) put(k, L[3 * ROOT + k] + euler(k));
   }
-  KO_SYNC();
+  if (fused) *sumsq = ko_total(c, acc);
+  else KO_SYNC();
 }
 
 // ---- LSMR (Fong & Saunders 2011, as scipy.sparse.linalg.lsmr with x0 = None) -----------------------------------------------------
@@ -365,25 +409,27 @@ KO_DEV void sym_ortho(double a, double b, double& cc, double& s, double& r) {
 }
 
 // min |J x - b|^2 + damp^2 |x|^2 into c.w.GN; uses U (m), V, H, HB (n).  Returns the iteration count.
+// The Golub-Kahan vectors are kept UNNORMALISED (u = su * U, v = sv * V with the scalars in registers): each half step is one
+// fused product pass, beta u = A v - alpha u  ->  U <- sv * (J V) - (alpha su) * U,  beta = |U|,  su = 1 / beta, and the same for V.
 KO_DEV int kin_lsmr(KinCtx& c, const double* b, double damp, int* istop_out) {
   const long long n = c.q->n, m = c.q->m;
   const KinParams& P = *c.P;
   const int maxiter = P.lsmr_maxiter > 0 ? P.lsmr_maxiter : (int)(m < n ? m : n);
   double *u = c.w.U, *v = c.w.V, *h = c.w.H, *hbar = c.w.HB, *x = c.w.GN;
-  const double normb = std::sqrt(ko_dot(c, b, b, m));
-  double beta = normb, alpha = 0;
-  for (long long i = KO_TID; i < n; i += KO_NT) { x[i] = 0; hbar[i] = 0; }
+  KoAcc s0;
+  for (long long i = KO_TID; i < m; i += KO_NT) { const double t = b[i]; u[i] = t; s0.add(i, t * t); }
+  const double normb = std::sqrt(ko_total(c, s0));
+  double beta = normb, alpha = 0, su = 0, sv = 0;
+  for (long long i = KO_TID; i < n; i += KO_NT) { x[i] = 0; hbar[i] = 0; v[i] = 0; }
+  KO_SYNC();
   if (beta > 0) {
-    const double ib = 1 / beta;
-    for (long long i = KO_TID; i < m; i += KO_NT) u[i] = ib * b[i];
-    KO_SYNC();
-    kin_jtu(c, u, v);
-    alpha = std::sqrt(ko_dot(c, v, v, n));
-  } else {
-    for (long long i = KO_TID; i < n; i += KO_NT) v[i] = 0;
+    su = 1 / beta;
+    double a2 = 0;
+    kin_jtu(c, u, v, su, 0.0, &a2);
+    alpha = std::sqrt(a2);
   }
-  if (alpha > 0) { const double ia = 1 / alpha; for (long long i = KO_TID; i < n; i += KO_NT) v[i] = ia * v[i]; }
-  for (long long i = KO_TID; i < n; i += KO_NT) h[i] = v[i];
+  if (alpha > 0) sv = 1 / alpha;
+  for (long long i = KO_TID; i < n; i += KO_NT) h[i] = sv * v[i];
   KO_SYNC();
   int itn = 0, istop = 0;
   double zetabar = alpha * beta, alphabar = alpha, rho = 1, rhobar = 1, cbar = 1, sbar = 0;
@@ -391,23 +437,17 @@ KO_DEV int kin_lsmr(KinCtx& c, const double* b, double damp, int* istop_out) {
   double normA2 = alpha * alpha, maxrbar = 0, minrbar = 1e100;
   const double ctol = P.conlim > 0 ? 1 / P.conlim : 0;
   if (alpha * beta == 0 || normb == 0) { *istop_out = 0; return 0; }
-  double* jv = c.w.T1;
   while (itn < maxiter) {
     ++itn;
-    kin_jv(c, v, jv);
-    double s2 = 0;
-    for (long long i = KO_TID; i < m; i += KO_NT) { const double t = u[i] * (-alpha) + jv[i]; u[i] = t; s2 += t * t; }
-    beta = std::sqrt(ko_sum(c, s2));
+    double b2 = 0;
+    kin_jv(c, v, u, sv, -alpha * su, &b2);
+    beta = std::sqrt(b2);
     if (beta > 0) {
-      const double ib = 1 / beta;
-      for (long long i = KO_TID; i < m; i += KO_NT) u[i] *= ib;
-      KO_SYNC();
-      double* jt = c.w.XN;                       // (free while LSMR runs)
-      kin_jtu(c, u, jt);
-      double s3 = 0;
-      for (long long i = KO_TID; i < n; i += KO_NT) { const double t = v[i] * (-beta) + jt[i]; v[i] = t; s3 += t * t; }
-      alpha = std::sqrt(ko_sum(c, s3));
-      if (alpha > 0) { const double ia = 1 / alpha; for (long long i = KO_TID; i < n; i += KO_NT) v[i] *= ia; }
+      su = 1 / beta;
+      double a2 = 0;
+      kin_jtu(c, u, v, su, -beta * sv, &a2);
+      alpha = std::sqrt(a2);
+      if (alpha > 0) sv = 1 / alpha;
     }
     double chat, shat, alphahat, cc, s, ctildeold, stildeold, rhotildeold;
     sym_ortho(alphabar, damp, chat, shat, alphahat);
@@ -420,15 +460,15 @@ KO_DEV int kin_lsmr(KinCtx& c, const double* b, double damp, int* istop_out) {
     zeta = cbar * zetabar;
     zetabar = -sbar * zetabar;
     const double k1 = -(thetabar * rho / (rhoold * rhobarold)), k2 = zeta / (rho * rhobar), k3 = -(thetanew / rho);
-    double sx = 0;
+    KoAcc sx;
     for (long long i = KO_TID; i < n; i += KO_NT) {
       const double hb = hbar[i] * k1 + h[i];
       hbar[i] = hb;
       const double xi = x[i] + k2 * hb;
-      x[i] = xi; sx += xi * xi;
-      h[i] = h[i] * k3 + v[i];
+      x[i] = xi; sx.add(i, xi * xi);
+      h[i] = h[i] * k3 + sv * v[i];
     }
-    const double normx = std::sqrt(ko_sum(c, sx));
+    const double normx = std::sqrt(ko_total(c, sx));
     const double betaacute = chat * betadd, betacheck = -shat * betadd;
     const double betahat = cc * betaacute;
     betadd = -s * betaacute;
@@ -554,20 +594,23 @@ KO_DEV void kin_solve(KinCtx& c, double* xio, double* stats) {
     for (long long i = KO_TID; i < n; i += KO_NT) w.S1[i] = w.GN[i] - pr * w.S0[i];
     KO_SYNC();
     pr = ko_dot(c, w.S0, w.S1, n);            // second pass
-    double s1 = 0;
-    for (long long i = KO_TID; i < n; i += KO_NT) { const double t = w.S1[i] - pr * w.S0[i]; w.S1[i] = t; s1 += t * t; }
-    s1 = std::sqrt(ko_sum(c, s1));
+    KoAcc s1a;
+    for (long long i = KO_TID; i < n; i += KO_NT) { const double t = w.S1[i] - pr * w.S0[i]; w.S1[i] = t; s1a.add(i, t * t); }
+    const double s1 = std::sqrt(ko_total(c, s1a));
     const double is1 = s1 > 0 ? 1 / s1 : 0.0;
     for (long long i = KO_TID; i < n; i += KO_NT) w.S1[i] *= is1;
     KO_SYNC();
     kin_jv(c, w.S0, w.T1);
     kin_jv(c, w.S1, w.T2);
-    double B00 = 0, B01 = 0, B11 = 0;
-    for (long long i = KO_TID; i < m; i += KO_NT) { B00 += w.T1[i] * w.T1[i]; B01 += w.T1[i] * w.T2[i]; B11 += w.T2[i] * w.T2[i]; }
-    ko_sum3(c, B00, B01, B11);
-    double gS0 = 0, gS1 = 0, dummy = 0;
-    for (long long i = KO_TID; i < n; i += KO_NT) { gS0 += w.S0[i] * w.G[i]; gS1 += w.S1[i] * w.G[i]; }
-    ko_sum3(c, gS0, gS1, dummy);
+    double B00, B01, B11, gS0, gS1, dummy;
+    {
+      KoAcc a00, a01, a11;
+      for (long long i = KO_TID; i < m; i += KO_NT) { a00.add(i, w.T1[i] * w.T1[i]); a01.add(i, w.T1[i] * w.T2[i]); a11.add(i, w.T2[i] * w.T2[i]); }
+      ko_total3(c, a00, a01, a11, B00, B01, B11);
+      KoAcc g0, g1, z;
+      for (long long i = KO_TID; i < n; i += KO_NT) { g0.add(i, w.S0[i] * w.G[i]); g1.add(i, w.S1[i] * w.G[i]); }
+      ko_total3(c, g0, g1, z, gS0, gS1, dummy);
+    }
     double actual = -1, cost_new = cost;
     while (actual <= 0 && nfev < P.max_nfev) {
       double p0, p1;
@@ -578,10 +621,13 @@ KO_DEV void kin_solve(KinCtx& c, double* xio, double* stats) {
       KO_SYNC();
       kin_residual(c, w.XN, w.PN, w.RGN, w.FN);
       ++nfev;
-      double cn = 0, bad = 0, xx = 0;
-      for (long long i = KO_TID; i < m; i += KO_NT) { const double t = w.FN[i]; cn += t * t; if (!(std::fabs(t) <= 1.79e308)) bad += 1; }
-      for (long long i = KO_TID; i < n; i += KO_NT) xx += w.X[i] * w.X[i];
-      ko_sum3(c, cn, bad, xx);
+      double cn, bad, xx;
+      {
+        KoAcc acn, abad, axx;
+        for (long long i = KO_TID; i < m; i += KO_NT) { const double t = w.FN[i]; acn.add(i, t * t); if (!(std::fabs(t) <= 1.79e308)) abad.add(i, 1.0); }
+        for (long long i = KO_TID; i < n; i += KO_NT) axx.add(i, w.X[i] * w.X[i]);
+        ko_total3(c, acn, abad, axx, cn, bad, xx);
+      }
       if (bad > 0) { Delta = 0.25 * step_norm; continue; }
       cost_new = 0.5 * cn;
       actual = cost - cost_new;

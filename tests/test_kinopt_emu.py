@@ -3,12 +3,17 @@
 the REFERENCE's own functions produced (tests/golden/kinopt_golden.npz).  The GPU twin is tests/test_kinopt_gpu.py.
 
 Tolerances.  The reference's quaternion constructor divides a unit axis by (1 + 1e-10) (Quaternions.py:394-399); the kernel uses
-exact rotation matrices, so residuals and Jacobian products agree with the reference to ~1e-9, not 1e-15.  LSMR amplifies that:
-5e-11 after 5 iterations, 2e-5 after 25, 2e-3 after 100, and the reference runs it to its limit of 87 F iterations.  So
+exact rotation matrices, so residuals and Jacobian products agree with the reference to ~1e-9, not 1e-15.  LSMR amplifies any
+difference -- 1e-10 after 5 iterations, 1e-4 after 25, 1e-2 after 100 (SciPy's own sparse and dense products differ that
+much) -- and the reference runs it to its limit of 87 F iterations, where the variants have come back to within ~1e-3.  So
  * with LSMR cut to 3 (8) iterations per trust-region iteration the whole 50-evaluation solve must take the oracle's path (same
    evaluation counts, same termination) and end within 1e-8 of it: the algorithm is the same;
- * with SciPy's settings the solution must match the reference's to 2e-3 (the same spread a 1e-10 perturbation of the INPUT
-   causes in the oracle itself: test_the_reference_solve_is_this_sensitive)."""
+ * with SciPy's settings the solutions must match the reference's to 5e-4 (the oracle under a 1e-10 perturbation of its input,
+   or SciPy with dense instead of sparse products, moves by up to 1e-4: tests/test_kinopt_oracle.py).
+What it took to get there: the accuracy of the norms.  With one running sum per norm (the emulation's single thread, before it
+modelled the workgroup's 512 partial sums + butterfly) the Golub-Kahan vectors lose orthogonality faster, LSMR is 5 % away from
+the others' iterate at its iteration limit and the final solutions differ by 1e-3..3e-3 -- the product's sums are the
+workgroup's tree sums, and the emulation reproduces them lane for lane."""
 import os
 import sys
 
@@ -102,7 +107,7 @@ def test_bounded_lsmr_solve_matches_the_oracle(gold):
 
 def test_the_reference_solve_is_this_sensitive(gold):
     """The oracle (which reproduces the reference's arithmetic to 1e-15 at the start point) on an input perturbed by 1e-10:
-    the solution moves by as much as the kernel's differs from the reference's."""
+    the solution moves by 1e-5..1e-4 -- the floor under any implementation's distance to the reference."""
     from oracle import kinopt_oracle as ko
     p, q = problem(gold, 0, 0)
     P = ko.Problem(p['offsets'], gold['c0_skel_parents'], p['pose3d'], p['root_trans'], p['pose2d_n'], p['proj_w'], p['data_w'], p['contact'], p['floor_n'], p['floor_p'],
@@ -110,16 +115,16 @@ def test_the_reference_solve_is_this_sensitive(gold):
     rng = np.random.default_rng(0)
     xa = ko.trf_lsmr(P.fun, P.jac, p['x0'])[0]
     xb = ko.trf_lsmr(P.fun, P.jac, p['x0'] * (1 + 1e-10 * rng.normal(size=p['x0'].size)))[0]
-    assert rel(xb, xa) > 2e-5
+    assert 2e-6 < rel(xb, xa) < 5e-4
 
 
 def test_every_solve_of_the_fixture_matches_the_reference(gold):
     import kin_emu
     ps = [problem(gold, ci, li) for ci in range(3) for li in range(2)]
     for (p, q), r in zip(ps, kin_emu.solve([p for p, _ in ps])):
-        assert rel(r['x'], gold[q + 'x']) < 2e-3
-        assert abs(r['cost'] - float(gold[q + 'cost'])) < 0.06 * float(gold[q + 'cost'])
-        assert r['status'] == int(gold[q + 'status']) and abs(r['nfev'] - int(gold[q + 'nfev'])) <= 3
+        assert rel(r['x'], gold[q + 'x']) < 5e-4
+        assert abs(r['cost'] - float(gold[q + 'cost'])) < 5e-3 * float(gold[q + 'cost'])
+        assert r['status'] == int(gold[q + 'status']) and abs(r['nfev'] - int(gold[q + 'nfev'])) <= 1
 
 
 def test_whole_optimisation_and_its_files(gold, tmp_path):
@@ -131,10 +136,10 @@ def test_whole_optimisation_and_its_files(gold, tmp_path):
         s = np.sign((r['ik_rot'] * g[k + 'ik_rot']).sum(-1, keepdims=True))
         assert rel(r['ik_rot'] * s, g[k + 'ik_rot']) < 1e-10                     # IK initialisation
         assert np.array_equal(r['velConstraints'], g[k + 'out_vel'])             # relabelled contacts: exact
-        assert np.abs(r['plane_normal'] - g[k + 'out_floor_n']).max() < 2e-2      # (a plane through two nearly static feet: 1 mm of foot position = 0.5 degrees)
-        assert np.abs(r['plane_point'] - g[k + 'out_floor_p']).max() < 3.0       # centimetres, the plane's height under the camera 3 m from the feet
-        assert rel(r['pose3d'], g[k + 'out_pose3d']) < 5e-3 and rel(r['proj2d'], g[k + 'out_proj2d']) < 5e-3       # two chained solves: ~1 cm at 3.3 m
-        assert rel(r['motion'].positions, g[k + 'out_pos']) < 5e-3
+        assert np.abs(r['plane_normal'] - g[k + 'out_floor_n']).max() < 2e-3
+        assert np.abs(r['plane_point'] - g[k + 'out_floor_p']).max() < 0.5       # centimetres, the plane's height under the camera 3 m from the feet
+        assert rel(r['pose3d'], g[k + 'out_pose3d']) < 2e-3 and rel(r['proj2d'], g[k + 'out_proj2d']) < 2e-3       # two chained solves
+        assert rel(r['motion'].positions, g[k + 'out_pos']) < 2e-3
         out = str(tmp_path / ('clip%d' % ci))
         kopt.save_results(out, r, ['j%d' % j for j in range(28)])
         fc = np.load(os.path.join(out, 'foot_contacts.npy'))

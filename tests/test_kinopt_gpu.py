@@ -46,9 +46,10 @@ def test_every_solve_of_the_fixture_matches_the_reference(gold):
     solver = kopt.KinSolver(device=0)
     res = solver.solve([p for p, _ in ps] * 3)                 # 18 workgroups; the three copies must agree bit for bit
     for i, ((p, q), r) in enumerate(zip(ps, res)):
-        assert rel(r['x'], gold[q + 'x']) < 2e-3
-        assert abs(r['cost'] - float(gold[q + 'cost'])) < 0.06 * float(gold[q + 'cost'])
-        assert r['status'] == int(gold[q + 'status']) and abs(r['nfev'] - int(gold[q + 'nfev'])) <= 3
+        assert rel(r['x'], gold[q + 'x']) < 5e-4
+        assert abs(r['cost'] - float(gold[q + 'cost'])) < 5e-3 * float(gold[q + 'cost'])
+        assert r['status'] == int(gold[q + 'status']) and abs(r['nfev'] - int(gold[q + 'nfev'])) <= 1
+        print('%s  x rel %.2e  cost %.3f (reference %.3f)  nfev %d (%d)  LSMR iterations %d' % (q, rel(r['x'], gold[q + 'x']), r['cost'], float(gold[q + 'cost']), r['nfev'], int(gold[q + 'nfev']), r['lsmr_iterations']))
         for rep in (1, 2):
             assert np.array_equal(res[i + rep * len(ps)]['x'], r['x'])
     assert solver.last_kernel_ms() > 0
@@ -62,7 +63,8 @@ def test_whole_optimisation_on_gpu(gold, tmp_path):
         s = np.sign((r['ik_rot'] * g[k + 'ik_rot']).sum(-1, keepdims=True))
         assert rel(r['ik_rot'] * s, g[k + 'ik_rot']) < 1e-10
         assert np.array_equal(r['velConstraints'], g[k + 'out_vel'])
-        assert np.abs(r['plane_normal'] - g[k + 'out_floor_n']).max() < 2e-2 and np.abs(r['plane_point'] - g[k + 'out_floor_p']).max() < 3.0
-        assert rel(r['pose3d'], g[k + 'out_pose3d']) < 5e-3 and rel(r['proj2d'], g[k + 'out_proj2d']) < 5e-3
+        assert np.abs(r['plane_normal'] - g[k + 'out_floor_n']).max() < 2e-3 and np.abs(r['plane_point'] - g[k + 'out_floor_p']).max() < 0.5
+        assert rel(r['pose3d'], g[k + 'out_pose3d']) < 2e-3 and rel(r['proj2d'], g[k + 'out_proj2d']) < 2e-3
+        print('clip %d  floor normal %.1e  pose3d %.1e  proj2d %.1e' % (ci, np.abs(r['plane_normal'] - g[k + 'out_floor_n']).max(), rel(r['pose3d'], g[k + 'out_pose3d']), rel(r['proj2d'], g[k + 'out_proj2d'])))
         kopt.save_results(str(tmp_path / ('clip%d' % ci)), r, ['j%d' % j for j in range(28)])
         assert np.array_equal(np.load(str(tmp_path / ('clip%d' % ci) / 'foot_contacts.npy')), kopt.refined_contacts(g[k + 'out_vel']))

@@ -63,6 +63,8 @@ if __name__ == '__main__':
     FO = int(sys.argv[3]) if len(sys.argv) > 3 else 12
     clips = [make_clip(s, F) for s in range(B)]
     opt = kopt.KinematicOptimizer(device=0)
+    if os.environ.get('KIN_THREADS'):
+        opt.kin.cfg.reserved[0] = int(os.environ['KIN_THREADS'])
     opt.optimize([make_clip(10_000, 8)])                      # warm-up (module load)
     kin_ms = []
     real_solve = opt.kin.solve
