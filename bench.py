@@ -162,6 +162,42 @@ def contact_net_rate(device, n_videos=128, frames=FRAMES, reps=20):
     return out
 
 
+def kinematic_optimisation_rate(device_index, n_clips=64, frames=30):
+    """Next row in front of the physics stage (DESIGN.md "Rank 3"): the reference's `optimize_trajectory`
+    for a batch of synthetic clips -- IK initialisation on libchd_ik.so, the two least-squares solves on libchd_kinopt.so, floor fit
+    on the host -- and, as the parity figure, the three clips of the committed fixture against the REFERENCE's own results."""
+    from chd_amd import kinematic_optimizer as kopt
+    from chd_amd.synth import make_kin_clip
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'kinopt_golden.npz'))
+    opt = kopt.KinematicOptimizer(device=device_index)
+    gold = []
+    for ci in range(int(g['n_cases'])):
+        k = 'c%d_' % ci
+        cl = dict(poses2D=g[k + 'poses2D'], joint_conf_2d=g[k + 'conf'], poses3D=g[k + 'poses3D'], root_pos=g[k + 'root_pos'], joint_angles=g[k + 'joint_angles'],
+                  offsets=g[k + 'skel_offsets'], parents=g[k + 'skel_parents'], ppx=g[k + 'pp'][0], ppy=g[k + 'pp'][1], camFocal=g[k + 'focal'], velConstraints=g[k + 'vel'])
+        if int(g[k + 'given_floor']):
+            cl['plane_normal'] = g[k + 'floor_in_n']; cl['plane_point'] = g[k + 'floor_in_p']
+        gold.append(cl)
+    res = opt.optimize(gold)                       # (also the warm-up)
+    worst = max(float(np.linalg.norm(r['pose3d'] - g['c%d_out_pose3d' % ci]) / np.linalg.norm(g['c%d_out_pose3d' % ci])) for ci, r in enumerate(res))
+    contacts_equal = all(np.array_equal(r['velConstraints'], g['c%d_out_vel' % ci]) for ci, r in enumerate(res))
+    clips = [make_kin_clip(s, frames, g['c0_skel_offsets'], g['c0_skel_parents']) for s in range(n_clips)]
+    ms = []
+    solve = opt.kin.solve
+
+    def timed(problems):
+        r = solve(problems)
+        ms.append(opt.kin.last_kernel_ms())
+        return r
+
+    opt.kin.solve = timed
+    t0 = time.perf_counter(); out = opt.optimize(clips); dt = time.perf_counter() - t0
+    its = float(np.mean([sum(s['lsmr_iterations'] for s in r['stages']) for r in out]))
+    return {'clips': n_clips, 'frames': frames, 'clips_per_s': n_clips / dt, 'least_squares_kernel_ms': ms, 'ik_kernel_ms': opt.ik.last_kernel_ms()[0],
+            'lsmr_iterations_per_clip': its, 'fixture_worst_rel_l2_vs_reference': worst, 'fixture_contacts_equal_reference': bool(contacts_equal),
+            'note': 'outside the timed region; 256 clips x 100 frames: profiles/r02i_kinopt_fused (30.7 clips/s)'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -298,6 +334,10 @@ def main():
                 out['contact_net'] = contact_net_rate(torch.device('cuda', local))
             except Exception as exc:
                 out['contact_net'] = {'error': '%s: %s' % (type(exc).__name__, exc)}
+            try:
+                out['kinematic_optimisation'] = kinematic_optimisation_rate(local)
+            except Exception as exc:
+                out['kinematic_optimisation'] = {'error': '%s: %s' % (type(exc).__name__, exc)}
         print(json.dumps(out), flush=True)
     batch.free()
     solver.close()

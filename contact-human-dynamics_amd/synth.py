@@ -189,3 +189,43 @@ def make_walk(seed=0, F=90, fps=30.0, randomize=True, tilt_deg=0.0, jitter=0.01,
 def make_batch(B, F=90, seed0=0, **kw):
     """BASELINE config 2/3: B independent sequences, seeds seed0..seed0+B-1."""
     return [make_walk(seed=seed0 + i, F=F, **kw) for i in range(B)]
+
+
+def make_kin_clip(seed, F, offsets_template, parents):
+    """A synthetic input of the kinematic optimisation (`optimize_trajectory`'s arguments) on the combined 28-joint skeleton: smooth
+    random joint angles with quiet legs, a swing-knee bend, a root drifting in front of the camera (y down, z forward, centimetres:
+    the monocular-total-capture frame), noisy 3D joints / 2D projections / confidences, alternating foot contacts with one spurious
+    label.  Same recipe as tests/golden/make_kinopt_golden.py.  `offsets_template` / `parents`: the skeleton's rest pose."""
+    from . import kinematic_optimizer as kopt
+    from . import skeleton_io as sio
+    OFFSETS, PARENTS = np.asarray(offsets_template, dtype=np.float64), np.asarray(parents)
+    rng = np.random.default_rng(seed)
+    nj = 28
+    t = np.arange(F)[:, None, None] / 30.0
+    amp = rng.uniform(0.05, 0.35, size=(1, nj, 3)); ph = rng.uniform(0, 2 * np.pi, size=(1, nj, 3)); fr = rng.uniform(0.5, 2.0, size=(1, nj, 3))
+    amp[:, 1:13] = rng.uniform(0.01, 0.04, size=(1, 12, 3))
+    eul = amp * np.sin(2 * np.pi * fr * t + ph)
+    eul[:, 0] += np.array([0.1, 0.4, 0.05])
+    half = F // 2
+    swing = np.sin(np.pi * np.clip((np.arange(F) - half) / max(F - half - 1, 1), 0, 1)) ** 2
+    eul[:, 2, 0] += 0.9 * swing; eul[:, 8, 0] += 0.9 * swing[::-1]
+    rot = sio.quat_from_euler(eul, order='xyz', world=True)
+    offsets = OFFSETS * rng.uniform(0.9, 1.15)
+    root = np.array([20.0, 40.0, 320.0]) + np.arange(F)[:, None] * np.array([1.5, 0.05, -0.8]) * (10.0 / F) + rng.normal(size=(F, 3)) * 0.3
+    pos = np.repeat(offsets[None], F, axis=0); pos[:, 0] = root
+    gp = sio.positions_global(sio.Motion(rot, pos, np.tile([1.0, 0, 0, 0], (nj, 1)), offsets, PARENTS))
+    gabs = gp[:, kopt.BACKWARD_MAPPING]
+    p3 = gabs - root[:, None] + rng.normal(size=gabs.shape) * 1.5
+    p3[:, kopt.ROOT_IDX] = 0.0
+    focal = np.array([2000.0, 2000.0])
+    p2 = np.stack([focal[0] * gabs[..., 0] / gabs[..., 2] + 960.0, focal[1] * gabs[..., 1] / gabs[..., 2] + 540.0], axis=2) + rng.normal(size=(F, nj, 2)) * 3.0
+    conf = rng.uniform(0.3, 1.0, size=(F, nj)); conf[rng.uniform(size=(F, nj)) < 0.05] = 0.0
+    p2[:, 25:] = 0.0; conf[:, 25:] = 0.0
+    ang = 2.0 * np.arccos(np.clip(rot[..., 0], -1, 1))
+    ax = rot[..., 1:] / np.maximum(np.linalg.norm(rot[..., 1:], axis=-1, keepdims=True), 1e-12)
+    vel = np.zeros((F, nj))
+    vel[:half + 1, 19] = 1; vel[:half + 1, 20] = 1; vel[:half, 21] = 1
+    vel[half:, 22] = 1; vel[half:, 23] = 1; vel[half + 1:, 24] = 1
+    vel[half + (F - half) // 2, 21] = 1
+    return dict(poses2D=p2, joint_conf_2d=conf, poses3D=p3, root_pos=root + rng.normal(size=root.shape), joint_angles=-(ax * ang[..., None]) + rng.normal(size=(F, nj, 3)) * 0.03,
+                offsets=OFFSETS, parents=PARENTS, ppx=960.0, ppy=540.0, camFocal=focal, velConstraints=vel)
