@@ -166,6 +166,7 @@ def kinematic_optimisation_rate(device_index, n_clips=64, frames=30):
     """Next row in front of the physics stage (DESIGN.md "Rank 3"): the reference's `optimize_trajectory`
     for a batch of synthetic clips -- IK initialisation on libchd_ik.so, the two least-squares solves on libchd_kinopt.so, floor fit
     on the host -- and, as the parity figure, the three clips of the committed fixture against the REFERENCE's own results."""
+    import numpy as np
     from chd_amd import kinematic_optimizer as kopt
     from chd_amd.synth import make_kin_clip
     g = np.load(os.path.join(ROOT, 'tests', 'golden', 'kinopt_golden.npz'))
