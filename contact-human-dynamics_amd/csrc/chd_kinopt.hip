@@ -19,14 +19,15 @@ int fail(const std::string& what, hipError_t e = hipSuccess) {
 }  // namespace
 
 __global__ void __launch_bounds__(512) chd_kin_solve_kernel(const KinSeq* seqs, KinParams P, const double* dpool, const int* ipool, double* work,
-                                                            double* state, double* stats) {
+                                                            double* state, double* stats, int lds_doubles) {
+  extern __shared__ double tile[];              // the products' frame tiles
   __shared__ double red[48];
   __shared__ KinParams Ps;
   if (threadIdx.x == 0) Ps = P;
   __syncthreads();
   KinCtx c;
   const KinSeq* q = seqs + blockIdx.x;
-  kin_bind(c, q, &Ps, dpool, ipool, work, red);
+  kin_bind(c, q, &Ps, dpool, ipool, work, red, tile, lds_doubles);
   kin_solve(c, state + q->o_x, stats + 8 * blockIdx.x);
 }
 
@@ -71,7 +72,10 @@ int chd_kin_solve_batch(const chd_kin_config* cfg, int device, int B, chd_kin_se
   // 512 threads: measured against 256 and 1024 (profiles/r02h_kinopt/sweep.md); results are bitwise reproducible for a fixed
   // workgroup size (fixed reduction trees) and move at the solve's own sensitivity level when it changes
   const int nthreads = cfg->reserved[0] == 256 ? 256 : 512;
-  hipLaunchKernelGGL(chd_kin_solve_kernel, dim3((unsigned)B), dim3((unsigned)nthreads), 0, 0, d_seqs, bt.P, d_dp, d_ip, d_work, d_state, d_stats);
+  // 72 KB of LDS per workgroup (two workgroups per compute unit): tiles of 34 frames for J v, 27 for J^T u
+  const int lds_doubles = cfg->reserved[1] > 0 ? cfg->reserved[1] : 9216;
+  KIN_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chd_kin_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * lds_doubles)), "hipFuncSetAttribute");
+  hipLaunchKernelGGL(chd_kin_solve_kernel, dim3((unsigned)B), dim3((unsigned)nthreads), sizeof(double) * (size_t)lds_doubles, 0, d_seqs, bt.P, d_dp, d_ip, d_work, d_state, d_stats, lds_doubles);
   KIN_TRY(hipGetLastError(), "launch");
   KIN_TRY(hipEventRecord(ev1, 0), "hipEventRecord");
   KIN_TRY(hipDeviceSynchronize(), "synchronize");

@@ -79,19 +79,18 @@ struct KinSeq {
 };
 
 KO_HD int rows_of(int F) { return 507 * F - 423; }      // 56F + 84(F-1) + 84(F-2) + 84F + 84(F-1) + 28F + 87(F-1)
-KO_HD long long work_doubles(int F) { return 9LL * NV * F + 5LL * rows_of(F) + 1176LL * F + 64; }
+KO_HD long long work_doubles(int F) { return 9LL * NV * F + 5LL * rows_of(F) + 1008LL * F + 64; }
 
 // views into a video's workspace
 struct KinWork {
   double *X, *XN, *G, *GN, *V, *H, *HB, *S0, *S1;      // n
   double *Fv, *FN, *U, *T1, *T2;                         // m
-  double *P, *E, *C, *RG, *PN, *RGN, *W, *DY;            // per frame: 84, 252, 84, 252, 84, 252, 84, 84
+  double *P, *E, *C, *RG, *PN, *RGN;                     // per frame: 84, 252, 84, 252, 84, 252
   KO_HD void carve(double* b, int F) {
     const long long n = (long long)NV * F, m = rows_of(F);
     X = b; b += n; XN = b; b += n; G = b; b += n; GN = b; b += n; V = b; b += n; H = b; b += n; HB = b; b += n; S0 = b; b += n; S1 = b; b += n;
     Fv = b; b += m; FN = b; b += m; U = b; b += m; T1 = b; b += m; T2 = b; b += m;
-    P = b; b += 84LL * F; E = b; b += 252LL * F; C = b; b += 84LL * F; RG = b; b += 252LL * F; PN = b; b += 84LL * F; RGN = b; b += 252LL * F;
-    W = b; b += 84LL * F; DY = b;
+    P = b; b += 84LL * F; E = b; b += 252LL * F; C = b; b += 84LL * F; RG = b; b += 252LL * F; PN = b; b += 84LL * F; RGN = b;
   }
 };
 
@@ -101,6 +100,7 @@ struct KinCtx {
   const int* contact;
   KinWork w;
   double* red;                   // workgroup reduction scratch (LDS on the device): 3 * 16 doubles
+  double* lds; int lds_doubles;  // the products' frame tiles (LDS on the device)
   int o2, o3, o4, o5, o6, o7;    // first row of each residual term after the projection rows
 };
 
@@ -259,36 +259,18 @@ KO_DEV void kin_linearise(KinCtx& c, const double* x) {
   KO_SYNC();
 }
 
-// ---- out = J v (:51-322 applied to a vector) -----------------------------------------------------------------------------------
+// ---- the two products, matrix free, frame tile by frame tile through LDS -------------------------------------------------------
+// A tile is as many consecutive frames as the workgroup's LDS block holds.  Everything a phase reads more than once -- joint
+// positions, the per-joint angular velocities / position increments (J v), the per-joint multipliers (J^T u) -- lives in LDS
+// for the tile, so the ancestor / descendant walks and the misplaced-root sums are LDS reads, and the intermediates never
+// touch HBM.  J v needs the position increments of frames f, f + 1, f + 2 for the rows of frame f: a tile carries two halo frames.
+
+// out = J v (:51-322 applied to a vector).
 // With `sumsq`: the fused form LSMR's bidiagonalisation needs, out <- scale * (J v) + keep * out in place and *sumsq = |out|^2
 // (every row has exactly one writer; saves writing J v, reading it back and a separate pass for the norm).
 KO_DEV void kin_jv(KinCtx& c, const double* v, double* out, const double scale = 1.0, const double keep = 0.0, double* sumsq = nullptr) {
   const int F = c.q->F;
-  KO_FOR(idx, F * NJ) {                       // omega_j = sum_a v_{j,a} axis_{j,a}
-    const int f = idx / NJ, j = idx % NJ;
-    const double* e = c.w.E + (long long)f * 252 + 9 * j;
-    const double* vv = v + (long long)f * NV + 3 + 3 * j;
-    for (int k = 0; k < 3; ++k) c.w.W[3 * idx + k] = vv[0] * e[k] + vv[1] * e[3 + k] + vv[2] * e[6 + k];
-  }
-  KO_SYNC();
-  KO_FOR(idx, F * NJ) {                       // dp_t = sum over the strict ancestors j of t of omega_j x (p_t - p_j); stored in data order
-    const int f = idx / NJ, t = idx % NJ;
-    double d[3] = {0, 0, 0};
-    if (t == 0) { for (int k = 0; k < 3; ++k) d[k] = v[(long long)f * NV + k]; }
-    else {
-      const double* Pf = c.w.P + (long long)f * 84;
-      for (int j = c.P->parents[t]; j >= 0; j = c.P->parents[j]) {
-        const double* om = c.w.W + 3 * ((long long)f * NJ + j);
-        const double r0 = Pf[3 * t] - Pf[3 * j], r1 = Pf[3 * t + 1] - Pf[3 * j + 1], r2 = Pf[3 * t + 2] - Pf[3 * j + 2];
-        d[0] += om[1] * r2 - om[2] * r1; d[1] += om[2] * r0 - om[0] * r2; d[2] += om[0] * r1 - om[1] * r0;
-      }
-    }
-    double* o = c.w.DY + 3 * ((long long)f * NJ + FWD[t]);
-    o[0] = d[0]; o[1] = d[1]; o[2] = d[2];
-  }
-  KO_SYNC();
   const double sv = c.q->w[1], sa = c.q->w[2], dw = c.q->w[3], vw = c.q->w[4], fw = c.q->w[5];
-  const double* DY = c.w.DY;
   const bool fused = sumsq != nullptr;
   KoAcc acc;
   long long cur = 0;                          // the loop index the running sum belongs to
@@ -296,107 +278,154 @@ KO_DEV void kin_jv(KinCtx& c, const double* v, double* out, const double scale =
     if (fused) { val = scale * val + keep * out[r]; acc.add(cur, val * val); }
     out[r] = val;
   };
-  KO_FOR(idx, F * NJ) {
-    const int f = idx / NJ, jd = idx % NJ;
-    cur = idx;
-    const double* dy = DY + 3 * (long long)idx;
-    const double* d0 = DY + 3 * (long long)f * NJ;                  // data joint 0: where the reference puts the root's projection derivative
-    const double* dr = DY + 3 * ((long long)f * NJ + ROOT);
-    const double* C = c.w.C + 3 * (long long)idx;
-    const double ex = jd == 0 ? dy[0] : d0[0] + dy[0], ey = jd == 0 ? dy[1] : d0[1] + dy[1], ez = jd == 0 ? dy[2] : d0[2] + dy[2];
-    put(2 * idx, C[0] * ex + C[1] * ez);
-    put(2 * idx + 1, C[0] * ey + C[2] * ez);
-    const bool ct = c.contact[idx] == 1;
-    for (int k = 0; k < 3; ++k) {
-      if (f < F - 1) {
-        put(c.o2 + 3 * idx + k, sv * SMOOTH_W[jd] * SMOOTH_VEL[k] * (dy[k] - dy[3 * NJ + k]));
-        put(c.o5 + 3 * idx + k, ct ? vw * ((dr[k] + dy[k]) - (dr[3 * NJ + k] + dy[3 * NJ + k])) : 0.0);
-      }
-      if (f < F - 2) put(c.o3 + 3 * idx + k, sa * (dy[k] - 2.0 * dy[3 * NJ + k] + dy[6 * NJ + k]));
-      put(c.o4 + 3 * idx + k, dw * c.data_w[idx] * dy[k]);
+  int TF = c.lds_doubles / 252 - 2;
+  if (TF < 1) TF = 1;
+  double* LP = c.lds; double* LW = LP + 84 * (TF + 2); double* LD = LW + 84 * (TF + 2);
+  for (int f0 = 0; f0 < F; f0 += TF) {
+    const int nf = F - f0 < TF ? F - f0 : TF;
+    const int nh = F - f0 < nf + 2 ? F - f0 : nf + 2;                 // with the halo
+    KO_FOR(idx, nh * NJ) {                    // positions into LDS; omega_j = sum_a v_{j,a} axis_{j,a}
+      const int f = f0 + idx / NJ, j = idx % NJ;
+      const double* pp = c.w.P + (long long)f * 84 + 3 * j;
+      const double* e = c.w.E + (long long)f * 252 + 9 * j;
+      const double* vv = v + (long long)f * NV + 3 + 3 * j;
+      const double v0 = vv[0], v1 = vv[1], v2 = vv[2];
+      for (int k = 0; k < 3; ++k) { LP[3 * idx + k] = pp[k]; LW[3 * idx + k] = v0 * e[k] + v1 * e[3 + k] + v2 * e[6 + k]; }
     }
-    double d = 0;
-    for (int k = 0; k < 3; ++k) d += c.q->floor_n[k] * (dr[k] + dy[k]);
-    put(c.o6 + idx, ct ? fw * d : 0.0);
+    KO_SYNC();
+    KO_FOR(idx, nh * NJ) {                    // dp_t = sum over the strict ancestors j of t of omega_j x (p_t - p_j); stored in data order
+      const int fl = idx / NJ, t = idx % NJ;
+      double d[3] = {0, 0, 0};
+      if (t == 0) { for (int k = 0; k < 3; ++k) d[k] = v[(long long)(f0 + fl) * NV + k]; }
+      else {
+        const double* Pf = LP + 84 * fl;
+        const double p0 = Pf[3 * t], p1 = Pf[3 * t + 1], p2 = Pf[3 * t + 2];
+        for (int j = c.P->parents[t]; j >= 0; j = c.P->parents[j]) {
+          const double* om = LW + 84 * fl + 3 * j;
+          const double r0 = p0 - Pf[3 * j], r1 = p1 - Pf[3 * j + 1], r2 = p2 - Pf[3 * j + 2];
+          d[0] += om[1] * r2 - om[2] * r1; d[1] += om[2] * r0 - om[0] * r2; d[2] += om[0] * r1 - om[1] * r0;
+        }
+      }
+      double* o = LD + 84 * fl + 3 * FWD[t];
+      o[0] = d[0]; o[1] = d[1]; o[2] = d[2];
+    }
+    KO_SYNC();
+    KO_FOR(idx, nf * NJ) {                    // the rows of frame f (the reference's order: term by term, frame, joint, coordinate)
+      cur = idx;
+      const int fl = idx / NJ, jd = idx % NJ, f = f0 + fl;
+      const long long gi = (long long)f * NJ + jd;
+      const double* dy = LD + 84 * fl + 3 * jd;
+      const double* d0 = LD + 84 * fl;                               // data joint 0: where the reference puts the root's projection derivative
+      const double* dr = LD + 84 * fl + 3 * ROOT;
+      const double* C = c.w.C + 3 * gi;
+      const double ex = jd == 0 ? dy[0] : d0[0] + dy[0], ey = jd == 0 ? dy[1] : d0[1] + dy[1], ez = jd == 0 ? dy[2] : d0[2] + dy[2];
+      put(2 * gi, C[0] * ex + C[1] * ez);
+      put(2 * gi + 1, C[0] * ey + C[2] * ez);
+      const bool ct = c.contact[gi] == 1;
+      const double dwj = dw * c.data_w[gi];
+      for (int k = 0; k < 3; ++k) {
+        if (f < F - 1) {
+          put(c.o2 + 3 * gi + k, sv * SMOOTH_W[jd] * SMOOTH_VEL[k] * (dy[k] - dy[84 + k]));
+          put(c.o5 + 3 * gi + k, ct ? vw * ((dr[k] + dy[k]) - (dr[84 + k] + dy[84 + k])) : 0.0);
+        }
+        if (f < F - 2) put(c.o3 + 3 * gi + k, sa * (dy[k] - 2.0 * dy[84 + k] + dy[168 + k]));
+        put(c.o4 + 3 * gi + k, dwj * dy[k]);
+      }
+      double d = 0;
+      for (int k = 0; k < 3; ++k) d += c.q->floor_n[k] * (dr[k] + dy[k]);
+      put(c.o6 + gi, ct ? fw * d : 0.0);
+    }
+    KO_FOR(idx, nf * NV) {                    // Euler-angle smoothness rows of the tile's frames
+      cur = idx;
+      const long long g0 = (long long)f0 * NV + idx;
+      if (f0 + idx / NV < F - 1) put(c.o7 + g0, sv * KO_SMOOTH_EULER * (v[g0] - v[g0 + NV]));
+    }
+    KO_SYNC();                                // the next tile overwrites the LDS block
   }
-  KO_FOR(idx, (F - 1) * NV) { cur = idx; put(c.o7 + idx, sv * KO_SMOOTH_EULER * (v[idx] - v[idx + NV])); }
-  if (fused) *sumsq = ko_total(c, acc);      // (its barriers order the stores before the next phase)
-  else KO_SYNC();
+  if (fused) *sumsq = ko_total(c, acc);
 }
 
-// ---- out = J^T u ---------------------------------------------------------------------------------------------------------------
+// out = J^T u.
 // With `sumsq`: out <- scale * (J^T u) + keep * out in place and *sumsq = |out|^2 (one writer per unknown).
 KO_DEV void kin_jtu(KinCtx& c, const double* u, double* out, const double scale = 1.0, const double keep = 0.0, double* sumsq = nullptr) {
   const int F = c.q->F;
   const double sv = c.q->w[1], sa = c.q->w[2], dw = c.q->w[3], vw = c.q->w[4], fw = c.q->w[5];
-  KO_FOR(idx, F * NJ) {                       // lambda of data joint jd of frame f
-    const int f = idx / NJ, jd = idx % NJ;
-    double lam[3] = {0, 0, 0};
-    auto proj = [&](int i2) {                 // projection rows of (f, joint i2 % NJ) acting on a position they reference
-      const double* C = c.w.C + 3 * (long long)i2;
-      const double ux = u[2 * i2], uy = u[2 * i2 + 1];
-      lam[0] += C[0] * ux; lam[1] += C[0] * uy; lam[2] += C[1] * ux + C[2] * uy;
-    };
-    proj(idx);
-    if (jd == 0) for (int j = 1; j < NJ; ++j) proj(f * NJ + j);     // the misplaced root column
-    auto contact_rows = [&](int i2) {         // contact-velocity and floor rows of (f, joint i2 % NJ)
-      const int f2 = i2 / NJ;
-      if (c.contact[i2] == 1) {
-        for (int k = 0; k < 3; ++k) {
-          if (f2 < F - 1) lam[k] += vw * u[c.o5 + 3 * i2 + k];
-          lam[k] += fw * c.q->floor_n[k] * u[c.o6 + i2];
-        }
-      }
-      if (f2 >= 1 && c.contact[i2 - NJ] == 1)
-        for (int k = 0; k < 3; ++k) lam[k] -= vw * u[c.o5 + 3 * (i2 - NJ) + k];
-    };
-    contact_rows(idx);
-    if (jd == ROOT) for (int j = 0; j < NJ; ++j) if (j != ROOT) contact_rows(f * NJ + j);
-    for (int k = 0; k < 3; ++k) {
-      const double s = sv * SMOOTH_W[jd] * SMOOTH_VEL[k];
-      if (f < F - 1) lam[k] += s * u[c.o2 + 3 * idx + k];
-      if (f >= 1) lam[k] -= s * u[c.o2 + 3 * (idx - NJ) + k];
-      if (f < F - 2) lam[k] += sa * u[c.o3 + 3 * idx + k];
-      if (f >= 1 && f - 1 < F - 2) lam[k] -= 2.0 * sa * u[c.o3 + 3 * (idx - NJ) + k];
-      if (f >= 2) lam[k] += sa * u[c.o3 + 3 * (idx - 2 * NJ) + k];
-      lam[k] += dw * c.data_w[idx] * u[c.o4 + 3 * idx + k];
-    }
-    double* o = c.w.DY + 3 * (long long)idx;
-    o[0] = lam[0]; o[1] = lam[1]; o[2] = lam[2];
-  }
-  KO_SYNC();
+  const double se = sv * KO_SMOOTH_EULER;
   const bool fused = sumsq != nullptr;
   KoAcc acc;
-  KO_FOR(idx, F * NJ) {                       // (J^T u)_{j,a} = axis_{j,a} . sum over the strict descendants t of j of (p_t - p_j) x lambda_t
-    const int f = idx / NJ, j = idx % NJ;
-    const double* Pf = c.w.P + (long long)f * 84;
-    const double* L = c.w.DY + 3 * (long long)f * NJ;
-    double M[3] = {0, 0, 0};
-    unsigned mask = c.P->desc[j];
-    for (int t = j + 1; t < NJ; ++t) {
-      if (!((mask >> t) & 1u)) continue;
-      const double* l = L + 3 * FWD[t];
-      const double r0 = Pf[3 * t] - Pf[3 * j], r1 = Pf[3 * t + 1] - Pf[3 * j + 1], r2 = Pf[3 * t + 2] - Pf[3 * j + 2];
-      M[0] += r1 * l[2] - r2 * l[1]; M[1] += r2 * l[0] - r0 * l[2]; M[2] += r0 * l[1] - r1 * l[0];
+  int TF = c.lds_doubles / 336;
+  if (TF < 1) TF = 1;
+  double* LP = c.lds; double* LQ = LP + 84 * TF; double* LR = LQ + 84 * TF; double* LL = LR + 84 * TF;
+  for (int f0 = 0; f0 < F; f0 += TF) {
+    const int nf = F - f0 < TF ? F - f0 : TF;
+    KO_FOR(idx, nf * NJ) {                    // positions; each joint's own projection rows and contact rows acting on a position they reference
+      const int f = f0 + idx / NJ, jd = idx % NJ;
+      const long long gi = (long long)f * NJ + jd;
+      const double* pp = c.w.P + (long long)f * 84 + 3 * jd;       // (LP is in skeleton order: entry jd here is skeleton joint jd)
+      for (int k = 0; k < 3; ++k) LP[3 * idx + k] = pp[k];
+      const double* C = c.w.C + 3 * gi;
+      const double ux = u[2 * gi], uy = u[2 * gi + 1];
+      LQ[3 * idx] = C[0] * ux; LQ[3 * idx + 1] = C[0] * uy; LQ[3 * idx + 2] = C[1] * ux + C[2] * uy;
+      double r[3] = {0, 0, 0};
+      if (c.contact[gi] == 1) {
+        const double uf = fw * u[c.o6 + gi];
+        for (int k = 0; k < 3; ++k) { if (f < F - 1) r[k] += vw * u[c.o5 + 3 * gi + k]; r[k] += c.q->floor_n[k] * uf; }
+      }
+      if (f >= 1 && c.contact[gi - NJ] == 1) for (int k = 0; k < 3; ++k) r[k] -= vw * u[c.o5 + 3 * (gi - NJ) + k];
+      LR[3 * idx] = r[0]; LR[3 * idx + 1] = r[1]; LR[3 * idx + 2] = r[2];
     }
-    const double* e = c.w.E + (long long)f * 252 + 9 * j;
-    double* o = out + (long long)f * NV;
-    const double se = sv * KO_SMOOTH_EULER;
-    auto put = [&](int k, double val) {
-      if (fused) { val = scale * val + keep * o[k]; acc.add(idx, val * val); }
-      o[k] = val;
-    };
-    auto euler = [&](int k) {                 // Euler-smoothness rows of unknown k of frame f
-      double a = 0;
-      if (f < F - 1) a += se * u[c.o7 + f * NV + k];
-      if (f >= 1) a -= se * u[c.o7 + (f - 1) * NV + k];
-      return a;
-    };
-    for (int a = 0; a < 3; ++a) put(3 + 3 * j + a, e[3 * a] * M[0] + e[3 * a + 1] * M[1] + e[3 * a + 2] * M[2] + euler(3 + 3 * j + a));
-    if (j == 0) for (int k = 0; k < 3; ++k) put(k, L[3 * ROOT + k] + euler(k));
+    KO_SYNC();
+    KO_FOR(idx, nf * NJ) {                    // lambda of data joint jd of frame f
+      const int fl = idx / NJ, jd = idx % NJ, f = f0 + fl;
+      const long long gi = (long long)f * NJ + jd;
+      double lam[3];
+      for (int k = 0; k < 3; ++k) lam[k] = LQ[3 * idx + k] + LR[3 * idx + k];
+      if (jd == 0) for (int j = 1; j < NJ; ++j) for (int k = 0; k < 3; ++k) lam[k] += LQ[84 * fl + 3 * j + k];                      // the misplaced root column
+      if (jd == ROOT) for (int j = 0; j < NJ; ++j) if (j != ROOT) for (int k = 0; k < 3; ++k) lam[k] += LR[84 * fl + 3 * j + k];   // root + joint in the contact rows
+      const double dwj = dw * c.data_w[gi];
+      for (int k = 0; k < 3; ++k) {
+        const double s = sv * SMOOTH_W[jd] * SMOOTH_VEL[k];
+        if (f < F - 1) lam[k] += s * u[c.o2 + 3 * gi + k];
+        if (f >= 1) lam[k] -= s * u[c.o2 + 3 * (gi - NJ) + k];
+        if (f < F - 2) lam[k] += sa * u[c.o3 + 3 * gi + k];
+        if (f >= 1 && f - 1 < F - 2) lam[k] -= 2.0 * sa * u[c.o3 + 3 * (gi - NJ) + k];
+        if (f >= 2) lam[k] += sa * u[c.o3 + 3 * (gi - 2 * NJ) + k];
+        lam[k] += dwj * u[c.o4 + 3 * gi + k];
+      }
+      LL[3 * idx] = lam[0]; LL[3 * idx + 1] = lam[1]; LL[3 * idx + 2] = lam[2];
+    }
+    KO_SYNC();
+    KO_FOR(idx, nf * NJ) {                    // (J^T u)_{j,a} = axis_{j,a} . sum over the strict descendants t of j of (p_t - p_j) x lambda_t
+      const int fl = idx / NJ, j = idx % NJ, f = f0 + fl;
+      const double* Pf = LP + 84 * fl;
+      const double* L = LL + 84 * fl;
+      const double q0 = Pf[3 * j], q1 = Pf[3 * j + 1], q2 = Pf[3 * j + 2];
+      double M[3] = {0, 0, 0};
+      const unsigned mask = c.P->desc[j];
+      for (int t = j + 1; t < NJ; ++t) {
+        if (!((mask >> t) & 1u)) continue;
+        const double* l = L + 3 * FWD[t];
+        const double r0 = Pf[3 * t] - q0, r1 = Pf[3 * t + 1] - q1, r2 = Pf[3 * t + 2] - q2;
+        M[0] += r1 * l[2] - r2 * l[1]; M[1] += r2 * l[0] - r0 * l[2]; M[2] += r0 * l[1] - r1 * l[0];
+      }
+      const double* e = c.w.E + (long long)f * 252 + 9 * j;
+      double* o = out + (long long)f * NV;
+      auto put = [&](int k, double val) {
+        if (fused) { val = scale * val + keep * o[k]; acc.add(idx, val * val); }
+        o[k] = val;
+      };
+      auto euler = [&](int k) {               // Euler-smoothness rows of unknown k of frame f
+        double a = 0;
+        if (f < F - 1) a += se * u[c.o7 + f * NV + k];
+        if (f >= 1) a -= se * u[c.o7 + (f - 1) * NV + k];
+        return a;
+      };
+      for (int a = 0; a < 3; ++a) put(3 + 3 * j + a, e[3 * a] * M[0] + e[3 * a + 1] * M[1] + e[3 * a + 2] * M[2] + euler(3 + 3 * j + a));
+      if (j == 0) for (int k = 0; k < 3; ++k) put(k, L[3 * ROOT + k] + euler(k));
+    }
+    KO_SYNC();
   }
   if (fused) *sumsq = ko_total(c, acc);
-  else KO_SYNC();
 }
 
 // ---- LSMR (Fong & Saunders 2011, as scipy.sparse.linalg.lsmr with x0 = None) -----------------------------------------------------
@@ -662,14 +691,14 @@ KO_DEV void kin_solve(KinCtx& c, double* xio, double* stats) {
   KO_SYNC();
 }
 
-KO_DEV void kin_bind(KinCtx& c, const KinSeq* q, const KinParams* P, const double* dpool, const int* ipool, double* work, double* red) {
+KO_DEV void kin_bind(KinCtx& c, const KinSeq* q, const KinParams* P, const double* dpool, const int* ipool, double* work, double* red, double* lds, int lds_doubles) {
   c.q = q; c.P = P;
   const int F = q->F;
   const double* d = dpool + q->o_const;
   c.offs = d; d += 84; c.pose3d = d; d += 84LL * F; c.root_trans = d; d += 3LL * F; c.pose2d = d; d += 56LL * F; c.proj_w = d; d += 28LL * F; c.data_w = d;
   c.contact = ipool + q->o_contact;
   c.w.carve(work + q->o_work, F);
-  c.red = red;
+  c.red = red; c.lds = lds; c.lds_doubles = lds_doubles;
   c.o2 = 56 * F; c.o3 = c.o2 + 84 * (F - 1); c.o4 = c.o3 + 84 * (F - 2); c.o5 = c.o4 + 84 * F; c.o6 = c.o5 + 84 * (F - 1); c.o7 = c.o6 + 28 * F;
 }
 

@@ -16,10 +16,11 @@ void kin_emu_config_default(chd_kin_config* cfg) { config_default(cfg); }
 int kin_emu_solve_batch(const chd_kin_config* cfg, int B, chd_kin_seq* in) {
   KinBatch bt;
   if (!bt.build(cfg, B, in)) { g_err = bt.err; return 1; }
-  std::vector<double> work((size_t)bt.work_total), stats(8 * (size_t)B), red(48);
+  const int lds_doubles = cfg->reserved[1] > 0 ? cfg->reserved[1] : 9216;
+  std::vector<double> work((size_t)bt.work_total), stats(8 * (size_t)B), red(48), lds((size_t)lds_doubles);
   for (int b = 0; b < B; ++b) {
     KinCtx c;
-    kin_bind(c, &bt.seqs[b], &bt.P, bt.dpool.data(), bt.ipool.data(), work.data(), red.data());
+    kin_bind(c, &bt.seqs[b], &bt.P, bt.dpool.data(), bt.ipool.data(), work.data(), red.data(), lds.data(), lds_doubles);
     kin_solve(c, bt.state.data() + bt.seqs[b].o_x, stats.data() + 8 * b);
   }
   bt.scatter(bt.state.data(), stats.data(), in);
@@ -32,9 +33,10 @@ int kin_emu_solve_batch(const chd_kin_config* cfg, int B, chd_kin_seq* in) {
 int kin_emu_probe(const chd_kin_config* cfg, chd_kin_seq* in, int mode, const double* vec, double* out, double* aux) {
   KinBatch bt;
   if (!bt.build(cfg, 1, in)) { g_err = bt.err; return 1; }
-  std::vector<double> work((size_t)bt.work_total), red(48);
+  const int lds_doubles = cfg->reserved[1] > 0 ? cfg->reserved[1] : 9216;
+  std::vector<double> work((size_t)bt.work_total), red(48), lds((size_t)lds_doubles);
   KinCtx c;
-  kin_bind(c, &bt.seqs[0], &bt.P, bt.dpool.data(), bt.ipool.data(), work.data(), red.data());
+  kin_bind(c, &bt.seqs[0], &bt.P, bt.dpool.data(), bt.ipool.data(), work.data(), red.data(), lds.data(), lds_doubles);
   const double* x = bt.state.data();
   const long long n = bt.seqs[0].n, m = bt.seqs[0].m;
   kin_residual(c, x, c.w.PN, c.w.RGN, c.w.Fv);

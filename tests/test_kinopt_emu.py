@@ -53,6 +53,16 @@ def clip_of(g, ci):
     return cl
 
 
+def plane_gap_at_feet(g, k, r):
+    """|height difference| of the fitted and the reference floor at the centroid of the reference's contact feet."""
+    feet = g[k + 'out_pose3d'][:, 19:25][g[k + 'out_vel'][:, 19:25] == 1]
+    c = feet.mean(axis=0)
+    ya = r['plane_point'][1] - (r['plane_normal'][0] * (c[0] - r['plane_point'][0]) + r['plane_normal'][2] * (c[2] - r['plane_point'][2])) / r['plane_normal'][1]
+    n, p = g[k + 'out_floor_n'], g[k + 'out_floor_p']
+    yb = p[1] - (n[0] * (c[0] - p[0]) + n[2] * (c[2] - p[2])) / n[1]
+    return abs(ya - yb)
+
+
 class EmuIk:
     def solve(self, seqs):
         import ik_emu
@@ -136,8 +146,10 @@ def test_whole_optimisation_and_its_files(gold, tmp_path):
         s = np.sign((r['ik_rot'] * g[k + 'ik_rot']).sum(-1, keepdims=True))
         assert rel(r['ik_rot'] * s, g[k + 'ik_rot']) < 1e-10                     # IK initialisation
         assert np.array_equal(r['velConstraints'], g[k + 'out_vel'])             # relabelled contacts: exact
-        assert np.abs(r['plane_normal'] - g[k + 'out_floor_n']).max() < 2e-3
-        assert np.abs(r['plane_point'] - g[k + 'out_floor_p']).max() < 0.5       # centimetres, the plane's height under the camera 3 m from the feet
+        # the floor: compared where it matters, under the feet (two nearly static feet pin the plane's height there, not its tilt:
+        # 1 mm of foot position turns the normal by 0.5 degrees and moves the plane under the camera, 3 m away, by centimetres)
+        assert plane_gap_at_feet(g, k, r) < 0.1                                  # centimetres
+        assert np.abs(r['plane_normal'] - g[k + 'out_floor_n']).max() < 2e-2
         assert rel(r['pose3d'], g[k + 'out_pose3d']) < 2e-3 and rel(r['proj2d'], g[k + 'out_proj2d']) < 2e-3       # two chained solves
         assert rel(r['motion'].positions, g[k + 'out_pos']) < 2e-3
         out = str(tmp_path / ('clip%d' % ci))
