@@ -196,7 +196,7 @@ def kinematic_optimisation_rate(device_index, n_clips=64, frames=30):
     its = float(np.mean([sum(s['lsmr_iterations'] for s in r['stages']) for r in out]))
     return {'clips': n_clips, 'frames': frames, 'clips_per_s': n_clips / dt, 'least_squares_kernel_ms': ms, 'ik_kernel_ms': opt.ik.last_kernel_ms()[0],
             'lsmr_iterations_per_clip': its, 'fixture_worst_rel_l2_vs_reference': worst, 'fixture_contacts_equal_reference': bool(contacts_equal),
-            'note': 'outside the timed region; 256 clips x 100 frames: profiles/r02i_kinopt_fused (30.7 clips/s)'}
+            'note': 'outside the timed region; 256 clips x 100 frames: profiles/r02j_kinopt_tiled (38.9 clips/s)'}
 
 
 def main():

@@ -35,6 +35,8 @@ if __name__ == '__main__':
     opt = kopt.KinematicOptimizer(device=0)
     if os.environ.get('KIN_THREADS'):
         opt.kin.cfg.reserved[0] = int(os.environ['KIN_THREADS'])
+    if os.environ.get('KIN_LDS_DOUBLES'):
+        opt.kin.cfg.reserved[1] = int(os.environ['KIN_LDS_DOUBLES'])
     opt.optimize([make_clip(10_000, 8)])                      # warm-up (module load)
     kin_ms = []
     real_solve = opt.kin.solve
