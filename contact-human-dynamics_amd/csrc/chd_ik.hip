@@ -1,5 +1,5 @@
 // chd_ik.hip -- C ABI of the IK back-projection step (include/chd_ik.h) on HIP / gfx950.
-// One launch per solver iteration; one workgroup of 128 threads per (video, frame); the state (local rotations and
+// One launch per solver iteration; one workgroup of 128 (<= 16 targets) or 512 threads per (video, frame); the state (local rotations and
 // translations of every joint of every frame) is double-buffered in HBM because a frame reads its neighbours' previous
 // iterate.  See chd_ik_kernels.hpp for the per-frame step and its reference citations.
 #include <hip/hip_runtime.h>
@@ -20,7 +20,7 @@ int fail(const std::string& what, hipError_t e = hipSuccess) {
 }
 }  // namespace
 
-__global__ void __launch_bounds__(128) chd_ik_step_kernel(const IkSeq* seqs, const int* frame_seq, const int* frame_idx, IkParams P,
+__global__ void __launch_bounds__(512) chd_ik_step_kernel(const IkSeq* seqs, const int* frame_seq, const int* frame_idx, IkParams P,
                                                           const int* ipool, const double* dpool, const double* Xin, double* Xout,
                                                           int max_J, int max_T) {
   extern __shared__ double scratch[];          // IkLds::doubles(max_J, max_T) doubles
@@ -75,10 +75,14 @@ int chd_ik_solve_batch(const chd_ik_config* cfg, int device, int B, const chd_ik
   auto drop_events = [&]() { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); };
 #undef IK_TRY
 #define IK_TRY(call, what) if ((e = (call)) != hipSuccess) { drop_events(); release(); return fail(what, e); }
+  // the 3T x 3T elimination dominates a step: 128 threads for the back-projection's 13 targets (39 x 39), 512 for the 25 targets
+  // (75 x 75) of the kinematic optimisation's initialisation -- measured 1 819 / 1 154 / 934 ms for 256 clips x 100 frames x 200
+  // iterations at 128 / 256 / 512 threads, no difference at 13 targets (profiles/r02k_final/ik_threads.md)
+  const unsigned nthreads = bt.max_T > 16 ? 512u : 128u;
   double* cur = d_x0; double* nxt = d_x1;
   IK_TRY(hipEventRecord(ev0, 0), "hipEventRecord");
   for (int it = 0; it < P.iterations; ++it) {
-    hipLaunchKernelGGL(chd_ik_step_kernel, dim3((unsigned)nwg), dim3(128), lds, 0, d_seqs, d_fs, d_fi, P, d_ip, d_dp, cur, nxt, bt.max_J, bt.max_T);
+    hipLaunchKernelGGL(chd_ik_step_kernel, dim3((unsigned)nwg), dim3(nthreads), lds, 0, d_seqs, d_fs, d_fi, P, d_ip, d_dp, cur, nxt, bt.max_J, bt.max_T);
     IK_TRY(hipGetLastError(), "launch");
     double* t = cur; cur = nxt; nxt = t;
   }
