@@ -194,8 +194,13 @@ def kinematic_optimisation_rate(device_index, n_clips=64, frames=30):
     opt.kin.solve = timed
     t0 = time.perf_counter(); out = opt.optimize(clips); dt = time.perf_counter() - t0
     its = float(np.mean([sum(s['lsmr_iterations'] for s in r['stages']) for r in out]))
+    n, m = 87 * frames, 507 * frames - 423
+    alg = 8.0 * (2 * m + 8 * n + 2 * 420 * frames) * its * n_clips          # bytes per LSMR iteration x iterations
     return {'clips': n_clips, 'frames': frames, 'clips_per_s': n_clips / dt, 'least_squares_kernel_ms': ms, 'ik_kernel_ms': opt.ik.last_kernel_ms()[0],
-            'lsmr_iterations_per_clip': its, 'fixture_worst_rel_l2_vs_reference': worst, 'fixture_contacts_equal_reference': bool(contacts_equal),
+            'lsmr_iterations_per_clip': its,
+            'roofline': {'bound': 'hbm', 'kernel': 'chd_kin_solve_kernel', 'achieved': alg / (sum(ms) * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': alg / (sum(ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None},
+            'fixture_worst_rel_l2_vs_reference': worst, 'fixture_contacts_equal_reference': bool(contacts_equal),
             'note': 'outside the timed region; 256 clips x 100 frames: profiles/r02j_kinopt_tiled (38.9 clips/s)'}
 
 
