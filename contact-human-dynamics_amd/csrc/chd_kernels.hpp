@@ -1627,7 +1627,7 @@ CHD_NOINLINE CHD_DEV void ksolve_once(LCtx& c, const GD* rhs, GD* x) {
   LdsD* base = c.lds + LDS_RED;
 #ifndef CHD_HOST_EMU
   const int spk = (bc * (bc + 1) / 2 + 1) & ~1;
-  if (room >= Npad + spk + tsz && c.w >= CHD_SOLVE_NB && c.w - CHD_SOLVE_NB <= 16 * CHD_NQ && c.w - CHD_SOLVE_NB <= CHD_BP * 112) {
+  if (CHD_NT == 512 && room >= Npad + spk + tsz && c.w >= CHD_SOLVE_NB && c.w - CHD_SOLVE_NB <= 16 * CHD_NQ && c.w - CHD_SOLVE_NB <= CHD_BP * 112) {      // (lane-group layout of ksolve_fast: eight wavefronts)
     ksolve_fast(c, rhs, x, base, base + Npad, base + Npad + spk);
     TOC(c, 3);
     return;

@@ -165,11 +165,14 @@ int chd_phys_create(const chd_config* cfg, int device_id, chd_handle** out) {
   hipFuncSetAttribute((const void*)chd_debug_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
   // the factorisation / substitution phases are written for eight wavefronts (wave-specialised look-ahead, register prefetch
   // by lane group): other workgroup sizes are refused rather than silently mis-solved
-  if (h->cfg.threads_per_sequence != 0 && h->cfg.threads_per_sequence != CHD_MAX_THREADS) {
+  // (experiment, profiles/r02k_final/two_workgroups.md: with CHD_EXPERIMENTAL_256 set, 256-thread workgroups -- two per compute unit with
+  //  76 KB of LDS each -- solve correctly through the generic substitution, at 0.8x the throughput)
+  const bool exp256 = h->cfg.threads_per_sequence == 256 && std::getenv("CHD_EXPERIMENTAL_256") != nullptr;
+  if (h->cfg.threads_per_sequence != 0 && h->cfg.threads_per_sequence != CHD_MAX_THREADS && !exp256) {
     std::fprintf(stderr, "chd_phys_create: threads_per_sequence must be 0 or %d\n", CHD_MAX_THREADS);
     (void)hipStreamDestroy(h->stream); delete h; return -7;
   }
-  h->threads = CHD_MAX_THREADS;
+  h->threads = exp256 ? 256 : CHD_MAX_THREADS;
   h->n_wg = h->cfg.max_workgroups > 0 ? h->cfg.max_workgroups : prop.multiProcessorCount;
   if (h->n_wg < 1) h->n_wg = 1;
   if (hipMalloc((void**)&h->d_counter, 64) != hipSuccess) { (void)hipStreamDestroy(h->stream); delete h; return -6; }
