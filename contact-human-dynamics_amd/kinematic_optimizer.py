@@ -216,7 +216,6 @@ class KinematicOptimizer:
             return [dict(offsets=p['offs'], pose3d=cl['poses3D'], root_trans=cl['root_pos'], pose2d_n=p['p2n'], proj_w=p['pw'], data_w=p['dw'],
                          contact=p['vel'], floor_n=p['floor_n'], floor_p=p['floor_p'], weights=STAGE_WEIGHTS[stage], x0=p['x']) for p, cl in zip(prep, clips)]
 
-        stats = []
         r1 = self.kin.solve(problems(0))                                                                         # :660-670
         for p, r in zip(prep, r1):
             p['x'] = r['x']
@@ -225,7 +224,12 @@ class KinematicOptimizer:
             feet_contact = FORWARD_MAPPING[FEET_IDX]
             fv = p['vel'][:, feet_contact]
             feet_pos = gp[:, FEET_IDX][fv == 1]
-            if not p['given']:
+            p['error'] = None
+            if not p['given'] and feet_pos.shape[0] < 3:
+                # (HuberRegressor.fit raises on an empty array and the reference dies with it; here the clip alone is marked and
+                #  finishes without a floor term -- a bad video does not take the batch with it)
+                p['error'] = 'fewer than 3 contact labels: no floor can be fitted'
+            elif not p['given']:
                 p['floor_n'], p['floor_p'], outl = fit_floor(feet_pos)
                 fv = fv.copy()
                 fv[fv == 1] = np.where(outl, 0, 1)                                                               # :755-767 (row-major walk = the reference's loops)
@@ -239,7 +243,7 @@ class KinematicOptimizer:
             proj = np.stack([cl['camFocal'][0] * new3d[..., 0] / new3d[..., 2] + cl['ppx'],
                              cl['camFocal'][1] * new3d[..., 1] / new3d[..., 2] + cl['ppy']], axis=-1)            # :816-830
             out.append(dict(motion=motion, pose3d=new3d, proj2d=proj, plane_normal=p['floor_n'], plane_point=p['floor_p'], velConstraints=p['vel'],
-                            ik_rot=p['ik_rot'], stages=[{k: v for k, v in s.items()} for s in (a, b)]))
+                            ik_rot=p['ik_rot'], stages=[{k: v for k, v in s.items()} for s in (a, b)], error=p['error']))
         return out
 
 
@@ -251,6 +255,8 @@ def refined_contacts(vel):
 
 def save_results(out_dir, result, names):
     """The three files the physics stage reads from `kinematic_results/` (kinematic_optimizer.py:204-219, optimize_trajectory.py:807)."""
+    if result.get('error'):
+        raise ValueError('no kinematic result to save: ' + result['error'])
     os.makedirs(out_dir, exist_ok=True)
     np.save(os.path.join(out_dir, 'foot_contacts'), refined_contacts(result['velConstraints']))
     n, p = result['plane_normal'], result['plane_point']

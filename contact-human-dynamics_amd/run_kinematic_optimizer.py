@@ -62,7 +62,8 @@ def optimize_videos(video_dirs, out_dirs, skel_path, start=0, ends=None, use_gt_
     opt = optimizer if optimizer is not None else kopt.KinematicOptimizer(device=device, parents=skeleton.parents)
     results = opt.optimize(clips)
     for out, r in zip(out_dirs, results):
-        kopt.save_results(out, r, names)
+        if not r.get('error'):
+            kopt.save_results(out, r, names)
     return results
 
 
@@ -95,6 +96,9 @@ def main(argv=None):
     if dirs:
         res = optimize_videos(dirs, outs, args.skel_path, args.start, ends, args.use_gt_floor, device=device)
         for d, r in zip(dirs, res):
+            if r.get('error'):
+                print('%s: FAILED -- %s' % (d, r['error']), flush=True)
+                continue
             print('%s: %d frames, cost %.4f (stage 1) / %.4f (with the floor), floor normal %s' % (d, r['pose3d'].shape[0], r['stages'][0]['cost'], r['stages'][1]['cost'],
                                                                                              np.round(r['plane_normal'], 4)), flush=True)
     print('Finished kinematic optimization!')

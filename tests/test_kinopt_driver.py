@@ -117,6 +117,22 @@ def test_batch_driver_writes_what_the_physics_stage_reads(data_root):
         assert np.abs(sio.positions_global(m)[:, kopt.BACKWARD_MAPPING] - r['pose3d']).max() < 1e-3       # '%f' digits of the file
 
 
+def test_a_clip_without_contacts_loses_only_itself(data_root):
+    """Two contact labels cannot pin a plane: scikit-learn raises inside the reference; here the clip is marked, the other one is solved."""
+    root, clips = data_root
+    d = str(root / 'walk_a')
+    fc = np.zeros_like(np.load(os.path.join(d, 'foot_contacts.npy'))); fc[0, 1] = 1
+    np.save(os.path.join(d, 'foot_contacts.npy'), fc)
+    opt = kopt.KinematicOptimizer(ik=EmuIk(), kin=EmuKin(max_nfev=4, lsmr_maxiter=5))
+    dirs = [d, str(root / 'walk_b')]
+    outs = [os.path.join(x, 'kinematic_results') for x in dirs]
+    res = drv.optimize_videos(dirs, outs, str(root / 'skel.bvh'), 0, [9, 12], optimizer=opt)
+    assert 'contact labels' in res[0]['error'] and res[1]['error'] is None
+    assert not os.path.exists(outs[0]) and os.path.exists(os.path.join(outs[1], 'floor_out.txt'))
+    with pytest.raises(ValueError):
+        kopt.save_results(outs[0], res[0], None)
+
+
 def test_command_line_flags_of_the_reference():
     """scripts/run_phys_mocap.py:103-115 passes --input_path --skel_path --output_path --end --character [--gt-floor] [--visualize]."""
     with pytest.raises(SystemExit):
