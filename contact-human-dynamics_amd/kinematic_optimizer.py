@@ -61,9 +61,10 @@ def build_library(force=False, verbose=False):
 
 
 def load_library():
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get('CHD_KINOPT_LIB', LIB_PATH)          # (another build of the same C ABI: kernel experiments)
+    if not os.path.exists(path):
         raise RuntimeError('libchd_kinopt.so is not built (run __graft_entry__.build()); the kinematic optimisation has no CPU path')
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     lib.chd_kin_version.restype = C.c_char_p
     lib.chd_kin_last_error.restype = C.c_char_p
     lib.chd_kin_last_kernel_ms.restype = C.c_double
