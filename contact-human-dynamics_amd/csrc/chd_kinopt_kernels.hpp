@@ -14,6 +14,12 @@
 //        J v  : omega_j = sum_a v_{j,a} axis_{j,a};  dp_t = sum_{j anc t} omega_j x (p_t - p_j);  rows from dp
 //        J^T u: lambda_t from the rows;  (J^T u)_{j,a} = axis_{j,a} . sum_{t desc j} (p_t - p_j) x lambda_t
 //    with the linearisation (positions, axes, projection coefficients: 420 doubles per frame) cached per accepted point;
+//    both products run frame tile by frame tile through the workgroup's LDS block (kin_jv / kin_jtu), and LSMR's two half steps
+//    are fused into them (kin_lsmr): per iteration HBM sees U read + written, V / H / H-bar / x read + written and the
+//    linearisation read twice -- measured 0.8 .. 1.3 x that (profiles/r02k_final/kinopt_pmc.md);
+//  * every norm is a tree sum over the workgroup's 512 per-thread partial sums (KoAcc): with a single running sum per norm LSMR's
+//    iterate at its iteration limit drifts 5 % away from SciPy's and the solves end 1e-3 .. 3e-3 from the reference's
+//    instead of 1e-4 (tests/test_kinopt_emu.py);
 //  * forward kinematics with rotation matrices instead of quaternions;
 //  * span{g, gn} is orthonormalised by Gram-Schmidt instead of Householder QR (same subspace, so the same step);
 //  * the boundary solution of the 2-D trust-region problem is found on the angle parametrisation (scan + bisection of the
