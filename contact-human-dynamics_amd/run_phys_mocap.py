@@ -4,9 +4,12 @@ Reference: ``scripts/run_phys_mocap.py`` — for every video directory it runs (
 (4) retargeting, writes ``phys_optim_in_<char>/`` and then starts ``./phys_optim`` once per video
 (:159-174).  This driver keeps the flags that concern the physics stage (:13-31, :33-44) and replaces the
 per-video child process by ONE batched call into ``libchd_phys.so`` over all directories (sharded over the
-GPUs of the node when launched with torch.distributed.run).  Kinematic optimisation and retargeting are outside
-this path.  The two stages either side of the solver are optional here:
+GPUs of the node when launched with torch.distributed.run).  Retargeting is outside this path.  The stages
+either side of the solver are optional here:
 
+* ``--kinematic`` runs the kinematic optimisation in front (chd_amd.run_kinematic_optimizer: all videos in one batched solve) and hands
+  its ``final_test.bvh`` on as ``combined_out.bvh`` (run_phys_mocap.py:103-131 for ``--character combined``; other characters need the
+  reference's re-targeting step, which is outside this path);
 * ``--prepare`` writes ``phys_optim_in_<character>/`` from ``kinematic_results/{<character>_out.bvh, floor_out.txt,
   foot_contacts.npy}`` (the ``towr_utils.py --anim ... --out ...`` child process of :137-150; `prepare_input.py`);
   without it the directories must already contain ``phys_optim_in_<character>/``;
@@ -14,7 +17,7 @@ this path.  The two stages either side of the solver are optional
   ``<video>_<character>_{no_dynamics,dynamics,durations}.bvh`` (the ``towr_utils.py --viz --out-bvh`` child process of
   :180-201 without its plots / video; `apply_results.py`, one batched IK launch sequence per solution kind).
 
-Both need the character's joint / segment tables as a JSON file (``--character-json``, fields of
+``--prepare`` and ``--out-bvh`` need the character's joint / segment tables as a JSON file (``--character-json``, fields of
 ``apply_results.Character``); none are baked in.
 """
 import argparse
@@ -38,6 +41,9 @@ def parse_args(argv):
     p.add_argument('--w-smooth', type=float, default=0.1)
     p.add_argument('--w-dur', type=float, default=0.1)
     p.add_argument('--batch', type=int, default=4096, help='most sequences handed to the library in one call (one persistent launch drains them all)')
+    p.add_argument('--kinematic', action='store_true', help='run the kinematic optimisation first (run_phys_mocap.py:103-131): every video directory with openpose_result/, '
+                   'tracked_results.json and foot_contacts.npy gets kinematic_results/; all videos in one batched solve')
+    p.add_argument('--skel-path', default='skeleton_fitting/combined_body_25.bvh', help='template of the combined skeleton for --kinematic (run_phys_mocap.py:106)')
     p.add_argument('--prepare', action='store_true', help='write phys_optim_in_<character>/ from kinematic_results/ first')
     p.add_argument('--out-bvh', action='store_true', help='back-project the solutions onto the skeleton and write BVH files')
     p.add_argument('--character-json', default=None, help='joint / segment tables of the character (apply_results.Character)')
@@ -67,9 +73,30 @@ def main(argv=None):
             raise SystemExit('--prepare / --out-bvh need --character-json')
         from .apply_results import Character
         character = Character.from_json(a.character_json)
+    if a.kinematic:
+        # run_phys_mocap.py:103-131: kinematic optimisation per video, then "re-targeting to character if needed".  Re-targeting
+        # (skeleton_fitting/combined_to_mixamo.py) is outside this path: only the combined skeleton itself goes straight on (:129-131)
+        if a.character != 'combined':
+            raise SystemExit("--kinematic produces the combined skeleton's final_test.bvh; any other --character needs the reference's re-targeting step in between")
+        if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+            raise SystemExit('--kinematic writes kinematic_results/: run it once as a single process (or python -m chd_amd.run_kinematic_optimizer under torch.distributed.run)')
+        import shutil
+        from . import run_kinematic_optimizer as rko
+        kvids = [v for v in vids if all(os.path.exists(os.path.join(a.data, v, q)) for q in ('openpose_result', 'tracked_results.json', 'foot_contacts.npy'))]
+        kdirs = [os.path.join(a.data, v) for v in kvids]
+        kouts = [os.path.join(d, 'kinematic_results') for d in kdirs]
+        res = rko.optimize_videos(kdirs, kouts, a.skel_path, 0, [a.nframes or count_frames(d, None) for d in kdirs])
+        for v, o, r in zip(kvids, kouts, res):
+            if r.get('error'):
+                print('[run_phys_mocap] %s: kinematic optimisation failed -- %s' % (v, r['error']))
+            else:
+                shutil.copyfile(os.path.join(o, 'final_test.bvh'), os.path.join(o, a.character + '_out.bvh'))
     for v in vids:
         vd = os.path.join(a.data, v)
         ind = os.path.join(vd, 'phys_optim_in_' + a.character)
+        if a.prepare and not os.path.exists(os.path.join(vd, 'kinematic_results', a.character + '_out.bvh')):
+            print('[run_phys_mocap] %s: no kinematic_results/%s_out.bvh, skipping' % (v, a.character))
+            continue
         if a.prepare and int(os.environ.get('WORLD_SIZE', '1')) > 1:
             raise SystemExit('--prepare writes the input directories: run it once as a single process, then launch the ranks')
         if a.prepare:

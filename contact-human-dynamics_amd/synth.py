@@ -191,7 +191,7 @@ def make_batch(B, F=90, seed0=0, **kw):
     return [make_walk(seed=seed0 + i, F=F, **kw) for i in range(B)]
 
 
-def make_kin_clip(seed, F, offsets_template, parents):
+def make_kin_clip(seed, F, offsets_template, parents, upright=False):
     """A synthetic input of the kinematic optimisation (`optimize_trajectory`'s arguments) on the combined 28-joint skeleton: smooth
     random joint angles with quiet legs, a swing-knee bend, a root drifting in front of the camera (y down, z forward, centimetres:
     the monocular-total-capture frame), noisy 3D joints / 2D projections / confidences, alternating foot contacts with one spurious
@@ -205,7 +205,7 @@ def make_kin_clip(seed, F, offsets_template, parents):
     amp = rng.uniform(0.05, 0.35, size=(1, nj, 3)); ph = rng.uniform(0, 2 * np.pi, size=(1, nj, 3)); fr = rng.uniform(0.5, 2.0, size=(1, nj, 3))
     amp[:, 1:13] = rng.uniform(0.01, 0.04, size=(1, 12, 3))
     eul = amp * np.sin(2 * np.pi * fr * t + ph)
-    eul[:, 0] += np.array([0.1, 0.4, 0.05])
+    eul[:, 0] += np.array([0.1 + (np.pi if upright else 0.0), 0.4, 0.05])      # upright: the template's legs (along -y) point down in the camera frame (y down), as a person stands
     half = F // 2
     swing = np.sin(np.pi * np.clip((np.arange(F) - half) / max(F - half - 1, 1), 0, 1)) ** 2
     eul[:, 2, 0] += 0.9 * swing; eul[:, 8, 0] += 0.9 * swing[::-1]

@@ -73,3 +73,52 @@ def test_openpose_json_to_bvh_on_one_gpu(tmp_path):
         assert m.n_frames == F and m.n_joints == 20 and names[0] == 'Hips'
         log = open(str(out / 'success_log.txt')).read().split()
         assert log[0] == 'dynamics' and log[1] in '01' and log[2] == 'durations' and log[3] in '01'
+
+
+# the reference's tables of its `combined` character (src/utils/character_info_utils.py:143-160, :181, :255-283): the skeleton the kinematic
+# optimisation works on, which run_phys_mocap.py:129-131 hands to the physics stage without re-targeting
+COMBINED = dict(toe_inds=[5, 11], ankle_inds=[3, 9], upper_body=[0] + list(range(13, 28)), heel_inds=[4, 10], left_leg_chain=[1, 2, 3, 5], hip_inds=[1, 7], mass=73.0,
+                seg_to_joints={'head': [17], 'upper_trunk': [15, 16], 'mid_trunk': [14, 15], 'lower_trunk': [13, 14], 'left_upper_arm': [22, 23], 'left_forearm': [23, 24],
+                               'left_hand': [24], 'left_thigh': [1, 2], 'left_shank': [2, 3], 'left_foot': [3, 4, 5, 6], 'right_upper_arm': [25, 26], 'right_forearm': [26, 27],
+                               'right_hand': [27], 'right_thigh': [7, 8], 'right_shank': [8, 9], 'right_foot': [9, 10, 11, 12]},
+                seg_to_mass_perc={'head': 6.94, 'upper_trunk': 15.96, 'mid_trunk': 16.33, 'lower_trunk': 11.17, 'left_upper_arm': 2.71, 'left_forearm': 1.62, 'left_hand': 0.61,
+                                  'left_thigh': 14.16, 'left_shank': 4.33, 'left_foot': 1.37, 'right_upper_arm': 2.71, 'right_forearm': 1.62, 'right_hand': 0.61,
+                                  'right_thigh': 14.16, 'right_shank': 4.33, 'right_foot': 1.37})
+
+
+def test_kinematic_optimisation_to_bvh_on_one_gpu(tmp_path):
+    """The chain of scripts/run_phys_mocap.py:97-201 for `--character combined`, every stage on the GPU libraries:
+
+        openpose_result/*.json + tracked_results.json + foot_contacts.npy
+            --kinematic (libchd_ik.so, libchd_kinopt.so)--> kinematic_results/{final_test.bvh = combined_out.bvh, floor_out.txt, foot_contacts.npy}
+            --prepare--> phys_optim_in_combined/ --libchd_phys.so--> sol_out_*.txt --out-bvh (libchd_ik.so)--> <video>_combined_*.bvh
+
+    on synthetic clips of a standing-up person (y down, as monocular total capture delivers them)."""
+    from chd_amd import io_formats as iof
+    from chd_amd import run_phys_mocap
+    from chd_amd import skeleton_io as sk
+    from chd_amd.synth import make_kin_clip
+    sys.path.insert(0, HERE)
+    from test_kinopt_driver import write_skeleton, write_video_dir
+    g = np.load(os.path.join(HERE, 'golden', 'kinopt_golden.npz'))
+    rng = np.random.default_rng(8)
+    root = tmp_path / 'data'
+    frames = {'walk_a': 24, 'walk_b': 30}
+    for i, (v, F) in enumerate(frames.items()):
+        write_video_dir(str(root / v), make_kin_clip(i, F, g['c0_skel_offsets'], g['c0_skel_parents'], upright=True), rng)
+    write_skeleton(str(tmp_path / 'skel.bvh'))
+    cj = str(tmp_path / 'combined.json')
+    json.dump(COMBINED, open(cj, 'w'))
+    rc = run_phys_mocap.main(['--data', str(root), '--character', 'combined', '--kinematic', '--skel-path', str(tmp_path / 'skel.bvh'), '--prepare', '--out-bvh', '--character-json', cj])
+    assert rc == 0
+    for v, F in frames.items():
+        kin = root / v / 'kinematic_results'
+        assert open(str(kin / 'combined_out.bvh')).read() == open(str(kin / 'final_test.bvh')).read()
+        assert np.load(str(kin / 'foot_contacts.npy')).shape == (F, 4)
+        out = root / v / 'phys_optim_out_combined'
+        sol = iof.load_results(str(out / 'sol_out_no_dynamics.txt'))
+        assert sol.num_frames == F and np.isfinite(sol.base_lin).all() and np.isfinite(sol.ee_pos).all() and sol.ee_pos.shape[0] == 4
+        log = open(str(out / 'success_log.txt')).read().split()
+        assert log[0] == 'dynamics' and log[1] in '01' and log[2] == 'durations' and log[3] in '01'
+        m, names, _ = sk.load_bvh(str(out / ('%s_combined_no_dynamics.bvh' % v)))
+        assert m.n_frames == F and m.n_joints == 28 and names[0] == 'J00'       # the heels are joints of this skeleton: nothing appended, nothing removed
