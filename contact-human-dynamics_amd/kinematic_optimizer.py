@@ -184,10 +184,23 @@ class KinematicOptimizer:
         self.kin = kin if kin is not None else KinSolver(device, parents=parents)
         self.timings = {}
 
-    def optimize(self, clips):
+    def optimize(self, clips, chunk=256, workers=2):
         """clips: dicts with poses2D (F,28,2), joint_conf_2d (F,28), poses3D (F,28,3), root_pos (F,3), joint_angles (F,28,3),
         offsets (28,3), parents (28,), ppx, ppy, camFocal (2,), velConstraints (F,28) and optionally plane_normal / plane_point --
-        the arguments of optimize_trajectory (:522-526).  Returns one dict per clip (see the end of this function)."""
+        the arguments of optimize_trajectory (:522-526).  Returns one dict per clip (see the end of `_optimize`).
+
+        More than `chunk` clips are processed chunk by chunk on `workers` threads: a chunk of 256 fills the GPU (one workgroup per
+        clip), and while one thread waits in a library call (ctypes releases the interpreter lock) the other does the host steps
+        of its chunk -- bone lengths, floor fits, forward kinematics -- which are a third of the time of a chunk.  The launches of
+        the two threads serialise on the device's default stream; a clip's result does not depend on the chunk it is in."""
+        if len(clips) <= chunk or workers < 2:
+            return self._optimize(clips)
+        from concurrent.futures import ThreadPoolExecutor
+        parts = [clips[i:i + chunk] for i in range(0, len(clips), chunk)]
+        with ThreadPoolExecutor(max_workers=workers) as ex:
+            return [r for part in ex.map(self._optimize, parts) for r in part]
+
+    def _optimize(self, clips):
         prep = []
         for cl in clips:
             F = cl['poses2D'].shape[0]

@@ -117,6 +117,16 @@ def test_batch_driver_writes_what_the_physics_stage_reads(data_root):
         assert np.abs(sio.positions_global(m)[:, kopt.BACKWARD_MAPPING] - r['pose3d']).max() < 1e-3       # '%f' digits of the file
 
 
+def test_chunked_two_thread_pipeline_gives_the_same_results():
+    clips = [make_kin_clip(s, 8, G['c0_skel_offsets'], G['c0_skel_parents']) for s in range(5)]
+    opt = kopt.KinematicOptimizer(ik=EmuIk(), kin=EmuKin(max_nfev=6, lsmr_maxiter=10))
+    a = opt.optimize(clips)
+    b = opt.optimize(clips, chunk=2, workers=2)
+    assert len(b) == 5
+    for x, y in zip(a, b):
+        assert np.array_equal(x['pose3d'], y['pose3d']) and np.array_equal(x['velConstraints'], y['velConstraints']) and np.array_equal(x['plane_normal'], y['plane_normal'])
+
+
 def test_a_clip_without_contacts_loses_only_itself(data_root):
     """Two contact labels cannot pin a plane: scikit-learn raises inside the reference; here the clip is marked, the other one is solved."""
     root, clips = data_root
