@@ -50,53 +50,59 @@ int chd_ik_solve_batch(const chd_ik_config* cfg, int device, int B, const chd_ik
   IkBatch bt;
   if (!bt.build(B, in)) return fail(bt.err);
   const IkParams P = params_of(cfg);
+  // a stream of its own per call (stream-ordered allocations, asynchronous copies, one synchronisation at the end): calls from two host
+  // threads queue back to back on the device instead of waiting for each other's kernels (see chd_kinopt.hip)
   IkSeq* d_seqs = nullptr; int *d_fs = nullptr, *d_fi = nullptr, *d_ip = nullptr; double *d_dp = nullptr, *d_x0 = nullptr, *d_x1 = nullptr;
-  auto release = [&]() { for (void* p : {(void*)d_seqs, (void*)d_fs, (void*)d_fi, (void*)d_ip, (void*)d_dp, (void*)d_x0, (void*)d_x1}) (void)hipFree(p); };
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipStream_t st = nullptr;
+  if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+  auto release = [&]() {
+    for (void* p : {(void*)d_seqs, (void*)d_fs, (void*)d_fi, (void*)d_ip, (void*)d_dp, (void*)d_x0, (void*)d_x1}) if (p) (void)hipFreeAsync(p, st);
+    (void)hipStreamSynchronize(st);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    (void)hipStreamDestroy(st);
+  };
 #define IK_TRY(call, what) if ((e = (call)) != hipSuccess) { release(); return fail(what, e); }
   const size_t nwg = bt.frame_seq.size(), nst = bt.state.size();
-  IK_TRY(hipMalloc(&d_seqs, sizeof(IkSeq) * bt.seqs.size()), "hipMalloc seqs");
-  IK_TRY(hipMalloc(&d_fs, sizeof(int) * nwg), "hipMalloc frame map");
-  IK_TRY(hipMalloc(&d_fi, sizeof(int) * nwg), "hipMalloc frame map");
-  IK_TRY(hipMalloc(&d_ip, sizeof(int) * bt.ipool.size()), "hipMalloc ints");
-  IK_TRY(hipMalloc(&d_dp, sizeof(double) * bt.dpool.size()), "hipMalloc targets");
-  IK_TRY(hipMalloc(&d_x0, sizeof(double) * nst), "hipMalloc state");
-  IK_TRY(hipMalloc(&d_x1, sizeof(double) * nst), "hipMalloc state");
-  IK_TRY(hipMemcpy(d_seqs, bt.seqs.data(), sizeof(IkSeq) * bt.seqs.size(), hipMemcpyHostToDevice), "copy seqs");
-  IK_TRY(hipMemcpy(d_fs, bt.frame_seq.data(), sizeof(int) * nwg, hipMemcpyHostToDevice), "copy frame map");
-  IK_TRY(hipMemcpy(d_fi, bt.frame_idx.data(), sizeof(int) * nwg, hipMemcpyHostToDevice), "copy frame map");
-  IK_TRY(hipMemcpy(d_ip, bt.ipool.data(), sizeof(int) * bt.ipool.size(), hipMemcpyHostToDevice), "copy ints");
-  IK_TRY(hipMemcpy(d_dp, bt.dpool.data(), sizeof(double) * bt.dpool.size(), hipMemcpyHostToDevice), "copy targets");
-  IK_TRY(hipMemcpy(d_x0, bt.state.data(), sizeof(double) * nst, hipMemcpyHostToDevice), "copy state");
+  IK_TRY(hipMallocAsync((void**)&d_seqs, sizeof(IkSeq) * bt.seqs.size(), st), "hipMalloc seqs");
+  IK_TRY(hipMallocAsync((void**)&d_fs, sizeof(int) * nwg, st), "hipMalloc frame map");
+  IK_TRY(hipMallocAsync((void**)&d_fi, sizeof(int) * nwg, st), "hipMalloc frame map");
+  IK_TRY(hipMallocAsync((void**)&d_ip, sizeof(int) * bt.ipool.size(), st), "hipMalloc ints");
+  IK_TRY(hipMallocAsync((void**)&d_dp, sizeof(double) * bt.dpool.size(), st), "hipMalloc targets");
+  IK_TRY(hipMallocAsync((void**)&d_x0, sizeof(double) * nst, st), "hipMalloc state");
+  IK_TRY(hipMallocAsync((void**)&d_x1, sizeof(double) * nst, st), "hipMalloc state");
+  IK_TRY(hipMemcpyAsync(d_seqs, bt.seqs.data(), sizeof(IkSeq) * bt.seqs.size(), hipMemcpyHostToDevice, st), "copy seqs");
+  IK_TRY(hipMemcpyAsync(d_fs, bt.frame_seq.data(), sizeof(int) * nwg, hipMemcpyHostToDevice, st), "copy frame map");
+  IK_TRY(hipMemcpyAsync(d_fi, bt.frame_idx.data(), sizeof(int) * nwg, hipMemcpyHostToDevice, st), "copy frame map");
+  IK_TRY(hipMemcpyAsync(d_ip, bt.ipool.data(), sizeof(int) * bt.ipool.size(), hipMemcpyHostToDevice, st), "copy ints");
+  IK_TRY(hipMemcpyAsync(d_dp, bt.dpool.data(), sizeof(double) * bt.dpool.size(), hipMemcpyHostToDevice, st), "copy targets");
+  IK_TRY(hipMemcpyAsync(d_x0, bt.state.data(), sizeof(double) * nst, hipMemcpyHostToDevice, st), "copy state");
   const size_t lds = sizeof(double) * (size_t)IkLds::doubles(bt.max_J, bt.max_T);      // 26 KB for J = 33, T = 13; 60 KB for the kinematic optimisation (J = 28, T = 25); 78 KB at the size limits
   if (lds > 48 * 1024) IK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chd_ik_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
   IK_TRY(hipEventCreate(&ev0), "hipEventCreate");
-  if ((e = hipEventCreate(&ev1)) != hipSuccess) { (void)hipEventDestroy(ev0); release(); return fail("hipEventCreate", e); }
-  auto drop_events = [&]() { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); };
-#undef IK_TRY
-#define IK_TRY(call, what) if ((e = (call)) != hipSuccess) { drop_events(); release(); return fail(what, e); }
+  IK_TRY(hipEventCreate(&ev1), "hipEventCreate");
   // the 3T x 3T elimination dominates a step: 128 threads for the back-projection's 13 targets (39 x 39), 512 for the 25 targets
   // (75 x 75) of the kinematic optimisation's initialisation -- measured 1 819 / 1 154 / 934 ms for 256 clips x 100 frames x 200
   // iterations at 128 / 256 / 512 threads, no difference at 13 targets (profiles/r02k_final/ik_threads.md)
   const unsigned nthreads = bt.max_T > 16 ? 512u : 128u;
   double* cur = d_x0; double* nxt = d_x1;
-  IK_TRY(hipEventRecord(ev0, 0), "hipEventRecord");
+  IK_TRY(hipEventRecord(ev0, st), "hipEventRecord");
   for (int it = 0; it < P.iterations; ++it) {
-    hipLaunchKernelGGL(chd_ik_step_kernel, dim3((unsigned)nwg), dim3(nthreads), lds, 0, d_seqs, d_fs, d_fi, P, d_ip, d_dp, cur, nxt, bt.max_J, bt.max_T);
+    hipLaunchKernelGGL(chd_ik_step_kernel, dim3((unsigned)nwg), dim3(nthreads), lds, st, d_seqs, d_fs, d_fi, P, d_ip, d_dp, cur, nxt, bt.max_J, bt.max_T);
     IK_TRY(hipGetLastError(), "launch");
     double* t = cur; cur = nxt; nxt = t;
   }
-  IK_TRY(hipEventRecord(ev1, 0), "hipEventRecord");
-  IK_TRY(hipDeviceSynchronize(), "synchronize");
+  IK_TRY(hipEventRecord(ev1, st), "hipEventRecord");
+  std::vector<double> fin(nst);
+  IK_TRY(hipMemcpyAsync(fin.data(), cur, sizeof(double) * nst, hipMemcpyDeviceToHost, st), "copy result");
+  IK_TRY(hipStreamSynchronize(st), "synchronize");
   float ms = 0.0f;
   IK_TRY(hipEventElapsedTime(&ms, ev0, ev1), "hipEventElapsedTime");
-  std::vector<double> fin(nst);
-  IK_TRY(hipMemcpy(fin.data(), cur, sizeof(double) * nst, hipMemcpyDeviceToHost), "copy result");
+#undef IK_TRY
   bt.scatter(fin.data(), in);
-  drop_events();
   release();
   g_kernel_ms = ms; g_frames = (long long)nwg;
-#undef IK_TRY
   g_err.clear();
   return 0;
 }

@@ -47,43 +47,50 @@ int chd_kin_solve_batch(const chd_kin_config* cfg, int device, int B, chd_kin_se
   if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
   KinBatch bt;
   if (!bt.build(cfg, B, in)) return fail(bt.err);
+  // Everything of a call is ordered on a stream of its own (stream-ordered allocations, asynchronous copies, one synchronisation at the
+  // end): two host threads can keep the device busy back to back -- with the default stream and hipDeviceSynchronize each call would also
+  // wait for the other thread's kernel, and the host steps of the two would fall into lockstep (kinematic_optimizer.KinematicOptimizer.optimize)
   KinSeq* d_seqs = nullptr; double *d_dp = nullptr, *d_work = nullptr, *d_state = nullptr, *d_stats = nullptr; int* d_ip = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipStream_t st = nullptr;
+  if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
   auto release = [&]() {
-    for (void* p : {(void*)d_seqs, (void*)d_dp, (void*)d_work, (void*)d_state, (void*)d_stats, (void*)d_ip}) (void)hipFree(p);
+    for (void* p : {(void*)d_seqs, (void*)d_dp, (void*)d_work, (void*)d_state, (void*)d_stats, (void*)d_ip}) if (p) (void)hipFreeAsync(p, st);
+    (void)hipStreamSynchronize(st);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
+    (void)hipStreamDestroy(st);
   };
 #define KIN_TRY(call, what) if ((e = (call)) != hipSuccess) { release(); return fail(what, e); }
-  KIN_TRY(hipMalloc(&d_seqs, sizeof(KinSeq) * bt.seqs.size()), "hipMalloc descriptors");
-  KIN_TRY(hipMalloc(&d_dp, sizeof(double) * bt.dpool.size()), "hipMalloc constants");
-  KIN_TRY(hipMalloc(&d_ip, sizeof(int) * bt.ipool.size()), "hipMalloc contacts");
-  KIN_TRY(hipMalloc(&d_work, sizeof(double) * (size_t)bt.work_total), "hipMalloc workspace");
-  KIN_TRY(hipMalloc(&d_state, sizeof(double) * bt.state.size()), "hipMalloc state");
-  KIN_TRY(hipMalloc(&d_stats, sizeof(double) * 8 * (size_t)B), "hipMalloc statistics");
-  KIN_TRY(hipMemcpy(d_seqs, bt.seqs.data(), sizeof(KinSeq) * bt.seqs.size(), hipMemcpyHostToDevice), "copy descriptors");
-  KIN_TRY(hipMemcpy(d_dp, bt.dpool.data(), sizeof(double) * bt.dpool.size(), hipMemcpyHostToDevice), "copy constants");
-  KIN_TRY(hipMemcpy(d_ip, bt.ipool.data(), sizeof(int) * bt.ipool.size(), hipMemcpyHostToDevice), "copy contacts");
-  KIN_TRY(hipMemcpy(d_state, bt.state.data(), sizeof(double) * bt.state.size(), hipMemcpyHostToDevice), "copy start points");
-  KIN_TRY(hipMemset(d_stats, 0, sizeof(double) * 8 * (size_t)B), "clear statistics");
+  KIN_TRY(hipMallocAsync((void**)&d_seqs, sizeof(KinSeq) * bt.seqs.size(), st), "hipMalloc descriptors");
+  KIN_TRY(hipMallocAsync((void**)&d_dp, sizeof(double) * bt.dpool.size(), st), "hipMalloc constants");
+  KIN_TRY(hipMallocAsync((void**)&d_ip, sizeof(int) * bt.ipool.size(), st), "hipMalloc contacts");
+  KIN_TRY(hipMallocAsync((void**)&d_work, sizeof(double) * (size_t)bt.work_total, st), "hipMalloc workspace");
+  KIN_TRY(hipMallocAsync((void**)&d_state, sizeof(double) * bt.state.size(), st), "hipMalloc state");
+  KIN_TRY(hipMallocAsync((void**)&d_stats, sizeof(double) * 8 * (size_t)B, st), "hipMalloc statistics");
+  KIN_TRY(hipMemcpyAsync(d_seqs, bt.seqs.data(), sizeof(KinSeq) * bt.seqs.size(), hipMemcpyHostToDevice, st), "copy descriptors");
+  KIN_TRY(hipMemcpyAsync(d_dp, bt.dpool.data(), sizeof(double) * bt.dpool.size(), hipMemcpyHostToDevice, st), "copy constants");
+  KIN_TRY(hipMemcpyAsync(d_ip, bt.ipool.data(), sizeof(int) * bt.ipool.size(), hipMemcpyHostToDevice, st), "copy contacts");
+  KIN_TRY(hipMemcpyAsync(d_state, bt.state.data(), sizeof(double) * bt.state.size(), hipMemcpyHostToDevice, st), "copy start points");
+  KIN_TRY(hipMemsetAsync(d_stats, 0, sizeof(double) * 8 * (size_t)B, st), "clear statistics");
   KIN_TRY(hipEventCreate(&ev0), "hipEventCreate");
   KIN_TRY(hipEventCreate(&ev1), "hipEventCreate");
-  KIN_TRY(hipEventRecord(ev0, 0), "hipEventRecord");
+  KIN_TRY(hipEventRecord(ev0, st), "hipEventRecord");
   // 512 threads: measured against 256 and 1024 (profiles/r02h_kinopt/sweep.md); results are bitwise reproducible for a fixed
   // workgroup size (fixed reduction trees) and move at the solve's own sensitivity level when it changes
   const int nthreads = cfg->reserved[0] == 256 ? 256 : 512;
   // 72 KB of LDS per workgroup (two workgroups per compute unit): tiles of 34 frames for J v, 27 for J^T u
   const int lds_doubles = cfg->reserved[1] > 0 ? cfg->reserved[1] : 9216;
   KIN_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chd_kin_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * lds_doubles)), "hipFuncSetAttribute");
-  hipLaunchKernelGGL(chd_kin_solve_kernel, dim3((unsigned)B), dim3((unsigned)nthreads), sizeof(double) * (size_t)lds_doubles, 0, d_seqs, bt.P, d_dp, d_ip, d_work, d_state, d_stats, lds_doubles);
+  hipLaunchKernelGGL(chd_kin_solve_kernel, dim3((unsigned)B), dim3((unsigned)nthreads), sizeof(double) * (size_t)lds_doubles, st, d_seqs, bt.P, d_dp, d_ip, d_work, d_state, d_stats, lds_doubles);
   KIN_TRY(hipGetLastError(), "launch");
-  KIN_TRY(hipEventRecord(ev1, 0), "hipEventRecord");
-  KIN_TRY(hipDeviceSynchronize(), "synchronize");
+  KIN_TRY(hipEventRecord(ev1, st), "hipEventRecord");
+  std::vector<double> fin(bt.state.size()), stats(8 * (size_t)B);
+  KIN_TRY(hipMemcpyAsync(fin.data(), d_state, sizeof(double) * fin.size(), hipMemcpyDeviceToHost, st), "copy solutions");
+  KIN_TRY(hipMemcpyAsync(stats.data(), d_stats, sizeof(double) * stats.size(), hipMemcpyDeviceToHost, st), "copy statistics");
+  KIN_TRY(hipStreamSynchronize(st), "synchronize");
   float ms = 0.0f;
   KIN_TRY(hipEventElapsedTime(&ms, ev0, ev1), "hipEventElapsedTime");
-  std::vector<double> fin(bt.state.size()), stats(8 * (size_t)B);
-  KIN_TRY(hipMemcpy(fin.data(), d_state, sizeof(double) * fin.size(), hipMemcpyDeviceToHost), "copy solutions");
-  KIN_TRY(hipMemcpy(stats.data(), d_stats, sizeof(double) * stats.size(), hipMemcpyDeviceToHost), "copy statistics");
 #undef KIN_TRY
   bt.scatter(fin.data(), stats.data(), in);
   release();
