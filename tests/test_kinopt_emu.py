@@ -165,3 +165,21 @@ def test_whole_optimisation_and_its_files(gold, tmp_path):
         assert rel(sio.positions_global(m), sio.positions_global(r['motion'])) < 1e-5       # '%f' precision of the file
     # the relabelling fired on the two clips without a given floor
     assert int(np.abs(res[0]['velConstraints'] - g['c0_vel']).sum()) == 1 and int(np.abs(res[1]['velConstraints'] - g['c1_vel']).sum()) == 1
+
+
+@pytest.mark.parametrize('lds_doubles', [1100, 2600])
+def test_products_across_tile_boundaries(gold, lds_doubles):
+    """The products walk the clip in frame tiles (with two halo frames for J v); the fixture's clips fit one default tile, so the tile
+    loops are forced here: 1 100 doubles of LDS = tiles of 2 (J v) and 3 (J^T u) frames, 2 600 = 8 and 7 -- neither divides 16 or 12."""
+    import kin_emu
+    for ci, li in [(1, 1), (2, 0)]:
+        p, q = problem(gold, ci, li)
+        cfg = kin_emu.default_config()
+        cfg.reserved[1] = lds_doubles
+        assert rel(kin_emu.probe(p, 0, cfg=cfg)[0], gold[q + 'f0']) < 5e-9
+        assert rel(kin_emu.probe(p, 1, gold[q + 'v'], cfg=cfg)[0], gold[q + 'Jv']) < 5e-9
+        assert rel(kin_emu.probe(p, 2, gold[q + 'u'], cfg=cfg)[0], gold[q + 'JTu']) < 5e-9
+        one = kin_emu.default_config(lsmr_maxiter=3)
+        many = kin_emu.default_config(lsmr_maxiter=3); many.reserved[1] = lds_doubles
+        a = kin_emu.solve([p], one)[0]; b = kin_emu.solve([p], many)[0]
+        assert (a['nfev'], a['status']) == (b['nfev'], b['status']) and rel(b['x'], a['x']) < 1e-9

@@ -41,6 +41,19 @@ def test_bounded_solve_in_lockstep_with_oracle_and_emulation(gold):
         assert rel(r['x'], x) < 1e-7 and rel(r['x'], e['x']) < 1e-7 and abs(r['cost'] - cost) < 1e-6 * cost
 
 
+def test_small_frame_tiles_on_gpu(gold):
+    """The frame-tile loops of the products with tiles of 2 / 3 frames (1 100 doubles of LDS) against the one-tile default and the emulation."""
+    import kin_emu
+    p, q = problem(gold, 1, 1)
+    small = kopt.KinSolver(device=0, lsmr_maxiter=3); small.cfg.reserved[1] = 1100
+    a = kopt.KinSolver(device=0, lsmr_maxiter=3).solve([p])[0]
+    b = small.solve([p, p])[1]
+    ecfg = kin_emu.default_config(lsmr_maxiter=3); ecfg.reserved[1] = 1100
+    e = kin_emu.solve([p], ecfg)[0]
+    assert (a['nfev'], a['status']) == (b['nfev'], b['status']) == (e['nfev'], e['status'])
+    assert rel(b['x'], a['x']) < 1e-8 and rel(b['x'], e['x']) < 1e-8
+
+
 def test_every_solve_of_the_fixture_matches_the_reference(gold):
     ps = [problem(gold, ci, li) for ci in range(3) for li in range(2)]
     solver = kopt.KinSolver(device=0)
