@@ -56,22 +56,29 @@ int chd_ik_solve_batch(const chd_ik_config* cfg, int device, int B, const chd_ik
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t st = nullptr;
   if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+  bool pool_ok = true;                          // stream-ordered allocation; plain hipMalloc / hipFree where the runtime has no memory pools
+  auto dmalloc = [&](void** p, size_t n) {
+    hipError_t r = pool_ok ? hipMallocAsync(p, n, st) : hipErrorNotSupported;
+    if (r == hipErrorNotSupported) { pool_ok = false; (void)hipGetLastError(); r = hipMalloc(p, n); }
+    return r;
+  };
   auto release = [&]() {
-    for (void* p : {(void*)d_seqs, (void*)d_fs, (void*)d_fi, (void*)d_ip, (void*)d_dp, (void*)d_x0, (void*)d_x1}) if (p) (void)hipFreeAsync(p, st);
+    for (void* p : {(void*)d_seqs, (void*)d_fs, (void*)d_fi, (void*)d_ip, (void*)d_dp, (void*)d_x0, (void*)d_x1}) if (p && pool_ok) (void)hipFreeAsync(p, st);
     (void)hipStreamSynchronize(st);
+    if (!pool_ok) for (void* p : {(void*)d_seqs, (void*)d_fs, (void*)d_fi, (void*)d_ip, (void*)d_dp, (void*)d_x0, (void*)d_x1}) if (p) (void)hipFree(p);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     (void)hipStreamDestroy(st);
   };
 #define IK_TRY(call, what) if ((e = (call)) != hipSuccess) { release(); return fail(what, e); }
   const size_t nwg = bt.frame_seq.size(), nst = bt.state.size();
-  IK_TRY(hipMallocAsync((void**)&d_seqs, sizeof(IkSeq) * bt.seqs.size(), st), "hipMalloc seqs");
-  IK_TRY(hipMallocAsync((void**)&d_fs, sizeof(int) * nwg, st), "hipMalloc frame map");
-  IK_TRY(hipMallocAsync((void**)&d_fi, sizeof(int) * nwg, st), "hipMalloc frame map");
-  IK_TRY(hipMallocAsync((void**)&d_ip, sizeof(int) * bt.ipool.size(), st), "hipMalloc ints");
-  IK_TRY(hipMallocAsync((void**)&d_dp, sizeof(double) * bt.dpool.size(), st), "hipMalloc targets");
-  IK_TRY(hipMallocAsync((void**)&d_x0, sizeof(double) * nst, st), "hipMalloc state");
-  IK_TRY(hipMallocAsync((void**)&d_x1, sizeof(double) * nst, st), "hipMalloc state");
+  IK_TRY(dmalloc((void**)&d_seqs, sizeof(IkSeq) * bt.seqs.size()), "hipMalloc seqs");
+  IK_TRY(dmalloc((void**)&d_fs, sizeof(int) * nwg), "hipMalloc frame map");
+  IK_TRY(dmalloc((void**)&d_fi, sizeof(int) * nwg), "hipMalloc frame map");
+  IK_TRY(dmalloc((void**)&d_ip, sizeof(int) * bt.ipool.size()), "hipMalloc ints");
+  IK_TRY(dmalloc((void**)&d_dp, sizeof(double) * bt.dpool.size()), "hipMalloc targets");
+  IK_TRY(dmalloc((void**)&d_x0, sizeof(double) * nst), "hipMalloc state");
+  IK_TRY(dmalloc((void**)&d_x1, sizeof(double) * nst), "hipMalloc state");
   IK_TRY(hipMemcpyAsync(d_seqs, bt.seqs.data(), sizeof(IkSeq) * bt.seqs.size(), hipMemcpyHostToDevice, st), "copy seqs");
   IK_TRY(hipMemcpyAsync(d_fs, bt.frame_seq.data(), sizeof(int) * nwg, hipMemcpyHostToDevice, st), "copy frame map");
   IK_TRY(hipMemcpyAsync(d_fi, bt.frame_idx.data(), sizeof(int) * nwg, hipMemcpyHostToDevice, st), "copy frame map");

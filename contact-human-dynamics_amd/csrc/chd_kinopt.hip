@@ -54,20 +54,27 @@ int chd_kin_solve_batch(const chd_kin_config* cfg, int device, int B, chd_kin_se
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t st = nullptr;
   if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+  bool pool_ok = true;                          // stream-ordered allocation; plain hipMalloc / hipFree where the runtime has no memory pools
+  auto dmalloc = [&](void** p, size_t n) {
+    hipError_t r = pool_ok ? hipMallocAsync(p, n, st) : hipErrorNotSupported;
+    if (r == hipErrorNotSupported) { pool_ok = false; (void)hipGetLastError(); r = hipMalloc(p, n); }
+    return r;
+  };
   auto release = [&]() {
-    for (void* p : {(void*)d_seqs, (void*)d_dp, (void*)d_work, (void*)d_state, (void*)d_stats, (void*)d_ip}) if (p) (void)hipFreeAsync(p, st);
+    for (void* p : {(void*)d_seqs, (void*)d_dp, (void*)d_work, (void*)d_state, (void*)d_stats, (void*)d_ip}) if (p && pool_ok) (void)hipFreeAsync(p, st);
     (void)hipStreamSynchronize(st);
+    if (!pool_ok) for (void* p : {(void*)d_seqs, (void*)d_dp, (void*)d_work, (void*)d_state, (void*)d_stats, (void*)d_ip}) if (p) (void)hipFree(p);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     (void)hipStreamDestroy(st);
   };
 #define KIN_TRY(call, what) if ((e = (call)) != hipSuccess) { release(); return fail(what, e); }
-  KIN_TRY(hipMallocAsync((void**)&d_seqs, sizeof(KinSeq) * bt.seqs.size(), st), "hipMalloc descriptors");
-  KIN_TRY(hipMallocAsync((void**)&d_dp, sizeof(double) * bt.dpool.size(), st), "hipMalloc constants");
-  KIN_TRY(hipMallocAsync((void**)&d_ip, sizeof(int) * bt.ipool.size(), st), "hipMalloc contacts");
-  KIN_TRY(hipMallocAsync((void**)&d_work, sizeof(double) * (size_t)bt.work_total, st), "hipMalloc workspace");
-  KIN_TRY(hipMallocAsync((void**)&d_state, sizeof(double) * bt.state.size(), st), "hipMalloc state");
-  KIN_TRY(hipMallocAsync((void**)&d_stats, sizeof(double) * 8 * (size_t)B, st), "hipMalloc statistics");
+  KIN_TRY(dmalloc((void**)&d_seqs, sizeof(KinSeq) * bt.seqs.size()), "hipMalloc descriptors");
+  KIN_TRY(dmalloc((void**)&d_dp, sizeof(double) * bt.dpool.size()), "hipMalloc constants");
+  KIN_TRY(dmalloc((void**)&d_ip, sizeof(int) * bt.ipool.size()), "hipMalloc contacts");
+  KIN_TRY(dmalloc((void**)&d_work, sizeof(double) * (size_t)bt.work_total), "hipMalloc workspace");
+  KIN_TRY(dmalloc((void**)&d_state, sizeof(double) * bt.state.size()), "hipMalloc state");
+  KIN_TRY(dmalloc((void**)&d_stats, sizeof(double) * 8 * (size_t)B), "hipMalloc statistics");
   KIN_TRY(hipMemcpyAsync(d_seqs, bt.seqs.data(), sizeof(KinSeq) * bt.seqs.size(), hipMemcpyHostToDevice, st), "copy descriptors");
   KIN_TRY(hipMemcpyAsync(d_dp, bt.dpool.data(), sizeof(double) * bt.dpool.size(), hipMemcpyHostToDevice, st), "copy constants");
   KIN_TRY(hipMemcpyAsync(d_ip, bt.ipool.data(), sizeof(int) * bt.ipool.size(), hipMemcpyHostToDevice, st), "copy contacts");
