@@ -150,3 +150,43 @@ def test_command_line_flags_of_the_reference():
     with pytest.raises(FileNotFoundError):
         drv.main(['--input_path', '/nonexistent/video/video.mp4', '--skel_path', os.path.join(HERE, 'nonexistent.bvh'), '--output_path', '/tmp/x', '--end', '30',
                   '--character', 'ybot', '--gt-floor', '--visualize'])
+
+
+# ---- shard determinism of the batch driver: `--data` over five video directories as one process and as two ranks (RANK / WORLD_SIZE, as
+#      torch.distributed.run sets them; the path has no collective).  This container has no GPU: the two library-backed solvers are replaced
+#      by the host emulation of the same kernel sources; directory handling, ingest, sharding and file output are the driver's own code.
+def _shard_worker(rank, world, root, skel):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, HERE)
+    import chd_amd  # noqa: F401
+    from chd_amd import kinematic_optimizer as k
+    from chd_amd import run_kinematic_optimizer as d
+    from test_kinopt_emu import EmuIk, EmuKin
+    k.IkBackProject = lambda device, cfg: EmuIk()
+    k.KinSolver = lambda device, parents=None: EmuKin(max_nfev=5, lsmr_maxiter=8)
+    sys.exit(d.main(['--data', root, '--skel_path', skel]))
+
+
+def test_two_ranks_write_the_same_files_as_one(tmp_path):
+    import multiprocessing as mp
+    import shutil
+    rng = np.random.default_rng(9)
+    one = tmp_path / 'one'
+    for i, F in enumerate((8, 11, 9, 12, 10)):
+        write_video_dir(str(one / ('clip_%d' % i)), make_kin_clip(20 + i, F, G['c0_skel_offsets'], G['c0_skel_parents']), rng)
+    write_skeleton(str(tmp_path / 'skel.bvh'))
+    two = tmp_path / 'two'
+    shutil.copytree(str(one), str(two))
+    ctx = mp.get_context('spawn')
+    for root, world in ((one, 1), (two, 2)):
+        procs = [ctx.Process(target=_shard_worker, args=(r, world, str(root), str(tmp_path / 'skel.bvh'))) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=300)
+            assert p.exitcode == 0
+    for i in range(5):
+        for name in ('foot_contacts.npy', 'floor_out.txt', 'final_test.bvh'):
+            a = open(str(one / ('clip_%d' % i) / 'kinematic_results' / name), 'rb').read()
+            b = open(str(two / ('clip_%d' % i) / 'kinematic_results' / name), 'rb').read()
+            assert a == b and len(a) > 0, (i, name)
