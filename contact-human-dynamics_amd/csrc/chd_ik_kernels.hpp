@@ -210,50 +210,17 @@ IK_DEV void ik_step_frame(const IkSeq& s, const int f, const IkParams& P, const 
   }
   IK_SYNC();
   // ---- F: (G + lambda^2 I) y = e.  G = L D L^T without pivoting or square roots (G is SPD), right-looking with unscaled
-  //         columns U[r][k] = L[r][k] d_k; the residual rides along as row R (its eliminated entries are
-  //         U[R][k] = (D^-1 L^-1 e)_k d_k, i.e. the forward substitution comes for free).
-  //         Four columns per step and TWO workgroup barriers per step: every thread factors the step's 4 x 4 diagonal block in
-  //         registers (ten LDS broadcast reads), one thread per row below eliminates its four entries against it, then the
-  //         trailing triangle takes the rank-4 update.  (One column per barrier -- 75 barriers for the kinematic optimisation's
-  //         25 targets -- was all of this kernel's time.)
-  for (int kb = 0; kb < R; kb += 4) {
-    const int bw = R - kb < 4 ? R - kb : 4;
-    // the diagonal block: d[j], and u[j][i] = U[kb+j][kb+i] for i < j  (G[r][c] is stored for c <= r)
-    double d[4] = {1.0, 1.0, 1.0, 1.0}, inv[4], ub[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-    for (int j = 0; j < bw; ++j) {
-      for (int i = 0; i < j; ++i) {
-        double v = L.G[(kb + j) * gs + kb + i];
-        for (int m = 0; m < i; ++m) v -= ub[j][m] * ub[i][m] * inv[m];
-        ub[j][i] = v;
-      }
-      double v = L.G[(kb + j) * gs + kb + j];
-      for (int m = 0; m < j; ++m) v -= ub[j][m] * ub[j][m] * inv[m];
-      d[j] = v; inv[j] = 1.0 / v;
-    }
-    for (int j = bw; j < 4; ++j) inv[j] = 0.0;
-    // rows below the block (and the residual row R): their four entries of this step's columns
-    for (int r = kb + bw + IK_TID; r <= R; r += IK_NT) {
-      double u[4];
-      for (int j = 0; j < bw; ++j) {
-        double v = L.G[r * gs + kb + j];
-        for (int m = 0; m < j; ++m) v -= u[m] * ub[j][m] * inv[m];
-        u[j] = v;
-      }
-      for (int j = 1; j < bw; ++j) L.G[r * gs + kb + j] = u[j];      // (column kb is final as it stands)
-    }
-    IK_SYNC();
-    if (IK_TID == 0)                                              // the block's own final entries (nobody reads them before the back substitution)
-      for (int j = 0; j < bw; ++j) { L.G[(kb + j) * gs + kb + j] = d[j]; for (int i = 1; i < j; ++i) L.G[(kb + j) * gs + kb + i] = ub[j][i]; }
-    const int k1 = kb + bw, n = R - k1 + 1;                        // trailing rows k1 .. R, columns k1 .. R-1, lower triangle
+  //         columns U[r][k] = L[r][k] d_k so that a column needs ONE workgroup barrier; the residual rides along as row R
+  //         (its eliminated entries are U[R][k] = (D^-1 L^-1 e)_k d_k, i.e. the forward substitution comes for free).
+  for (int k = 0; k < R; ++k) {
+    const double inv = 1.0 / L.G[k * gs + k];
+    const int n = R - k;                                          // rows k+1 .. R, columns k+1 .. R-1, lower triangle
     for (int idx = IK_TID; idx < n * (n + 1) / 2 - 1; idx += IK_NT) {      // the last entry would be (R, R): not needed
       int i = (int)((std::sqrt(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
       while (i * (i + 1) / 2 > idx) --i;
       while ((i + 1) * (i + 2) / 2 <= idx) ++i;
-      const int r = k1 + i, cc = k1 + (idx - i * (i + 1) / 2);
-      const double* ur = L.G + r * gs + kb; const double* uc = L.G + cc * gs + kb;
-      double acc = 0.0;
-      for (int j = 0; j < bw; ++j) acc += ur[j] * uc[j] * inv[j];
-      L.G[r * gs + cc] -= acc;
+      const int r = k + 1 + i, cc = k + 1 + (idx - i * (i + 1) / 2);
+      L.G[r * gs + cc] -= L.G[r * gs + k] * L.G[cc * gs + k] * inv;
     }
     IK_SYNC();
   }
