@@ -85,7 +85,7 @@ int chd_ik_solve_batch(const chd_ik_config* cfg, int device, int B, const chd_ik
   IK_TRY(hipMemcpyAsync(d_ip, bt.ipool.data(), sizeof(int) * bt.ipool.size(), hipMemcpyHostToDevice, st), "copy ints");
   IK_TRY(hipMemcpyAsync(d_dp, bt.dpool.data(), sizeof(double) * bt.dpool.size(), hipMemcpyHostToDevice, st), "copy targets");
   IK_TRY(hipMemcpyAsync(d_x0, bt.state.data(), sizeof(double) * nst, hipMemcpyHostToDevice, st), "copy state");
-  const size_t lds = sizeof(double) * (size_t)IkLds::doubles(bt.max_J, bt.max_T);      // 26 KB for J = 33, T = 13; 60 KB for the kinematic optimisation (J = 28, T = 25); 78 KB at the size limits
+  const size_t lds = sizeof(double) * (size_t)IkLds::doubles(bt.max_J, bt.max_T);      // 28 KB for J = 33, T = 13; 66 KB for the kinematic optimisation (J = 28, T = 25); 85 KB at the size limits
   if (lds > 48 * 1024) IK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chd_ik_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
   IK_TRY(hipEventCreate(&ev0), "hipEventCreate");
   IK_TRY(hipEventCreate(&ev1), "hipEventCreate");

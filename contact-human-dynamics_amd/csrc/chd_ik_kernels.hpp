@@ -73,11 +73,14 @@ struct IkLds {
   int* itab;                        // the sequence's index tables (3J + 5T ints: parents | target joints | masks, as in the pool),
                                     // staged once per step: the chain walks and mask tests would otherwise be dependent L2 round trips
   static IK_HD int stride(int T) { return (3 * T) | 1; }
-  static IK_HD int doubles(int J, int T) { return 51 * J + 6 * T + (3 * T + 1) * stride(T) + (3 * J + 5 * T + 1) / 2; }
+  unsigned short* pair;             // (row, column) offsets of the idx-th entry of a lower triangle, (i << 8) | j: decoded once per step
+                                    // instead of a square root per entry per eliminated column (the same table serves every column)
+  static IK_HD int doubles(int J, int T) { return 51 * J + 6 * T + (3 * T + 1) * stride(T) + (3 * J + 5 * T + 1) / 2 + (3 * T * (3 * T + 1) / 2 + 3) / 4; }
   IK_HD void carve(double* b, int J, int T) {
     x = b; b += 6 * J; Rl = b; b += 9 * J; Rg = b; b += 9 * J; pg = b; b += 3 * J; es = b; b += 18 * J; dx = b; b += 6 * J;
     e = b; b += 3 * T; y = b; b += 3 * T; G = b; gs = stride(T); b += (3 * T + 1) * gs;
     itab = reinterpret_cast<int*>(b);
+    pair = reinterpret_cast<unsigned short*>(b + (3 * J + 5 * T + 1) / 2);
   }
 };
 
@@ -212,14 +215,19 @@ IK_DEV void ik_step_frame(const IkSeq& s, const int f, const IkParams& P, const 
   // ---- F: (G + lambda^2 I) y = e.  G = L D L^T without pivoting or square roots (G is SPD), right-looking with unscaled
   //         columns U[r][k] = L[r][k] d_k so that a column needs ONE workgroup barrier; the residual rides along as row R
   //         (its eliminated entries are U[R][k] = (D^-1 L^-1 e)_k d_k, i.e. the forward substitution comes for free).
+  IK_FOR(idx, R * (R + 1) / 2) {
+    int i = (int)((std::sqrt(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
+    while (i * (i + 1) / 2 > idx) --i;
+    while ((i + 1) * (i + 2) / 2 <= idx) ++i;
+    L.pair[idx] = (unsigned short)((i << 8) | (idx - i * (i + 1) / 2));
+  }
+  IK_SYNC();
   for (int k = 0; k < R; ++k) {
     const double inv = 1.0 / L.G[k * gs + k];
     const int n = R - k;                                          // rows k+1 .. R, columns k+1 .. R-1, lower triangle
     for (int idx = IK_TID; idx < n * (n + 1) / 2 - 1; idx += IK_NT) {      // the last entry would be (R, R): not needed
-      int i = (int)((std::sqrt(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
-      while (i * (i + 1) / 2 > idx) --i;
-      while ((i + 1) * (i + 2) / 2 <= idx) ++i;
-      const int r = k + 1 + i, cc = k + 1 + (idx - i * (i + 1) / 2);
+      const unsigned pr = L.pair[idx];
+      const int r = k + 1 + (int)(pr >> 8), cc = k + 1 + (int)(pr & 255u);
       L.G[r * gs + cc] -= L.G[r * gs + k] * L.G[cc * gs + k] * inv;
     }
     IK_SYNC();
