@@ -235,12 +235,16 @@ IK_DEV void ik_step_frame(const IkSeq& s, const int f, const IkParams& P, const 
   IK_FOR(k, R) { L.e[k] = L.G[R * gs + k]; L.G[k * gs + k] = 1.0 / L.G[k * gs + k]; }      // right-hand side of L^T y = D^-1 (.), and 1 / d_k
   IK_SYNC();
   // back substitution y_k = (U[R][k] - sum_{r > k} U[r][k] y_r) / d_k by one wavefront, scatter form: once y_k is known
-  // every lane r < k takes U[k][r] y_k off its own accumulator e[r] (row k of G is contiguous)
+  // every lane r < k takes U[k][r] y_k off its own accumulator e[r] (row k of G is contiguous).  Two unknowns per wavefront
+  // synchronisation: y_{k-1} only needs y_k on top of what the lanes hold (same operations in the same order as one at a time).
   if (IK_WAVE0) {
-    for (int k = R - 1; k >= 0; --k) {
+    for (int k = R - 1; k >= 0; k -= 2) {
       const double yk = L.e[k] * L.G[k * gs + k];
-      for (int r = IK_WLANE; r < k; r += IK_WSTEP) L.e[r] -= L.G[k * gs + r] * yk;
-      if (IK_WLANE == 0) L.y[k] = yk;
+      const bool two = k >= 1;
+      const double yk1 = two ? (L.e[k - 1] - L.G[k * gs + k - 1] * yk) * L.G[(k - 1) * gs + k - 1] : 0.0;
+      const int lim = two ? k - 1 : 0;
+      for (int r = IK_WLANE; r < lim; r += IK_WSTEP) L.e[r] = (L.e[r] - L.G[k * gs + r] * yk) - L.G[(k - 1) * gs + r] * yk1;
+      if (IK_WLANE == 0) { L.y[k] = yk; if (two) L.y[k - 1] = yk1; }
       IK_WSYNC();
     }
   }
