@@ -496,12 +496,31 @@ KO_DEV int kin_lsmr(KinCtx& c, const double* b, double damp, int* istop_out) {
     zetabar = -sbar * zetabar;
     const double k1 = -(thetabar * rho / (rhoold * rhobarold)), k2 = zeta / (rho * rhobar), k3 = -(thetanew / rho);
     KoAcc sx;
-    for (long long i = KO_TID; i < n; i += KO_NT) {
-      const double hb = hbar[i] * k1 + h[i];
-      hbar[i] = hb;
-      const double xi = x[i] + k2 * hb;
-      x[i] = xi; sx.add(i, xi * xi);
-      h[i] = h[i] * k3 + sv * v[i];
+    {   // four elements per thread per pass, all sixteen loads issued before the first use (one element at a time leaves four loads in
+        // flight per wavefront: the pass is latency bound)
+      const double* __restrict__ vr = v; double* __restrict__ hr = h; double* __restrict__ hbr = hbar; double* __restrict__ xr = x;
+      long long i = KO_TID;
+      for (; i + 3LL * KO_NT < n; i += 4LL * KO_NT) {
+        double a[4], b[4], cx[4], dv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const long long k = i + (long long)q * KO_NT; a[q] = hbr[k]; b[q] = hr[k]; cx[q] = xr[k]; dv[q] = vr[k]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const long long k = i + (long long)q * KO_NT;
+          const double hb = a[q] * k1 + b[q];
+          hbr[k] = hb;
+          const double xi = cx[q] + k2 * hb;
+          xr[k] = xi; sx.add(k, xi * xi);
+          hr[k] = b[q] * k3 + sv * dv[q];
+        }
+      }
+      for (; i < n; i += KO_NT) {
+        const double hb = hbr[i] * k1 + hr[i];
+        hbr[i] = hb;
+        const double xi = xr[i] + k2 * hb;
+        xr[i] = xi; sx.add(i, xi * xi);
+        hr[i] = hr[i] * k3 + sv * vr[i];
+      }
     }
     const double normx = std::sqrt(ko_total(c, sx));
     const double betaacute = chat * betadd, betacheck = -shat * betadd;
