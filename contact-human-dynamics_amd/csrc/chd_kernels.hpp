@@ -202,6 +202,20 @@ CHD_DEV double pair_sum(double v) { return v + __shfl_xor(v, 32); }
 // ------------------------------------------------------------------------------------------
 // Cubic Hermite splines (TOWR CubicHermitePolynomial / NodeSpline)
 // ------------------------------------------------------------------------------------------
+// Cumulative end times of the polynomials / phases, staged in LDS by refresh_durations: every spline evaluation starts with a binary
+// search over them -- five dependent loads, ten searches per dynamics unit -- which from HBM / L2 was a chain of ~50 round trips
+// per thread in the row phases.  (Larger problems than the tables hold keep searching the workspace copy.)
+#define CHD_PEND_CAP 640
+#define CHD_PHEND_CAP 64
+#ifdef CHD_HOST_EMU
+static double chd_pend_l[CHD_PEND_CAP], chd_phend_l[CHD_PHEND_CAP];
+static int chd_tab_ok = 0;
+#else
+__shared__ double chd_pend_l[CHD_PEND_CAP];
+__shared__ double chd_phend_l[CHD_PHEND_CAP];
+__shared__ int chd_tab_ok;
+#endif
+
 struct PE {
   int poly;
   double tl, T;
@@ -239,6 +253,12 @@ CHD_DEV void hermite_eval(QP q, int s, int id, double tl, PE& e) {
 
 CHD_DEV void spline_eval(QP q, int s, double tg, PE& e) {
   const auto& sp = q->sp[s];
+  if (chd_tab_ok) {
+    const LdsD* pend = (const LdsD*)chd_pend_l + sp.poly_off;
+    const int id = seg_lookup(pend, sp.n_polys, tg);
+    hermite_eval(q, s, id, tg - (id > 0 ? pend[id - 1] : 0.0), e);
+    return;
+  }
   const GD* pend = q->wd + q->o_pend + sp.poly_off;
   const int id = seg_lookup(pend, sp.n_polys, tg);
   hermite_eval(q, s, id, tg - (id > 0 ? pend[id - 1] : 0.0), e);
@@ -258,6 +278,7 @@ CHD_DEV void dpos_dT(QP q, int s, const PE& e, double* out) {
 
 // phase of end-effector e at time t, and whether it is the last one
 CHD_DEV int phase_lookup(QP q, int e, double t) {
+  if (chd_tab_ok) return seg_lookup((const LdsD*)chd_phend_l + q->phase_off[e], q->n_phase[e], t);
   return seg_lookup(q->wd + q->o_phend + q->phase_off[e], q->n_phase[e], t);
 }
 
@@ -1681,6 +1702,14 @@ CHD_DEV void refresh_durations(QP q) {     // polynomial durations + cumulative 
       for (int p = 0; p < q->n_phase[e]; ++p) { t += wd[q->o_phase_dur + q->phase_off[e] + p]; wd[q->o_phend + q->phase_off[e] + p] = t; }
     }
   }
+  CHD_SYNC();
+  const int nph = q->phase_off[N_EE - 1] + q->n_phase[N_EE - 1];
+  const bool fits = q->tot_polys <= CHD_PEND_CAP && nph <= CHD_PHEND_CAP;
+  if (fits) {
+    PAR_FOR(i, q->tot_polys) ((LdsD*)chd_pend_l)[i] = wd[q->o_pend + i];
+    PAR_FOR(i, nph) ((LdsD*)chd_phend_l)[i] = wd[q->o_phend + i];
+  }
+  if (CHD_TID == 0) chd_tab_ok = fits ? 1 : 0;
   CHD_SYNC();
 }
 

@@ -159,7 +159,7 @@ int chd_phys_create(const chd_config* cfg, int device_id, chd_handle** out) {
   size_t lds = prop.maxSharedMemoryPerMultiProcessor;
   if (lds > 160 * 1024) lds = 160 * 1024;
   if (lds < 64 * 1024) lds = 64 * 1024;
-  h->lds_bytes = (int)lds - 4096;     // the 4 KB hold the kernel's static LDS: sequence descriptor + solver context
+  h->lds_bytes = (int)lds - 12288;    // the 12 KB hold the kernel's static LDS: sequence descriptor + solver context (2.4 KB), cumulative-time tables (5.6 KB)
   if (h->cfg.lds_kilobytes > 0 && h->cfg.lds_kilobytes * 1024 < h->lds_bytes) h->lds_bytes = std::max(32, h->cfg.lds_kilobytes) * 1024;
   hipFuncSetAttribute((const void*)chd_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
   hipFuncSetAttribute((const void*)chd_debug_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
