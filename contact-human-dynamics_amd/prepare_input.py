@@ -6,7 +6,10 @@
 reads a BVH, the fitted floor (`floor_out.txt`: normal, point) and the per-frame foot contacts (`foot_contacts.npy`,
 columns left heel, left toe, right heel, right toe) and writes ``skel_info.txt``, ``motion_info.txt``,
 ``terrain_info.txt`` and ``contact_info.txt`` -- or, with `prepare_sequence`, hands the same data to the solver in
-memory (`io_formats.SeqInput`), skipping the files.  Small per-video array work: NumPy on the host, as in the reference.
+memory (`io_formats.SeqInput`), skipping the files.  Per video this is small array work (NumPy on the host, as in the reference);
+for a run of thousands of videos (BASELINE configs[2]) `prepare_sequences_device` does the per-frame numerics -- two forward-kinematics
+passes, centre of mass, inertia, hip offsets, toe / heel trajectories -- for ALL clips at once as float64 tensor operations on the GPU
+(PyTorch-ROCm; padded over the frames), and leaves the sequential pieces (root-angle unwrapping, contact run lengths) on the host.
 
 Coordinates: the animation is y-up in centimetres; the solver is z-up in metres with x, y negated
 (``p_solver = -0.01 * p[[x, z, y]]``, towr_utils.py:519-521, 568-571).
@@ -113,6 +116,97 @@ def prepare_sequence(motion: sk.Motion, floor, foot_contacts, character: Charact
                         com=com_traj[sl], euler=root_rot[sl], ltoe=ltoe[sl], lheel=lheel[sl], rtoe=rtoe[sl], rheel=rheel[sl],
                         normal=np.asarray(floor[0], dtype=np.float64), point=np.asarray(floor[1], dtype=np.float64),
                         start_contact=start, durations=durations)
+
+
+def _fk_device(rot, pos, parents):
+    """Animation.transforms_global on tensors: rot (B, F, J, 4), pos (B, F, J, 3) -> global positions (B, F, J, 3).  Rotation matrices from
+    the quaternions as Quaternions.transforms does it (no normalisation), child = parent o local."""
+    import torch
+    w, x, y, z = rot.unbind(-1)
+    x2, y2, z2 = x + x, y + y, z + z
+    Rl = torch.stack([1.0 - (y * y2 + z * z2), x * y2 - w * z2, x * z2 + w * y2,
+                      x * y2 + w * z2, 1.0 - (x * x2 + z * z2), y * z2 - w * x2,
+                      x * z2 - w * y2, y * z2 + w * x2, 1.0 - (x * x2 + y * y2)], dim=-1).reshape(rot.shape[:-1] + (3, 3))
+    R, P = [None] * len(parents), [None] * len(parents)
+    for j, a in enumerate(parents):
+        if a < 0:
+            R[j] = Rl[:, :, j]; P[j] = pos[:, :, j]
+        else:
+            R[j] = R[a] @ Rl[:, :, j]
+            P[j] = P[a] + (R[a] @ pos[:, :, j, :, None])[..., 0]
+    return torch.stack(P, dim=2)
+
+
+def prepare_sequences_device(motions, floors, foot_contacts, character: Character, starts=None, ends=None, dt=1.0 / 30.0, combined_contacts=False,
+                             device='cuda'):
+    """`prepare_sequence` for a list of clips of one character (same hierarchy) with the per-frame numerics batched on `device`.
+    Equal to the NumPy path to rounding (tests/test_prepare_input.py; tests/test_config4_gpu.py on the MI355X)."""
+    import torch
+    for need in ('left_leg_chain', 'hip_inds', 'mass'):
+        if getattr(character, need) is None:
+            raise ValueError('Character.%s is required by prepare_input' % need)
+    B = len(motions)
+    starts = [0 if s is None else s for s in (starts or [None] * B)]
+    ends = [m.n_frames if e is None else e for m, e in zip(motions, ends or [None] * B)]
+    anims = [m.copy() if character.heel_inds is not None else add_heels(m, character.toe_inds, character.ankle_inds) for m in motions]
+    J0, J1 = motions[0].n_joints, anims[0].n_joints
+    parents0, parents1 = [int(a) for a in motions[0].parents], [int(a) for a in anims[0].parents]
+    if any(m.n_joints != J0 or [int(a) for a in m.parents] != parents0 for m in motions):
+        raise ValueError('prepare_sequences_device: the clips of a batch share one skeleton hierarchy')
+    Fm = max(m.n_frames for m in motions)
+    dev = torch.device(device)
+
+    def pad(arrs, tail):                        # (F_i, ...) -> (B, Fm, ...) repeating the last frame
+        out = np.empty((B, Fm) + tail)
+        for b, a in enumerate(arrs):
+            out[b, :a.shape[0]] = a; out[b, a.shape[0]:] = a[-1]
+        return torch.from_numpy(out).to(dev)
+
+    rot1 = pad([a.rotations for a in anims], (J1, 4)); pos1 = pad([a.positions for a in anims], (J1, 3))
+    swap = torch.tensor(_SWAP, device=dev)
+    seg = [(character.seg_to_mass_perc[k] * 0.01, torch.tensor(list(j), device=dev)) for k, j in character.seg_to_joints.items()]
+
+    def com_of(gp):
+        return sum(fr * gp[:, :, jj].mean(dim=2) for fr, jj in seg)
+
+    # pass 1 (towr_utils.py:483-535): root rotation and translation zeroed -> hip offsets from the COM, inertia about it
+    rot0 = rot1[:, :, :J0].clone(); pos0 = pos1[:, :, :J0].clone()
+    rot0[:, :, 0] = torch.tensor([1.0, 0.0, 0.0, 0.0], dtype=torch.float64, device=dev); pos0[:, :, 0] = 0.0
+    gp = _fk_device(rot0, pos0, parents0)
+    com = com_of(gp)
+    hip = -0.01 * (gp[:, :, list(character.hip_inds)] - com[:, :, None])[..., swap]
+    pos0[:, :, 0] = pos0[:, :, 0] - com
+    rel = -0.01 * _fk_device(rot0, pos0, parents0)[..., swap]
+    eye = torch.eye(3, dtype=torch.float64, device=dev)
+    inertia = torch.zeros((B, Fm, 3, 3), dtype=torch.float64, device=dev)
+    for (fr, jj) in seg:
+        r = rel[:, :, jj].mean(dim=2)
+        inertia = inertia + fr * character.mass * ((r * r).sum(dim=-1)[..., None, None] * eye - r[..., :, None] * r[..., None, :])
+    # pass 2 (towr_utils.py:542-655): the animation as it is (heels appended) -> COM, toe / heel trajectories
+    pos = -0.01 * _fk_device(rot1, pos1, parents1)[..., swap]
+    lh, rh = (J1 - 2, J1 - 1) if character.heel_inds is None else character.heel_inds
+    com_traj = com_of(pos)
+    feet = pos[:, :, [character.toe_inds[0], lh, character.toe_inds[1], rh]]
+    hd = (feet[:, :, 0] - feet[:, :, 1]).norm(dim=-1)
+    hip, inertia, com_traj, feet, hd = [t.cpu().numpy() for t in (hip, inertia, com_traj, feet, hd)]
+    chain = list(character.left_leg_chain)
+    out = []
+    for b, (m, a) in enumerate(zip(motions, anims)):
+        F = m.n_frames
+        sl = slice(starts[b], ends[b])
+        angle, axis = sk.quat_angle_axis(a.rotations[:, 0])
+        root_rot = unwrap_like_reference(sk.quat_to_euler_xyz(sk.quat_from_angle_axis(angle, -axis[:, _SWAP])))
+        start, durations = contact_schedule(foot_contacts[b], starts[b], ends[b], dt, combined_contacts)
+        I = inertia[b, :F][sl]
+        out.append(iof.SeqInput(F=ends[b] - starts[b], dt=dt, hip_l=hip[b, :F][sl, 0], hip_r=hip[b, :F][sl, 1],
+                                leg_len=float(np.sum(np.linalg.norm(m.offsets[chain[1:]], axis=1)) * 0.01),
+                                heel_len=float((np.sum(np.linalg.norm(a.offsets[chain[1:-1]], axis=1)) + np.linalg.norm(a.offsets[lh])) * 0.01),
+                                heel_dist=float(np.mean(hd[b, :F])), mass=float(character.mass),
+                                inertia=np.stack([I[:, 0, 0], I[:, 1, 1], I[:, 2, 2], I[:, 0, 1], I[:, 0, 2], I[:, 1, 2]], axis=1),
+                                com=com_traj[b, :F][sl], euler=root_rot[sl], ltoe=feet[b, :F][sl, 0], lheel=feet[b, :F][sl, 1], rtoe=feet[b, :F][sl, 2],
+                                rheel=feet[b, :F][sl, 3], normal=np.asarray(floors[b][0], dtype=np.float64), point=np.asarray(floors[b][1], dtype=np.float64),
+                                start_contact=start, durations=durations))
+    return out
 
 
 def prepare_input(anim_bvh, floor_file, contacts_file, out_dir, character: Character, start_idx=None, end_idx=None, dt=1.0 / 30.0,

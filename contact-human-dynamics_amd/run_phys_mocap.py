@@ -45,6 +45,8 @@ def parse_args(argv):
                    'tracked_results.json and foot_contacts.npy gets kinematic_results/; all videos in one batched solve')
     p.add_argument('--skel-path', default='skeleton_fitting/combined_body_25.bvh', help='template of the combined skeleton for --kinematic (run_phys_mocap.py:106)')
     p.add_argument('--prepare', action='store_true', help='write phys_optim_in_<character>/ from kinematic_results/ first')
+    p.add_argument('--prepare-device', action='store_true', help='with --prepare: the per-frame numerics of all videos as one batch of tensor operations on the GPU '
+                   '(prepare_input.prepare_sequences_device) instead of NumPy video by video')
     p.add_argument('--out-bvh', action='store_true', help='back-project the solutions onto the skeleton and write BVH files')
     p.add_argument('--character-json', default=None, help='joint / segment tables of the character (apply_results.Character)')
     p.add_argument('--fps', type=float, default=30.0, help='frame rate of the animation (the reference reads it from the video, :90-91)')
@@ -91,6 +93,7 @@ def main(argv=None):
                 print('[run_phys_mocap] %s: kinematic optimisation failed -- %s' % (v, r['error']))
             else:
                 shutil.copyfile(os.path.join(o, 'final_test.bvh'), os.path.join(o, a.character + '_out.bvh'))
+    prep_batch = []
     for v in vids:
         vd = os.path.join(a.data, v)
         ind = os.path.join(vd, 'phys_optim_in_' + a.character)
@@ -99,18 +102,36 @@ def main(argv=None):
             continue
         if a.prepare and int(os.environ.get('WORLD_SIZE', '1')) > 1:
             raise SystemExit('--prepare writes the input directories: run it once as a single process, then launch the ranks')
-        if a.prepare:
+        if a.prepare and not a.prepare_device:
             from .prepare_input import prepare_input
             kin = os.path.join(vd, 'kinematic_results')
             n = a.nframes or count_frames(vd, None)
             prepare_input(os.path.join(kin, a.character + '_out.bvh'), os.path.join(kin, 'floor_out.txt'), os.path.join(kin, 'foot_contacts.npy'),
                           ind, character, start_idx=0, end_idx=n, dt=1.0 / a.fps)
+        elif a.prepare:
+            prep_batch.append((vd, ind, a.nframes or count_frames(vd, None)))
+            continue
         if not os.path.isdir(ind):
             print('[run_phys_mocap] %s: no %s, skipping' % (v, os.path.basename(ind)))
             continue
         outd = os.path.join(vd, 'phys_optim_out_' + a.character)
         os.makedirs(outd, exist_ok=True)                                   # run_phys_mocap.py:156-158
         jobs.append((ind, outd, a.nframes or count_frames(vd, ind)))
+    if prep_batch:                                   # --prepare-device: every video of the run in one batch of tensor operations
+        import numpy as np
+        from . import io_formats as iof
+        from . import prepare_input as pi
+        from . import skeleton_io as sk
+        kins = [os.path.join(vd, 'kinematic_results') for vd, _, _ in prep_batch]
+        motions = [sk.load_bvh(os.path.join(k, a.character + '_out.bvh'))[0] for k in kins]
+        seqs = pi.prepare_sequences_device(motions, [pi.read_floor(os.path.join(k, 'floor_out.txt')) for k in kins],
+                                           [np.load(os.path.join(k, 'foot_contacts.npy')) for k in kins], character,
+                                           starts=[0] * len(kins), ends=[n for _, _, n in prep_batch], dt=1.0 / a.fps, device='cuda:%d' % sharding.rank_world()[2])
+        for (vd, ind, n), seq in zip(prep_batch, seqs):
+            iof.write_inputs(seq, ind)
+            outd = os.path.join(vd, 'phys_optim_out_' + a.character)
+            os.makedirs(outd, exist_ok=True)
+            jobs.append((ind, outd, seq.F))
     rank, world, local = sharding.rank_world()
     mine = sharding.my_shard([j[2] for j in jobs])
     cfg = default_config(w_com_lin=a.w_com_lin, w_com_ang=a.w_com_ang, w_ee=a.w_ee, w_smooth=a.w_smooth, w_dur=a.w_dur)

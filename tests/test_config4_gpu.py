@@ -91,7 +91,7 @@ def test_kinematic_optimisation_to_bvh_on_one_gpu(tmp_path):
 
         openpose_result/*.json + tracked_results.json + foot_contacts.npy
             --kinematic (libchd_ik.so, libchd_kinopt.so)--> kinematic_results/{final_test.bvh = combined_out.bvh, floor_out.txt, foot_contacts.npy}
-            --prepare--> phys_optim_in_combined/ --libchd_phys.so--> sol_out_*.txt --out-bvh (libchd_ik.so)--> <video>_combined_*.bvh
+            --prepare --prepare-device (batched tensor operations)--> phys_optim_in_combined/ --libchd_phys.so--> sol_out_*.txt --out-bvh (libchd_ik.so)--> <video>_combined_*.bvh
 
     on synthetic clips of a standing-up person (y down, as monocular total capture delivers them)."""
     from chd_amd import io_formats as iof
@@ -109,7 +109,7 @@ def test_kinematic_optimisation_to_bvh_on_one_gpu(tmp_path):
     write_skeleton(str(tmp_path / 'skel.bvh'))
     cj = str(tmp_path / 'combined.json')
     json.dump(COMBINED, open(cj, 'w'))
-    rc = run_phys_mocap.main(['--data', str(root), '--character', 'combined', '--kinematic', '--skel-path', str(tmp_path / 'skel.bvh'), '--prepare', '--out-bvh', '--character-json', cj])
+    rc = run_phys_mocap.main(['--data', str(root), '--character', 'combined', '--kinematic', '--skel-path', str(tmp_path / 'skel.bvh'), '--prepare', '--prepare-device', '--out-bvh', '--character-json', cj])
     assert rc == 0
     for v, F in frames.items():
         kin = root / v / 'kinematic_results'
@@ -122,3 +122,13 @@ def test_kinematic_optimisation_to_bvh_on_one_gpu(tmp_path):
         assert log[0] == 'dynamics' and log[1] in '01' and log[2] == 'durations' and log[3] in '01'
         m, names, _ = sk.load_bvh(str(out / ('%s_combined_no_dynamics.bvh' % v)))
         assert m.n_frames == F and m.n_joints == 28 and names[0] == 'J00'       # the heels are joints of this skeleton: nothing appended, nothing removed
+
+
+def test_prepare_input_batched_on_gpu(tmp_path):
+    """prepare_input's per-frame numerics for a batch of clips of different lengths as tensor operations on the MI355X against the NumPy
+    mirror (which tests/test_prepare_input.py pins to the files the reference's own prepare_input wrote)."""
+    sys.path.insert(0, HERE); sys.path.insert(0, os.path.join(HERE, 'golden'))
+    from make_apply_golden import CHARACTER
+    from chd_amd import apply_results as ar
+    from test_prepare_input import check_device_batch
+    check_device_batch(np.load(os.path.join(HERE, 'golden', 'apply_golden.npz')), tmp_path, ar.Character(**CHARACTER), 'cuda:0')

@@ -174,3 +174,37 @@ def test_driver_out_bvh_stage(gold, tmp_path, character, monkeypatch):
     assert got == ['clip_synth_dynamics.bvh', 'clip_synth_no_dynamics.bvh']
     m, names, _ = sk.load_bvh(str(out / got[0]))
     assert m.n_frames == 10 and m.n_joints == 20 and names[0] == 'Hips'
+
+
+ARRAYS = ('hip_l', 'hip_r', 'inertia', 'com', 'euler', 'ltoe', 'lheel', 'rtoe', 'rheel', 'normal', 'point')
+SCALARS = ('dt', 'leg_len', 'heel_len', 'heel_dist', 'mass')
+
+
+def _batch_inputs(gold, tmp_path):
+    from chd_amd import skeleton_io as sk
+    bvh, floor, contacts = _inputs(gold, tmp_path)
+    m, _, _ = sk.load_bvh(bvh)
+    s, e = [int(v) for v in gold['start_end']]
+    rng = np.random.default_rng(3)
+    clips = [m, m.frames(1, m.n_frames), m.frames(0, m.n_frames - 2)]                  # different lengths: the batch is padded over the frames
+    clips[1].rotations[:, 3] = clips[1].rotations[:, 3] * np.array([1.0, 0.98, 1.02, 1.0]); clips[2].positions[:, 0] += rng.normal(size=3)
+    fcs = [gold['prep_contacts'], gold['prep_contacts'][1:], gold['prep_contacts'][:-2]]
+    fl = pi.read_floor(floor)
+    return clips, [fl] * 3, fcs, [s, 0, 1], [e, None, 9]
+
+
+def check_device_batch(gold, tmp_path, character, device):
+    clips, floors, fcs, starts, ends = _batch_inputs(gold, tmp_path)
+    got = pi.prepare_sequences_device(clips, floors, fcs, character, starts, ends, dt=1.0 / 30.0, device=device)
+    for b, seq in enumerate(got):
+        ref = pi.prepare_sequence(clips[b], floors[b], fcs[b], character, starts[b], ends[b], dt=1.0 / 30.0)
+        assert seq.F == ref.F and seq.start_contact == ref.start_contact and seq.durations == ref.durations
+        for k in ARRAYS:
+            assert np.allclose(getattr(seq, k), getattr(ref, k), rtol=1e-11, atol=1e-13), (b, k)
+        for k in SCALARS:
+            assert abs(getattr(seq, k) - getattr(ref, k)) <= 1e-12 * abs(getattr(ref, k)), (b, k)
+
+
+def test_batched_tensor_path_equals_the_numpy_path(gold, tmp_path, character):
+    """prepare_sequences_device on the CPU device of torch: the same tensor code the GPU runs (its GPU twin: tests/test_config4_gpu.py)."""
+    check_device_batch(gold, tmp_path, character, 'cpu')
