@@ -40,17 +40,25 @@ class ClipResult:
     written: List[str] = field(default_factory=list)
 
 
-def run_clips(clips: Sequence[Clip], character: ar.Character, phys, ik, dt=1.0 / 30.0, combined_contacts=False) -> List[ClipResult]:
+def run_clips(clips: Sequence[Clip], character: ar.Character, phys, ik, dt=1.0 / 30.0, combined_contacts=False, prepare_device=None) -> List[ClipResult]:
+    """`prepare_device` (e.g. 'cuda:0'): prepare_input's per-frame numerics of all clips as one batch of tensor operations on that device."""
     loaded = []
     seqs = []
+    pending = []
     for c in clips:
         motion, names, _ = sk.load_bvh(c.bvh)
         floor = pi.read_floor(c.floor) if isinstance(c.floor, str) else c.floor
         contacts = np.load(c.contacts) if isinstance(c.contacts, str) else np.asarray(c.contacts)
         start = 0 if c.start is None else c.start
         end = motion.n_frames if c.end is None else c.end
-        seqs.append(pi.prepare_sequence(motion, floor, contacts, character, start, end, dt, combined_contacts))
+        if prepare_device is None:
+            seqs.append(pi.prepare_sequence(motion, floor, contacts, character, start, end, dt, combined_contacts))
+        else:
+            pending.append((motion, floor, contacts, start, end))
         loaded.append((motion, names, start, end))
+    if pending:
+        seqs = pi.prepare_sequences_device([p[0] for p in pending], [p[1] for p in pending], [p[2] for p in pending], character, [p[3] for p in pending],
+                                           [p[4] for p in pending], dt, combined_contacts, device=prepare_device)
     results, _ = phys.solve(seqs)                                                     # one batched launch sequence
     out = [ClipResult(seq=s, phys=r) for s, r in zip(seqs, results)]
     tasks, dest = [], []

@@ -108,3 +108,7 @@ def test_in_memory_pipeline_matches_the_file_chain(tmp_path):
     b = np.array(open(ref_out).read().split('Time:')[1].split(), dtype=np.float64)
     assert a.shape == b.shape and np.abs(a - b).max() < 1e-4
     assert sk.load_bvh(outs[1])[0].n_frames == 12
+    # prepare_input's batched tensor path (torch's CPU device here) feeds the solver the same sequences
+    res_t = pipeline.run_clips(clips, character, EmuPhys(), EmuIk(), prepare_device='cpu')
+    for r0, r1 in zip(res, res_t):
+        assert r1.seq.F == r0.seq.F and np.allclose(r1.seq.com, r0.seq.com, rtol=1e-12, atol=1e-14) and np.allclose(r1.seq.inertia, r0.seq.inertia, rtol=1e-11, atol=1e-13)
