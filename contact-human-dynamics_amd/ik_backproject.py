@@ -10,8 +10,8 @@ for a whole batch of videos at once: ``solve(seqs)`` takes, per video, what that
 F x 3 global positions) -- and returns the rotations / positions ``ik()`` leaves in ``anim``.  All arithmetic happens in
 the HIP library; there is no CPU fallback (the constructor raises without the library or a GPU).
 
-STATUS: checked against reference-generated vectors through the host emulation of the kernel source only
-(tests/test_ik_emu.py); not yet run on an MI355X -- see include/chd_ik.h.
+Checked against reference-generated vectors on the MI355X (tests/test_ik_gpu.py) and through the host emulation of the kernel source
+(tests/test_ik_emu.py).  The kinematic optimisation's initialisation uses the same entry point (translate = 0, 200 iterations, 25 targets).
 """
 import ctypes as C
 import os
