@@ -3,7 +3,7 @@ libchd_ik.so, checked against the numpy oracle on the first video and timed agai
 
     python tests/tools/ik_bench.py [videos=128] [frames=90]
 
-Round 1 ended before this could be run on a GPU; it is the first measurement of round 2 for this row."""
+Measurements: profiles/r02a_round_start/ik_bench.log (first MI355X run), profiles/r02k_final/ik_bench.log (end of round 2)."""
 import os
 import sys
 import time
