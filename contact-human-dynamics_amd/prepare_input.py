@@ -50,6 +50,31 @@ def unwrap_like_reference(root_rot):
     return out
 
 
+def unwrap_batch(root_rots):
+    """`unwrap_like_reference` for a list of (F_i, 3) arrays at once: the walk along the frames stays sequential, the clips and the three
+    angles go through it together (same additions in the same order per entry)."""
+    B = len(root_rots)
+    Fm = max(r.shape[0] for r in root_rots)
+    out = np.empty((B, Fm, 3))
+    for b, r in enumerate(root_rots):
+        out[b, :r.shape[0]] = r; out[b, r.shape[0]:] = r[-1]
+    cur = out[:, 0].copy()
+    for f in range(1, Fm):
+        step = np.where(cur >= 0.0, 2 * np.pi, -2 * np.pi)
+        nxt = out[:, f].copy()
+        for _ in range(4):
+            far = np.abs(nxt - cur) > np.pi
+            if not far.any():
+                break
+            nxt = np.where(far, nxt + step, nxt)
+        if (np.abs(nxt - cur) > np.pi).any():
+            b = int(np.argwhere(np.abs(nxt - cur) > np.pi)[0][0])
+            raise ValueError('clip %d: root orientation jumps away from its previous value at frame %d (the reference loops forever here)' % (b, f))
+        out[:, f] = nxt
+        cur = nxt
+    return [out[b, :r.shape[0]] for b, r in enumerate(root_rots)]
+
+
 def contact_schedule(foot_contacts, start_idx, end_idx, dt, combined_contacts=False):
     """towr_utils.py:695-725: start flags and phase durations in file order (left toe, left heel, right toe, right
     heel).  As in the reference, the toes' START flag is taken from the foot's combined (heel or toe) signal unless
@@ -191,11 +216,15 @@ def prepare_sequences_device(motions, floors, foot_contacts, character: Characte
     hip, inertia, com_traj, feet, hd = [t.cpu().numpy() for t in (hip, inertia, com_traj, feet, hd)]
     chain = list(character.left_leg_chain)
     out = []
+    raw = []
+    for a in anims:
+        angle, axis = sk.quat_angle_axis(a.rotations[:, 0])
+        raw.append(sk.quat_to_euler_xyz(sk.quat_from_angle_axis(angle, -axis[:, _SWAP])))
+    root_rots = unwrap_batch(raw)
     for b, (m, a) in enumerate(zip(motions, anims)):
         F = m.n_frames
         sl = slice(starts[b], ends[b])
-        angle, axis = sk.quat_angle_axis(a.rotations[:, 0])
-        root_rot = unwrap_like_reference(sk.quat_to_euler_xyz(sk.quat_from_angle_axis(angle, -axis[:, _SWAP])))
+        root_rot = root_rots[b]
         start, durations = contact_schedule(foot_contacts[b], starts[b], ends[b], dt, combined_contacts)
         I = inertia[b, :F][sl]
         out.append(iof.SeqInput(F=ends[b] - starts[b], dt=dt, hip_l=hip[b, :F][sl, 0], hip_r=hip[b, :F][sl, 1],

@@ -205,6 +205,27 @@ def check_device_batch(gold, tmp_path, character, device):
             assert abs(getattr(seq, k) - getattr(ref, k)) <= 1e-12 * abs(getattr(ref, k)), (b, k)
 
 
+def test_batched_unwrapping_equals_the_sequential_one():
+    rng = np.random.default_rng(6)
+    clips = []
+    for F in (5, 40, 17):
+        a = np.cumsum(rng.normal(size=(F, 3)) * 0.9, axis=0)
+        clips.append((a + np.pi) % (2 * np.pi) - np.pi)                       # wrapped into (-pi, pi]: jumps of ~2 pi to undo
+    clips[1][:, 0] = np.abs(clips[1][:, 0])                                  # a positive previous value: the only direction the reference can undo there
+    ok = []
+    for c in clips:
+        try:
+            ok.append(pi.unwrap_like_reference(c))
+        except ValueError:
+            ok.append(None)
+    good = [c for c, o in zip(clips, ok) if o is not None]
+    for got, want in zip(pi.unwrap_batch(good), [o for o in ok if o is not None]):
+        assert np.array_equal(got, want)
+    if any(o is None for o in ok):
+        with pytest.raises(ValueError):
+            pi.unwrap_batch(clips)
+
+
 def test_batched_tensor_path_equals_the_numpy_path(gold, tmp_path, character):
     """prepare_sequences_device on the CPU device of torch: the same tensor code the GPU runs (its GPU twin: tests/test_config4_gpu.py)."""
     check_device_batch(gold, tmp_path, character, 'cpu')
