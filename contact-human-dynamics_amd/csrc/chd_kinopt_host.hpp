@@ -67,7 +67,7 @@ struct KinBatch {
       const KinSeq& s = seqs[b];
       for (long long i = 0; i < s.n; ++i) out[b].x[i] = final_state[s.o_x + i];
       const double* st = stats + 8 * b;
-      out[b].cost = st[0]; out[b].nfev = (int)st[1]; out[b].njev = (int)st[2]; out[b].status = (int)st[3]; out[b].lsmr_iterations = (int)st[4]; out[b].optimality = st[5];
+      out[b].cost = st[0]; out[b].nfev = (int)st[1]; out[b].njev = (int)st[2]; out[b].status = (int)st[3]; out[b].lsmr_iterations = (int)st[4]; out[b].optimality = st[5]; out[b].jv_fraction = st[6]; out[b].jtu_fraction = st[7];
     }
   }
 };

@@ -53,6 +53,11 @@
 #define KO_CONST __constant__ const
 #endif
 #define KO_FOR(i, n) for (int i = KO_TID; i < (n); i += KO_NT)
+#ifdef CHD_HOST_EMU
+#define KO_CLOCK() 0LL
+#else
+#define KO_CLOCK() ((long long)wall_clock64())
+#endif
 
 namespace chd_kin {
 
@@ -107,6 +112,7 @@ struct KinCtx {
   KinWork w;
   double* red;                   // workgroup reduction scratch (LDS on the device): 3 * 16 doubles
   double* lds; int lds_doubles;  // the products' frame tiles (LDS on the device)
+  long long t_jv, t_jtu, t_all;  // wall-clock ticks spent in J v / J^T u / the whole solve (first thread's view; monitoring only)
   int o2, o3, o4, o5, o6, o7;    // first row of each residual term after the projection rows
 };
 
@@ -460,7 +466,7 @@ KO_DEV int kin_lsmr(KinCtx& c, const double* b, double damp, int* istop_out) {
   if (beta > 0) {
     su = 1 / beta;
     double a2 = 0;
-    kin_jtu(c, u, v, su, 0.0, &a2);
+    { const long long t0_ = KO_CLOCK(); kin_jtu(c, u, v, su, 0.0, &a2); c.t_jtu += KO_CLOCK() - t0_; }
     alpha = std::sqrt(a2);
   }
   if (alpha > 0) sv = 1 / alpha;
@@ -475,12 +481,12 @@ KO_DEV int kin_lsmr(KinCtx& c, const double* b, double damp, int* istop_out) {
   while (itn < maxiter) {
     ++itn;
     double b2 = 0;
-    kin_jv(c, v, u, sv, -alpha * su, &b2);
+    { const long long t0_ = KO_CLOCK(); kin_jv(c, v, u, sv, -alpha * su, &b2); c.t_jv += KO_CLOCK() - t0_; }
     beta = std::sqrt(b2);
     if (beta > 0) {
       su = 1 / beta;
       double a2 = 0;
-      kin_jtu(c, u, v, su, -beta * sv, &a2);
+      { const long long t0_ = KO_CLOCK(); kin_jtu(c, u, v, su, -beta * sv, &a2); c.t_jtu += KO_CLOCK() - t0_; }
       alpha = std::sqrt(a2);
       if (alpha > 0) sv = 1 / alpha;
     }
@@ -600,6 +606,8 @@ KO_DEV void kin_solve(KinCtx& c, double* xio, double* stats) {
   const long long n = c.q->n, m = c.q->m;
   const KinParams& P = *c.P;
   KinWork& w = c.w;
+  c.t_jv = c.t_jtu = 0;
+  const long long t_begin = KO_CLOCK();
   for (long long i = KO_TID; i < n; i += KO_NT) w.X[i] = xio[i];
   KO_SYNC();
   kin_residual(c, w.X, w.PN, w.RGN, w.Fv);
@@ -712,6 +720,8 @@ KO_DEV void kin_solve(KinCtx& c, double* xio, double* stats) {
   for (long long i = KO_TID; i < n; i += KO_NT) xio[i] = w.X[i];
   if (KO_TID == 0) {
     stats[0] = cost; stats[1] = nfev; stats[2] = njev; stats[3] = status == -1 ? 0 : status; stats[4] = (double)lsmr_total; stats[5] = g_norm;
+    const double tall = (double)(KO_CLOCK() - t_begin);
+    stats[6] = tall > 0 ? (double)c.t_jv / tall : 0.0; stats[7] = tall > 0 ? (double)c.t_jtu / tall : 0.0;
   }
   KO_SYNC();
 }

@@ -19,7 +19,7 @@ class ChdKinSeq(C.Structure):
     _fields_ = [('n_frames', C.c_int), ('offsets', PD), ('pose3d', PD), ('root_trans', PD), ('pose2d_n', PD), ('proj_w', PD), ('data_w', PD),
                 ('contact', PI), ('floor_n', C.c_double * 3), ('floor_p', C.c_double * 3),
                 ('w_proj', C.c_double), ('w_smooth_vel', C.c_double), ('w_smooth_acc', C.c_double), ('w_data', C.c_double), ('w_vel', C.c_double), ('w_floor', C.c_double),
-                ('x', PD), ('cost', C.c_double), ('nfev', C.c_int), ('njev', C.c_int), ('status', C.c_int), ('lsmr_iterations', C.c_int), ('optimality', C.c_double)]
+                ('x', PD), ('cost', C.c_double), ('nfev', C.c_int), ('njev', C.c_int), ('status', C.c_int), ('lsmr_iterations', C.c_int), ('optimality', C.c_double), ('jv_fraction', C.c_double), ('jtu_fraction', C.c_double)]
 
 
 def problems_to_c(problems):
@@ -53,4 +53,4 @@ def problems_to_c(problems):
 
 def results_of(arr, xs):
     return [dict(x=xs[i], cost=arr[i].cost, nfev=arr[i].nfev, njev=arr[i].njev, status=arr[i].status, lsmr_iterations=arr[i].lsmr_iterations,
-                 optimality=arr[i].optimality) for i in range(len(xs))]
+                 optimality=arr[i].optimality, jv_fraction=arr[i].jv_fraction, jtu_fraction=arr[i].jtu_fraction) for i in range(len(xs))]

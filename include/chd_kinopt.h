@@ -49,6 +49,7 @@ typedef struct chd_kin_seq {
   int nfev, njev, status;      /* out: as scipy.optimize.OptimizeResult (status 0 max_nfev, 1 gtol, 2 ftol, 3 xtol, 4 both) */
   int lsmr_iterations;         /* out: LSMR iterations summed over the solve */
   double optimality;           /* out: infinity norm of the gradient at the solution */
+  double jv_fraction, jtu_fraction;   /* out (monitoring): share of the solve's device time spent in the products J v and J^T u inside LSMR */
 } chd_kin_seq;
 
 const char* chd_kin_version(void);

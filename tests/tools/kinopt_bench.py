@@ -59,6 +59,7 @@ if __name__ == '__main__':
                lsmr_iterations_per_clip=float(its.sum(axis=1).mean()), nfev_per_stage=nfev.mean(axis=0).tolist(),
                status_counts={str(k): int(v) for k, v in zip(*np.unique([s['status'] for r in res for s in r['stages']], return_counts=True))},
                algorithmic_GBps=alg_bytes / (sum(kin_ms) * 1e-3) / 1e9, us_per_lsmr_iteration_per_workgroup=1e3 * sum(kin_ms) / max(1.0, its.sum() / min(B, 256 * 2)),
+               lsq_time_share={'jv': float(np.mean([s['jv_fraction'] for r in res for s in r['stages']])), 'jtu': float(np.mean([s['jtu_fraction'] for r in res for s in r['stages']]))},
                relabelled_contacts_per_clip=float(np.mean([np.abs(r['velConstraints'] - c['velConstraints']).sum() for r, c in zip(res, clips)])))
     # CPU: the oracle (dense restatement of the reference, with SciPy's sparse products) on a short clip, scaled per frame
     if FO > 0:
