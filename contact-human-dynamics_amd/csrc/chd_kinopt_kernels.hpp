@@ -330,22 +330,36 @@ KO_DEV void kin_jv(KinCtx& c, const double* v, double* out, const double scale =
       const double* d0 = LD + 84 * fl;                               // data joint 0: where the reference puts the root's projection derivative
       const double* dr = LD + 84 * fl + 3 * ROOT;
       const double* C = c.w.C + 3 * gi;
-      const double ex = jd == 0 ? dy[0] : d0[0] + dy[0], ey = jd == 0 ? dy[1] : d0[1] + dy[1], ez = jd == 0 ? dy[2] : d0[2] + dy[2];
-      put(2 * gi, C[0] * ex + C[1] * ez);
-      put(2 * gi + 1, C[0] * ey + C[2] * ez);
+      const double C0 = C[0], C1 = C[1], C2 = C[2];
       const bool ct = c.contact[gi] == 1;
       const double dwj = dw * c.data_w[gi];
+      const bool has1 = f < F - 1, has2 = f < F - 2;
+      // the fifteen rows of this (frame, joint): row index, whether it exists, its value.  In the fused form the old entries of all of them
+      // are requested before the first one is used (one after the other they were fifteen dependent HBM round trips per item)
+      long long rr[15]; bool on[15]; double val[15];
+      const double ex = jd == 0 ? dy[0] : d0[0] + dy[0], ey = jd == 0 ? dy[1] : d0[1] + dy[1], ez = jd == 0 ? dy[2] : d0[2] + dy[2];
+      rr[0] = 2 * gi; on[0] = true; val[0] = C0 * ex + C1 * ez;
+      rr[1] = 2 * gi + 1; on[1] = true; val[1] = C0 * ey + C2 * ez;
+#pragma unroll
       for (int k = 0; k < 3; ++k) {
-        if (f < F - 1) {
-          put(c.o2 + 3 * gi + k, sv * SMOOTH_W[jd] * SMOOTH_VEL[k] * (dy[k] - dy[84 + k]));
-          put(c.o5 + 3 * gi + k, ct ? vw * ((dr[k] + dy[k]) - (dr[84 + k] + dy[84 + k])) : 0.0);
-        }
-        if (f < F - 2) put(c.o3 + 3 * gi + k, sa * (dy[k] - 2.0 * dy[84 + k] + dy[168 + k]));
-        put(c.o4 + 3 * gi + k, dwj * dy[k]);
+        const int o = 2 + 4 * k;
+        rr[o] = c.o2 + 3 * gi + k; on[o] = has1; val[o] = sv * SMOOTH_W[jd] * SMOOTH_VEL[k] * (dy[k] - dy[84 + k]);
+        rr[o + 1] = c.o5 + 3 * gi + k; on[o + 1] = has1; val[o + 1] = ct ? vw * ((dr[k] + dy[k]) - (dr[84 + k] + dy[84 + k])) : 0.0;
+        rr[o + 2] = c.o3 + 3 * gi + k; on[o + 2] = has2; val[o + 2] = sa * (dy[k] - 2.0 * dy[84 + k] + dy[168 + k]);
+        rr[o + 3] = c.o4 + 3 * gi + k; on[o + 3] = true; val[o + 3] = dwj * dy[k];
       }
       double d = 0;
       for (int k = 0; k < 3; ++k) d += c.q->floor_n[k] * (dr[k] + dy[k]);
-      put(c.o6 + gi, ct ? fw * d : 0.0);
+      rr[14] = c.o6 + gi; on[14] = true; val[14] = ct ? fw * d : 0.0;
+      if (fused) {
+        double old[15];
+#pragma unroll
+        for (int q = 0; q < 15; ++q) old[q] = out[on[q] ? rr[q] : 0];
+#pragma unroll
+        for (int q = 0; q < 15; ++q) { val[q] = scale * val[q] + keep * old[q]; acc.add(cur, on[q] ? val[q] * val[q] : 0.0); }
+      }
+#pragma unroll
+      for (int q = 0; q < 15; ++q) if (on[q]) out[rr[q]] = val[q];
     }
     KO_FOR(idx, nf * NV) {                    // Euler-angle smoothness rows of the tile's frames
       cur = idx;
@@ -373,18 +387,28 @@ KO_DEV void kin_jtu(KinCtx& c, const double* u, double* out, const double scale 
     KO_FOR(idx, nf * NJ) {                    // positions; each joint's own projection rows and contact rows acting on a position they reference
       const int f = f0 + idx / NJ, jd = idx % NJ;
       const long long gi = (long long)f * NJ + jd;
+      const bool has1 = f < F - 1, hasm = f >= 1;
+      // every load is unconditional (a masked-off one reads entry 0 instead): the requests go out together, not one per branch
       const double* pp = c.w.P + (long long)f * 84 + 3 * jd;       // (LP is in skeleton order: entry jd here is skeleton joint jd)
-      for (int k = 0; k < 3; ++k) LP[3 * idx + k] = pp[k];
       const double* C = c.w.C + 3 * gi;
+      const double p0 = pp[0], p1 = pp[1], p2 = pp[2], C0 = C[0], C1 = C[1], C2 = C[2];
       const double ux = u[2 * gi], uy = u[2 * gi + 1];
-      LQ[3 * idx] = C[0] * ux; LQ[3 * idx + 1] = C[0] * uy; LQ[3 * idx + 2] = C[1] * ux + C[2] * uy;
-      double r[3] = {0, 0, 0};
-      if (c.contact[gi] == 1) {
-        const double uf = fw * u[c.o6 + gi];
-        for (int k = 0; k < 3; ++k) { if (f < F - 1) r[k] += vw * u[c.o5 + 3 * gi + k]; r[k] += c.q->floor_n[k] * uf; }
+      const bool ct = c.contact[gi] == 1, ctm = c.contact[hasm ? gi - NJ : gi] == 1 && hasm;
+      const double u6 = u[c.o6 + gi];
+      double u5[3], u5m[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { u5[k] = u[has1 ? c.o5 + 3 * gi + k : 0]; u5m[k] = u[hasm ? c.o5 + 3 * (gi - NJ) + k : 0]; }
+      LP[3 * idx] = p0; LP[3 * idx + 1] = p1; LP[3 * idx + 2] = p2;
+      LQ[3 * idx] = C0 * ux; LQ[3 * idx + 1] = C0 * uy; LQ[3 * idx + 2] = C1 * ux + C2 * uy;
+      const double uf = fw * u6;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        double r = 0.0;
+        r += (ct && has1) ? vw * u5[k] : 0.0;
+        r += ct ? c.q->floor_n[k] * uf : 0.0;
+        r -= ctm ? vw * u5m[k] : 0.0;
+        LR[3 * idx + k] = r;
       }
-      if (f >= 1 && c.contact[gi - NJ] == 1) for (int k = 0; k < 3; ++k) r[k] -= vw * u[c.o5 + 3 * (gi - NJ) + k];
-      LR[3 * idx] = r[0]; LR[3 * idx + 1] = r[1]; LR[3 * idx + 2] = r[2];
     }
     KO_SYNC();
     KO_FOR(idx, nf * NJ) {                    // lambda of data joint jd of frame f
@@ -395,14 +419,23 @@ KO_DEV void kin_jtu(KinCtx& c, const double* u, double* out, const double scale 
       if (jd == 0) for (int j = 1; j < NJ; ++j) for (int k = 0; k < 3; ++k) lam[k] += LQ[84 * fl + 3 * j + k];                      // the misplaced root column
       if (jd == ROOT) for (int j = 0; j < NJ; ++j) if (j != ROOT) for (int k = 0; k < 3; ++k) lam[k] += LR[84 * fl + 3 * j + k];   // root + joint in the contact rows
       const double dwj = dw * c.data_w[gi];
+      const bool b0 = f < F - 1, b1 = f >= 1, b2 = f < F - 2, b3 = f >= 1 && f - 1 < F - 2, b4 = f >= 2;
+      double t0[3], t1[3], t2[3], t3[3], t4[3], t5[3];      // all eighteen entries of u requested together (masked-off ones read entry 0)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        t0[k] = u[b0 ? c.o2 + 3 * gi + k : 0]; t1[k] = u[b1 ? c.o2 + 3 * (gi - NJ) + k : 0];
+        t2[k] = u[b2 ? c.o3 + 3 * gi + k : 0]; t3[k] = u[b3 ? c.o3 + 3 * (gi - NJ) + k : 0]; t4[k] = u[b4 ? c.o3 + 3 * (gi - 2 * NJ) + k : 0];
+        t5[k] = u[c.o4 + 3 * gi + k];
+      }
+#pragma unroll
       for (int k = 0; k < 3; ++k) {
         const double s = sv * SMOOTH_W[jd] * SMOOTH_VEL[k];
-        if (f < F - 1) lam[k] += s * u[c.o2 + 3 * gi + k];
-        if (f >= 1) lam[k] -= s * u[c.o2 + 3 * (gi - NJ) + k];
-        if (f < F - 2) lam[k] += sa * u[c.o3 + 3 * gi + k];
-        if (f >= 1 && f - 1 < F - 2) lam[k] -= 2.0 * sa * u[c.o3 + 3 * (gi - NJ) + k];
-        if (f >= 2) lam[k] += sa * u[c.o3 + 3 * (gi - 2 * NJ) + k];
-        lam[k] += dwj * u[c.o4 + 3 * gi + k];
+        lam[k] += b0 ? s * t0[k] : 0.0;
+        lam[k] -= b1 ? s * t1[k] : 0.0;
+        lam[k] += b2 ? sa * t2[k] : 0.0;
+        lam[k] -= b3 ? 2.0 * sa * t3[k] : 0.0;
+        lam[k] += b4 ? sa * t4[k] : 0.0;
+        lam[k] += dwj * t5[k];
       }
       LL[3 * idx] = lam[0]; LL[3 * idx + 1] = lam[1]; LL[3 * idx + 2] = lam[2];
     }
@@ -422,18 +455,34 @@ KO_DEV void kin_jtu(KinCtx& c, const double* u, double* out, const double scale 
       }
       const double* e = c.w.E + (long long)f * 252 + 9 * j;
       double* o = out + (long long)f * NV;
-      auto put = [&](int k, double val) {
-        if (fused) { val = scale * val + keep * o[k]; acc.add(idx, val * val); }
-        o[k] = val;
-      };
-      auto euler = [&](int k) {               // Euler-smoothness rows of unknown k of frame f
-        double a = 0;
-        if (f < F - 1) a += se * u[c.o7 + f * NV + k];
-        if (f >= 1) a -= se * u[c.o7 + (f - 1) * NV + k];
-        return a;
-      };
-      for (int a = 0; a < 3; ++a) put(3 + 3 * j + a, e[3 * a] * M[0] + e[3 * a + 1] * M[1] + e[3 * a + 2] * M[2] + euler(3 + 3 * j + a));
-      if (j == 0) for (int k = 0; k < 3; ++k) put(k, L[3 * ROOT + k] + euler(k));
+      const bool has1 = f < F - 1, hasm = f >= 1, isroot = j == 0;
+      // the six unknowns this item may write (three angles; the root translation for joint 0): Euler-smoothness entries of u and, in
+      // the fused form, the old values are requested up front (masked-off requests read entry 0)
+      int kk[6]; double ua[6], ub[6], oldv[6], val[6];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        kk[q] = q < 3 ? 3 + 3 * j + q : q - 3;
+        const bool live = q < 3 || isroot;
+        ua[q] = u[(live && has1) ? c.o7 + f * NV + kk[q] : 0];
+        ub[q] = u[(live && hasm) ? c.o7 + (f - 1) * NV + kk[q] : 0];
+        oldv[q] = (fused && live) ? o[kk[q]] : 0.0;
+      }
+      double ee[9];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) ee[q] = e[q];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        double eu = 0.0;
+        eu += has1 ? se * ua[q] : 0.0;
+        eu -= hasm ? se * ub[q] : 0.0;
+        val[q] = (q < 3 ? ee[3 * q] * M[0] + ee[3 * q + 1] * M[1] + ee[3 * q + 2] * M[2] : L[3 * ROOT + (q - 3)]) + eu;
+      }
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const bool live = q < 3 || isroot;
+        if (fused) { val[q] = scale * val[q] + keep * oldv[q]; acc.add(idx, live ? val[q] * val[q] : 0.0); }
+        if (live) o[kk[q]] = val[q];
+      }
     }
     KO_SYNC();
   }
