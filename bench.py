@@ -201,7 +201,7 @@ def kinematic_optimisation_rate(device_index, n_clips=64, frames=30):
             'roofline': {'bound': 'hbm', 'kernel': 'chd_kin_solve_kernel', 'achieved': alg / (sum(ms) * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': alg / (sum(ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None},
             'fixture_worst_rel_l2_vs_reference': worst, 'fixture_contacts_equal_reference': bool(contacts_equal),
-            'note': 'outside the timed region; 256 clips x 100 frames: profiles/r02k_final/kinopt_bench_256x100.json (47 clips/s)'}
+            'note': 'outside the timed region; 256 clips x 100 frames: profiles/r02k_final/kinopt_bench_256x100.json (52 clips/s)'}
 
 
 def main():
