@@ -169,3 +169,23 @@ extern "C" void emu_nact_stats(void* h, int stage, double* out) {
   }
   out[0] = sa / np; out[1] = sb / np; out[2] = sx / np; out[3] = st / np; out[4] = np; out[5] = mx;      // mx: largest front (panel rows + active rows)
 }
+
+// front profile of `stage` (analysis helper): for panels of `nb` columns, out[3*p + 0] = active band rows below the panel,
+// out[3*p + 1] = active border rows, out[3*p + 2] = jb.  Returns the number of panels.
+extern "C" int emu_front_profile(void* h, int stage, int nb, int* out, int cap) {
+  Emu* e = (Emu*)h; e->bind();
+  double fo[2];
+  debug_eval(&e->M.d, e->ctx, stage, 0, e->lds.data(), (int)e->lds.size(), nullptr, nullptr, fo);
+  Ctx c; c.lds = e->lds.data(); c.lds_cap = (int)e->lds.size();
+  bind_stage(c, &e->M.d, stage);
+  int np = 0;
+  for (int c0 = 0; c0 < c.Nb && np < cap; c0 += nb, ++np) {
+    const int jb = std::min(nb, c.Nb - c0), last = c0 + jb - 1;
+    const int nbr = std::min(c.Nb - c0, jb + c.w), nbelow = nbr - jb;
+    int nb_ = 0, nx_ = 0;
+    for (int u = 0; u < nbelow; ++u) if (c.env[2 * (c0 + jb + u)] <= last) ++nb_;
+    for (int r = 0; r < c.bc; ++r) if (c.env[2 * (c.Nb + r)] <= last) ++nx_;
+    out[3 * np] = nb_; out[3 * np + 1] = nx_; out[3 * np + 2] = jb;
+  }
+  return np;
+}
