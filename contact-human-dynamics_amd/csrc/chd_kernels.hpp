@@ -137,6 +137,7 @@ struct Ctx {
   double sf;            // objective scaling
   double tol;           // IPOPT tol of the stage (phys_optim.cpp:578)
   int stall_window;     // 0 = no stall guard (chd_config.stall_window)
+  int clip_heel;        // 1 while the second model of an iteration is built: heel-distance curvature with max(lam, 0) (solve_stage)
   int err;              // sticky error flag (band overflow): any thread may set it, read after a barrier
   int n_bad_pivots;     // thread 0 counts
   long long tacc[24];    // cycles per phase (thread 0): 0 eval full, 1 eval values, 2 factor, 3 solve, 4 matvec, 5 total
@@ -1100,7 +1101,7 @@ CHD_DEV void dense_ldlt(LCtx& c, P Sp, const int ld, const int n, const GI* sign
   CHD_SYNC();
 }
 
-CHD_NOINLINE CHD_DEV void kfactor(LCtx& c, const GD* diag, const GI* sign) {
+CHD_NOINLINE CHD_DEV void kfactor_rl(LCtx& c, const GD* diag, const GI* sign) {
   TIC();
   const int Nb = c.Nb, w = c.w, W2 = c.W2, W1 = c.w + 1, LD = c.LD, bc = c.bc;
   if (CHD_TID == 0) c.n_bad_pivots = 0;
@@ -1196,6 +1197,475 @@ CHD_NOINLINE CHD_DEV void kfactor(LCtx& c, const GD* diag, const GI* sign) {
   }
   TACC(c, 12, CHD_CLOCK() - td_);
   TOC(c, 2);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Left-looking blocked L D L^T of the bordered band (the factorisation that runs: kfactor below; kfactor_rl above is the
+// right-looking round-1/2 version, kept as the fall-back for shapes this one does not take).
+//
+// Right-looking, every 32-column panel read-modify-wrote its whole trailing window in HBM / L2 (the window, ~100-200 active
+// rows, fits neither LDS nor -- as a sliding structure -- the register file): per panel a chain of dependent memory round
+// trips (panel load, store, window load, window store) for ~25 tiles of matrix-core work; 40 % of the kernel's time at 1 % of the
+// CU's arithmetic rate, and 12 x the algorithmic HBM traffic.  Left-looking, a panel's columns are formed ONCE, in registers,
+// from the finished part of the factor:
+//     S(i, J) = K0(i, J) + diag - sum_{k < c0} L(i, k) d_k L(J, k)^T            i in {panel rows} + {active rows below}
+// as 16 x 16 fp64 matrix-core tiles whose operands are gathered straight from the factor storage in the MFMA register layout
+// (lane = (row, k)), read-only and independent of each other -- no copy K0 -> Kf, no window, no read-modify-write; then the
+// diagonal block is factored by one wavefront, the rows below are solved against it and stored.  Per panel: one batch of
+// independent loads, three workgroup barriers.  The border's Schur complement is formed the same way at the end (tiles of
+// border rows x border rows over all band columns) and factored densely in LDS as before.
+// The factor storage has the same layout as before (unit-lower L in the band / border rows, pivots on the diagonal), and
+// every entry inside a row's envelope is rewritten by each factorisation; left of the envelope it stays zero.
+// ------------------------------------------------------------------------------------------
+#define CHD_LL_RING 512            // pivots of the last CHD_LL_RING band columns, in LDS (w + panel width must stay below it)
+struct LLPanel {
+  int c0, jb, nrows;               // first column, columns, rows of the panel's list (NB panel slots + active rows)
+  int pf;                          // first band column any row of the panel reaches (min of their envelope starts)
+};
+// the row list of a panel: slots [0, NB) = the panel's own rows c0 + a (-1 beyond jb), then the active rows below in ascending
+// order (band rows i, then border rows as Nb + r); `cnt[0]` = length, `cnt[1]` = pf.  Built by one wavefront.
+#ifdef CHD_HOST_EMU
+template <int NB>
+CHD_DEV void ll_build_rows(LCtx& c, int* rows, int* cnt, const int c0, const int jb) {
+  const int Nb = c.Nb, w = c.w, bc = c.bc, last = c0 + jb - 1;
+  int n = 0, pf = c0;
+  for (int a = 0; a < NB; ++a) { rows[n++] = a < jb ? c0 + a : -1; if (a < jb && c.env[2 * (c0 + a)] < pf) pf = c.env[2 * (c0 + a)]; }
+  const int iend = c0 + jb + w < Nb ? c0 + jb + w : Nb;
+  for (int i = c0 + jb; i < iend; ++i) if (c.env[2 * i] <= last) rows[n++] = i;
+  for (int r = 0; r < bc; ++r) if (c.env[2 * (Nb + r)] <= last) rows[n++] = Nb + r;
+  cnt[0] = n; cnt[1] = pf;
+}
+#else
+template <int NB>
+CHD_DEV void ll_build_rows(LCtx& c, int* rows_, int* cnt_, const int c0, const int jb) {
+  LdsI* rows = (LdsI*)rows_; LdsI* cnt = (LdsI*)cnt_;
+  const int Nb = c.Nb, w = c.w, bc = c.bc, last = c0 + jb - 1;
+  const int ln = threadIdx.x & 63;
+  int pf = c0;
+  if (ln < NB) { rows[ln] = ln < jb ? c0 + ln : -1; if (ln < jb) pf = c.env[2 * (c0 + ln)]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(pf, o); pf = t < pf ? t : pf; }
+  const int nbelow = (c0 + jb + w < Nb ? c0 + jb + w : Nb) - (c0 + jb);
+  const int wr = nbelow + bc;
+  int base = NB;
+  for (int u0 = 0; u0 < wr; u0 += 256) {         // four 64-row groups per pass: their envelope starts are fetched together
+    int ef[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int u = u0 + 64 * r + ln; ef[r] = c.env[u < wr ? 2 * (u < nbelow ? c0 + jb + u : Nb + u - nbelow) : 0]; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int u = u0 + 64 * r + ln;
+      const bool on = u < wr && ef[r] <= last;
+      const unsigned long long m = __ballot(on);
+      if (on) rows[base + __popcll(m & ((1ull << ln) - 1ull))] = u < nbelow ? c0 + jb + u : Nb + u - nbelow;
+      base += __popcll(m);
+    }
+  }
+  if (ln == 0) { cnt[0] = base; cnt[1] = pf; }
+}
+#endif
+
+// S tiles of one panel -> PT (column-major, PT[j * ldp + t] for list slot t), NB = 16 NC columns
+#ifdef CHD_HOST_EMU
+template <int NC>
+CHD_DEV void ll_tiles(LCtx& c, const GD* diag, const int* rows, const int nrows, const int pf, const int c0, const int jb, LdsD* PT, const int ldp, const LdsD* dring) {
+  constexpr int NB = 16 * NC;
+  const int Nb = c.Nb, w = c.w, W1 = c.w + 1, W2 = c.W2, LD = c.LD;
+  auto Lf = [&](int p, int k) -> double {          // L(p, k), k < c0 <= p or p in the panel
+    if (p < Nb) return (p - k <= w) ? c.Kfb[(long long)p * W1 + (k - p + w)] : 0.0;
+    return c.Kfx[(long long)(p - Nb) * LD + k];
+  };
+  for (int t = 0; t < nrows; ++t)
+    for (int j = 0; j < NB; ++j) {
+      const int p = rows[t], kc = c0 + j;
+      double v;
+      if (p < 0 || j >= jb) v = (t == j) ? 1.0 : 0.0;          // padding of a short last panel: identity
+      else {
+        if (p < Nb) v = (p - kc <= w && kc - p <= w) ? c.K0b[(long long)p * W2 + (kc - p + w)] : 0.0;
+        else v = c.K0x[(long long)(p - Nb) * LD + kc];
+        if (p == kc) v += diag[p];
+        int klo = c.env[2 * p] > pf ? c.env[2 * p] : pf;
+        for (int k = klo; k < c0; ++k) v -= Lf(p, k) * dring[k & (CHD_LL_RING - 1)] * Lf(kc, k);
+      }
+      PT[j * ldp + t] = v;
+    }
+}
+#else
+template <int NC>
+CHD_NOINLINE CHD_DEV void ll_tiles(LCtx& c, const GD* diag, const int* rows_, const int nrows, const int pf, const int c0, const int jb, LdsD* PT, const int ldp, const LdsD* dring) {
+  constexpr int NB = 16 * NC;
+  const LdsI* rows = (const LdsI*)rows_;
+  const int Nb = c.Nb, w = c.w, W1 = c.w + 1, W2 = c.W2, LD = c.LD;
+  const int wave = threadIdx.x >> 6, nwv = blockDim.x >> 6, lane = threadIdx.x & 63;
+  const int lr = lane & 15, lk = lane >> 4;
+  const GD* Kfb = c.Kfb; const GD* Kfx = c.Kfx;
+  const GD* safe = c.Kfb + w;
+  const int nblk = (nrows + 15) >> 4;
+  // B operand rows: the panel's own rows (same for every block of this wavefront)
+  const GD* pB[NC]; int kminB[NC]; bool okB[NC];
+#pragma unroll
+  for (int cb = 0; cb < NC; ++cb) {
+    const int j = 16 * cb + lr, p = c0 + j;
+    okB[cb] = j < jb;
+    pB[cb] = Kfb + (long long)(okB[cb] ? p : 0) * W1 + (w - (okB[cb] ? p : 0));
+    kminB[cb] = okB[cb] ? (p - w > 0 ? p - w : 0) : 0x3fffffff;
+  }
+  for (int blk = wave; blk < nblk; blk += nwv) {
+    // A operand row of this lane, and the block's first column
+    const int ta = 16 * blk + lr;
+    const int pa = ta < nrows ? rows[ta] : -1;
+    const bool okA = pa >= 0;
+    const bool bandA = pa < Nb;
+    const GD* pA = okA ? (bandA ? Kfb + (long long)pa * W1 + (w - pa) : Kfx + (long long)(pa - Nb) * LD) : safe;
+    const int kminA = okA ? (bandA ? (pa - w > 0 ? pa - w : 0) : 0) : 0x3fffffff;
+    int ef = okA ? c.env[2 * pa] : 0x3fffffff;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) { const int t = __shfl_xor(ef, o); ef = t < ef ? t : ef; }
+    const int klo = ef > pf ? ef : pf;
+    const int nst = klo < c0 ? (c0 - klo + 3) >> 2 : 0;          // steps of four columns, ending at c0
+    const int kstart = c0 - 4 * nst;
+    // accumulators <- K0 (+ diagonal shift); D layout: rows lk + 4 q, column lr
+    chd_f64x4 acc[NC];
+    {
+      int pq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int t = 16 * blk + lk + 4 * q; pq[q] = t < nrows ? rows[t] : -1; }
+#pragma unroll
+      for (int cb = 0; cb < NC; ++cb) {
+        const int j = 16 * cb + lr, kc = c0 + j;
+        double v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int p = pq[q];
+          const bool real = p >= 0 && j < jb;
+          const bool inb = real && (p >= Nb || (p - kc <= w && kc - p <= w));
+          const GD* src = !inb ? safe : (p < Nb ? c.K0b + (long long)p * W2 + (kc - p + w) : c.K0x + (long long)(p - Nb) * LD + kc);
+          const double t = *src;
+          const double dg = (real && p == kc) ? diag[p] : 0.0;
+          v[q] = real ? (inb ? t : 0.0) + dg : ((16 * blk + lk + 4 * q == j) ? 1.0 : 0.0);
+        }
+        acc[cb] = chd_f64x4{v[0], v[1], v[2], v[3]};
+      }
+    }
+    // - sum_k L(rows, k) d_k L(panel rows, k)^T, eight steps of four columns per pass, all loads of a pass issued together
+    constexpr int U = 8;
+    for (int k0 = kstart; k0 < c0; k0 += 4 * U) {
+      double a[U], b[NC][U], dk[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = k0 + 4 * u + lk;
+        const bool in = k < c0;
+        a[u] = *((in && k >= kminA) ? pA + k : safe);
+#pragma unroll
+        for (int cb = 0; cb < NC; ++cb) b[cb][u] = *((in && k >= kminB[cb]) ? pB[cb] + k : safe);
+        dk[u] = (in && k >= 0) ? dring[k & (CHD_LL_RING - 1)] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = k0 + 4 * u + lk;
+        const bool in = k < c0;
+        const double av = (in && k >= kminA) ? a[u] : 0.0;
+#pragma unroll
+        for (int cb = 0; cb < NC; ++cb) {
+          const double bv = (in && k >= kminB[cb]) ? -dk[u] * b[cb][u] : 0.0;
+          acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[cb], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int cb = 0; cb < NC; ++cb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int t = 16 * blk + lk + 4 * q; if (t < nrows) PT[(16 * cb + lr) * ldp + t] = acc[cb][q]; }
+  }
+}
+#endif
+
+// diagonal block of the panel from PT slots [0, NB) -> unit-lower DL, pivots dv (+ reciprocals at dv[32 ..]), the pivot ring, and the
+// block's rows of the factor storage.  One wavefront.
+#ifdef CHD_HOST_EMU
+template <int NB>
+CHD_DEV void ll_diag(LCtx& c, const GI* sign, LdsD* dv, LdsD* DL, const LdsD* PT, const int ldp, LdsD* dring, const int c0, const int jb) {
+  const int W1 = c.w + 1, w = c.w;
+  double A[NB][NB];
+  for (int a = 0; a < NB; ++a) for (int j = 0; j < NB; ++j) A[a][j] = j <= a ? PT[j * ldp + a] : 0.0;
+  for (int j = 0; j < NB; ++j) {
+    double d = A[j][j];
+    if (j < jb) d = pivot_fix(c, d, sign[c0 + j]);
+    const double inv = 1.0 / d;
+    for (int a = j + 1; a < NB; ++a) { A[a][j] *= inv; DL[j * NB + a] = A[a][j]; }
+    dv[j] = d; dv[32 + j] = inv;
+    for (int jj = j + 1; jj < NB; ++jj) for (int a = jj; a < NB; ++a) A[a][jj] -= A[a][j] * d * A[jj][j];
+  }
+  for (int a = 0; a < jb; ++a) {
+    dring[(c0 + a) & (CHD_LL_RING - 1)] = dv[a];
+    GD* dst = c.Kfb + (long long)(c0 + a) * W1 + (w - a);
+    for (int j = 0; j < a; ++j) dst[j] = DL[j * NB + a];
+    dst[a] = dv[a];
+  }
+}
+#else
+template <int NB>
+CHD_NOINLINE CHD_DEV void ll_diag(LCtx& c, const GI* sign, LdsD* dv, LdsD* DL, const LdsD* PT, const int ldp, LdsD* dring, const int c0, const int jb) {
+  if (threadIdx.x < 64) {
+    const int W1 = c.w + 1, w = c.w;
+    const int a = threadIdx.x;
+    const bool act = a < NB;
+    const int sg_a = a < jb ? sign[c0 + a] : 1;
+    double ar[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) ar[j] = (act && j <= a) ? PT[j * ldp + a] : (a == j ? 1.0 : 0.0);
+    const unsigned long long sg_pos = __ballot(sg_a > 0);
+    double u[NB], row[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) { u[k] = 0.0; row[k] = 0.0; }
+    double lprev = 0.0;
+    int bad = 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      if (j > 0) row[j - 1] = readlane_f64(lprev, j);
+      double s0 = ar[j], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+      for (int k = 0; k + 3 < j; k += 4) { s0 -= u[k] * row[k]; s1 -= u[k + 1] * row[k + 1]; s2 -= u[k + 2] * row[k + 2]; s3 -= u[k + 3] * row[k + 3]; }
+#pragma unroll
+      for (int k = j & ~3; k < j; ++k) s0 -= u[k] * row[k];
+      const double v = (s0 + s1) + (s2 + s3);
+      if (j + 1 < NB) {
+#pragma unroll
+        for (int k = 0; k < j; ++k) row[k] = DL[k * NB + (j + 1)];
+      }
+      double d = readlane_f64(v, j);
+      if (j < jb) { const double sg = ((sg_pos >> j) & 1ull) ? 1.0 : -1.0; if (!(d * sg > 1e-14)) { d = sg * 1e-10; ++bad; } }
+      const double inv = rcp_f64(d);
+      const double lj = v * inv;
+      u[j] = v; lprev = lj;
+      if (act && a > j) DL[j * NB + a] = lj;
+      if (a == j) { dv[j] = d; dv[32 + j] = inv; if (j < jb) dring[(c0 + j) & (CHD_LL_RING - 1)] = d; }
+      // this lane's row of the factor storage: L(a, j) for j < a, the pivot at j == a
+      if (a < jb && j <= a) c.Kfb[(long long)(c0 + a) * W1 + (w - a + j)] = (j == a) ? d : lj;
+    }
+    if (threadIdx.x == 0) c.n_bad_pivots += bad;
+  }
+}
+#endif
+
+// rows below the diagonal block: y_j = S(t, j) - sum_{k<j} y_k L(j, k);  L(t, j) = y_j / d_j, in place in PT (one list row per
+// thread; column k + 1 of the diagonal block's L is requested while column k's multiply-adds run)
+template <int NB>
+CHD_NOINLINE CHD_DEV void ll_rows(const int nrows, LdsD* PT, const int ldp, const LdsD* DL, const LdsD* dv) {
+  PAR_FOR(t2, nrows - NB) {
+    const int t = NB + t2;
+    double y0[NB], cur[NB], nx[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) { y0[j] = PT[j * ldp + t]; cur[j] = j > 0 ? DL[j] : 0.0; nx[j] = 0.0; }
+#pragma unroll
+    for (int k = 0; k < NB - 1; ++k) {
+#pragma unroll
+      for (int j = k + 2; j < NB; ++j) nx[j] = DL[(k + 1) * NB + j];
+      CHD_SCHED_FENCE();
+#pragma unroll
+      for (int j = k + 1; j < NB; ++j) y0[j] -= y0[k] * cur[j];
+      CHD_SCHED_FENCE();
+#pragma unroll
+      for (int j = k + 2; j < NB; ++j) cur[j] = nx[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) PT[j * ldp + t] = y0[j] * dv[32 + j];
+  }
+}
+// the solved rows -> factor storage: one task = 8 consecutive columns of one list row
+template <int NB>
+CHD_NOINLINE CHD_DEV void ll_store(LCtx& c, const int* rows_, const int nrows, const int c0, const int jb, const LdsD* PT, const int ldp) {
+  const int Nb = c.Nb, w = c.w, W1 = c.w + 1, LD = c.LD;
+#ifdef CHD_HOST_EMU
+  const int* rows = rows_;
+#else
+  const LdsI* rows = (const LdsI*)rows_;
+#endif
+  PAR_FOR(idx, (nrows - NB) * (NB / 8)) {
+    const int t = NB + idx / (NB / 8), j0 = (idx % (NB / 8)) * 8;
+    const int p = rows[t];
+    const bool band = p < Nb;
+    GD* dst = band ? c.Kfb + (long long)p * W1 + (c0 + j0 - p + w) : c.Kfx + (long long)(p - Nb) * LD + c0 + j0;
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = PT[(j0 + q) * ldp + t];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (j0 + q < jb && (!band || p - (c0 + j0 + q) <= w)) dst[q] = v[q];
+  }
+}
+
+// Schur complement of the border: S(r, q) = K0(r, q) + diag - sum_{k < Nb} L(r, k) d_k L(q, k), r >= q border rows, as 16 x 16 tiles
+// (one wavefront per tile, operands gathered from the border rows of the factor storage, pivots from its diagonal) -> SL (dense bc x bc, lower)
+#ifdef CHD_HOST_EMU
+CHD_DEV void ll_border_schur(LCtx& c, const GD* diag, LdsD* SL, const int lds_) {
+  const int Nb = c.Nb, W1 = c.w + 1, w = c.w, LD = c.LD, bc = c.bc;
+  for (int r = 0; r < bc; ++r)
+    for (int q = 0; q <= r; ++q) {
+      double v = c.K0x[(long long)r * LD + Nb + q] + (r == q ? diag[Nb + r] : 0.0);
+      const int fr = c.env[2 * (Nb + r)], fq = c.env[2 * (Nb + q)];
+      for (int k = fr > fq ? fr : fq; k < Nb; ++k) v -= c.Kfx[(long long)r * LD + k] * c.Kfb[(long long)k * W1 + w] * c.Kfx[(long long)q * LD + k];
+      SL[(long long)r * lds_ + q] = v;
+    }
+}
+#else
+template <class SP>
+CHD_NOINLINE CHD_DEV void ll_border_schur(LCtx& c, const GD* diag, SP SL, const int lds_) {
+  const int Nb = c.Nb, W1 = c.w + 1, w = c.w, LD = c.LD, bc = c.bc;
+  const int wave = threadIdx.x >> 6, nwv = blockDim.x >> 6, lane = threadIdx.x & 63;
+  const int lr = lane & 15, lk = lane >> 4;
+  const GD* Kfx = c.Kfx; const GD* Kfb = c.Kfb;
+  const GD* safe = c.Kfb + w;
+  const int nt = (bc + 15) >> 4, ntri = nt * (nt + 1) / 2;
+  for (int t = wave; t < ntri; t += nwv) {
+    int tr = (int)((__fsqrt_rn(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
+    while (tr * (tr + 1) / 2 > t) --tr;
+    const int tc = t - tr * (tr + 1) / 2;
+    const int ra = 16 * tr + lr, rb = 16 * tc + lr;
+    const bool okA = ra < bc, okB = rb < bc;
+    const GD* pA = Kfx + (long long)(okA ? ra : 0) * LD;
+    const GD* pB = Kfx + (long long)(okB ? rb : 0) * LD;
+    int fa = okA ? c.env[2 * (Nb + ra)] : 0x3fffffff, fb = okB ? c.env[2 * (Nb + rb)] : 0x3fffffff;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) { int u = __shfl_xor(fa, o); fa = u < fa ? u : fa; u = __shfl_xor(fb, o); fb = u < fb ? u : fb; }
+    const int klo = fa > fb ? fa : fb;
+    const int nst = klo < Nb ? (Nb - klo + 3) >> 2 : 0;
+    const int kstart = Nb - 4 * nst;
+    chd_f64x4 acc;
+    {
+      double v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = 16 * tr + lk + 4 * q, col = 16 * tc + lr;
+        const bool real = r < bc && col < bc;
+        const double t0 = *(real ? c.K0x + (long long)r * LD + Nb + col : safe);
+        v[q] = real ? t0 + (r == col ? diag[Nb + r] : 0.0) : 0.0;
+      }
+      acc = chd_f64x4{v[0], v[1], v[2], v[3]};
+    }
+    constexpr int U = 8;
+    for (int k0 = kstart; k0 < Nb; k0 += 4 * U) {
+      double a[U], b[U], dk[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = k0 + 4 * u + lk;
+        const bool in = k < Nb && k >= 0;
+        a[u] = *((in && okA) ? pA + k : safe);
+        b[u] = *((in && okB) ? pB + k : safe);
+        dk[u] = *(in ? Kfb + (long long)k * W1 + w : safe);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = k0 + 4 * u + lk;
+        const bool in = k < Nb && k >= 0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((in && okA) ? a[u] : 0.0, (in && okB) ? -dk[u] * b[u] : 0.0, acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = 16 * tr + lk + 4 * q, col = 16 * tc + lr;
+      if (r < bc && col <= r) SL[(long long)r * lds_ + col] = acc[q];
+    }
+  }
+}
+#endif
+
+template <int NC>
+CHD_DEV void kfactor_ll_band(LCtx& c, const GD* diag, const GI* sign, LdsD* dv, LdsD* DL, LdsD* dring, LdsD* PT, const int ldp, int* rowsA, int* rowsB, const int lsz) {
+  constexpr int NB = 16 * NC;
+  const int Nb = c.Nb;
+  // the list of panel J + 1 is built by the second wavefront while the first one factors panel J's diagonal block
+#ifdef CHD_HOST_EMU
+  ll_build_rows<NB>(c, rowsA, rowsA + lsz - 2, 0, Nb < NB ? Nb : NB);
+#else
+  if (CHD_WAVE_ID == 1) ll_build_rows<NB>(c, rowsA, rowsA + lsz - 2, 0, Nb < NB ? Nb : NB);
+#endif
+  CHD_SYNC();
+  for (int c0 = 0; c0 < Nb; c0 += NB) {
+    const int jb = Nb - c0 < NB ? Nb - c0 : NB;
+#ifdef CHD_HOST_EMU
+    const int nrows = rowsA[lsz - 2], pf = rowsA[lsz - 1];
+#else
+    const int nrows = ((const LdsI*)rowsA)[lsz - 2], pf = ((const LdsI*)rowsA)[lsz - 1];
+#endif
+    long long tp_ = CHD_CLOCK();
+    ll_tiles<NC>(c, diag, rowsA, nrows, pf, c0, jb, PT, ldp, dring);
+    CHD_SYNC();
+    TACC(c, 8, CHD_CLOCK() - tp_); tp_ = CHD_CLOCK();
+    ll_diag<NB>(c, sign, dv, DL, PT, ldp, dring, c0, jb);
+    const int c0n = c0 + NB;
+#ifdef CHD_HOST_EMU
+    if (c0n < Nb) ll_build_rows<NB>(c, rowsB, rowsB + lsz - 2, c0n, Nb - c0n < NB ? Nb - c0n : NB);
+#else
+    if (c0n < Nb && CHD_WAVE_ID == 1) ll_build_rows<NB>(c, rowsB, rowsB + lsz - 2, c0n, Nb - c0n < NB ? Nb - c0n : NB);
+#endif
+    CHD_SYNC();
+    TACC(c, 9, CHD_CLOCK() - tp_); tp_ = CHD_CLOCK();
+#if CHD_INERTIA_RETRY && CHD_ABORT_BAD_FACTOR
+    if (c.n_bad_pivots > 0) return;          // the factorisation is going to be discarded (inertia retry)
+#endif
+    ll_rows<NB>(nrows, PT, ldp, DL, dv);
+    CHD_SYNC();
+    TACC(c, 10, CHD_CLOCK() - tp_); tp_ = CHD_CLOCK();
+    ll_store<NB>(c, rowsA, nrows, c0, jb, PT, ldp);
+    CHD_SYNC();                              // (the stores above are operands of the next panel's tiles)
+    TACC(c, 11, CHD_CLOCK() - tp_);
+    int* t_ = rowsA; rowsA = rowsB; rowsB = t_;
+  }
+}
+
+// returns false when the shape does not fit (the caller then runs the right-looking version)
+CHD_DEV bool kfactor_ll(LCtx& c, const GD* diag, const GI* sign) {
+  const int Nb = c.Nb, w = c.w, LD = c.LD, bc = c.bc;
+  const int lsz = 32 + w + bc + 2;                     // ints per row list (+ count, + pf)
+  const int fixed = LDS_RED + 64 + 32 * 32 + CHD_LL_RING + (2 * lsz + 1) / 2 + 8;
+  int nc = 2;
+  while (nc >= 1 && (long long)(16 * nc + w + bc + 18) * (16 * nc) > c.lds_cap - fixed) --nc;
+  if (nc < 1 || w + 32 >= CHD_LL_RING) return false;
+  if (CHD_TID == 0) c.n_bad_pivots = 0;
+  LdsD* dv = c.lds + LDS_RED;
+  LdsD* DL = dv + 64;
+  LdsD* dring = DL + 32 * 32;
+  LdsD* PT = dring + CHD_LL_RING;
+  const int NB = 16 * nc;
+  const int ldp = (NB + w + bc + 17) | 1;
+  int* rowsA = (int*)(PT + (long long)ldp * NB); int* rowsB = rowsA + lsz;
+  CHD_SYNC();
+  if (nc == 2) kfactor_ll_band<2>(c, diag, sign, dv, DL, dring, PT, ldp, rowsA, rowsB, lsz);
+  else kfactor_ll_band<1>(c, diag, sign, dv, DL, dring, PT, ldp, rowsA, rowsB, lsz);
+  CHD_SYNC();
+  // ---- border: Schur complement from the finished band factor, dense L D L^T in LDS
+  const long long td_ = CHD_CLOCK();
+  if (bc > 0 && !(CHD_INERTIA_RETRY && CHD_ABORT_BAD_FACTOR && c.n_bad_pivots > 0)) {
+    LdsD* SL = c.lds + LDS_RED;
+    const bool in_lds = (long long)bc * bc <= c.lds_cap - LDS_RED;
+    if (in_lds) {
+      ll_border_schur(c, diag, SL, bc);
+      CHD_SYNC();
+      dense_ldlt(c, SL, bc, bc, sign + Nb);
+      PAR_FOR(idx, bc * bc) { const int r = idx / bc, k = idx % bc; if (k <= r) c.Kfx[(long long)r * LD + Nb + k] = SL[idx]; }
+      CHD_SYNC();
+    } else {
+      ll_border_schur(c, diag, c.Kfx + Nb, LD);
+      CHD_SYNC();
+      dense_ldlt(c, c.Kfx + Nb, LD, bc, sign + Nb);
+    }
+  }
+  TACC(c, 12, CHD_CLOCK() - td_);
+  return true;
+}
+
+#ifndef CHD_FACTOR_LL
+#define CHD_FACTOR_LL 1
+#endif
+CHD_NOINLINE CHD_DEV void kfactor(LCtx& c, const GD* diag, const GI* sign) {
+#if CHD_FACTOR_LL
+  TIC();
+  if (kfactor_ll(c, diag, sign)) { TOC(c, 2); return; }
+#endif
+  kfactor_rl(c, diag, sign);
 }
 
 // in-block triangular solves for the substitution (wave-cooperative on the device)
@@ -2166,7 +2636,7 @@ CHD_DEV void fill_rom_cache(LCtx& c, const GD* lam) {
     GD* r = q->wd + q->o_rcache + (long long)idx * RC_STRIDE;
     for (int j = 0; j < 4; ++j) r[SC_WP + j] = e.w[0][j];
     const int row = S->heel_row0 + (ee % 2) * q->n_trom + k;          // pairs (0, 2) and (1, 3): nlp_formulation.cpp:249-257
-    r[RC_MU] = lam[row] * sc[row];
+    r[RC_MU] = (c.clip_heel ? fmax(lam[row], 0.0) : lam[row]) * sc[row];
     r[SC_POLY] = e.poly;
   }
   CHD_SYNC();
@@ -2710,6 +3180,21 @@ CHD_NOINLINE CHD_DEV void solve_stage(LCtx& c, StageResult& res) {
     bool ok = false, used_soc = false;
     double alpha = 0, a_du = 1.0;
     int nls = 0, attempt = 0;
+    // Second model of an iteration: when an attempt fails (wrong inertia, or the line search runs out of backtracks) the model is
+    // rebuilt ONCE with the negative part of the heel-distance curvature dropped (lam -> max(lam, 0) in that block) and the attempt
+    // is repeated with the same damping; only if that fails too does the damping grow.  The exact block is what makes the easy
+    // sequences converge in few iterations; its negative part kept the hard ones at dw ~ 10..1e4 for hundreds of iterations.
+    bool clipped = false;
+    auto second_model = [&]() -> bool {
+      if (clipped || it == 0) return false;          // (the first model of a stage has no curvature terms)
+      clipped = true;
+      if (CHD_TID == 0) c.clip_heel = 1;
+      CHD_SYNC();
+      f = eval_nlp(c, x, EV_FULL, cc, g, lam);
+      if (CHD_TID == 0) c.clip_heel = 0;
+      CHD_SYNC();
+      return true;
+    };
     for (attempt = 0; attempt < CHD_MAX_ATTEMPTS; ++attempt) {
       PAR_FOR(j, n) diag[pos_var[j]] = dw * Dw[j];
       PAR_FOR(i, m) diag[pos_row[i]] = -D[i];
@@ -2717,7 +3202,7 @@ CHD_NOINLINE CHD_DEV void solve_stage(LCtx& c, StageResult& res) {
       kfactor(c, diag, sign); ++n_factor;
 #if CHD_INERTIA_RETRY
       // a pivot of unexpected sign was replaced (wrong inertia): more damping instead of a step from the modified matrix
-      if (block_sum(c, CHD_TID == 0 ? (double)c.n_bad_pivots : 0.0) > 0.0) { dw *= 10.0; if (dw > CHD_DELTA_W_MAX) break; continue; }
+      if (block_sum(c, CHD_TID == 0 ? (double)c.n_bad_pivots : 0.0) > 0.0) { if (second_model()) continue; dw *= 10.0; if (dw > CHD_DELTA_W_MAX) break; continue; }
 #endif
       ksolve(c, rhs, sol, diag, 1);
       PAR_FOR(j, n) dx[j] = sol[pos_var[j]];
@@ -2754,7 +3239,13 @@ CHD_NOINLINE CHD_DEV void solve_stage(LCtx& c, StageResult& res) {
       PAR_FOR(i, m) dHd -= (rhs[pos_row[i]] + D[i] * dlam[i]) * dlam[i];
       dHd = block_sum(c, dHd) + sSds; gdx = block_sum(c, gdx);
       const double dphi_bar = gdx + dbar;
-      if (cn > 1e-14) { const double nut = (dphi_bar + 0.5 * fmax(dHd, 0.0)) / ((1 - 0.1) * cn); if (nut > nu) nu = nut * 1.1 + 1e-8; }
+      // penalty parameter of the merit function, recomputed for every step (not monotone): a value that was needed once -- typically a
+      // quotient by a constraint violation at noise level -- otherwise stays for the rest of the stage, and every later step is then
+      // judged by second-order changes of a violation of 1e-7 times nu = 1e3 (the duration-stage stragglers of round 2)
+      {
+        const double nut = cn >= 1e-6 ? (dphi_bar + 0.5 * fmax(dHd, 0.0)) / ((1 - 0.1) * cn) : 0.0;
+        nu = fmax(1.0, nut * 1.1 + 1e-8);
+      }
       const double Dphi = dphi_bar - nu * cn;
       const double phi0 = f + barrier_val(c, s, mu) + nu * cn;
       alpha = a_pr; ok = false; nls = 0; used_soc = false;
@@ -2803,6 +3294,7 @@ CHD_NOINLINE CHD_DEV void solve_stage(LCtx& c, StageResult& res) {
         alpha *= 0.5; ++nls;
       }
       if (ok) break;
+      if (second_model()) continue;
       dw *= 10.0;
       if (dw > CHD_DELTA_W_MAX) break;
     }
@@ -2873,7 +3365,7 @@ CHD_DEV void bind_stage(LCtx& c, QP q, int stage) {
     c.W2 = 2 * c.w + 1; c.LD = c.N;
     c.K0b = q->wd + q->o_K0b; c.K0x = q->wd + q->o_K0x; c.Kfb = q->wd + q->o_Kfb; c.Kfx = q->wd + q->o_Kfx;
     c.pos_var = q->ci + c.S->o_pos_var; c.pos_row = q->ci + c.S->o_pos_row; c.env = q->wi + q->o_envw; c.rcnt = q->wi + q->o_rcntw;
-    c.sf = 1.0; c.err = 0; c.n_bad_pivots = 0;
+    c.sf = 1.0; c.err = 0; c.n_bad_pivots = 0; c.clip_heel = 0;
   }
   CHD_SYNC();
 }
@@ -2970,6 +3462,35 @@ CHD_DEV void debug_eval(QP q, LCtx& c, int stage, int use_x, LdsD* lds, int lds_
   CHD_SYNC();
   const double f = eval_nlp(c, x, EV_FULL, VM(c, VM_C), VN(c, VN_G), lamin ? VM(c, VM_LAM) : nullptr);
   if (CHD_TID == 0) { f_out[0] = f; f_out[1] = c.err; }
+  CHD_SYNC();
+}
+
+// Debug entry: K0 of `stage` at the initial state, + (dw Dw, -dval) on the diagonal, factored `reps` times by the left-looking
+// (which = 0) or the right-looking (1) factorisation and solved for `rhs` (one refinement step).  out: [0] replaced pivots,
+// [1] clock ticks (100 MHz) of the factorisations, [2] of the solve, [3] which one ran (0 / 1).
+CHD_DEV void debug_linsolve(QP q, LCtx& c, int stage, LdsD* lds, int lds_cap, double dw, double dval, int which, int reps, const GD* rhs_in, GD* x_out, double* out) {
+  double fo[2];
+  debug_eval(q, c, stage, 0, lds, lds_cap, nullptr, nullptr, fo);
+  GD* diag = VK(c, VK_DIAG); GI* sign = q->wi + q->o_sign;
+  const GD* Dw = q->cd + c.S->o_Dw;
+  PAR_FOR(j, c.n) { diag[c.pos_var[j]] = dw * Dw[j]; sign[c.pos_var[j]] = 1; }
+  PAR_FOR(i, c.m) { diag[c.pos_row[i]] = -dval; sign[c.pos_row[i]] = -1; }
+  CHD_SYNC();
+  int ran = which;
+  const long long t0 = CHD_CLOCK();
+  for (int r = 0; r < reps; ++r) {
+    if (which == 0) { if (!kfactor_ll(c, diag, sign)) { kfactor_rl(c, diag, sign); ran = 1; } }
+    else kfactor_rl(c, diag, sign);
+    CHD_SYNC();
+  }
+  const long long t1 = CHD_CLOCK();
+  GD* rhs = VK(c, VK_RHS); GD* sol = VK(c, VK_SOL);
+  PAR_FOR(i, c.N) rhs[i] = rhs_in[i];
+  CHD_SYNC();
+  ksolve(c, rhs, sol, diag, 1);
+  const long long t2 = CHD_CLOCK();
+  PAR_FOR(i, c.N) x_out[i] = sol[i];
+  if (CHD_TID == 0) { out[0] = c.n_bad_pivots; out[1] = (double)(t1 - t0); out[2] = (double)(t2 - t1); out[3] = ran; }
   CHD_SYNC();
 }
 

@@ -73,6 +73,17 @@ __global__ __launch_bounds__(CHD_MAX_THREADS) void chd_debug_eval_kernel(const S
   debug_eval((QP)&s_desc, *(LCtx*)&s_ctx, stage, xin != nullptr, (LdsD*)lds, lds_doubles, (const GD*)xin, (const GD*)nullptr, f_out);
 }
 
+__global__ __launch_bounds__(CHD_MAX_THREADS) void chd_debug_linsolve_kernel(const SeqDesc* descs, const int* order, int* counter, double* wd_pool, int* wi_pool,
+                                                                             int stage, int lds_doubles, double dw, double dval, int which, int reps,
+                                                                             const double* rhs, double* x, double* out) {
+  extern __shared__ double lds[];
+  __shared__ SeqDesc s_desc;
+  __shared__ Ctx s_ctx;
+  __shared__ int s_item;
+  if (!take_sequence(&s_desc, &s_item, descs, order, 1, counter, wd_pool, 0, wi_pool, 0)) return;
+  debug_linsolve((QP)&s_desc, *(LCtx*)&s_ctx, stage, (LdsD*)lds, lds_doubles, dw, dval, which, reps, (const GD*)rhs, (GD*)x, out);
+}
+
 struct chd_handle {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -163,6 +174,7 @@ int chd_phys_create(const chd_config* cfg, int device_id, chd_handle** out) {
   if (h->cfg.lds_kilobytes > 0 && h->cfg.lds_kilobytes * 1024 < h->lds_bytes) h->lds_bytes = std::max(32, h->cfg.lds_kilobytes) * 1024;
   hipFuncSetAttribute((const void*)chd_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
   hipFuncSetAttribute((const void*)chd_debug_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
+  hipFuncSetAttribute((const void*)chd_debug_linsolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
   // the factorisation / substitution phases are written for eight wavefronts (wave-specialised look-ahead, register prefetch
   // by lane group): other workgroup sizes are refused rather than silently mis-solved
   // (experiment, profiles/r02k_final/two_workgroups.md: with CHD_EXPERIMENTAL_256 set, 256-thread workgroups -- two per compute unit with
@@ -584,6 +596,31 @@ int chd_debug_eval(chd_handle* h, chd_batch* b, int seq, int stage, const double
     if (H) for (int a = 0; a < n; ++a) for (int c2 = 0; c2 < n; ++c2) H[(size_t)a * n + c2] = get(pv[a], pv[c2]);
   }
   return (int)fo[1];
+}
+
+// Factor / solve self test of one sequence's KKT matrix (stage `stage` at the initial state, diagonal dw Dw / -dval):
+// which = 0 the left-looking factorisation (what the solver runs), 1 the right-looking one.  info: [0] replaced pivots,
+// [1] / [2] clock ticks (100 MHz) of `reps` factorisations / of the solve, [3] the factorisation that actually ran.
+int chd_debug_linsolve(chd_handle* h, chd_batch* b, int seq, int stage, double dw, double dval, int which, int reps, const double* rhs, double* x, double* info) {
+  if (!h || !b || seq < 0 || seq >= b->B || stage < 0 || stage >= N_STAGES || !b->ok[seq] || !rhs || !x) return fail(h, "chd_debug_linsolve: bad arguments");
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (ensure_workspace(h, b->wd_need, b->wi_need) != 0) return -1;
+  const StageDesc& S = b->models[seq].d.st[stage];
+  const int N = S.n + S.m;
+  double* d_buf = nullptr;
+  HIP_TRY(h, hipMalloc((void**)&d_buf, (size_t)(2 * N + 8) * 8));
+  HIP_TRY(h, hipMemcpy(d_buf, rhs, (size_t)N * 8, hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMemcpyAsync(b->d_order, &seq, sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->d_counter, 0, sizeof(int), h->stream));
+  hipLaunchKernelGGL(chd_debug_linsolve_kernel, dim3(1), dim3(h->threads), h->lds_bytes, h->stream, b->d_descs, (const int*)b->d_order, h->d_counter, h->d_wd, h->d_wi,
+                     stage, h->lds_bytes / 8, dw, dval, which, reps < 1 ? 1 : reps, (const double*)d_buf, d_buf + N, d_buf + 2 * N);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e == hipSuccess) e = hipMemcpy(x, d_buf + N, (size_t)N * 8, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && info) e = hipMemcpy(info, d_buf + 2 * N, 4 * 8, hipMemcpyDeviceToHost);
+  (void)hipFree(d_buf);
+  if (e != hipSuccess) return fail(h, std::string("chd_debug_linsolve: ") + hipGetErrorString(e));
+  return 0;
 }
 
 }  // extern "C"

@@ -24,7 +24,7 @@ SNAPSHOT_FILES = ('sol_out_no_dynamics.txt', 'sol_out_dynamics.txt', 'sol_out_du
 
 EXPORTS = ['chd_phys_version', 'chd_config_default', 'chd_phys_create', 'chd_phys_destroy', 'chd_phys_last_error',
            'chd_batch_upload', 'chd_batch_solve', 'chd_batch_fetch', 'chd_batch_free', 'chd_batch_get_stats',
-           'chd_phys_solve_batch', 'chd_phys_solve_dirs', 'chd_debug_sizes', 'chd_debug_eval']
+           'chd_phys_solve_batch', 'chd_phys_solve_dirs', 'chd_debug_sizes', 'chd_debug_eval', 'chd_debug_linsolve']
 
 
 def build_library(force=False, verbose=False):
@@ -84,6 +84,7 @@ def load_library():
     L.chd_phys_solve_dirs.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.chd_debug_sizes.argtypes = [vp, vp, C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 5
     L.chd_debug_eval.argtypes = [vp, vp, C.c_int, C.c_int, PD, PD, PD, PD, PD, PD, PD]
+    L.chd_debug_linsolve.argtypes = [vp, vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, PD, PD, PD]
     _LIB = L
     return L
 
@@ -178,6 +179,17 @@ class Batch:
         if rc < 0:
             raise PhysError('chd_debug_eval: ' + self.solver.last_error())
         return dict(x=xo, f=f.value, g=g, c=c, J=J, H=H, err=rc)
+
+    def debug_linsolve(self, seq, stage, rhs, dw=1e-4, dval=1e-3, which=0, reps=1):
+        """Factor / solve self test of the KKT matrix of (seq, stage) at the initial state: which = 0 the left-looking factorisation (what
+        the solver runs), 1 the right-looking one.  Returns (x, info) with info = dict(bad_pivots, factor_us, solve_us, ran)."""
+        sz = self.sizes(seq, stage)
+        rhs = np.ascontiguousarray(rhs, dtype=np.float64)
+        assert rhs.size == sz['kkt_dim']
+        x = np.zeros(sz['kkt_dim']); info = np.zeros(4)
+        self.solver._check(self.solver.L.chd_debug_linsolve(self.solver.h, self.h, seq, stage, dw, dval, which, reps, rhs.ctypes.data_as(PD), x.ctypes.data_as(PD),
+                                                            info.ctypes.data_as(PD)), 'chd_debug_linsolve')
+        return x, dict(bad_pivots=int(info[0]), factor_us=info[1] / 100.0 / max(1, reps), solve_us=info[2] / 100.0, ran=int(info[3]))
 
     def free(self):
         if self.h:

@@ -166,6 +166,12 @@ int chd_phys_solve_dirs(chd_handle* h, int B, const char* const* in_dirs, const 
  *   Gauss-Newton objective Hessian H (n x n) of `stage` at x (NULL = initial guess) for
  *   sequence `seq` of an uploaded batch, on the device.  Any output pointer may be NULL. */
 int chd_debug_sizes(chd_handle* h, chd_batch* b, int seq, int stage, int* n, int* m, int* kkt_dim, int* halfband, int* border);
+/* chd_debug_linsolve: factor / solve self test of the sequence's KKT matrix of `stage` at the initial state, with dw * Dw on the
+ * variable diagonal and -dval on the row diagonal: which = 0 the left-looking factorisation (what the solver runs), 1 the
+ * right-looking one; `reps` factorisations are timed.  rhs, x: kkt_dim doubles (KKT ordering).  info (4 doubles): replaced
+ * pivots, clock ticks (100 MHz) of the factorisations, of the solve, the factorisation that ran (0 / 1). */
+int chd_debug_linsolve(chd_handle* h, chd_batch* b, int seq, int stage, double dw, double dval, int which, int reps,
+                       const double* rhs, double* x, double* info);
 int chd_debug_eval(chd_handle* h, chd_batch* b, int seq, int stage, const double* x,
                    double* x_out, double* f, double* grad, double* c, double* J, double* H);
 

@@ -18,8 +18,9 @@
 //   * Hessian: Gauss-Newton Hessian of the sum-of-squares objective, plus the exact duration-duration
 //     block of the Lagrangian Hessian when the phase durations are variables (nlp_model.hpp), plus an
 //     adaptive Levenberg damping dw*Dw, instead of L-BFGS(6);
-//   * globalisation: l1 merit function with backtracking instead of the filter +
-//     restoration phase;
+//   * globalisation: l1 merit function (penalty parameter recomputed per step) with backtracking and a
+//     second-order correction instead of the filter + restoration phase; a failed attempt first retries with the
+//     negative part of the heel-distance curvature dropped, then with more damping;
 //   * mu_init = 1e-3 and mu-based bound multipliers for the warm-started stages;
 //   * linear algebra: bordered banded LDL^T without pivoting in a time ordering
 //     (stance positions / durations in the border) instead of MA57.
@@ -388,6 +389,18 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
     res.bandwidth = std::max(res.bandwidth, w);
 
     bool ok = false, used_soc = false; double alpha = 0, a_du = 1.0; int nls = 0, attempt = 0;
+    // Second model of an iteration: when an attempt fails (wrong inertia, or the line search runs out of backtracks) the Hessian is
+    // rebuilt ONCE with the negative part of the heel-distance curvature dropped (lam -> max(lam, 0) in that block) and the attempt is
+    // repeated with the same damping; only if that fails too does the damping grow.  The exact block is what makes the easy sequences
+    // converge in few iterations; its negative part is what kept the hard ones at dw ~ 10..1e4 for hundreds of iterations.
+    bool clipped = false;
+    auto second_model = [&]() {
+      if (clipped || it == 0 || opt.lbfgs) return false;          // (the first model of a stage has no curvature terms)
+      clipped = true;
+      P.eval(x.data(), &fraw, graw.data(), craw.data(), J.data(), H.data(), lraw.data(), true);
+      apply_scaling(true);
+      return true;
+    };
     for (attempt = 0; attempt < opt.max_attempts; ++attempt) {
       K.resize(Nb, bcount, w);
       if (opt.lbfgs) {
@@ -404,7 +417,7 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
         K.add(pos_row[i], pos_row[i], -D[i]);
       }
       K.factor(); ++res.n_factor;
-      if (opt.inertia_retry && K.n_bad_pivots > 0) { dw *= 10.0; if (dw > opt.delta_w_max) break; continue; }
+      if (opt.inertia_retry && K.n_bad_pivots > 0) { if (second_model()) continue; dw *= 10.0; if (dw > opt.delta_w_max) break; continue; }
       const int lk = opt.lbfgs ? (int)lb_S.size() : 0;
       std::vector<double> lbZ, lbC;          // Z = K_sigma^-1 What (N x 2k, column major), C = M - What^T Z (2k x 2k)
       if (lk > 0) {
@@ -473,7 +486,13 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
       for (int i = 0; i < m; ++i) dHd -= (rhs[pos_row[i]] + D[i] * dlam[i]) * dlam[i];
       dHd += sSds;
       double dphi_bar = gdx + dbar;
-      if (cn > 1e-14) { double nut = (dphi_bar + 0.5 * std::max(dHd, 0.0)) / ((1 - 0.1) * cn); if (nut > nu) nu = nut * 1.1 + 1e-8; }
+      // penalty parameter of the merit function, recomputed for every step (not monotone): a value that was needed once -- typically
+      // a quotient by a constraint violation at noise level -- otherwise stays for the rest of the stage and every later step is then
+      // judged by second-order changes of a violation of 1e-7 times nu = 1e3 (the stage-3 stragglers of round 2)
+      {
+        const double nut = cn >= 1e-6 ? (dphi_bar + 0.5 * std::max(dHd, 0.0)) / ((1 - 0.1) * cn) : 0.0;
+        nu = std::max(1.0, nut * 1.1 + 1e-8);
+      }
       double Dphi = dphi_bar - nu * cn;
       double phi0 = f + barrier(s, mu) + nu * cn;
       alpha = a_pr; ok = false; nls = 0; used_soc = false;
@@ -518,6 +537,7 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
         alpha *= 0.5; ++nls;
       }
       if (ok) break;
+      if (second_model()) continue;
       dw *= 10.0;
       if (dw > opt.delta_w_max) break;
     }

@@ -751,7 +751,9 @@ class Problem {
   // H: dense n x n Gauss-Newton Hessian of the (sum-of-squares) objective (may be null).
   // lam (optional, m entries): multipliers of the unscaled rows; when given together with H and the durations are
   // variables, the exact duration-duration block of sum_i lam_i grad^2 c_i + (grad^2 f - Gauss-Newton part) is added to H.
-  void eval(const double* x, double* f_out, double* grad, double* c, double* J, double* H = nullptr, const double* lam = nullptr) {
+  // clip_neg_heel: the node-node curvature block of the heel-distance rows takes max(lam, 0) (the solver's second model of an
+  // iteration, ipm_solver.hpp: the negative part of that block is what makes the line search / the inertia fail on the hard sequences).
+  void eval(const double* x, double* f_out, double* grad, double* c, double* J, double* H = nullptr, const double* lam = nullptr, bool clip_neg_heel = false) {
     set_x(x);
     if (J) std::fill(J, J + (size_t)m * n, 0.0);
     if (grad) std::fill(grad, grad + n, 0.0);
@@ -897,7 +899,7 @@ class Problem {
                 };
                 push(sp[2 + e1], pe, 1.0); push(sp[2 + e2], pe2, -1.0);
                 for (int a = 0; a < ng; ++a)
-                  for (int b2 = 0; b2 < ng; ++b2) H[(size_t)gv[a] * n + gv[b2]] += lam[row] * gw[a] * gw[b2];
+                  for (int b2 = 0; b2 < ng; ++b2) H[(size_t)gv[a] * n + gv[b2]] += (clip_neg_heel ? std::max(lam[row], 0.0) : lam[row]) * gw[a] * gw[b2];
               }
             }
             if (D2) {

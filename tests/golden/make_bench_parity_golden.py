@@ -5,6 +5,7 @@ HIP path to the oracle on EVERY bench sequence without spending GPU-box minutes 
   flat    seeds 0..127, F = 90, flat floor        (BASELINE.json configs[1]: exactly bench.py's batch of rank 0)
   tilted  seeds 200..231, F = 90, floor tilted by 2..9.75 degrees about x (the sequences on which round 1's
           parity holes showed up were mostly tilted ones)
+  hard    36 seeds of bench.py's --steps 20 workload that the round-2 solver struggled with (stage-4 fallbacks, most iterations)
   long    one 600-frame sequence, 10 degree tilt  (configs[4]) -- only with --long (takes tens of minutes on one core)
 
 Reference iteration caps 7000/7000/7000/2500/2000/7000, tol 1e-3 (phys_optim.cpp:571-743) and the solver's default
@@ -31,6 +32,10 @@ CAPS = [7000, 7000, 7000, 2500, 2000, 7000]
 FLAT = [(s, 90, 0.0) for s in range(128)]
 TILTED = [(200 + i, 90, 2.0 + 0.25 * i) for i in range(32)]
 LONG = [(0, 600, 10.0)]
+# the sequences of bench.py's 2 560 (--steps 20) that were hard for the round-2 solver: its 20 stage-4 fallbacks (six of them ended by
+# the stall guard) and the 24 with the most iterations (gpurun_out/r03a/seq_stats.npz, tests/tools/gpu_seq_stats.py)
+HARD = [(s, 90, 0.0) for s in (139, 162, 197, 284, 302, 436, 659, 731, 827, 842, 983, 1051, 1231, 1288, 1384, 1416, 1449, 1554, 1682, 1688, 1779, 1823,
+                               1887, 1907, 1945, 2010, 2105, 2133, 2194, 2242, 2256, 2281, 2395, 2459, 2510, 2556)]
 
 
 def case_key(seed, F, tilt):
@@ -61,7 +66,7 @@ if __name__ == '__main__':
     args = ap.parse_args()
     from oracle import oracle
     oracle.build()
-    cases = FLAT + TILTED + (LONG if args.long else [])
+    cases = FLAT + TILTED + HARD + (LONG if args.long else [])
     out = {}
     if args.long and os.path.exists(args.out):          # keep what a previous run produced: only missing cases are solved
         old = np.load(args.out)
@@ -80,5 +85,5 @@ if __name__ == '__main__':
                 out['%s_snap%d_contact' % (key, k)] = np.asarray(sn['contact'], dtype=np.uint8)
             print('%s  %5.1f s  %s' % (key, dt, [(s[0], s[1]) for s in stats]), flush=True)
     np.savez_compressed(args.out, **out)
-    print('wrote %s: %d cases, %.0f s wall, %.1f MB' % (args.out, len(FLAT + TILTED) + (1 if args.long else 0), time.time() - t0,
+    print('wrote %s: %d cases, %.0f s wall, %.1f MB' % (args.out, len(FLAT + TILTED + HARD) + (1 if args.long else 0), time.time() - t0,
                                                       os.path.getsize(args.out) / 1e6))

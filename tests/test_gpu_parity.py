@@ -150,7 +150,7 @@ def test_bench_workload_matches_oracle():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
     import make_bench_parity_golden as mk
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'bench_parity_golden.npz'))
-    cases = [c for c in mk.FLAT + mk.TILTED if mk.case_key(*c) + '_status' in g.files]
+    cases = [c for c in mk.FLAT + mk.TILTED + mk.HARD if mk.case_key(*c) + '_status' in g.files]
     assert len(cases) >= 160
     seqs = [mk.make_case(*c) for c in cases]
     s = PhysOptim(device=0, config=default_config(max_iter=REF_CAPS))
@@ -183,7 +183,7 @@ def test_bench_workload_matches_oracle():
             assert r.stage_status[first_bad] == gs[first_bad] and list(r.stage_status[:first_bad]) == gs[:first_bad], (key, r.stage_status, gs)
             assert err < 1e-2, (key, err)
     print('bench workload parity: %d sequences, worst rel-L2 %.2e on the %d converging ones' % (len(cases), worst, len(cases) - n_failed))
-    assert n_failed <= 2
+    assert n_failed <= 6          # (the 36 "hard" seeds include the 20 whose duration stage failed in round 2; 4 still fail in the oracle)
 
 
 def test_bad_sequence_loses_only_itself(tmp_path):
@@ -254,3 +254,28 @@ def test_long_sequence_matches_oracle():
         assert np.array_equal(np.asarray(sn.contact), g['%s_snap%d_contact' % (key, k)])
     print('600-frame sequence: worst rel-L2 %.2e, kernel %.0f ms' % (worst, st['kernel_ms'][0]))
     assert worst < 1e-3
+
+
+def test_left_looking_factorisation_matches_right_looking():
+    """The factorisation the solver runs (left-looking, matrix-core tiles gathered from the factor storage: kfactor_ll) against the
+    right-looking one of rounds 1-2 (kfactor_rl) on the KKT matrices of all stages: same solution of K x = b to 1e-8 (both with one
+    refinement step), no replaced pivots, and it is the left-looking one that ran."""
+    from chd_amd.phys_optim import PhysOptim, default_config
+    s = PhysOptim(device=0, config=default_config())
+    seqs = [make_walk(seed=3, F=90, randomize=True), make_walk(seed=11, F=60, randomize=True, tilt_deg=5.0)]
+    b = s.upload(seqs)
+    rng = np.random.default_rng(0)
+    try:
+        for q in range(len(seqs)):
+            for stage in range(5):
+                N = b.sizes(q, stage)['kkt_dim']
+                rhs = rng.normal(size=N)
+                x0, i0 = b.debug_linsolve(q, stage, rhs, dw=1e-2, dval=1e-3, which=0)
+                x1, i1 = b.debug_linsolve(q, stage, rhs, dw=1e-2, dval=1e-3, which=1)
+                assert i0['ran'] == 0 and i1['ran'] == 1
+                assert i0['bad_pivots'] == 0 and i1['bad_pivots'] == 0
+                assert np.isfinite(x0).all()
+                err = np.linalg.norm(x0 - x1) / np.linalg.norm(x1)
+                assert err < 1e-8, (q, stage, err)
+    finally:
+        b.free(); s.close()
