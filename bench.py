@@ -5,10 +5,10 @@
 
 One "step" = one full staged solve (stages 1.1, 1.2, 2.1, 2.2, 3 and the stage-4 fallback where stage 3 fails;
 phys_optim.cpp:544-749, reference iteration caps and tolerance) of one batch of 128 synthetic 90-frame sequences
-(BASELINE.json configs[1]).  The solver's stall guard is ON in the measured configuration (chd_config.stall_window = 150,
---stall-window 0 switches it off; its hits are reported): roughly one 90-frame sequence in a thousand stagnates in the
-duration stage and would otherwise run to the 2000-iteration cap -- ~13 s on one compute unit -- before taking the same
-stage-4 fallback.  The K steps of the timed region are K DIFFERENT batches -- seeds
+(BASELINE.json configs[1]).  Reference semantics: every stage runs until it converges, fails or reaches the reference's
+iteration cap -- the solver's optional stall guard (chd_config.stall_window, not an IPOPT rule) is OFF in the measured
+configuration; the same workload with the guard at 150 is timed afterwards and reported next to `value`
+(`config.value_with_stall_guard_150`).  The K steps of the timed region are K DIFFERENT batches -- seeds
 rank*K*128 .. (rank+1)*K*128 - 1, a one-GPU slice of configs[2] -- handed to the library in one call: inputs and
 structure tables are resident in HBM when the clock starts, and ONE persistent launch (one resident workgroup per
 compute unit taking sequences from a queue) drains them; one handle, one stream, no replicated batches.
@@ -32,19 +32,29 @@ FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector = matrix peak (AMD spec)
 CAPS = [7000, 7000, 7000, 2500, 2000, 7000]
 
 
+def kernel_sources_sha256():
+    """Hash of the solver kernel's sources: profiles/traffic.json carries the one its PMC passes were measured with (tools/pmc_summary.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ('chd_kernels.hpp', 'chd_phys.hip', 'chd_model.hpp', 'chd_device.hpp'):
+        with open(os.path.join(ROOT, 'contact-human-dynamics_amd', 'csrc', f), 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def _gen(args):
     import chd_amd  # noqa: F401
     from chd_amd.synth import make_walk
-    seed0, n = args
-    return [make_walk(seed=seed0 + i, F=FRAMES, randomize=True) for i in range(n)]
+    seed0, n, frames = args
+    return [make_walk(seed=seed0 + i, F=frames, randomize=True) for i in range(n)]
 
 
-def make_sequences(seed0, n, workers):
+def make_sequences(seed0, n, workers, frames=FRAMES):
     """Seeds seed0 .. seed0 + n - 1 (synth.make_walk is a Python loop over frames: spread over a few processes)."""
     if workers <= 1 or n < 64:
-        return _gen((seed0, n))
+        return _gen((seed0, n, frames))
     chunk = 32
-    parts = [(seed0 + a, min(chunk, n - a)) for a in range(0, n, chunk)]
+    parts = [(seed0 + a, min(chunk, n - a), frames) for a in range(0, n, chunk)]
     with mp.get_context('fork').Pool(workers) as pool:          # (forked before the HIP runtime is initialised)
         out = pool.map(_gen, parts)
     return [s for p in out for s in p]
@@ -204,22 +214,29 @@ def kinematic_optimisation_rate(device_index, n_clips=64, frames=30):
             'note': 'outside the timed region; 256 clips x 100 frames: profiles/r02k_final/kinopt_bench_256x100.json (52 clips/s)'}
 
 
-def main():
+def main(argv=None, solver_factory=None):
+    """`solver_factory` (tests only): a stand-in for PhysOptim on a box without a GPU -- the multi-rank plumbing (process group, barrier,
+    the three all-reduces, rank 0's JSON line) then runs on the gloo backend with CPU tensors (tests/test_bench_multirank.py)."""
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=12)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--batch', type=int, default=BATCH, help=argparse.SUPPRESS)
-    ap.add_argument('--stall-window', type=int, default=150,
+    ap.add_argument('--stall-window', type=int, default=0,
                     help='chd_config.stall_window of the measured configuration (0 = off: a stagnating stage runs to its iteration cap)')
     ap.add_argument('--gen-workers', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--max-workgroups', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--threads', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--lds-kb', type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument('--factorisation', type=int, default=0, help=argparse.SUPPRESS)        # chd_config.factorisation (1 = left-looking)
+    ap.add_argument('--towr_phys_optim_path', default=os.environ.get('TOWR_PHYS_OPTIM_PATH', ''),
+                    help='directory of a REFERENCE phys_optim binary (scripts/run_phys_mocap.py:26): if one is found there it is run on the first sequences of the workload, '
+                         'compared with the HIP results and timed as the CPU baseline (kind "reference")')
     ap.add_argument('--no-cpu-baseline', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--no-side-metrics', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--worker', action='store_true', help=argparse.SUPPRESS)        # (accepted for old command lines; no effect)
-    args = ap.parse_args()
+    ap.add_argument('--frames', type=int, default=FRAMES, help=argparse.SUPPRESS)     # (tests: shorter sequences for the CPU stand-in)
+    args = ap.parse_args(argv)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -228,27 +245,35 @@ def main():
     steps = max(1, args.steps)
     workers = args.gen_workers if args.gen_workers > 0 else max(1, min(8, (os.cpu_count() or 1) // max(1, world)))
     seed0 = rank * steps * B
-    seqs = make_sequences(seed0, steps * B, workers)                      # before the HIP runtime exists in this process (fork)
+    seqs = make_sequences(seed0, steps * B, workers, args.frames)         # before the HIP runtime exists in this process (fork)
 
     import torch
     import torch.distributed as dist
     import chd_amd  # noqa: F401
     from chd_amd.phys_optim import PhysOptim, default_config
 
-    if not torch.cuda.is_available():
+    on_gpu = solver_factory is None
+    if on_gpu and not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the physics stage has no CPU path')
-    torch.cuda.set_device(local)
+    tdev = 'cuda' if on_gpu else 'cpu'
+    if on_gpu:
+        torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if on_gpu:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group('gloo')
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
-    cfg = default_config(stall_window=args.stall_window, max_workgroups=args.max_workgroups, threads_per_sequence=args.threads, lds_kilobytes=args.lds_kb)   # reference caps and tol
-    solver = PhysOptim(device=local, config=cfg)
+    cfg = default_config(stall_window=args.stall_window, max_workgroups=args.max_workgroups, threads_per_sequence=args.threads, lds_kilobytes=args.lds_kb,
+                         factorisation=args.factorisation)   # reference caps and tol
+    solver = (PhysOptim if on_gpu else solver_factory)(device=local, config=cfg)
     batch = solver.upload(seqs)                                           # inputs + tables -> HBM (not timed)
     if args.warmup > 0:                                                   # W untimed steps: the first W batches
         wb = solver.upload(seqs[:min(len(seqs), args.warmup * B)])
@@ -261,10 +286,10 @@ def main():
     kernel_ms = st['kernel_ms'][0] + st['kernel_ms'][1]
     alg_bytes = st['alg_bytes']; iters = st['total_iters']; nfact = st['total_factorizations']
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        agg = torch.tensor([float(iters), float(alg_bytes)], dtype=torch.float64, device='cuda')
+        agg = torch.tensor([float(iters), float(alg_bytes)], dtype=torch.float64, device=tdev)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
         tot_iters_all, alg_bytes_all = float(agg[0].item()), float(agg[1].item())
     else:
@@ -273,6 +298,29 @@ def main():
     res = batch.fetch()
     n_ok = sum(1 for r in res if r.dynamics_succeed and r.durations_succeed)
     sizes = res[0].sizes
+
+    # side runs (one GPU, outside the timed region of `value`): the same workload with the stall guard, with the other factorisation,
+    # and BASELINE configs[2]'s per-GPU slice (4 000 sequences / 8 GPUs = 500 in one call)
+    side = {}
+    if world == 1 and not args.no_side_metrics:
+        def timed_solve(sq, **kw):
+            c2 = default_config(max_workgroups=args.max_workgroups, threads_per_sequence=args.threads, lds_kilobytes=args.lds_kb,
+                                **{**dict(stall_window=args.stall_window, factorisation=args.factorisation), **kw})
+            s2 = PhysOptim(device=local, config=c2)
+            b2 = s2.upload(sq)
+            torch.cuda.synchronize(); t1 = time.perf_counter(); st2 = b2.solve(); torch.cuda.synchronize(); dt2 = time.perf_counter() - t1
+            b2.free(); s2.close()
+            return len(sq) / dt2, st2
+        try:
+            v, st2 = timed_solve(seqs, stall_window=150)
+            side['value_with_stall_guard_150'] = v; side['stall_guard_150_hits'] = st2['n_stalled']; side['stall_guard_150_fallbacks'] = st2['n_fallback']
+            v, st2 = timed_solve(seqs, factorisation=1 - args.factorisation)
+            side['value_%s_factorisation' % ('left_looking' if args.factorisation == 0 else 'right_looking')] = v
+            v, st2 = timed_solve(seqs[:500])
+            side['value_500_sequences_in_one_call'] = v
+            side['kernel_busy_fraction_500_sequences'] = st2['phase_ms'][5] / max(1e-9, st2['n_workgroups'] * (st2['kernel_ms'][0] + st2['kernel_ms'][1]))
+        except Exception as exc:
+            side['side_run_error'] = '%s: %s' % (type(exc).__name__, exc)
 
     if rank == 0:
         import numpy as np
@@ -295,6 +343,8 @@ def main():
                 tj = json.load(open(tfile))
                 traffic = tj.get('hbm_bytes_per_step')
                 traffic_note = tj.get('note', '')
+                if tj.get('sources_sha256') != kernel_sources_sha256():      # the PMC passes were made with other kernel sources than the ones that just ran
+                    traffic_note = 'STALE (kernel sources changed since the PMC passes): ' + traffic_note
             except Exception:
                 traffic = None
         it_seq = np.array([r.total_iters for r in res], dtype=np.float64)
@@ -304,21 +354,24 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': '%d batches (steps) of %d synthetic Mixamo-like %d-frame walks per GPU (BASELINE configs[1]; seeds rank*%d .. : a slice of configs[2]), '
                                    'staged NLP solve, reference iteration caps 7000/7000/7000/2500/2000/7000, tol 1e-3, stall guard %s'
-                                   % (steps, B, FRAMES, steps * B, 'off' if args.stall_window <= 0 else 'window %d' % args.stall_window),
-                       'sequences_per_gpu': B * steps, 'frames': FRAMES,
+                                   % (steps, B, args.frames, steps * B, 'off' if args.stall_window <= 0 else 'window %d' % args.stall_window),
+                       'sequences_per_gpu': B * steps, 'frames': args.frames,
                        'parallelism': 'independent sequences; %d process(es); per GPU one persistent launch of %d resident workgroups (1 per CU) draining a queue; one handle, one stream'
                                       % (world, st['n_workgroups']),
                        'kkt_dim': sizes['kkt_dim'], 'halfband': sizes['halfband'], 'border': sizes['border'], 'nnz_jac': sizes['nnz_jac'],
                        'ipm_iterations_per_sequence': tot_iters_all / total_seqs,
                        'ipm_iterations_rank0': {'p50': float(np.percentile(it_seq, 50)), 'p90': float(np.percentile(it_seq, 90)), 'max': float(it_seq.max())},
                        'factorizations_rank0': nfact, 'stage4_fallbacks_rank0': st['n_fallback'], 'stall_guard_hits_rank0': st['n_stalled'],
-                       'converged_rank0': '%d/%d' % (n_ok, len(res)),
+                       'converged_rank0': '%d/%d' % (n_ok, len(res)), 'factorisation': 'left-looking' if args.factorisation == 1 else 'right-looking', **side,
                        'slowest_sequence_ms': st['max_seq_ms'], 'mean_sequence_ms': st['phase_ms'][5] / max(1, len(res)),
                        'in_kernel_phase_ms_per_sequence': [round(v / max(1, len(res)), 3) for v in st['phase_ms']],
                        'in_kernel_time_share': {k: st['phase_ms'][i] / max(1e-9, st['phase_ms'][5]) for k, i in
                                                 (('evaluation_full', 0), ('evaluation_values', 1), ('factorisation', 2), ('substitution', 3), ('kkt_matvec', 4),
                                                  ('factor_copy', 6), ('factor_panel_load', 8), ('factor_row_solve', 9), ('factor_store', 10),
-                                                 ('factor_trailing_update', 11), ('factor_border', 12))}},
+                                                 ('factor_trailing_update', 11), ('factor_border', 12))} if args.factorisation == 0 else
+                                                {k: st['phase_ms'][i] / max(1e-9, st['phase_ms'][5]) for k, i in
+                                                 (('evaluation_full', 0), ('evaluation_values', 1), ('factorisation', 2), ('substitution', 3), ('kkt_matvec', 4),
+                                                  ('factor_tiles', 8), ('factor_diagonal_block', 9), ('factor_row_solve', 10), ('factor_store', 11), ('factor_border', 12))}},
             'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS * world, 'unit': 'GB/s', 'frac': ach / (HBM_PEAK_GBS * world),
                          'definition': 'sum over sequences of SURVEY 8(d) bytes_iter x IPM iterations / wall time of the timed region / (8 TB/s x GPUs)',
                          'algorithmic_bytes_per_step': alg_bytes_all / steps / world, 'algorithmic_bytes_per_iteration': alg_bytes / max(1, iters),
@@ -333,8 +386,18 @@ def main():
                 out['parity'] = parity_block(res, seed0)
             except Exception as exc:
                 out['parity'] = {'error': '%s: %s' % (type(exc).__name__, exc)}
+        ref_base = None
+        if world == 1:
+            try:
+                sys.path.insert(0, os.path.join(ROOT, 'tests', 'tools'))
+                import compare_with_reference as cwr
+                out['reference_binary'], ref_base = cwr.reference_block(args.towr_phys_optim_path, seqs, res)
+            except Exception as exc:
+                out['reference_binary'] = {'status': 'not measured', 'reason': '%s: %s' % (type(exc).__name__, exc)}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
+            if ref_base is not None:          # the reference's own binary, timed on this box: that is the CPU baseline; the oracle's rate stays beside it
+                ref_base['oracle_port'] = out['cpu_baseline']; out['cpu_baseline'] = ref_base
         if world == 1 and not args.no_side_metrics:
             try:
                 out['contact_net'] = contact_net_rate(torch.device('cuda', local))

@@ -137,6 +137,7 @@ struct Ctx {
   double sf;            // objective scaling
   double tol;           // IPOPT tol of the stage (phys_optim.cpp:578)
   int stall_window;     // 0 = no stall guard (chd_config.stall_window)
+  int factor_ll;        // chd_config.factorisation: 1 = left-looking factorisation (kfactor_ll), 0 = right-looking (kfactor_rl)
   int clip_heel;        // 1 while the second model of an iteration is built: heel-distance curvature with max(lam, 0) (solve_stage)
   int err;              // sticky error flag (band overflow): any thread may set it, read after a barrier
   int n_bad_pivots;     // thread 0 counts
@@ -1657,14 +1658,11 @@ CHD_DEV bool kfactor_ll(LCtx& c, const GD* diag, const GI* sign) {
   return true;
 }
 
-#ifndef CHD_FACTOR_LL
-#define CHD_FACTOR_LL 1
-#endif
 CHD_NOINLINE CHD_DEV void kfactor(LCtx& c, const GD* diag, const GI* sign) {
-#if CHD_FACTOR_LL
-  TIC();
-  if (kfactor_ll(c, diag, sign)) { TOC(c, 2); return; }
-#endif
+  if (c.factor_ll) {
+    TIC();
+    if (kfactor_ll(c, diag, sign)) { TOC(c, 2); return; }
+  }
   kfactor_rl(c, diag, sign);
 }
 
@@ -3404,16 +3402,16 @@ CHD_DEV void load_state(QP q) {
   refresh_durations(q);
 }
 
-CHD_DEV void reset_context(LCtx& c, LdsD* lds, int lds_cap, double tol, int stall_window) {
+CHD_DEV void reset_context(LCtx& c, LdsD* lds, int lds_cap, double tol, int stall_window, int factor_ll = 0) {
   if (CHD_TID == 0) {
-    c.lds = lds; c.lds_cap = lds_cap; c.tol = tol; c.stall_window = stall_window;
+    c.lds = lds; c.lds_cap = lds_cap; c.tol = tol; c.stall_window = stall_window; c.factor_ll = factor_ll;
     for (int k = 0; k < 24; ++k) c.tacc[k] = 0;
   }
   CHD_SYNC();
 }
 
-CHD_DEV void run_sequence(QP q, LCtx& c, LdsD* lds, int lds_cap, double tol, int stall_window, int stage_first, int stage_last) {
-  reset_context(c, lds, lds_cap, tol, stall_window);
+CHD_DEV void run_sequence(QP q, LCtx& c, LdsD* lds, int lds_cap, double tol, int stall_window, int stage_first, int stage_last, int factor_ll = 0) {
+  reset_context(c, lds, lds_cap, tol, stall_window, factor_ll);
   const long long t_begin = CHD_CLOCK();
   // the workgroup's workspace still holds the previous sequence: everything below the KKT storage (state, solver
   // vectors, tables) starts from zero; the KKT storage is cleared stage by stage (kreset)

@@ -45,6 +45,11 @@ int chd_kin_solve_batch(const chd_kin_config* cfg, int device, int B, chd_kin_se
   if (device < 0 || device >= ndev) return fail("device index out of range");
   hipError_t e;
   if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
+  if (cfg->reserved[1] > 0) {   // LDS doubles per workgroup: the product passes address 3 * 84 * (TF + 2) doubles with TF >= 1 (kin_jv) and 336 (kin_jtu)
+    int lds_max = 0;
+    if ((e = hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device)) != hipSuccess) return fail("hipDeviceGetAttribute", e);
+    if (cfg->reserved[1] < 756 || (long long)cfg->reserved[1] * 8 > lds_max) return fail("reserved[1] (LDS doubles per workgroup) out of range: 756 .. device limit");
+  }
   KinBatch bt;
   if (!bt.build(cfg, B, in)) return fail(bt.err);
   // Everything of a call is ordered on a stream of its own (stream-ordered allocations, asynchronous copies, one synchronisation at the

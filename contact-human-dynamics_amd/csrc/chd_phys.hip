@@ -52,14 +52,14 @@ __device__ inline bool take_sequence(SeqDesc* s_desc, int* s_item, const SeqDesc
 
 __global__ __launch_bounds__(CHD_MAX_THREADS) void chd_solve_kernel(const SeqDesc* descs, const int* order, int n_items, int* counter,
                                                                     double* wd_pool, long long wd_stride, int* wi_pool, long long wi_stride,
-                                                                    int lds_doubles, double tol, int stall_window, int stage_first, int stage_last) {
+                                                                    int lds_doubles, double tol, int stall_window, int stage_first, int stage_last, int factor_ll) {
   extern __shared__ double lds[];
   __shared__ SeqDesc s_desc;
   __shared__ Ctx s_ctx;
   __shared__ int s_item;
   for (;;) {
     if (!take_sequence(&s_desc, &s_item, descs, order, n_items, counter, wd_pool, wd_stride, wi_pool, wi_stride)) break;
-    run_sequence((QP)&s_desc, *(LCtx*)&s_ctx, (LdsD*)lds, lds_doubles, tol, stall_window, stage_first, stage_last);
+    run_sequence((QP)&s_desc, *(LCtx*)&s_ctx, (LdsD*)lds, lds_doubles, tol, stall_window, stage_first, stage_last, factor_ll);
   }
 }
 
@@ -149,7 +149,8 @@ void chd_config_default(chd_config* c) {
   c->stall_window = 0;
   c->max_workgroups = 0;
   c->lds_kilobytes = 0;
-  for (int i = 0; i < 4; ++i) c->reserved[i] = 0;
+  c->factorisation = 0;
+  for (int i = 0; i < 3; ++i) c->reserved[i] = 0;
 }
 
 int chd_phys_create(const chd_config* cfg, int device_id, chd_handle** out) {
@@ -321,7 +322,7 @@ static int launch_queue(chd_handle* h, chd_batch* b, const std::vector<int>& ite
   const unsigned grid = (unsigned)std::min<size_t>(items.size(), (size_t)h->n_wg);
   HIP_TRY(h, hipEventRecord(e0, h->stream));
   hipLaunchKernelGGL(chd_solve_kernel, dim3(grid), dim3(h->threads), h->lds_bytes, h->stream, b->d_descs, (const int*)b->d_order, (int)items.size(),
-                     h->d_counter, h->d_wd, h->wd_stride, h->d_wi, h->wi_stride, h->lds_bytes / 8, h->cfg.tol, h->cfg.stall_window, stage_first, stage_last);
+                     h->d_counter, h->d_wd, h->wd_stride, h->d_wi, h->wi_stride, h->lds_bytes / 8, h->cfg.tol, h->cfg.stall_window, stage_first, stage_last, h->cfg.factorisation == 1 ? 1 : 0);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipEventRecord(e1, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));

@@ -193,8 +193,9 @@ class KinematicOptimizer:
 
         More than `chunk` clips are processed chunk by chunk on `workers` threads: a chunk of 256 fills the GPU (one workgroup per
         clip), and while one thread waits in a library call (ctypes releases the interpreter lock) the other does the host steps
-        of its chunk -- bone lengths, floor fits, forward kinematics -- which are a third of the time of a chunk.  The launches of
-        the two threads serialise on the device's default stream; a clip's result does not depend on the chunk it is in."""
+        of its chunk -- bone lengths, floor fits, forward kinematics -- which are a third of the time of a chunk.  Every library call
+        runs on a non-blocking stream of its own (chd_kinopt.hip, chd_ik.hip), so the kernels of the two threads can overlap; a clip's
+        result does not depend on the chunk it is in."""
         if len(clips) <= chunk or workers < 2:
             return self._optimize(clips)
         from concurrent.futures import ThreadPoolExecutor

@@ -93,16 +93,18 @@ def main(argv=None):
         ends = [args.end]
     else:
         ap.error('give --data, or --input_path and --output_path')
+    n_failed = 0
     if dirs:
         res = optimize_videos(dirs, outs, args.skel_path, args.start, ends, args.use_gt_floor, device=device)
         for d, r in zip(dirs, res):
             if r.get('error'):
                 print('%s: FAILED -- %s' % (d, r['error']), flush=True)
+                n_failed += 1
                 continue
             print('%s: %d frames, cost %.4f (stage 1) / %.4f (with the floor), floor normal %s' % (d, r['pose3d'].shape[0], r['stages'][0]['cost'], r['stages'][1]['cost'],
                                                                                              np.round(r['plane_normal'], 4)), flush=True)
-    print('Finished kinematic optimization!')
-    return 0
+    print('Finished kinematic optimization!' if n_failed == 0 else 'Finished kinematic optimization: %d video(s) FAILED (no kinematic_results written for them)' % n_failed)
+    return 1 if n_failed else 0          # a sharded / batched run sees dropped videos in the exit code
 
 
 if __name__ == '__main__':

@@ -88,9 +88,11 @@ def main(argv=None):
         kdirs = [os.path.join(a.data, v) for v in kvids]
         kouts = [os.path.join(d, 'kinematic_results') for d in kdirs]
         res = rko.optimize_videos(kdirs, kouts, a.skel_path, 0, [a.nframes or count_frames(d, None) for d in kdirs])
+        kin_failed = []
         for v, o, r in zip(kvids, kouts, res):
             if r.get('error'):
                 print('[run_phys_mocap] %s: kinematic optimisation failed -- %s' % (v, r['error']))
+                kin_failed.append(v)
             else:
                 shutil.copyfile(os.path.join(o, 'final_test.bvh'), os.path.join(o, a.character + '_out.bvh'))
     prep_batch = []
@@ -136,7 +138,7 @@ def main(argv=None):
     mine = sharding.my_shard([j[2] for j in jobs])
     cfg = default_config(w_com_lin=a.w_com_lin, w_com_ang=a.w_com_ang, w_ee=a.w_ee, w_smooth=a.w_smooth, w_dur=a.w_dur)
     solver = PhysOptim(device=local, config=cfg)
-    bad = 0
+    bad = len(kin_failed) if a.kinematic else 0          # videos the kinematic optimisation dropped count as failures of the run
     for s in range(0, len(mine), a.batch):
         part = [jobs[i] for i in mine[s:s + a.batch]]
         st = solver.solve_dirs([p[0] for p in part], [p[1] for p in part], [p[2] for p in part])

@@ -47,7 +47,10 @@ typedef struct chd_config {
   int max_workgroups;           /* resident workgroups of the solver launch; 0 = one per compute unit */
   int lds_kilobytes;            /* dynamic LDS per workgroup; 0 = all of a compute unit's (156 KB); smaller values narrow the
                                    factorisation panels (tuning / test knob) */
-  int reserved[4];
+  int factorisation;            /* 0 = right-looking panels with a matrix-core trailing update (default: the faster one on the MI355X);
+                                 * 1 = left-looking matrix-core tiles gathered from the factor storage (no K0 -> Kf copy, no window
+                                 * read-modify-write: a fifth of the HBM traffic of the factorisation; csrc/chd_kernels.hpp kfactor_ll) */
+  int reserved[3];
 } chd_config;
 
 /* One sequence = the content of phys_optim_in_<char>/{skel,motion,terrain,contact}_info.txt

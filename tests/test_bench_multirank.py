@@ -1,0 +1,98 @@
+"""bench.py's multi-rank path without hardware: `bench.main` as TWO ranks on the gloo backend, the solver handle replaced by the host
+emulation of the kernel source (tests/host_emu) behind the same upload / solve / fetch interface.  What runs is bench.py's own code:
+process-group set-up from the launcher's environment, barrier, the timed region, the max / sum all-reduces, rank 0's single JSON line
+with the contract's keys and whole-job aggregates.  (On a GPU box the backend is nccl = RCCL; no collective touches the data path.)"""
+import io
+import json
+import os
+import sys
+import contextlib
+
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+class _EmuBatch:
+    def __init__(self, seqs):
+        self.seqs = list(seqs)
+        self.res = None
+
+    def solve(self):
+        import time
+        import types
+        sys.path.insert(0, os.path.join(HERE, 'host_emu'))
+        import emu
+        from chd_amd.phys_capi import default_config
+        t0 = time.perf_counter()
+        self.res = []
+        iters = 0
+        for seq in self.seqs:
+            e = emu.EmuProblem(seq, default_config(max_iter=[15] * 6))
+            e.solve(0, 1)
+            stats, snaps = e.results()
+            sz = e.sizes(1)
+            it = int(stats[0, 1] + stats[1, 1]); iters += it
+            self.res.append(types.SimpleNamespace(total_iters=it, dynamics_succeed=False, durations_succeed=False,
+                                                  sizes=dict(n=sz['n'], m=sz['m'], kkt_dim=sz['n'] + sz['m'], halfband=sz['w'], border=sz['bc'], nnz_jac=sz['nnz_jac'])))
+        ms = 1e3 * (time.perf_counter() - t0)
+        return dict(kernel_ms=[ms, 0.0], host_ms=0.0, total_iters=iters, total_factorizations=iters, alg_bytes=1e6 * iters, n_fallback=0,
+                    phase_ms=[ms] * 24, max_seq_ms=ms, n_stalled=0, n_rejected=0, n_workgroups=1)
+
+    def fetch(self):
+        return self.res
+
+    def free(self):
+        pass
+
+
+class _EmuSolver:
+    def __init__(self, device=0, config=None):
+        self.cfg = config
+
+    def upload(self, seqs):
+        return _EmuBatch(seqs)
+
+    def close(self):
+        pass
+
+
+def _rank(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    import bench
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main(['--gpus', str(world), '--steps', '1', '--warmup', '1', '--batch', '2', '--frames', '24', '--no-cpu-baseline', '--no-side-metrics'],
+                   solver_factory=_EmuSolver)
+    q.put((rank, buf.getvalue()))
+
+
+def test_bench_main_as_two_gloo_ranks():
+    sys.path.insert(0, os.path.join(HERE, 'host_emu'))
+    import emu
+    emu.build()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + ((os.getpid() + 911) % 2000)
+    procs = [ctx.Process(target=_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got[1].strip() == ''                                   # only rank 0 prints
+    lines = [ln for ln in got[0].splitlines() if ln.strip()]
+    assert len(lines) == 1
+    o = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
+        assert k in o
+    assert o['n_gpus'] == 2 and o['steps'] == 1 and o['scaling'] == 'weak' and o['dtype'] == 'f64'
+    assert o['config']['sequences_per_gpu'] == 2
+    # whole-job aggregates over both ranks: 4 sequences in the timed region, iterations summed by the all-reduce
+    assert abs(o['value'] * o['ms_per_step'] * 1e-3 - 4.0) < 1e-6
+    assert o['config']['ipm_iterations_per_sequence'] > 0
+    assert o['roofline']['peak'] == 16000.0
+    assert 'cpu_baseline' not in o                                 # N > 1: rank 0 does not time the CPU baseline

@@ -216,7 +216,8 @@ def test_bad_sequence_loses_only_itself(tmp_path):
         dirs.append((din, dout, q.F))
     missing = str(tmp_path / 'nowhere')
     stt = s.solve_dirs([d[0] for d in dirs] + [missing], [d[1] for d in dirs] + [str(tmp_path / 'out0')], [d[2] for d in dirs] + [40])
-    assert stt == [0, -3, 0, -1] and 'rejected' in s.last_error() or 'nowhere' in s.last_error()
+    assert stt == [0, -3, 0, -1]
+    assert 'rejected' in s.last_error() or 'nowhere' in s.last_error()
     assert len(os.listdir(dirs[0][1])) == 4 and len(os.listdir(dirs[1][1])) == 0 and len(os.listdir(dirs[2][1])) == 4
     with pytest.raises(Exception):
         s.solve([short])                       # nothing solvable: the call itself fails

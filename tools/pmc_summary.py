@@ -17,6 +17,7 @@ import sys
 
 src, dst = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
 os.makedirs(dst, exist_ok=True)
 commit = subprocess.run(['git', 'log', '-1', '--format=%h'], cwd=root, stdout=subprocess.PIPE, text=True).stdout.strip()
 open(os.path.join(dst, 'COMMIT'), 'w').write(commit + '\n')
@@ -45,7 +46,7 @@ if 'FETCH_SIZE' in tot and 'WRITE_SIZE' in tot:
     out += ['', 'One step (128 sequences): FETCH_SIZE %.1f GB + WRITE_SIZE %.1f GB = %.1f GB raw = %.1f x the algorithmic bytes (%.2f GB); with the gfx950 FETCH x 2 correction %.1f GB = %.1f x.'
             % (tot['FETCH_SIZE'] * 1024 / 1e9, tot['WRITE_SIZE'] * 1024 / 1e9, raw / 1e9, raw / alg, alg / 1e9, corr / 1e9, corr / alg)]
     json.dump({'hbm_bytes_per_step': corr, 'hbm_bytes_per_step_raw': raw, 'fetch_kb': tot['FETCH_SIZE'], 'write_kb': tot['WRITE_SIZE'], 'algorithmic_bytes_per_step': alg,
-               'tag': os.path.basename(dst.rstrip('/')), 'commit': commit,
+               'tag': os.path.basename(dst.rstrip('/')), 'commit': commit, 'sources_sha256': __import__('bench').kernel_sources_sha256(),
                'note': 'rocprofv3 PMC passes of %s (one step = 128 sequences, seeds 0..127); FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section; measured on commit %s' % (dst, commit)},
               open(os.path.join(root, 'profiles', 'traffic.json'), 'w'), indent=1)
 if 'SQ_INSTS_VALU_MFMA_MOPS_F64' in tot:
