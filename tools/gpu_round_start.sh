@@ -11,7 +11,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/start
 mkdir -p $OUT
 cd $R
-timeout 400 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
+timeout 600 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
 timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/bench_driver.err; tail -c 1500 $OUT/bench_driver.json; tail -3 $OUT/bench_driver.err
 cd /tmp && export TMPDIR=/tmp
@@ -21,4 +21,7 @@ timeout 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o 
 timeout 150 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o write -- $P --steps 1 --warmup 0 > $OUT/write_bench.json 2> $OUT/write.err
 timeout 150 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAVE_CYCLES --output-format csv -d $OUT/pmc_mfma -o mfma -- $P --steps 2 --warmup 0 > $OUT/mfma_bench.json 2> $OUT/mfma.err
 timeout 150 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM --output-format csv -d $OUT/pmc_sq -o sq -- $P --steps 2 --warmup 0 > $OUT/sq_bench.json 2> $OUT/sq.err
+# the same two HBM passes with the left-looking factorisation (chd_config.factorisation = 1)
+timeout 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_ll -o fetch -- $P --factorisation 1 --steps 1 --warmup 0 > $OUT/fetch_ll_bench.json 2> $OUT/fetch_ll.err
+timeout 150 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_ll -o write -- $P --factorisation 1 --steps 1 --warmup 0 > $OUT/write_ll_bench.json 2> $OUT/write_ll.err
 find $OUT -name "*counter_collection.csv" | head

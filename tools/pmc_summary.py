@@ -21,7 +21,7 @@ sys.path.insert(0, root)
 os.makedirs(dst, exist_ok=True)
 commit = subprocess.run(['git', 'log', '-1', '--format=%h'], cwd=root, stdout=subprocess.PIPE, text=True).stdout.strip()
 open(os.path.join(dst, 'COMMIT'), 'w').write(commit + '\n')
-for f in ('pytest_gpu.log', 'smoke.log', 'bench_driver.json', 'trace_bench.json', 'fetch_bench.json', 'write_bench.json', 'mfma_bench.json', 'sq_bench.json'):
+for f in ('pytest_gpu.log', 'smoke.log', 'bench_driver.json', 'trace_bench.json', 'fetch_bench.json', 'write_bench.json', 'mfma_bench.json', 'sq_bench.json', 'fetch_ll_bench.json', 'write_ll_bench.json'):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), dst)
 ks = os.path.join(src, 'trace', 'trace_kernel_stats.csv')
@@ -29,7 +29,7 @@ if os.path.exists(ks):
     shutil.copy(ks, dst)
 out = ['# rocprofv3 PMC passes on the solver kernel (commit %s)' % commit, '', '| pass | counter | value summed over the device, main launch | fallback launch |', '|---|---|---|---|']
 tot = {}
-for sub in ('pmc_fetch', 'pmc_write', 'pmc_mfma', 'pmc_sq'):
+for sub in ('pmc_fetch', 'pmc_write', 'pmc_mfma', 'pmc_sq', 'pmc_fetch_ll', 'pmc_write_ll'):
     for f in glob.glob(os.path.join(src, sub, '*counter_collection.csv')):
         agg = collections.defaultdict(lambda: collections.defaultdict(float))
         for r in csv.DictReader(open(f)):
@@ -38,7 +38,7 @@ for sub in ('pmc_fetch', 'pmc_write', 'pmc_mfma', 'pmc_sq'):
         for c in sorted(agg):
             d = agg[c]; k = sorted(d, key=lambda x: -d[x])
             out.append('| %s | %s | %.6g | %.6g |' % (sub, c, d[k[0]], d[k[1]] if len(k) > 1 else 0.0))
-            tot[c] = sum(d.values())
+            tot[c + ('_LL' if sub.endswith('_ll') else '')] = sum(d.values())
 if 'FETCH_SIZE' in tot and 'WRITE_SIZE' in tot:
     b = json.loads(open(os.path.join(src, 'fetch_bench.json')).read().strip().splitlines()[-1])
     alg = b['roofline']['algorithmic_bytes_per_step']
@@ -49,6 +49,12 @@ if 'FETCH_SIZE' in tot and 'WRITE_SIZE' in tot:
                'tag': os.path.basename(dst.rstrip('/')), 'commit': commit, 'sources_sha256': __import__('bench').kernel_sources_sha256(),
                'note': 'rocprofv3 PMC passes of %s (one step = 128 sequences, seeds 0..127); FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section; measured on commit %s' % (dst, commit)},
               open(os.path.join(root, 'profiles', 'traffic.json'), 'w'), indent=1)
+if 'FETCH_SIZE_LL' in tot and 'WRITE_SIZE_LL' in tot:
+    b = json.loads(open(os.path.join(src, 'fetch_ll_bench.json')).read().strip().splitlines()[-1])
+    alg = b['roofline']['algorithmic_bytes_per_step']
+    raw = (tot['FETCH_SIZE_LL'] + tot['WRITE_SIZE_LL']) * 1024.0; corr = (2 * tot['FETCH_SIZE_LL'] + tot['WRITE_SIZE_LL']) * 1024.0
+    out += ['', 'Left-looking factorisation (chd_config.factorisation = 1), one step: FETCH_SIZE %.1f GB + WRITE_SIZE %.1f GB = %.1f GB raw = %.1f x the algorithmic bytes (%.2f GB); with the FETCH x 2 correction %.1f GB = %.1f x.'
+            % (tot['FETCH_SIZE_LL'] * 1024 / 1e9, tot['WRITE_SIZE_LL'] * 1024 / 1e9, raw / 1e9, raw / alg, alg / 1e9, corr / 1e9, corr / alg)]
 if 'SQ_INSTS_VALU_MFMA_MOPS_F64' in tot:
     b = json.loads(open(os.path.join(src, 'mfma_bench.json')).read().strip().splitlines()[-1])
     ms = b['roofline']['kernel_ms_rank0']
