@@ -35,10 +35,14 @@ CAPS = [7000, 7000, 7000, 2500, 2000, 7000]
 def kernel_sources_sha256():
     """Hash of the solver kernel's sources: profiles/traffic.json carries the one its PMC passes were measured with (tools/pmc_summary.py)."""
     import hashlib
+    import re
     h = hashlib.sha256()
     for f in ('chd_kernels.hpp', 'chd_phys.hip', 'chd_model.hpp', 'chd_device.hpp'):
-        with open(os.path.join(ROOT, 'contact-human-dynamics_amd', 'csrc', f), 'rb') as fh:
-            h.update(fh.read())
+        with open(os.path.join(ROOT, 'contact-human-dynamics_amd', 'csrc', f), 'r', errors='replace') as fh:
+            for line in fh:                                  # code only: comments and blank lines do not make a measurement stale
+                line = re.sub(r'//.*$', '', line).strip()
+                if line:
+                    h.update(line.encode() + b'\n')
     return h.hexdigest()
 
 

@@ -1202,20 +1202,25 @@ CHD_NOINLINE CHD_DEV void kfactor_rl(LCtx& c, const GD* diag, const GI* sign) {
 
 
 // ------------------------------------------------------------------------------------------
-// Left-looking blocked L D L^T of the bordered band (the factorisation that runs: kfactor below; kfactor_rl above is the
-// right-looking round-1/2 version, kept as the fall-back for shapes this one does not take).
+// Left-looking blocked L D L^T of the bordered band -- the ALTERNATIVE factorisation (chd_config.factorisation = 1); the
+// right-looking kfactor_rl above is the default because it is the faster one on the MI355X (profiles/r03a_merit_clip:
+// 512 against 444 sequences/s on the bench workload).
 //
-// Right-looking, every 32-column panel read-modify-wrote its whole trailing window in HBM / L2 (the window, ~100-200 active
-// rows, fits neither LDS nor -- as a sliding structure -- the register file): per panel a chain of dependent memory round
-// trips (panel load, store, window load, window store) for ~25 tiles of matrix-core work; 40 % of the kernel's time at 1 % of the
-// CU's arithmetic rate, and 12 x the algorithmic HBM traffic.  Left-looking, a panel's columns are formed ONCE, in registers,
-// from the finished part of the factor:
+// Right-looking, every 32-column panel read-modify-writes its trailing window in HBM / L2 (the window, ~100-200 active rows,
+// fits neither LDS nor -- as a sliding structure -- the register file).  Left-looking, a panel's columns are formed ONCE, in
+// registers, from the finished part of the factor:
 //     S(i, J) = K0(i, J) + diag - sum_{k < c0} L(i, k) d_k L(J, k)^T            i in {panel rows} + {active rows below}
 // as 16 x 16 fp64 matrix-core tiles whose operands are gathered straight from the factor storage in the MFMA register layout
 // (lane = (row, k)), read-only and independent of each other -- no copy K0 -> Kf, no window, no read-modify-write; then the
-// diagonal block is factored by one wavefront, the rows below are solved against it and stored.  Per panel: one batch of
-// independent loads, three workgroup barriers.  The border's Schur complement is formed the same way at the end (tiles of
-// border rows x border rows over all band columns) and factored densely in LDS as before.
+// diagonal block is factored by one wavefront, the rows below are solved against it and stored.  The border's Schur complement
+// is formed the same way at the end (tiles of border rows x border rows over all band columns) and factored densely in LDS.
+// What the MI355X measurement says (PMC passes of the same profile): the gathers re-read every row of L once per panel it is
+// active in (~9 MB per factorisation; the 1.2 MB factor of 256 resident sequences does not stay in L2 / MALL), so the HBM-side
+// traffic is HIGHER than right-looking (17.5 x against 13.3 x the algorithmic bytes), the tile phase waits for one batch of
+// gathers per 32 columns of depth (22 % of the kernel time), and the diagonal block -- hidden behind the trailing update by
+// the right-looking version's look-ahead -- is on the critical path here (8.5 %).  Making it win needs the far part of a
+// panel's tiles computed during the previous panel's diagonal block / row solve (two panel buffers: 16-column panels) with the
+// near part from LDS; not done.
 // The factor storage has the same layout as before (unit-lower L in the band / border rows, pivots on the diagonal), and
 // every entry inside a row's envelope is rewritten by each factorisation; left of the envelope it stays zero.
 // ------------------------------------------------------------------------------------------

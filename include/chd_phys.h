@@ -49,7 +49,7 @@ typedef struct chd_config {
                                    factorisation panels (tuning / test knob) */
   int factorisation;            /* 0 = right-looking panels with a matrix-core trailing update (default: the faster one on the MI355X);
                                  * 1 = left-looking matrix-core tiles gathered from the factor storage (no K0 -> Kf copy, no window
-                                 * read-modify-write: a fifth of the HBM traffic of the factorisation; csrc/chd_kernels.hpp kfactor_ll) */
+                                 * read-modify-write; measured slower and with more HBM traffic: csrc/chd_kernels.hpp kfactor_ll) */
   int reserved[3];
 } chd_config;
 
