@@ -411,6 +411,14 @@ def main(argv=None, solver_factory=None):
                 out['kinematic_optimisation'] = kinematic_optimisation_rate(local)
             except Exception as exc:
                 out['kinematic_optimisation'] = {'error': '%s: %s' % (type(exc).__name__, exc)}
+            try:                                                                  # the whole chain, file to file (tests/tools/pipeline_bench.py)
+                sys.path.insert(0, os.path.join(ROOT, 'tests', 'tools'))
+                import pipeline_bench
+                import contextlib
+                with contextlib.redirect_stdout(sys.stderr):                       # the drivers print progress lines; stdout carries exactly one JSON line
+                    out['pipeline'] = pipeline_bench.run(32, 60)
+            except BaseException as exc:                                           # (the drivers end with SystemExit on bad arguments)
+                out['pipeline'] = {'error': '%s: %s' % (type(exc).__name__, exc)}
         print(json.dumps(out), flush=True)
     batch.free()
     solver.close()

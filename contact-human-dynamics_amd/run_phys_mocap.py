@@ -65,6 +65,9 @@ def count_frames(video_dir, in_dir):
         return (len(f.read().split()) - 1) // 18
 
 
+LAST_TIMINGS = {}          # seconds per stage of the last main() call: kinematic / prepare / physics / back_projection (pipeline benchmark)
+
+
 def main(argv=None):
     a = parse_args(sys.argv[1:] if argv is None else argv)
     vids = sorted(d for d in os.listdir(a.data) if os.path.isdir(os.path.join(a.data, d)) and not d.startswith('.'))
@@ -75,6 +78,9 @@ def main(argv=None):
             raise SystemExit('--prepare / --out-bvh need --character-json')
         from .apply_results import Character
         character = Character.from_json(a.character_json)
+    import time as _time
+    LAST_TIMINGS.clear()
+    _t = _time.perf_counter()
     if a.kinematic:
         # run_phys_mocap.py:103-131: kinematic optimisation per video, then "re-targeting to character if needed".  Re-targeting
         # (skeleton_fitting/combined_to_mixamo.py) is outside this path: only the combined skeleton itself goes straight on (:129-131)
@@ -95,6 +101,7 @@ def main(argv=None):
                 kin_failed.append(v)
             else:
                 shutil.copyfile(os.path.join(o, 'final_test.bvh'), os.path.join(o, a.character + '_out.bvh'))
+    LAST_TIMINGS['kinematic'] = _time.perf_counter() - _t; _t = _time.perf_counter()
     prep_batch = []
     for v in vids:
         vd = os.path.join(a.data, v)
@@ -134,6 +141,7 @@ def main(argv=None):
             outd = os.path.join(vd, 'phys_optim_out_' + a.character)
             os.makedirs(outd, exist_ok=True)
             jobs.append((ind, outd, seq.F))
+    LAST_TIMINGS['prepare'] = _time.perf_counter() - _t; _t = _time.perf_counter()
     rank, world, local = sharding.rank_world()
     mine = sharding.my_shard([j[2] for j in jobs])
     cfg = default_config(w_com_lin=a.w_com_lin, w_com_ang=a.w_com_ang, w_ee=a.w_ee, w_smooth=a.w_smooth, w_dur=a.w_dur)
@@ -144,6 +152,7 @@ def main(argv=None):
         st = solver.solve_dirs([p[0] for p in part], [p[1] for p in part], [p[2] for p in part])
         bad += sum(1 for x in st if x != 0)
     solver.close()
+    LAST_TIMINGS['physics'] = _time.perf_counter() - _t; _t = _time.perf_counter()
     if a.out_bvh:
         from . import apply_results as ar
         from .ik_backproject import IkBackProject
@@ -157,6 +166,7 @@ def main(argv=None):
                                    [os.path.join(vd, 'kinematic_results', a.character + '_out.bvh') for vd in vdirs],
                                    [os.path.join(p[1], '%s_%s_%s.bvh' % (os.path.basename(vd), a.character, kind)) for p, vd in zip(part, vdirs)],
                                    character, ik, starts=[0] * len(part), ends=[p[2] for p in part])
+    LAST_TIMINGS['back_projection'] = _time.perf_counter() - _t
     print('[run_phys_mocap] rank %d/%d: %d sequences, %d failed (unreadable inputs, rejected at set-up or unwritable outputs: each loses only itself)' % (rank, world, len(mine), bad))
     return 0 if bad == 0 else 1
 
