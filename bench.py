@@ -34,10 +34,14 @@ CAPS = [7000, 7000, 7000, 2500, 2000, 7000]
 
 def kernel_sources_sha256():
     """Hash of the solver kernel's sources: profiles/traffic.json carries the one its PMC passes were measured with (tools/pmc_summary.py)."""
+    return _sources_sha256(('chd_kernels.hpp', 'chd_phys.hip', 'chd_model.hpp', 'chd_device.hpp'))
+
+
+def _sources_sha256(files):
     import hashlib
     import re
     h = hashlib.sha256()
-    for f in ('chd_kernels.hpp', 'chd_phys.hip', 'chd_model.hpp', 'chd_device.hpp'):
+    for f in files:
         with open(os.path.join(ROOT, 'contact-human-dynamics_amd', 'csrc', f), 'r', errors='replace') as fh:
             for line in fh:                                  # code only: comments and blank lines do not make a measurement stale
                 line = re.sub(r'//.*$', '', line).strip()
@@ -176,7 +180,7 @@ def contact_net_rate(device, n_videos=128, frames=FRAMES, reps=20):
     return out
 
 
-def kinematic_optimisation_rate(device_index, n_clips=64, frames=30):
+def kinematic_optimisation_rate(device_index, n_clips=256, frames=100):
     """Next row in front of the physics stage (DESIGN.md "Rank 3"): the reference's `optimize_trajectory`
     for a batch of synthetic clips -- IK initialisation on libchd_ik.so, the two least-squares solves on libchd_kinopt.so, floor fit
     on the host -- and, as the parity figure, the three clips of the committed fixture against the REFERENCE's own results."""
@@ -210,12 +214,21 @@ def kinematic_optimisation_rate(device_index, n_clips=64, frames=30):
     its = float(np.mean([sum(s['lsmr_iterations'] for s in r['stages']) for r in out]))
     n, m = 87 * frames, 507 * frames - 423
     alg = 8.0 * (2 * m + 8 * n + 2 * 420 * frames) * its * n_clips          # bytes per LSMR iteration x iterations
+    traffic = None; tnote = 'not measured for this configuration'
+    try:                                                                        # PMC passes of the same configuration (profiles/kinopt_traffic.json)
+        tj = json.load(open(os.path.join(ROOT, 'profiles', 'kinopt_traffic.json')))
+        if (tj['clips'], tj['frames']) == (n_clips, frames):
+            traffic = tj['hbm_bytes_per_batch']; tnote = tj.get('note', '')
+            if tj.get('sources_sha256') != _sources_sha256(('chd_kinopt_kernels.hpp',)):
+                tnote = 'STALE (kernel source changed since the PMC passes): ' + tnote
+    except Exception:
+        pass
     return {'clips': n_clips, 'frames': frames, 'clips_per_s': n_clips / dt, 'least_squares_kernel_ms': ms, 'ik_kernel_ms': opt.ik.last_kernel_ms()[0],
-            'lsmr_iterations_per_clip': its,
+            'lsmr_iterations_per_clip': its, 'algorithmic_bytes_per_batch': alg,
             'roofline': {'bound': 'hbm', 'kernel': 'chd_kin_solve_kernel', 'achieved': alg / (sum(ms) * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': alg / (sum(ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None},
+                         'frac': alg / (sum(ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_note': tnote},
             'fixture_worst_rel_l2_vs_reference': worst, 'fixture_contacts_equal_reference': bool(contacts_equal),
-            'note': 'outside the timed region; 256 clips x 100 frames: profiles/r02k_final/kinopt_bench_256x100.json (52 clips/s)'}
+            'note': 'outside the timed region; the whole optimize() of %d clips x %d frames (IK initialisation, two least-squares solves, host floor fits)' % (n_clips, frames)}
 
 
 def main(argv=None, solver_factory=None):

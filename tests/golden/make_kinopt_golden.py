@@ -13,7 +13,8 @@ The reference library needs three stand-ins under NumPy 2 / this image: `numpy.c
 (removed alias) and empty modules for `cv2` / `openpose_utils` / `totalcap_utils` (imported by optimize_trajectory.py:29-30 but
 not used on this path).  Run in the build container only (it reads /root/reference); tests use the committed fixture.
 
-    python tests/golden/make_kinopt_golden.py
+    python tests/golden/make_kinopt_golden.py                      # the three short clips (10 / 16 / 12 frames)
+    python tests/golden/make_kinopt_golden.py --long 40 60         # kinopt_golden_long.npz: clips of 40 and 60 frames (tens of minutes: the reference's dense Jacobians)
 """
 import contextlib
 import io
@@ -105,6 +106,10 @@ if __name__ == '__main__':
     import sklearn
     cases = [dict(seed=1, F=10, floor=None), dict(seed=2, F=16, floor=None),
              dict(seed=3, F=12, floor='refit')]
+    out_name = 'kinopt_golden.npz'
+    if len(sys.argv) > 1 and sys.argv[1] == '--long':          # clips of a realistic length: kinopt_golden_long.npz, frames from the command line
+        cases = [dict(seed=10 + i, F=int(f), floor=None) for i, f in enumerate(sys.argv[2:] or ['40', '60'])]
+        out_name = 'kinopt_golden_long.npz'
     out = {'n_cases': np.array(len(cases)), 'scipy_version': np.array(scipy.__version__), 'sklearn_version': np.array(sklearn.__version__),
            'forward_mapping': np.array([ot.FORWARD_MAPPING[j] for j in range(28)]), 'backward_mapping': np.array([ot.BACKWARD_MAPPING[j] for j in range(28)])}
     real_lsq = ot.least_squares
@@ -174,5 +179,5 @@ if __name__ == '__main__':
         print('case %d: F %d  lsq nfev %s status %s cost %s  floor %s  contacts changed %d' % (
             ci, cs['F'], [int(r['nfev']) for r in rec['lsq']], [int(r['status']) for r in rec['lsq']], ['%.4f' % r['cost'] for r in rec['lsq']],
             np.round(out[k + 'out_floor_n'], 4), int(np.abs(out[k + 'out_vel'] - data['vel']).sum())), flush=True)
-    np.savez_compressed(os.path.join(HERE, 'kinopt_golden.npz'), **out)
-    print('wrote kinopt_golden.npz: %.2f MB' % (os.path.getsize(os.path.join(HERE, 'kinopt_golden.npz')) / 1e6))
+    np.savez_compressed(os.path.join(HERE, out_name), **out)
+    print('wrote %s: %.2f MB' % (out_name, os.path.getsize(os.path.join(HERE, out_name)) / 1e6))

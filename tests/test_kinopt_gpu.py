@@ -104,3 +104,31 @@ def test_batch_driver_on_gpu(gold, tmp_path):
         assert abs(np.linalg.norm(n) - 1) < 1e-12 and n[1] < -0.9              # y is down in the camera frame: the floor's normal points up
         m, _, _ = sio.load_bvh(str(out / 'final_test.bvh'))
         assert m.n_frames == F and m.n_joints == 28
+
+
+def test_realistic_clip_lengths_match_the_reference():
+    """Clips of 40 and 60 frames (tests/golden/kinopt_golden_long.npz: the reference's own `optimize_trajectory` run on them,
+    make_kinopt_golden.py --long) through the kernel at its DEFAULT frame tiles (34 / 27 frames of LDS: both clips cross tile boundaries):
+    every least-squares solve within 5e-4 of the reference's solution, the relabelled contacts exact."""
+    path = os.path.join(HERE, 'golden', 'kinopt_golden_long.npz')
+    if not os.path.exists(path):
+        pytest.skip('kinopt_golden_long.npz not generated')
+    torch = pytest.importorskip('torch')
+    if not torch.cuda.is_available():
+        pytest.skip('needs an MI355X')
+    g = np.load(path)
+    n = int(g['n_cases'])
+    ps = [problem(g, ci, li) for ci in range(n) for li in range(2)]
+    res = kopt.KinSolver(device=0).solve([p for p, _ in ps])
+    for (p, q), r in zip(ps, res):
+        err = rel(r['x'], g[q + 'x'])
+        print('%s  frames %d  x rel %.2e  cost %.3f (reference %.3f)  nfev %d (%d)  LSMR iterations %d' % (q, p['pose3d'].shape[0], err, r['cost'], float(g[q + 'cost']), r['nfev'],
+                                                                                                 int(g[q + 'nfev']), r['lsmr_iterations']))
+        assert err < 5e-4, (q, err)
+        assert abs(r['cost'] - float(g[q + 'cost'])) < 1e-2 * float(g[q + 'cost'])
+    whole = kopt.KinematicOptimizer(device=0).optimize([clip_of(g, ci) for ci in range(n)])
+    for ci, r in enumerate(whole):
+        k = 'c%d_' % ci
+        assert np.array_equal(r['velConstraints'], g[k + 'out_vel'])
+        assert rel(r['pose3d'], g[k + 'out_pose3d']) < 2e-3
+        print('clip %d (%d frames): pose3d %.1e vs the reference' % (ci, r['pose3d'].shape[0], rel(r['pose3d'], g[k + 'out_pose3d'])))
