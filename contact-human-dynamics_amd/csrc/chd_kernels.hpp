@@ -137,7 +137,7 @@ struct Ctx {
   double sf;            // objective scaling
   double tol;           // IPOPT tol of the stage (phys_optim.cpp:578)
   int stall_window;     // 0 = no stall guard (chd_config.stall_window)
-  int factor_ll;        // chd_config.factorisation: 1 = left-looking factorisation (kfactor_ll), 0 = right-looking (kfactor_rl)
+  int factor_ll;        // chd_config.factorisation: 0 = right-looking (kfactor_rl), 1 = left-looking (kfactor_ll), 2 = register-resident front (kfactor_rf)
   int clip_heel;        // 1 while the second model of an iteration is built: heel-distance curvature with max(lam, 0) (solve_stage)
   int err;              // sticky error flag (band overflow): any thread may set it, read after a barrier
   int n_bad_pivots;     // thread 0 counts
@@ -1663,10 +1663,12 @@ CHD_DEV bool kfactor_ll(LCtx& c, const GD* diag, const GI* sign) {
   return true;
 }
 
+#include "chd_kfront.hpp"
+
 CHD_NOINLINE CHD_DEV void kfactor(LCtx& c, const GD* diag, const GI* sign) {
-  if (c.factor_ll) {
+  if (c.factor_ll) {      // chd_config.factorisation: 1 = left-looking tiles from the factor storage, 2 = frontal with the front in the accumulator registers
     TIC();
-    if (kfactor_ll(c, diag, sign)) { TOC(c, 2); return; }
+    if (c.factor_ll == 2 ? kfactor_rf(c, diag, sign) : kfactor_ll(c, diag, sign)) { TOC(c, 2); return; }
   }
   kfactor_rl(c, diag, sign);
 }
@@ -3470,7 +3472,7 @@ CHD_DEV void debug_eval(QP q, LCtx& c, int stage, int use_x, LdsD* lds, int lds_
 
 // Debug entry: K0 of `stage` at the initial state, + (dw Dw, -dval) on the diagonal, factored `reps` times by the left-looking
 // (which = 0) or the right-looking (1) factorisation and solved for `rhs` (one refinement step).  out: [0] replaced pivots,
-// [1] clock ticks (100 MHz) of the factorisations, [2] of the solve, [3] which one ran (0 / 1).
+// [1] clock ticks (100 MHz) of the factorisations, [2] of the solve, [3] which one ran (0 / 1 / 2), [4..11] the factorisation's phase timers 6..13.
 CHD_DEV void debug_linsolve(QP q, LCtx& c, int stage, LdsD* lds, int lds_cap, double dw, double dval, int which, int reps, const GD* rhs_in, GD* x_out, double* out) {
   double fo[2];
   debug_eval(q, c, stage, 0, lds, lds_cap, nullptr, nullptr, fo);
@@ -3483,6 +3485,7 @@ CHD_DEV void debug_linsolve(QP q, LCtx& c, int stage, LdsD* lds, int lds_cap, do
   const long long t0 = CHD_CLOCK();
   for (int r = 0; r < reps; ++r) {
     if (which == 0) { if (!kfactor_ll(c, diag, sign)) { kfactor_rl(c, diag, sign); ran = 1; } }
+    else if (which == 2) { ran = 2; if (!kfactor_rf(c, diag, sign)) { kfactor_rl(c, diag, sign); ran = 1; } }
     else kfactor_rl(c, diag, sign);
     CHD_SYNC();
   }
@@ -3493,7 +3496,7 @@ CHD_DEV void debug_linsolve(QP q, LCtx& c, int stage, LdsD* lds, int lds_cap, do
   ksolve(c, rhs, sol, diag, 1);
   const long long t2 = CHD_CLOCK();
   PAR_FOR(i, c.N) x_out[i] = sol[i];
-  if (CHD_TID == 0) { out[0] = c.n_bad_pivots; out[1] = (double)(t1 - t0); out[2] = (double)(t2 - t1); out[3] = ran; }
+  if (CHD_TID == 0) { out[0] = c.n_bad_pivots; out[1] = (double)(t1 - t0); out[2] = (double)(t2 - t1); out[3] = ran; for (int k = 0; k < 10; ++k) out[4 + k] = (double)c.tacc[6 + k]; }
   CHD_SYNC();
 }
 

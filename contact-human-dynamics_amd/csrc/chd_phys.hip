@@ -322,7 +322,7 @@ static int launch_queue(chd_handle* h, chd_batch* b, const std::vector<int>& ite
   const unsigned grid = (unsigned)std::min<size_t>(items.size(), (size_t)h->n_wg);
   HIP_TRY(h, hipEventRecord(e0, h->stream));
   hipLaunchKernelGGL(chd_solve_kernel, dim3(grid), dim3(h->threads), h->lds_bytes, h->stream, b->d_descs, (const int*)b->d_order, (int)items.size(),
-                     h->d_counter, h->d_wd, h->wd_stride, h->d_wi, h->wi_stride, h->lds_bytes / 8, h->cfg.tol, h->cfg.stall_window, stage_first, stage_last, h->cfg.factorisation == 1 ? 1 : 0);
+                     h->d_counter, h->d_wd, h->wd_stride, h->d_wi, h->wi_stride, h->lds_bytes / 8, h->cfg.tol, h->cfg.stall_window, stage_first, stage_last, (h->cfg.factorisation == 1 || h->cfg.factorisation == 2) ? h->cfg.factorisation : 0);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipEventRecord(e1, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -609,7 +609,7 @@ int chd_debug_linsolve(chd_handle* h, chd_batch* b, int seq, int stage, double d
   const StageDesc& S = b->models[seq].d.st[stage];
   const int N = S.n + S.m;
   double* d_buf = nullptr;
-  HIP_TRY(h, hipMalloc((void**)&d_buf, (size_t)(2 * N + 8) * 8));
+  HIP_TRY(h, hipMalloc((void**)&d_buf, (size_t)(2 * N + 16) * 8));
   HIP_TRY(h, hipMemcpy(d_buf, rhs, (size_t)N * 8, hipMemcpyHostToDevice));
   HIP_TRY(h, hipMemcpyAsync(b->d_order, &seq, sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemsetAsync(h->d_counter, 0, sizeof(int), h->stream));
@@ -618,7 +618,7 @@ int chd_debug_linsolve(chd_handle* h, chd_batch* b, int seq, int stage, double d
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   if (e == hipSuccess) e = hipMemcpy(x, d_buf + N, (size_t)N * 8, hipMemcpyDeviceToHost);
-  if (e == hipSuccess && info) e = hipMemcpy(info, d_buf + 2 * N, 4 * 8, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && info) e = hipMemcpy(info, d_buf + 2 * N, 14 * 8, hipMemcpyDeviceToHost);
   (void)hipFree(d_buf);
   if (e != hipSuccess) return fail(h, std::string("chd_debug_linsolve: ") + hipGetErrorString(e));
   return 0;

@@ -19,7 +19,7 @@ from .phys_capi import (ChdBatchStats, ChdConfig, ChdSeqIn, ChdSeqOut, N_SNAPSHO
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.environ.get('CHD_PHYS_LIB') or os.path.join(_CSRC, 'libchd_phys.so')      # (override: kernel experiments with variant builds)
-SOURCES = ['chd_phys.hip', 'chd_kernels.hpp', 'chd_model.hpp', 'chd_device.hpp', 'chd_io.hpp']
+SOURCES = ['chd_phys.hip', 'chd_kernels.hpp', 'chd_kfront.hpp', 'chd_model.hpp', 'chd_device.hpp', 'chd_io.hpp']
 SNAPSHOT_FILES = ('sol_out_no_dynamics.txt', 'sol_out_dynamics.txt', 'sol_out_durations.txt')
 
 EXPORTS = ['chd_phys_version', 'chd_config_default', 'chd_phys_create', 'chd_phys_destroy', 'chd_phys_last_error',
@@ -186,10 +186,11 @@ class Batch:
         sz = self.sizes(seq, stage)
         rhs = np.ascontiguousarray(rhs, dtype=np.float64)
         assert rhs.size == sz['kkt_dim']
-        x = np.zeros(sz['kkt_dim']); info = np.zeros(4)
+        x = np.zeros(sz['kkt_dim']); info = np.zeros(14)
         self.solver._check(self.solver.L.chd_debug_linsolve(self.solver.h, self.h, seq, stage, dw, dval, which, reps, rhs.ctypes.data_as(PD), x.ctypes.data_as(PD),
                                                             info.ctypes.data_as(PD)), 'chd_debug_linsolve')
-        return x, dict(bad_pivots=int(info[0]), factor_us=info[1] / 100.0 / max(1, reps), solve_us=info[2] / 100.0, ran=int(info[3]))
+        return x, dict(bad_pivots=int(info[0]), factor_us=info[1] / 100.0 / max(1, reps), solve_us=info[2] / 100.0, ran=int(info[3]),
+                       phase_us={k: info[4 + k - 6] / 100.0 / max(1, reps) for k in range(6, 16)})
 
     def free(self):
         if self.h:

@@ -50,9 +50,9 @@ def test_eval_parity_all_stages(emu, oracle_lib):
         o.set_x(x0 if st != 4 else np.concatenate([x0, o.get_x()[x0.size:]]))
 
 
-@pytest.mark.parametrize('kind', [0, 1])
+@pytest.mark.parametrize('kind', [0, 1, 2])
 def test_bordered_band_factorisation(emu, kind):
-    """Both factorisations of the kernel source (chd_config.factorisation: 0 right-looking, 1 left-looking) solve K x = b."""
+    """The three factorisations of the kernel source (chd_config.factorisation: 0 right-looking, 1 left-looking, 2 frontal with slot bookkeeping) solve K x = b."""
     seq = make_walk(seed=0, F=40, randomize=True)
     e = emu.EmuProblem(seq, default_config(factorisation=kind))
     for st in (1, 4):
@@ -62,10 +62,10 @@ def test_bordered_band_factorisation(emu, kind):
         assert bad == 0 and np.isfinite(x).all()
 
 
-@pytest.mark.parametrize('seed,F,tilt,kind', [(2, 40, 0.0, 0), (6, 60, 5.0, 0), (9, 90, 0.0, 0), (6, 60, 5.0, 1)])
+@pytest.mark.parametrize('seed,F,tilt,kind', [(2, 40, 0.0, 0), (6, 60, 5.0, 0), (9, 90, 0.0, 0), (6, 60, 5.0, 1), (2, 40, 0.0, 2)])
 def test_staged_solve_parity(emu, oracle_lib, seed, F, tilt, kind):
     """Kernel source (host emulation) vs oracle through all stages: same statuses, same iteration counts, snapshots to
-    1e-8 -- flat and tilted floors, 40 / 60 / 90 frames; the last case with the left-looking factorisation."""
+    1e-8 -- flat and tilted floors, 40 / 60 / 90 frames; the last two cases with the left-looking and the frontal factorisation."""
     seq = make_walk(seed=seed, F=F, randomize=True, tilt_deg=tilt)
     caps = [300] * 6
     e = emu.EmuProblem(seq, default_config(max_iter=caps, factorisation=kind))
