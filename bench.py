@@ -331,8 +331,10 @@ def main(argv=None, solver_factory=None):
         try:
             v, st2 = timed_solve(seqs, stall_window=150)
             side['value_with_stall_guard_150'] = v; side['stall_guard_150_hits'] = st2['n_stalled']; side['stall_guard_150_fallbacks'] = st2['n_fallback']
-            v, st2 = timed_solve(seqs, factorisation=1 - args.factorisation)
-            side['value_%s_factorisation' % ('left_looking' if args.factorisation == 0 else 'right_looking')] = v
+            for kind, name in ((0, 'right_looking'), (1, 'left_looking'), (2, 'register_front')):      # the other factorisations on the same workload
+                if kind != args.factorisation:
+                    v, st2 = timed_solve(seqs, factorisation=kind)
+                    side['value_%s_factorisation' % name] = v
             v, st2 = timed_solve(seqs[:500])
             side['value_500_sequences_in_one_call'] = v
             side['kernel_busy_fraction_500_sequences'] = st2['phase_ms'][5] / max(1e-9, st2['n_workgroups'] * (st2['kernel_ms'][0] + st2['kernel_ms'][1]))
@@ -379,7 +381,7 @@ def main(argv=None, solver_factory=None):
                        'ipm_iterations_per_sequence': tot_iters_all / total_seqs,
                        'ipm_iterations_rank0': {'p50': float(np.percentile(it_seq, 50)), 'p90': float(np.percentile(it_seq, 90)), 'max': float(it_seq.max())},
                        'factorizations_rank0': nfact, 'stage4_fallbacks_rank0': st['n_fallback'], 'stall_guard_hits_rank0': st['n_stalled'],
-                       'converged_rank0': '%d/%d' % (n_ok, len(res)), 'factorisation': 'left-looking' if args.factorisation == 1 else 'right-looking', **side,
+                       'converged_rank0': '%d/%d' % (n_ok, len(res)), 'factorisation': ('right-looking', 'left-looking', 'register-front')[args.factorisation] if 0 <= args.factorisation <= 2 else str(args.factorisation), **side,
                        'slowest_sequence_ms': st['max_seq_ms'], 'mean_sequence_ms': st['phase_ms'][5] / max(1, len(res)),
                        'in_kernel_phase_ms_per_sequence': [round(v / max(1, len(res)), 3) for v in st['phase_ms']],
                        'in_kernel_time_share': {k: st['phase_ms'][i] / max(1e-9, st['phase_ms'][5]) for k, i in

@@ -6,6 +6,7 @@ HIP path to the oracle on EVERY bench sequence without spending GPU-box minutes 
   tilted  seeds 200..231, F = 90, floor tilted by 2..9.75 degrees about x (the sequences on which round 1's
           parity holes showed up were mostly tilted ones)
   hard    36 seeds of bench.py's --steps 20 workload that the round-2 solver struggled with (stage-4 fallbacks, most iterations)
+  pipe    four 60-frame sequences of the kind the kinematic optimisation produces (tests/golden/pipe_inputs/)
   long    one 600-frame sequence, 10 degree tilt  (configs[4]) -- only with --long (takes tens of minutes on one core)
 
 Reference iteration caps 7000/7000/7000/2500/2000/7000, tol 1e-3 (phys_optim.cpp:571-743) and the solver's default
@@ -38,12 +39,20 @@ HARD = [(s, 90, 0.0) for s in (139, 162, 197, 284, 302, 436, 659, 731, 827, 842,
                                1887, 1907, 1945, 2010, 2105, 2133, 2194, 2242, 2256, 2281, 2395, 2459, 2510, 2556)]
 
 
+# sequences of another family: what the kinematic optimisation hands to the physics stage for synthetic standing-up clips (the pipeline
+# benchmark's videos 16, 8, 17, 4: tests/golden/pipe_inputs/video_0XX/ = their phys_optim_in_combined/ directories, 60 frames) -- seeds >= 100000
+PIPE = [(100000 + v, 60, 0.0) for v in (16, 8, 17, 4)]
+
+
 def case_key(seed, F, tilt):
     return 's%d_F%d_t%03d' % (seed, F, int(round(tilt * 100)))
 
 
 def make_case(seed, F, tilt):
     import chd_amd  # noqa: F401
+    if seed >= 100000:
+        from chd_amd import io_formats as iof
+        return iof.read_inputs(os.path.join(HERE, 'pipe_inputs', 'video_%03d' % (seed - 100000)), F)
     from chd_amd.synth import make_walk
     return make_walk(seed=seed, F=F, randomize=True, tilt_deg=tilt)
 
@@ -62,13 +71,14 @@ if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--workers', type=int, default=8)
     ap.add_argument('--long', action='store_true')
+    ap.add_argument('--missing', action='store_true', help='solve only the cases the existing fixture lacks')
     ap.add_argument('--out', default=os.path.join(HERE, 'bench_parity_golden.npz'))
     args = ap.parse_args()
     from oracle import oracle
     oracle.build()
-    cases = FLAT + TILTED + HARD + (LONG if args.long else [])
+    cases = FLAT + TILTED + HARD + PIPE + (LONG if args.long else [])
     out = {}
-    if args.long and os.path.exists(args.out):          # keep what a previous run produced: only missing cases are solved
+    if (args.long or args.missing) and os.path.exists(args.out):          # keep what a previous run produced: only missing cases are solved
         old = np.load(args.out)
         out = {k: old[k] for k in old.files}
         cases = [c for c in cases if case_key(*c) + '_status' not in out]
@@ -85,5 +95,5 @@ if __name__ == '__main__':
                 out['%s_snap%d_contact' % (key, k)] = np.asarray(sn['contact'], dtype=np.uint8)
             print('%s  %5.1f s  %s' % (key, dt, [(s[0], s[1]) for s in stats]), flush=True)
     np.savez_compressed(args.out, **out)
-    print('wrote %s: %d cases, %.0f s wall, %.1f MB' % (args.out, len(FLAT + TILTED + HARD) + (1 if args.long else 0), time.time() - t0,
+    print('wrote %s: %d cases, %.0f s wall, %.1f MB' % (args.out, len(FLAT + TILTED + HARD + PIPE) + (1 if args.long else 0), time.time() - t0,
                                                       os.path.getsize(args.out) / 1e6))

@@ -150,7 +150,7 @@ def test_bench_workload_matches_oracle():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
     import make_bench_parity_golden as mk
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'bench_parity_golden.npz'))
-    cases = [c for c in mk.FLAT + mk.TILTED + mk.HARD if mk.case_key(*c) + '_status' in g.files]
+    cases = [c for c in mk.FLAT + mk.TILTED + mk.HARD + mk.PIPE if mk.case_key(*c) + '_status' in g.files]
     assert len(cases) >= 160
     seqs = [mk.make_case(*c) for c in cases]
     s = PhysOptim(device=0, config=default_config(max_iter=REF_CAPS))
