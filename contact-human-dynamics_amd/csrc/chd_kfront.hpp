@@ -22,16 +22,18 @@
 // Falls back (returns false, the caller runs kfactor_rl) when the front needs more than C slots (the 600-frame configuration:
 // 700 border rows), the band is wider than the slot ring or the workgroup is not eight wavefronts.
 //
-// STATUS (profiles/r03b_register_front/factor_bench.md, one workgroup on an idle MI355X, stage 2.2 of a 90-frame sequence, N = 2 125):
-// correct on the first GPU run (1e-15 of the right-looking solution on every stage) and NOT faster: 3.4 ms against 1.78 ms right-looking
-// (2.2 ms left-looking).  129 panels of 16 columns at ~26 us each: entry + extraction 6.6 us, diagonal block 4.2 us (slot bookkeeping
-// 3.2 us beside it), row solve 3.1 us, update 11.5 us (8.5 us on the tile wavefronts themselves).  The panel's critical path has no
-// HBM access any more, but it is instruction-bound instead: slot indirection (every register <-> LDS move is predicated on table
-// look-ups), 15-18 statically owned tiles per wavefront whose skip tests and address arithmetic are issued whether or not the tile is
-// touched, loop invariants spilled to scratch beside 120-144 accumulator registers, and a 16 x 16 pivot block + row solve that are
-// serial chains repeated twice as often as with 32-column panels.  What it would take: pivots and entering rows confined to whole
-// 16-slot blocks (allocation by block) so that extraction and entry become plain tile copies, 32-column panels, the row solve as a
-// matrix-core TRSM.  Kept selectable (chd_config.factorisation = 2) and tested (tests/test_gpu_parity.py, tests/test_host_emu.py).
+// STATUS (profiles/r03b_register_front/, MI355X): correct on the first GPU run (1e-15 of the right-looking solution on every stage) and
+// NOT faster.  One workgroup on an idle GPU, stage 2.2 of a 90-frame sequence (N = 2 125): 3.2 ms against 1.78 ms right-looking (2.2 ms
+// left-looking); the whole bench workload: 368 against 500 sequences/s.  129 panels of 16 columns at ~25 us each: entry + extraction 7.4 us,
+// diagonal block 4.1 us (slot bookkeeping 3.2 us beside it), row solve 3.4 us, update 9.3 us -- of which the tile wavefronts' matrix-core
+// work is 2.8 us since it became branch-free straight-line code (8.5 us with a skip test per tile); the rest of that phase is the service
+// wavefronts gathering the entering rows' K0 values, ~3 500 scattered loads per panel.  The panel's critical path has no window
+// read-modify-write any more, but it is instruction-bound instead: slot indirection (every register <-> LDS move is predicated on table
+// look-ups), 15-18 statically owned tiles per wavefront, loop invariants spilled to scratch beside 120-144 accumulator registers, and a
+// 16 x 16 pivot block + row solve that are serial chains repeated twice as often as with 32-column panels.  What it would take: entry and
+// extraction as straight-line code too (slots handed out by whole 16-slot blocks so that both are plain tile copies), the entering rows'
+// K0 segments staged as contiguous rows, 32-column panels, the row solve as a matrix-core triangular solve.  Kept selectable
+// (chd_config.factorisation = 2) and tested (tests/test_gpu_parity.py, tests/test_host_emu.py).
 #define CHD_RF_CMAX 224           // slots of the largest instantiation (sizes the LDS tables); instantiated for 208 (stages without duration
                                  // variables: fronts <= 170 rows on 90-frame sequences) and 224 (duration stage: <= 210)
 #define CHD_RF_NBKMAX (CHD_RF_CMAX / 16)
@@ -52,11 +54,12 @@ struct RfLds {                     // LDS layout of the factorisation (after the
   LdsI* pcA; LdsI* pcB;            // [NBKMAX] each: pivots of the current / next panel per block
   LdsI* newl;                      // [EMAX + 1]: [0] = rows entering at the next panel, then their slots (isnew[slot] = 1 + index in this list)
   LdsD* KST;                       // [EMAX][C]: K0 (+ shift) of the entering rows against every slot, staged by the service wavefronts
+  LdsD* PTD;                       // [NB][C]: -d_j L(t, j): the update's second operand, scaled once by the row solve
 };
 #define CHD_RF_EMAX 32
 #define CHD_RF_LDS_INTS (CHD_RF_RING + CHD_RF_BMAX + 5 * CHD_RF_CMAX + 32 + 2 + 2 * CHD_RF_NBKMAX + 2 + 2 * CHD_RF_NBKMAX + CHD_RF_EMAX + 2)
 #define CHD_RF_LDS_DOUBLES_TABLES (64 + CHD_RF_NB * CHD_RF_NB + CHD_RF_NB * CHD_RF_CMAX + (CHD_RF_LDS_INTS + 1) / 2 + 2)
-#define CHD_RF_LDS_DOUBLES (CHD_RF_LDS_DOUBLES_TABLES + CHD_RF_EMAX * CHD_RF_CMAX)
+#define CHD_RF_LDS_DOUBLES (CHD_RF_LDS_DOUBLES_TABLES + CHD_RF_EMAX * CHD_RF_CMAX + CHD_RF_NB * CHD_RF_CMAX)
 CHD_DEV RfLds rf_layout(LdsD* base) {
   RfLds L;
   L.dv = base; L.DL = L.dv + 64; L.PT = L.DL + CHD_RF_NB * CHD_RF_NB;
@@ -71,6 +74,7 @@ CHD_DEV RfLds rf_layout(LdsD* base) {
   L.pcA = ip; ip += CHD_RF_NBKMAX; L.pcB = ip; ip += CHD_RF_NBKMAX;
   L.newl = ip; ip += CHD_RF_EMAX + 2;
   L.KST = base + CHD_RF_LDS_DOUBLES_TABLES;
+  L.PTD = L.KST + CHD_RF_EMAX * CHD_RF_CMAX;
   return L;
 }
 
@@ -383,11 +387,11 @@ CHD_DEV void rf_rows(const RfLds& L, const LdsI* pj, const int t0, const int nt)
         for (int j = k2 + 1; j < NB; ++j) y0[j] -= y0[k2] * L.DL[k2 * NB + j];          // (broadcast reads of the diagonal block's column)
       }
 #pragma unroll
-      for (int j = 0; j < NB; ++j) L.PT[j * C + t] = y0[j] * L.dv[32 + j];
+      for (int j = 0; j < NB; ++j) { L.PT[j * C + t] = y0[j] * L.dv[32 + j]; L.PTD[j * C + t] = -y0[j]; }          // (L = y / d, so -d L = -y)
       __hip_atomic_fetch_or(&L.misc[2], 1 << (t >> 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
 #pragma unroll
-      for (int j = 0; j < NB; ++j) L.PT[j * C + t] = 0.0;
+      for (int j = 0; j < NB; ++j) { L.PT[j * C + t] = 0.0; L.PTD[j * C + t] = 0.0; }
     }
   }
 }
@@ -578,17 +582,13 @@ CHD_NOINLINE CHD_DEV bool rf_tile_loop(LCtx& c, const GD* diag, LdsD* base) {
       const long long tt1_ = CHD_CLOCK();
       const unsigned occm = (unsigned)__builtin_amdgcn_readfirstlane(L.misc[2]);
       CHD_RF_FOR_TILES(k) {
-        if (tbr[k] < 0) continue;
-        const int br = tbr[k], bcl = tbc[k];
-        const bool upd = ((occm >> br) & (occm >> bcl) & 1u) != 0;
-        if (upd) {
+        const int br = tbr[k] < 0 ? 0 : tbr[k], bcl = tbr[k] < 0 ? 0 : tbc[k];          // (a wavefront's unused tile slot mirrors tile (0, 0); nobody reads it)
+        (void)occm;          // every tile, no branches: rows that are not in the panel's front are zero in PT / PTD, and straight-line code lets
+                             // the LDS reads of one tile overlap the matrix-core chain of the previous one
 #pragma unroll
-          for (int s4 = 0; s4 < NB / 4; ++s4) {
-            const int j = 4 * s4 + lk;
-            const double a = L.PT[j * C + 16 * br + lr];
-            const double b = -L.dv[j] * L.PT[j * C + 16 * bcl + lr];
-            acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[k], 0, 0, 0);
-          }
+        for (int s4 = 0; s4 < NB / 4; ++s4) {
+          const int j = 4 * s4 + lk;
+          acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(L.PT[j * C + 16 * br + lr], L.PTD[j * C + 16 * bcl + lr], acc[k], 0, 0, 0);
         }
       }
       if (tid == 128) c.tacc[14] += CHD_CLOCK() - tt1_;
