@@ -10,6 +10,9 @@ the stage's objective, the largest violation of any constraint row (unscaled), t
 All on the CPU oracle (test infrastructure); the HIP path equals A to 1e-12 (tests/test_gpu_parity.py).
 
     python tests/tools/solution_quality.py [n_seeds] [n_ipopt_like] [frames] [workers]      -> markdown on stdout
+
+(The IPOPT-like variant needs thousands of iterations per stage with a dense limited-memory update: hours for 90 frames.  The committed
+study runs it as a second invocation on 40-frame sequences: `solution_quality.py 6 6 40 6`.)
 """
 import multiprocessing as mp
 import os
