@@ -197,13 +197,17 @@ struct BorderedBandLDL {
       y[Nb + r] += C0[(size_t)r * b + r] * x[Nb + r];
     }
   }
+  // up to `refine` steps of iterative refinement; a step is taken only while the residual is above refine_skip x |rhs| (max norms)
+  static constexpr double refine_skip = 1e-8;
   void solve(const double* rhs, double* x, int refine = 2) const {
     const int N = Nb + b;
     solve_once(rhs, x);
     std::vector<double> r(N), dx(N);
     for (int it = 0; it < refine; ++it) {
       matvec0(x, r.data());
-      for (int i = 0; i < N; ++i) r[i] = rhs[i] - r[i];
+      double rn = 0.0, bn = 0.0;
+      for (int i = 0; i < N; ++i) { r[i] = rhs[i] - r[i]; rn = std::fmax(rn, std::fabs(r[i])); bn = std::fmax(bn, std::fabs(rhs[i])); }
+      if (rn <= refine_skip * bn) break;
       solve_once(r.data(), dx.data());
       for (int i = 0; i < N; ++i) x[i] += dx[i];
     }
