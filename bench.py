@@ -386,8 +386,8 @@ def main(argv=None, solver_factory=None):
                        'in_kernel_phase_ms_per_sequence': [round(v / max(1, len(res)), 3) for v in st['phase_ms']],
                        'in_kernel_time_share': {k: st['phase_ms'][i] / max(1e-9, st['phase_ms'][5]) for k, i in
                                                 (('evaluation_full', 0), ('evaluation_values', 1), ('factorisation', 2), ('substitution', 3), ('kkt_matvec', 4),
-                                                 ('factor_copy', 6), ('factor_panel_load', 8), ('factor_row_solve', 9), ('factor_store', 10),
-                                                 ('factor_trailing_update', 11), ('factor_border', 12))} if args.factorisation == 0 else
+                                                 ('factor_copy', 6), ('factor_panel_load', 8), ('factor_row_solve', 9), ('factor_lookahead_wavefront', 11),
+                                                 ('factor_store_and_wait_for_trailing_tiles', 10), ('factor_border', 12))} if args.factorisation == 0 else
                                                 {k: st['phase_ms'][i] / max(1e-9, st['phase_ms'][5]) for k, i in
                                                  (('evaluation_full', 0), ('evaluation_values', 1), ('factorisation', 2), ('substitution', 3), ('kkt_matvec', 4),
                                                   ('factor_tiles', 8), ('factor_diagonal_block', 9), ('factor_row_solve', 10), ('factor_store', 11), ('factor_border', 12))}},

@@ -66,6 +66,8 @@ typedef __attribute__((address_space(3))) int LdsI;
 #define CHD_WAVE_SZ 64
 #endif
 #define PAR_FOR(i, n) for (int i = CHD_TID; i < (n); i += CHD_NT)
+// the same loop shared by the threads t0 .. CHD_NT - 1 only (threads below t0 skip it)
+#define PAR_FOR_FROM(i, n, t0) for (int i = CHD_TID - (t0); i >= 0 && i < (n); i += CHD_NT - (t0))
 // one group of CHD_GL consecutive lanes per item; `lane_` is the lane inside the group
 #define GROUP_FOR(i, n) for (int i = CHD_TID / CHD_GL, lane_ = CHD_TID % CHD_GL; i < (n); i += CHD_NT / CHD_GL)
 
@@ -730,46 +732,56 @@ CHD_DEV double rcp_f64(double d) {
 // LDS copy column by column at the earlier steps, so it arrives as pipelined broadcast reads issued one step ahead;
 // only L(j, j-1) and the pivot travel by v_readlane (whose result takes tens of cycles to reach the VALU -- the
 // right-looking form needed 31 - j of them per column and took ~11 us per block).
+// (first wavefront only)  ar[j] = row a = lane of the block, as the factor storage holds it
+template <int NB>
+__device__ __forceinline__ void diag_load(LCtx& c, double (&ar)[NB], const int c0, const int jb) {
+  const int W1 = c.w + 1, w = c.w;
+  const int a = threadIdx.x;
+  const GD* src = c.Kfb + (long long)(c0 + (a < jb ? a : 0)) * W1 + (w - (a < jb ? a : 0));      // (left of a row's envelope the factor storage is zero)
+#pragma unroll
+  for (int j = 0; j < NB; ++j) { const bool in = a < jb && j <= a; const double t = *(in ? src + j : c.Kfb + w); ar[j] = in ? t : (a == j ? 1.0 : 0.0); }
+}
+template <int NB>
+__device__ __forceinline__ void diag_chain(LCtx& c, const GI* sign, LdsD* dv, LdsD* DL, const double (&ar)[NB], const int c0, const int jb) {
+  const int a = threadIdx.x;
+  const bool act = a < NB;
+  const int sg_a = a < jb ? sign[c0 + a] : 1;          // expected pivot signs, fetched once
+  const unsigned long long sg_pos = __ballot(sg_a > 0);
+  double u[NB], row[NB];           // u[k] = L(a,k) d_k; row[k] = L(j,k) of the column being formed
+#pragma unroll
+  for (int k = 0; k < NB; ++k) { u[k] = 0.0; row[k] = 0.0; }
+  double lprev = 0.0;
+  int bad = 0;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    if (j > 0) row[j - 1] = readlane_f64(lprev, j);          // L(j, j-1): produced by the previous column
+    double s0 = ar[j], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+    for (int k = 0; k + 3 < j; k += 4) { s0 -= u[k] * row[k]; s1 -= u[k + 1] * row[k + 1]; s2 -= u[k + 2] * row[k + 2]; s3 -= u[k + 3] * row[k + 3]; }
+#pragma unroll
+    for (int k = j & ~3; k < j; ++k) s0 -= u[k] * row[k];
+    const double v = (s0 + s1) + (s2 + s3);
+    // row j + 1 of L up to column j - 1 (written at earlier columns): requested now, arrives while the pivot chain runs
+    if (j + 1 < NB) {
+#pragma unroll
+      for (int k = 0; k < j; ++k) row[k] = DL[k * NB + (j + 1)];
+    }
+    double d = readlane_f64(v, j);
+    if (j < jb) { const double sg = ((sg_pos >> j) & 1ull) ? 1.0 : -1.0; if (!(d * sg > 1e-14)) { d = sg * 1e-10; ++bad; } }
+    const double inv = rcp_f64(d);
+    const double lj = v * inv;            // L(a, j) for a > j
+    u[j] = v; lprev = lj;
+    if (act && a > j) DL[j * NB + a] = lj;
+    if (a == j) { dv[j] = d; dv[32 + j] = inv; }
+  }
+  if (threadIdx.x == 0) c.n_bad_pivots += bad;
+}
 template <int NB>
 CHD_DEV void diag_block_g(LCtx& c, const GI* sign, LdsD* dv, LdsD* DL, const int c0, const int jb) {
   if (threadIdx.x < 64) {
-    const int W1 = c.w + 1, w = c.w;
-    const int a = threadIdx.x;
-    const bool act = a < NB;
-    const int sg_a = a < jb ? sign[c0 + a] : 1;          // expected pivot signs, fetched once
-    double ar[NB];                  // row a of the block (left of a row's envelope the factor storage is zero)
-    const GD* src = c.Kfb + (long long)(c0 + (a < jb ? a : 0)) * W1 + (w - (a < jb ? a : 0));
-#pragma unroll
-    for (int j = 0; j < NB; ++j) { const bool in = a < jb && j <= a; const double t = *(in ? src + j : c.Kfb + w); ar[j] = in ? t : (a == j ? 1.0 : 0.0); }
-    const unsigned long long sg_pos = __ballot(sg_a > 0);
-    double u[NB], row[NB];           // u[k] = L(a,k) d_k; row[k] = L(j,k) of the column being formed
-#pragma unroll
-    for (int k = 0; k < NB; ++k) { u[k] = 0.0; row[k] = 0.0; }
-    double lprev = 0.0;
-    int bad = 0;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      if (j > 0) row[j - 1] = readlane_f64(lprev, j);          // L(j, j-1): produced by the previous column
-      double s0 = ar[j], s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-      for (int k = 0; k + 3 < j; k += 4) { s0 -= u[k] * row[k]; s1 -= u[k + 1] * row[k + 1]; s2 -= u[k + 2] * row[k + 2]; s3 -= u[k + 3] * row[k + 3]; }
-#pragma unroll
-      for (int k = j & ~3; k < j; ++k) s0 -= u[k] * row[k];
-      const double v = (s0 + s1) + (s2 + s3);
-      // row j + 1 of L up to column j - 1 (written at earlier columns): requested now, arrives while the pivot chain runs
-      if (j + 1 < NB) {
-#pragma unroll
-        for (int k = 0; k < j; ++k) row[k] = DL[k * NB + (j + 1)];
-      }
-      double d = readlane_f64(v, j);
-      if (j < jb) { const double sg = ((sg_pos >> j) & 1ull) ? 1.0 : -1.0; if (!(d * sg > 1e-14)) { d = sg * 1e-10; ++bad; } }
-      const double inv = rcp_f64(d);
-      const double lj = v * inv;            // L(a, j) for a > j
-      u[j] = v; lprev = lj;
-      if (act && a > j) DL[j * NB + a] = lj;
-      if (a == j) { dv[j] = d; dv[32 + j] = inv; }
-    }
-    if (threadIdx.x == 0) c.n_bad_pivots += bad;
+    double ar[NB];
+    diag_load<NB>(c, ar, c0, jb);
+    diag_chain<NB>(c, sign, dv, DL, ar, c0, jb);
   }
 }
 #endif
@@ -861,9 +873,10 @@ CHD_DEV void trailing_update(LCtx& c, const LdsD* dv, const LdsD* PT, const int 
   const int t_first = !split ? wave : wave == 0 ? 0 : 3 + (wave - 1);
   const int t_stride = !split ? nwv : wave == 0 ? 1 : nwv - 1;                 // between the TP tiles of one pass
   const int t_limit = (split && wave == 0) ? (ntri < 3 ? ntri : 3) : ntri;
-  for (int t0 = t_first; t0 < t_limit; t0 += TP * t_stride) {
-    GD* pd[TP][4]; double old_[TP][4]; bool ok[TP][4];
-    const LdsD* pa[TP]; const LdsD* pb[TP];
+  // two passes in flight: the old window values of pass p + 1 are requested before the matrix-core chains of pass p start, so a
+  // wavefront's passes cost one round trip to L2 / HBM together instead of one each (ping-pong between two register sets)
+  struct TileSet { GD* pd[TP][4]; double old_[TP][4]; bool ok[TP][4]; const LdsD* pa[TP]; const LdsD* pb[TP]; };
+  auto fetch = [&](TileSet& S, const int t0) {
 #pragma unroll
     for (int u = 0; u < TP; ++u) {
       const int t = t0 + u * t_stride;
@@ -872,16 +885,18 @@ CHD_DEV void trailing_update(LCtx& c, const LdsD* dv, const LdsD* PT, const int 
       tile_of(live ? t : t0, tr, tc);
       const int ira = 16 * tr + lr, icb = 16 * tc + lr;           // compact indices of this lane's A row / B column
       const int ua = ira < nact ? act[ira] : zrow, ub = icb < nact ? act[icb] : zrow;
-      pa[u] = PT + NB + ua; pb[u] = PT + NB + ub;
+      S.pa[u] = PT + NB + ua; S.pb[u] = PT + NB + ub;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int irr = 16 * tr + lk + 4 * r;                     // compact row index of D register r
-        ok[u][r] = live && irr < nact && icb < nact && icb <= irr;
-        const int ur = ok[u][r] ? act[irr] : 0;
-        pd[u][r] = dest(ok[u][r] ? ur : 0, ok[u][r] ? ub : 0);
-        old_[u][r] = ok[u][r] ? *pd[u][r] : 0.0;
+        S.ok[u][r] = live && irr < nact && icb < nact && icb <= irr;
+        const int ur = S.ok[u][r] ? act[irr] : 0;
+        S.pd[u][r] = dest(S.ok[u][r] ? ur : 0, S.ok[u][r] ? ub : 0);
+        S.old_[u][r] = S.ok[u][r] ? *S.pd[u][r] : 0.0;
       }
     }
+  };
+  auto finish = [&](const TileSet& S) {
     chd_f64x4 acc[TP];
 #pragma unroll
     for (int u = 0; u < TP; ++u) acc[u] = chd_f64x4{0.0, 0.0, 0.0, 0.0};
@@ -890,27 +905,138 @@ CHD_DEV void trailing_update(LCtx& c, const LdsD* dv, const LdsD* PT, const int 
       const int j = kk * 4 + lk;
       const double dj = dv[j];
 #pragma unroll
-      for (int u = 0; u < TP; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[u][j * ldp], pb[u][j * ldp] * dj, acc[u], 0, 0, 0);
+      for (int u = 0; u < TP; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(S.pa[u][j * ldp], S.pb[u][j * ldp] * dj, acc[u], 0, 0, 0);
     }
 #pragma unroll
     for (int u = 0; u < TP; ++u)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (ok[u][r]) *pd[u][r] = old_[u][r] - acc[u][r];
+        if (S.ok[u][r]) *S.pd[u][r] = S.old_[u][r] - acc[u][r];
+  };
+  const int t_step = TP * t_stride;
+  TileSet A, B;
+  int t0 = t_first;
+  if (t0 < t_limit) fetch(A, t0);
+  while (t0 < t_limit) {
+    if (t0 + t_step < t_limit) fetch(B, t0 + t_step);
+    finish(A);
+    if (!(t0 + t_step < t_limit)) break;
+    if (t0 + 2 * t_step < t_limit) fetch(A, t0 + 2 * t_step);
+    finish(B);
+    t0 += 2 * t_step;
   }
+}
+#endif
+
+#ifndef CHD_HOST_EMU
+// The first wavefront's share of a panel's trailing update when another panel follows (look-ahead): the three tiles of the compacted
+// window that cover the next panel's diagonal block, then that block's L D L^T.  The block never goes through memory on the way:
+// its old values are requested row-per-lane (the layout of the column chain) TOGETHER with the tiles' old values, the three
+// accumulator tiles are handed from the matrix-core layout to row-per-lane through the LDS buffer that is about to receive the
+// block's L (DL_n), and the chain starts from old - update in registers.  (Before: tiles, read-modify-write, fence, reload of the
+// block, chain -- two dependent round trips to L2 and a store drain on the critical path of the whole workgroup, 5.9 + 5.5 us of the
+// 13.8 us the phase took per panel.)
+template <int NB>
+CHD_NOINLINE CHD_DEV void lookahead_wave(LCtx& c, const GI* sign, const LdsD* dv, const LdsD* PT, const int ldp, const int wr, const int nbelow, const int i0,
+                            const int* act_, const int nact, LdsD* dv_n, LdsD* DL_n, const int c0n, const int jbn) {
+  const int W1 = c.w + 1, w = c.w, LD = c.LD, Nb = c.Nb;
+  const LdsI* act = (const LdsI*)act_;
+  const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+  const int zrow = wr + 8;          // a zero (padding) row of the panel
+#ifdef CHD_DIAG_TIMING
+  const long long tl0_ = CHD_CLOCK();
+#endif
+  double ar[NB];
+  diag_load<NB>(c, ar, c0n, jbn);                    // (requests only: nothing waits on them before the tiles' loads are out as well)
+  auto dest = [&](int ur, int uc) -> GD* {
+    if (ur < nbelow) { const int i = i0 + ur, k = i0 + uc; return c.Kfb + (long long)i * W1 + (k - i + w); }
+    if (uc < nbelow) return c.Kfx + (long long)(ur - nbelow) * LD + i0 + uc;
+    return c.Kfx + (long long)(ur - nbelow) * LD + Nb + (uc - nbelow);
+  };
+  constexpr int TT = 3;                              // tiles (0,0), (1,0), (1,1) of the compacted window
+  const int ntl = nact > 16 ? 3 : nact > 0 ? 1 : 0;
+  GD* pd[TT][4]; double old_[TT][4]; bool ok[TT][4]; int urr[TT][4]; int ubb[TT];
+  const LdsD* pa[TT]; const LdsD* pb[TT];
+#pragma unroll
+  for (int u = 0; u < TT; ++u) {
+    const int tr = u == 0 ? 0 : 1, tc = u == 2 ? 1 : 0;
+    const bool live = u < ntl;
+    const int ira = 16 * tr + lr, icb = 16 * tc + lr;
+    const int ua = ira < nact ? act[ira] : zrow, ub = icb < nact ? act[icb] : zrow;
+    pa[u] = PT + NB + ua; pb[u] = PT + NB + ub; ubb[u] = ub;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int irr = 16 * tr + lk + 4 * r;
+      ok[u][r] = live && irr < nact && icb < nact && icb <= irr;
+      const int ur = ok[u][r] ? act[irr] : 0;
+      urr[u][r] = ur;
+      pd[u][r] = dest(ok[u][r] ? ur : 0, ok[u][r] ? ub : 0);
+      old_[u][r] = ok[u][r] ? *pd[u][r] : 0.0;
+    }
+  }
+  // the hand-over buffer S[row * NB + col] (= DL_n, not yet in use): zero where no tile entry lands
+#pragma unroll
+  for (int q = 0; q < NB * NB / 64; ++q) DL_n[lane + 64 * q] = 0.0;
+  chd_f64x4 acc[TT];
+#pragma unroll
+  for (int u = 0; u < TT; ++u) acc[u] = chd_f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < NB / 4; ++kk) {
+    const int j = kk * 4 + lk;
+    const double dj = dv[j];
+#pragma unroll
+    for (int u = 0; u < TT; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[u][j * ldp], pb[u][j * ldp] * dj, acc[u], 0, 0, 0);
+  }
+#ifdef CHD_DIAG_TIMING
+  asm volatile("s_nop 0" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]));
+  const long long tl1_ = CHD_CLOCK();
+#endif
+  // (one wavefront, and LDS operations complete in program order: zeros, entries and the reads below need no wait between them, only
+  //  the compiler kept from reordering; columns rotated by the row index -- S[row][(col + row) mod NB] -- so that the 32 lanes of a
+  //  column read hit 32 different banks)
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int u = 0; u < TT; ++u)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (ok[u][r] && urr[u][r] < jbn) DL_n[urr[u][r] * NB + ((ubb[u] + urr[u][r]) & (NB - 1))] = acc[u][r];      // a pivot row of the next panel (then so is the column: ub <= ur)
+  asm volatile("" ::: "memory");
+  {
+    const int a = lane < NB ? lane : 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) ar[j] -= DL_n[a * NB + ((j + a) & (NB - 1))];      // (lanes >= NB: identity padding rows; they stay out of the block)
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // all of S is in registers before the chain writes L into the same buffer
+#ifdef CHD_DIAG_TIMING
+  const long long tl2_ = CHD_CLOCK();
+#endif
+  // the rest of the three tiles: window rows below the block that sit among the first 32 active ones (when some of the next pivot rows
+  // are not active yet).  The block's own updated values are NOT written back: nothing reads them again -- the next panel stores L there.
+#pragma unroll
+  for (int u = 0; u < TT; ++u)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (ok[u][r] && urr[u][r] >= jbn) *pd[u][r] = old_[u][r] - acc[u][r];
+#ifdef CHD_DIAG_TIMING
+  const long long tl3_ = CHD_CLOCK();
+#endif
+  diag_chain<NB>(c, sign, dv_n, DL_n, ar, c0n, jbn);
+#ifdef CHD_DIAG_TIMING
+  if (threadIdx.x == 0) { c.tacc[7] += tl1_ - tl0_; c.tacc[13] += tl2_ - tl1_; c.tacc[14] += tl3_ - tl2_; c.tacc[15] += CHD_CLOCK() - tl3_; }
+#endif
 }
 #endif
 
 template <int NB>
 CHD_NOINLINE CHD_DEV void trailing_phase(LCtx& c, const GI* sign, const LdsD* dv, const LdsD* PT, const int ldp, const int wr, const int nbelow, const int i0,
                                          const int* act, const int nact, const bool more, LdsD* dv_n, LdsD* DL_n, const int c0n, const int jbn) {
+#ifdef CHD_HOST_EMU
   trailing_update<NB>(c, dv, PT, ldp, wr, nbelow, i0, act, nact, more);
-  if (more) {
-#ifndef CHD_HOST_EMU
-    if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // this wavefront's window updates precede its reads below
+  if (more) diag_block_g<NB>(c, sign, dv_n, DL_n, c0n, jbn);
+#else
+  (void)sign; (void)dv_n; (void)DL_n; (void)c0n; (void)jbn;      // (the look-ahead wavefront is dispatched by the caller: lookahead_wave)
+  trailing_update<NB>(c, dv, PT, ldp, wr, nbelow, i0, act, nact, more);
 #endif
-    diag_block_g<NB>(c, sign, dv_n, DL_n, c0n, jbn);
-  }
 }
 
 // Banded part of the factorisation, NB columns per panel.  Panel in LDS, column-major PT[j * ldp + a];
@@ -990,13 +1116,14 @@ CHD_DEV void panel_rows(LCtx& c, const Panel P, const int nact) {
 
 // ---- write the panel back (8 consecutive columns of one row per task): the diagonal block rows and the active rows.
 //      Entries left of a row's envelope are exact zeros (as is what the storage holds there): only the band limit is checked.
+//      (`t0`: first participating thread -- the wavefront that factors the next diagonal block stays out of it)
 template <int NB>
-CHD_NOINLINE CHD_DEV void panel_store(LCtx& c, const Panel P, const int nact) {
+CHD_NOINLINE CHD_DEV void panel_store(LCtx& c, const Panel P, const int nact, const int t0) {
   const int W1 = c.w + 1, w = c.w, LD = c.LD;
   const int c0 = P.c0, jb = P.jb, nbelow = P.nbelow, ldp = P.ldp;
   const LdsD* PT = P.PT; const LdsD* dv = P.dv; const LdsD* DL = P.DL;
   const LdsI* act = (const LdsI*)P.act;
-  PAR_FOR(idx, (jb + nact) * (NB / 8)) {
+  PAR_FOR_FROM(idx, (jb + nact) * (NB / 8), t0) {
     const int r = idx / (NB / 8), j0 = (idx % (NB / 8)) * 8;
     if (r < jb) {                 // a row of the diagonal block (it only lives in its dense copy)
       const int a = r, i = c0 + a;
@@ -1033,8 +1160,9 @@ template <int NB>
 CHD_DEV void kfactor_band(LCtx& c, const GI* sign, LdsD* dv, LdsD* DL, LdsD* dv2, LdsD* DL2, LdsD* PT, const int ldp) {
   const int Nb = c.Nb, w = c.w, bc = c.bc;
   // look-ahead: the diagonal block of panel J + 1 is factored by the first wavefront during panel J's trailing update
-  // (after it has applied the three tiles of that update which touch the block), into the other (dv, DL) pair; the
-  // second wavefront builds panel J + 1's list of active rows at the start of the same phase (second list buffer)
+  // (lookahead_wave: the three tiles of that update which touch the block stay in registers / LDS on the way), into the other
+  // (dv, DL) pair; the second wavefront builds panel J + 1's list of active rows at the start of the same phase (second list
+  // buffer); the panel's own columns are stored after the update (by the other seven wavefronts)
   const int lsz = w + bc + 64 + 2;                           // ints per list (+ its count)
   int* actA = (int*)(PT + (long long)ldp * NB); int* actB = actA + lsz;
   {
@@ -1062,19 +1190,33 @@ CHD_DEV void kfactor_band(LCtx& c, const GI* sign, LdsD* dv, LdsD* DL, LdsD* dv2
     panel_rows<NB>(c, P, nact);
     CHD_SYNC();
     TACC(c, 9, CHD_CLOCK() - tp_); tp_ = CHD_CLOCK();
-    panel_store<NB>(c, P, nact);               // stores of the panel columns; the update below touches other columns
-    TACC(c, 10, CHD_CLOCK() - tp_); tp_ = CHD_CLOCK();
     // ---- trailing update of the window (+ the next diagonal block and the next list of active rows)
     const int c0n = c0 + NB;
     const bool more = c0n < Nb;
     if (more) {
       Panel Pn; panel_geometry<NB>(c, Pn, c0n, ldp);
       Pn.dv = dv2; Pn.DL = DL2; Pn.PT = PT; Pn.act = actB; Pn.nact_p = actB + lsz - 2;
+#ifdef CHD_HOST_EMU
       panel_load<NB>(c, Pn, 0);
+#else
+      if (threadIdx.x >= 64 && threadIdx.x < 128) panel_load<NB>(c, Pn, 0);      // (the list is built by the second wavefront: the others skip the call)
+#endif
     }
+#ifndef CHD_HOST_EMU
+    if (more && threadIdx.x < 64) lookahead_wave<NB>(c, sign, dv, PT, ldp, P.pr - NB, P.nbelow, c0 + P.jb, P.act, nact, dv2, DL2, c0n, Nb - c0n < NB ? Nb - c0n : NB);
+    else
+#endif
     trailing_phase<NB>(c, sign, dv, PT, ldp, P.pr - NB, P.nbelow, c0 + P.jb, P.act, nact, more, dv2, DL2, c0n, Nb - c0n < NB ? Nb - c0n : NB);
+    TACC(c, 11, CHD_CLOCK() - tp_); tp_ = CHD_CLOCK();
+    // the panel's own columns go out last: nothing reads them before the barrier, and ahead of the update they would only stand
+    // between its loads and the memory (the vector-memory counter retires in order)
+#ifdef CHD_HOST_EMU
+    panel_store<NB>(c, P, nact, 0);
+#else
+    panel_store<NB>(c, P, nact, more ? 64 : 0);
+#endif
     CHD_SYNC();
-    TACC(c, 11, CHD_CLOCK() - tp_);
+    TACC(c, 10, CHD_CLOCK() - tp_);
     LdsD* t_ = dv; dv = dv2; dv2 = t_; t_ = DL; DL = DL2; DL2 = t_;
     int* ti_ = actA; actA = actB; actB = ti_;
   }

@@ -145,7 +145,8 @@ typedef struct chd_batch_stats {
   int n_fallback;              /* sequences that needed stage 4 */
   double phase_ms[24];         /* in-kernel wall-clock per phase, summed over sequences: 0 evaluation (f, grad, c, J, H), 1 evaluation (values only),
                                   2 factorisation, 3 substitution, 4 KKT mat-vec, 5 whole sequence,
-                                  6-12 factorisation sub-phases (copy, panel load, diagonal block, row solves, write-back, trailing update, border) */
+                                  6-12 factorisation sub-phases, as the first wavefront sees them (6 copy, 8 panel load, 9 row solves,
+                                  11 its look-ahead: three tiles + the next diagonal block, 10 write-back + wait for the other wavefronts' tiles, 12 border) */
   double max_seq_ms;           /* slowest single sequence (in-kernel wall clock) */
   int n_stalled;               /* stages ended by the stall guard (0 unless chd_config.stall_window > 0) */
   int n_rejected;              /* sequences rejected at set-up (not solved; stage_status -4) */

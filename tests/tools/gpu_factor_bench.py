@@ -36,6 +36,6 @@ if __name__ == '__main__':
                                                                                       i0['factor_us'], '' if i0['ran'] == 0 else ' (fell back)', i1['factor_us'], i0['solve_us'],
                                                                                       np.linalg.norm(x2 - x1) / np.linalg.norm(x1), np.linalg.norm(x0 - x1) / np.linalg.norm(x1)), flush=True)
             if stage in (2, 4):
-                print('|   | phases (us) | front: extract %.0f (tile wavefronts %.0f), diagonal+slots %.0f (slots alone %.0f), rows %.0f, update %.0f (tile wavefronts %.0f), border %.0f | right-looking: copy %.0f, load %.0f, rows %.0f, store %.0f, trailing %.0f, border %.0f | | | | |'
-                      % tuple([i2['phase_us'][k] for k in (8, 15, 9, 13, 10, 11, 14, 12)] + [i1['phase_us'][k] for k in (6, 8, 9, 10, 11, 12)]), flush=True)
+                print('|   | phases (us) | front: extract %.0f (tile wavefronts %.0f), diagonal+slots %.0f (slots alone %.0f), rows %.0f, update %.0f (tile wavefronts %.0f), border %.0f | right-looking: copy %.0f, load %.0f, rows %.0f, look-ahead wavefront %.0f, store + wait %.0f, border %.0f; look-ahead wavefront (CHD_DIAG_TIMING builds): loads + tiles %.0f, hand-over (waits for the block) %.0f, stores %.0f, chain %.0f | | | | |'
+                      % tuple([i2['phase_us'][k] for k in (8, 15, 9, 13, 10, 11, 14, 12)] + [i1['phase_us'][k] for k in (6, 8, 9, 11, 10, 12, 7, 13, 14, 15)]), flush=True)
     b.free(); s.close()
