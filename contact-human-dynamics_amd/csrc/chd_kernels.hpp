@@ -31,6 +31,7 @@
 #define CHD_SYNC() ((void)0)
 #define CHD_GL 1
 #define CHD_NOINLINE
+#define CHD_ALWAYS_INLINE
 #else
 #define CHD_DEV __device__ inline
 #define CHD_TID ((int)threadIdx.x)
@@ -40,6 +41,7 @@
 // internal linkage: with every caller known the compiler drops the callee-saved register convention (no
 // prologue/epilogue scratch traffic in functions that need more than the 144 caller-saved VGPRs)
 #define CHD_NOINLINE static __attribute__((noinline))
+#define CHD_ALWAYS_INLINE __attribute__((always_inline))
 #endif
 // LDS data is addressed through an explicit local-address-space pointer: a generic `double*` would make
 // hipcc emit flat_load/flat_store for every access instead of ds_read/ds_write
@@ -1028,7 +1030,7 @@ CHD_NOINLINE CHD_DEV void lookahead_wave(LCtx& c, const GI* sign, const LdsD* dv
 #endif
 
 template <int NB>
-CHD_NOINLINE CHD_DEV void trailing_phase(LCtx& c, const GI* sign, const LdsD* dv, const LdsD* PT, const int ldp, const int wr, const int nbelow, const int i0,
+CHD_DEV void trailing_phase(LCtx& c, const GI* sign, const LdsD* dv, const LdsD* PT, const int ldp, const int wr, const int nbelow, const int i0,
                                          const int* act, const int nact, const bool more, LdsD* dv_n, LdsD* DL_n, const int c0n, const int jbn) {
 #ifdef CHD_HOST_EMU
   trailing_update<NB>(c, dv, PT, ldp, wr, nbelow, i0, act, nact, more);
@@ -2467,7 +2469,7 @@ CHD_DEV int frame_index(QP q, double t) {       // humanoid_rigid_body_dynamics.
 //   units 4-15: end-effector e = (unit - 4) / 3, rows i = (unit - 4) % 3 (force nodes, position nodes, durations;
 //               the unit with i = 0 also stores the second-order duration terms of e)
 // Every unit evaluates only the splines it needs.
-CHD_DEV void dyn_unit(LCtx& c, const int ti, const int unit, const bool D2, GD* cout_, const GD* lam, const GD* sc) {
+CHD_ALWAYS_INLINE CHD_DEV void dyn_unit(LCtx& c, const int ti, const int unit, const bool D2, GD* cout_, const GD* lam, const GD* sc) {
   QP q = c.q; SDP S = c.S;
   const GI* tk = q->ci + S->o_task + 4 * ti;
   const int B = tk[2], row0 = tk[3];
@@ -2555,14 +2557,21 @@ CHD_DEV void dyn_unit(LCtx& c, const int ti, const int unit, const bool D2, GD* 
   }
 }
 
+// all dynamics samples of the stage.  A function of its own around the inlined unit: as a called function the unit saved and
+// restored ~120 callee-saved registers per CALL (five or six calls per thread per evaluation); here that happens once
+CHD_NOINLINE CHD_DEV void dyn_rows(LCtx& c, const bool J, const bool D2, GD* cout_, const GD* lam, const GD* sc) {
+  SDP S = c.S;
+  if (J) { PAR_FOR(u, S->n_dyn * 16) dyn_unit(c, S->dyn_first + u / 16, u % 16, D2, cout_, lam, sc); }
+  else { PAR_FOR(u, S->n_dyn) dyn_unit(c, S->dyn_first + u, 0, false, cout_, lam, sc); }
+}
+
 CHD_NOINLINE CHD_DEV void eval_rows(LCtx& c, int mode, GD* cout_, const GD* lam) {
   QP q = c.q; SDP S = c.S;
   const GD* sc = VM(c, VM_SC);
   const bool J = mode == EV_FULL;
   const bool D2 = J && S->opt_dur && lam != nullptr;      // exact duration block of the Lagrangian Hessian
   const int slot_height = q->n_tdyn, slot_rom = 2 * q->n_tdyn, slot_heel = 2 * q->n_tdyn + q->n_trom;
-  if (J) { PAR_FOR(u, S->n_dyn * 16) dyn_unit(c, S->dyn_first + u / 16, u % 16, D2, cout_, lam, sc); }
-  else { PAR_FOR(u, S->n_dyn) dyn_unit(c, S->dyn_first + u, 0, false, cout_, lam, sc); }
+  dyn_rows(c, J, D2, cout_, lam, sc);
   PAR_FOR(ti, S->n_tasks) {
     const GI* tk = q->ci + S->o_task + 4 * ti;
     const int type = tk[0], A = tk[1], B = tk[2], row0 = tk[3];

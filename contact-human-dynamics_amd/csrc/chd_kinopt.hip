@@ -18,7 +18,12 @@ int fail(const std::string& what, hipError_t e = hipSuccess) {
 }
 }  // namespace
 
-__global__ void __launch_bounds__(512) chd_kin_solve_kernel(const KinSeq* seqs, KinParams P, const double* dpool, const int* ipool, double* work,
+// waves per SIMD the register budget is set for: 2 = one 512-thread workgroup per compute unit with up to 256 VGPRs,
+// 4 = two resident workgroups with up to 128 each
+#ifndef CHD_KIN_WAVES_PER_EU
+#define CHD_KIN_WAVES_PER_EU 2
+#endif
+__global__ void __launch_bounds__(512, CHD_KIN_WAVES_PER_EU) chd_kin_solve_kernel(const KinSeq* seqs, KinParams P, const double* dpool, const int* ipool, double* work,
                                                             double* state, double* stats, int lds_doubles) {
   extern __shared__ double tile[];              // the products' frame tiles
   __shared__ double red[48];
@@ -91,8 +96,10 @@ int chd_kin_solve_batch(const chd_kin_config* cfg, int device, int B, chd_kin_se
   // 512 threads: measured against 256 and 1024 (profiles/r02h_kinopt/sweep.md); results are bitwise reproducible for a fixed
   // workgroup size (fixed reduction trees) and move at the solve's own sensitivity level when it changes
   const int nthreads = cfg->reserved[0] == 256 ? 256 : 512;
-  // 72 KB of LDS per workgroup (two workgroups per compute unit): tiles of 34 frames for J v, 27 for J^T u
-  const int lds_doubles = cfg->reserved[1] > 0 ? cfg->reserved[1] : 9216;
+  // 144 KB of LDS per workgroup: tiles of 71 frames for J v, 54 for J^T u.  (The kernel's 256 VGPRs allow one 512-thread workgroup
+  // per compute unit anyway; against 72 KB the larger tiles halve the number of phases and barriers per product: 2.54 -> 2.32 s of
+  // least-squares kernels for 256 clips x 100 frames.  A 128-VGPR build with two resident workgroups was measured too: 3.45 s.)
+  const int lds_doubles = cfg->reserved[1] > 0 ? cfg->reserved[1] : 18432;
   KIN_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chd_kin_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * lds_doubles)), "hipFuncSetAttribute");
   hipLaunchKernelGGL(chd_kin_solve_kernel, dim3((unsigned)B), dim3((unsigned)nthreads), sizeof(double) * (size_t)lds_doubles, st, d_seqs, bt.P, d_dp, d_ip, d_work, d_state, d_stats, lds_doubles);
   KIN_TRY(hipGetLastError(), "launch");

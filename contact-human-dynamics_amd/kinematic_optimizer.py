@@ -32,7 +32,7 @@ from .kinopt_capi import ChdKinConfig, NJ, NV, problems_to_c, results_of
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, 'csrc')
-LIB_PATH = os.path.join(_CSRC, 'libchd_kinopt.so')
+LIB_PATH = os.environ.get('CHD_KINOPT_LIB') or os.path.join(_CSRC, 'libchd_kinopt.so')      # (override: kernel experiments with variant builds)
 SOURCES = ['chd_kinopt.hip', 'chd_kinopt_kernels.hpp', 'chd_kinopt_host.hpp']
 EXPORTS = ['chd_kin_version', 'chd_kin_config_default', 'chd_kin_solve_batch', 'chd_kin_last_error', 'chd_kin_last_kernel_ms']
 

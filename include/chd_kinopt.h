@@ -28,7 +28,7 @@ typedef struct chd_kin_config {
   int lsmr_maxiter;        /* 0 = min(rows, unknowns), SciPy's default */
   int parents[CHD_KIN_JOINTS];   /* skeleton.parents (BVH order); parents[0] = -1, parents[j] < j */
   int reserved[4];         /* tuning knobs, 0 = default: [0] threads per workgroup (256 or 512; default 512), [1] doubles of LDS per workgroup for
-                              the products' frame tiles (default 9 216 = 72 KB: two workgroups per compute unit).  Results are bitwise
+                              the products' frame tiles (default 18 432 = 144 KB: one workgroup per compute unit, two tiles per 100 frames).  Results are bitwise
                               reproducible for fixed values and independent of the batch a clip is in. */
 } chd_kin_config;
 
