@@ -16,7 +16,7 @@ void kin_emu_config_default(chd_kin_config* cfg) { config_default(cfg); }
 int kin_emu_solve_batch(const chd_kin_config* cfg, int B, chd_kin_seq* in) {
   KinBatch bt;
   if (!bt.build(cfg, B, in)) { g_err = bt.err; return 1; }
-  const int lds_doubles = cfg->reserved[1] > 0 ? cfg->reserved[1] : 9216;
+  const int lds_doubles = cfg->reserved[1] > 0 ? cfg->reserved[1] : 18432;
   std::vector<double> work((size_t)bt.work_total), stats(8 * (size_t)B), red(48), lds((size_t)lds_doubles);
   for (int b = 0; b < B; ++b) {
     KinCtx c;
@@ -33,7 +33,7 @@ int kin_emu_solve_batch(const chd_kin_config* cfg, int B, chd_kin_seq* in) {
 int kin_emu_probe(const chd_kin_config* cfg, chd_kin_seq* in, int mode, const double* vec, double* out, double* aux) {
   KinBatch bt;
   if (!bt.build(cfg, 1, in)) { g_err = bt.err; return 1; }
-  const int lds_doubles = cfg->reserved[1] > 0 ? cfg->reserved[1] : 9216;
+  const int lds_doubles = cfg->reserved[1] > 0 ? cfg->reserved[1] : 18432;
   std::vector<double> work((size_t)bt.work_total), red(48), lds((size_t)lds_doubles);
   KinCtx c;
   kin_bind(c, &bt.seqs[0], &bt.P, bt.dpool.data(), bt.ipool.data(), work.data(), red.data(), lds.data(), lds_doubles);
