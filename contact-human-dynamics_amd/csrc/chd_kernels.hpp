@@ -100,7 +100,9 @@ namespace chd {
 #define CHD_ABORT_BAD_FACTOR 1
 #endif
 #ifndef CHD_TRAIL_TP
-#define CHD_TRAIL_TP 4      // independent 16x16 tiles per wavefront pass of the trailing update
+#define CHD_TRAIL_TP 1      // independent 16x16 tiles per wavefront pass of the trailing update (two passes are in flight).  Measured on one
+                            // box, sequences/s of the bench workload: 1: 553, 2: 545, 3: 538, 4: 517, 6: 433 -- the update is inlined into the
+                            // panel loop, and what more tiles per pass buy in loads in flight they cost in registers spilled there
 #endif
 #define CHD_G 9.80665
 #define CHD_MU_FRICTION 0.5
