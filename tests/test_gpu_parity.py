@@ -283,3 +283,41 @@ def test_alternative_factorisations_match_right_looking():
                 assert err2 < 1e-8, (q, stage, err2)
     finally:
         b.free(); s.close()
+
+
+@pytest.mark.gpu
+def test_narrow_panels_match_the_default_width():
+    """chd_config.lds_kilobytes narrows the factorisation's panels (32 -> 16 -> 8 columns: the look-ahead wavefront, its hand-over buffer and the
+    tile passes are written for any of them).  K x = b on the KKT matrices of all stages with 80 KB and 44 KB of LDS against the default: the same
+    solution to 1e-9 (a narrower panel is a different elimination order), no replaced pivots -- and a whole staged solve that ends where the default's does."""
+    from chd_amd.phys_optim import PhysOptim, default_config
+    seqs = [make_walk(seed=5, F=60, randomize=True)]
+    rng = np.random.default_rng(1)
+    ref = None
+    sols = {}
+    for kb in (0, 80, 44):
+        s = PhysOptim(device=0, config=default_config(lds_kilobytes=kb))
+        b = s.upload(seqs)
+        try:
+            xs = []
+            r2 = np.random.default_rng(1)
+            for stage in range(5):
+                N = b.sizes(0, stage)['kkt_dim']
+                rhs = r2.normal(size=N)
+                x, info = b.debug_linsolve(0, stage, rhs, dw=1e-2, dval=1e-3, which=1)
+                assert info['ran'] == 1 and info['bad_pivots'] == 0 and np.isfinite(x).all(), (kb, stage, info)
+                xs.append(x)
+            b.solve()
+            res = b.fetch()[0]
+            sols[kb] = (xs, res)
+        finally:
+            b.free(); s.close()
+    for kb in (80, 44):
+        for stage in range(5):
+            err = np.linalg.norm(sols[kb][0][stage] - sols[0][0][stage]) / np.linalg.norm(sols[0][0][stage])
+            assert err < 1e-9, (kb, stage, err)
+        a, d = sols[kb][1], sols[0][1]
+        assert list(a.stage_status) == list(d.stage_status), (kb, a.stage_status, d.stage_status)
+        for key in ('base_lin', 'ee_pos'):
+            va, vd = getattr(a.snapshots[-1], key), getattr(d.snapshots[-1], key)
+            assert np.allclose(va, vd, rtol=0, atol=1e-6), (kb, key, np.abs(va - vd).max())
