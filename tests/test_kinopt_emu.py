@@ -183,3 +183,40 @@ def test_products_across_tile_boundaries(gold, lds_doubles):
         many = kin_emu.default_config(lsmr_maxiter=3); many.reserved[1] = lds_doubles
         a = kin_emu.solve([p], one)[0]; b = kin_emu.solve([p], many)[0]
         assert (a['nfev'], a['status']) == (b['nfev'], b['status']) and rel(b['x'], a['x']) < 1e-9
+
+
+def test_batched_huber_fits_find_the_regressors_minimum():
+    """The floor fits of a batch (`huber_fit_batch`: block descent on all clips' problems at once) against the per-clip solve that mirrors
+    HuberRegressor (`huber_fit`: SciPy's L-BFGS-B, gtol 1e-5) and against scikit-learn itself: never a higher objective, the same outlier
+    labels, coefficients within the regressor's own stopping error; ragged sizes and an outlier-heavy problem included."""
+    from sklearn.linear_model import HuberRegressor
+    rng = np.random.default_rng(4)
+    Xs, ys = [], []
+    for b in range(40):
+        n = int(rng.integers(3, 300))
+        X = rng.normal(size=(n, 2)) * np.array([30.0, 50.0]) + np.array([10.0, 200.0])
+        y = X @ (rng.normal(size=2) * 0.05) + rng.normal() * 20 - 90 + rng.normal(size=n) * rng.uniform(0.2, 3.0)
+        k = int(rng.integers(0, max(1, n // 4)))
+        y[:k] += rng.normal(size=k) * 40
+        Xs.append(X); ys.append(y)
+    for eps in (1.5, 2.2):
+        new = kopt.huber_fit_batch(Xs, ys, eps)
+        for X, y, q in zip(Xs, ys, new):
+            r = kopt.huber_fit(X, y, eps)
+            f_new = kopt._huber_objective(np.r_[q[0], q[1], q[2]], X, y, eps, 1e-4)[0]
+            f_ref = kopt._huber_objective(np.r_[r[0], r[1], r[2]], X, y, eps, 1e-4)[0]
+            assert f_new <= f_ref + 1e-9 * abs(f_ref)
+            if len(y) >= 20:            # (tiny problems are flat enough for L-BFGS-B to stop visibly early)
+                assert np.abs(q[0] - r[0]).max() < 1e-4 and abs(q[1] - r[1]) < 2e-2 and abs(q[2] - r[2]) < 2e-3 * r[2]
+                assert np.array_equal(q[3], r[3])
+    X, y = Xs[5], ys[5]
+    h = HuberRegressor(epsilon=1.5).fit(X, y)
+    q = kopt.huber_fit_batch([X], [y], 1.5)[0]
+    assert np.abs(q[0] - h.coef_).max() < 1e-4 and abs(q[1] - h.intercept_) < 2e-2 and np.array_equal(q[3], h.outliers_)
+    # the two-fit floor of a batch = the per-clip one
+    fp = [np.c_[X[:, 0], y_, X[:, 1]] for X, y_ in zip(Xs[:6], ys[:6])] + [None]
+    for a, b in zip(kopt.fit_floor_batch(fp), [kopt.fit_floor(f) if f is not None else None for f in fp]):
+        if a is None:
+            assert b is None
+        else:
+            assert np.abs(a[0] - b[0]).max() < 1e-5 and np.abs(a[1] - b[1]).max() < 2e-2 and np.array_equal(a[2], b[2])
