@@ -95,6 +95,7 @@ namespace chd {
 #define CHD_DELTA_C 1e-9
 #define CHD_CONSTR_VIOL_TOL 1e-4
 #define CHD_MAX_BACKTRACK 3
+#define CHD_DUAL_RISE_K 6
 #define CHD_MAX_ATTEMPTS 12
 #ifndef CHD_ABORT_BAD_FACTOR
 #define CHD_ABORT_BAD_FACTOR 1
@@ -3286,6 +3287,8 @@ CHD_NOINLINE CHD_DEV void solve_stage(LCtx& c, StageResult& res) {
 
   int status = -1, it = 0, n_factor = 0, stalled_out = 0;
   double E0 = 0, e_d = 0, e_p = 0, e_pu = 0;
+  // damping safeguard (oracle/ipm_solver.hpp, dual_rise_k): the dual infeasibility rising in six consecutive iterations raises delta_w
+  double ed_prev = -1.0; int ed_rise = 0;
   for (it = 0; it < S->max_iter; ++it) {
     // ---- optimality error (IPOPT eq. (5)/(6))
     PAR_FOR(i, N) t1[i] = 0.0;
@@ -3309,6 +3312,9 @@ CHD_NOINLINE CHD_DEV void solve_stage(LCtx& c, StageResult& res) {
     const double s_c = fmax(smax, sumz / fmax(1.0, cnt)) / smax;
     e_d = d1 / s_d;
     E0 = fmax(e_d, fmax(e_p, compl_error(c, 0.0) / s_c));
+    if (ed_prev >= 0 && e_d > ed_prev) ++ed_rise; else ed_rise = 0;
+    ed_prev = e_d;
+    if (ed_rise >= CHD_DUAL_RISE_K) { dw = fmin(CHD_DELTA_W_MAX, fmax(dw, 1e-6) * 4.0); ed_rise = 0; }
     if (E0 <= tol_ && e_pu <= CHD_CONSTR_VIOL_TOL) { status = 0; break; }
     // stall guard (chd_config.stall_window, 0 = off): no factor-2 reduction of the optimality error over the last `window`
     // iterations -> status -2 instead of running to the iteration cap (stage 3 then takes the reference's stage-4

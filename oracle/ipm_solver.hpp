@@ -353,8 +353,17 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
   std::vector<double> lb_xold, lb_Jold, lb_gold;
   std::vector<double> e0_hist(150, 0.0);
   double last_alpha = 0; int last_nls = 0, last_att = 0; bool last_soc = false;
+  // Damping safeguard: the dual infeasibility rising in `dual_rise_k` consecutive iterations means the quadratic model is being
+  // trusted too far (full steps along a direction whose constraint curvature the Gauss-Newton Hessian lacks: seen on standing-up
+  // clips, where the duration stage drifted for 2 000 iterations with delta_w at 1e-8) -- the Levenberg damping is raised to at
+  // least 4e-6 (x 4 above 1e-6).  Never fires on the 160 flat / tilted bench sequences of the fixture; -9 % iterations on the 40 hard ones.
+  constexpr int dual_rise_k = 6;
+  double ed_prev = -1.0; int ed_rise = 0;
   for (it = 0; it < opt.max_iter; ++it) {
     double E0 = errors(0.0);
+    if (ed_prev >= 0 && e_d > ed_prev) ++ed_rise; else ed_rise = 0;
+    ed_prev = e_d;
+    if (ed_rise >= dual_rise_k) { dw = std::min(opt.delta_w_max, std::max(dw, 1e-6) * 4.0); ed_rise = 0; }
     if (opt.verbose) { int wj = 0; double wv2 = 0; for (int j = 0; j < n; ++j) if (std::fabs(dualx[j]) > wv2) { wv2 = std::fabs(dualx[j]); wj = j; } int spl = 10; for (int q = 0; q < 10; ++q) if (wj >= P.sp[q].var_off && wj < P.sp[q].var_off + P.sp[q].n_var) spl = q; std::printf("[dual worst var %d spline %d t=%.2f val %.2e] ", wj, spl, vtime[wj], dualx[wj]); }
     if (opt.verbose) { int wi = 0; double wv = 0; for (int i = 0; i < m; ++i) { double v = std::fabs(eq[i] ? c[i] - l[i] : c[i] - s[i]); if (v > wv) { wv = v; wi = i; } } std::printf("[worst row %d fam %d eq %d c=%.4e s=%.4e l=%.3e u=%.3e lam=%.3e] ", wi, P.row_family[wi], (int)eq[wi], c[wi], s[wi], l[wi], u[wi], lam[wi]); }
     if (opt.verbose) std::printf("%4d f=%.6e E0=%.2e (d %.1e p %.1e pu %.1e c %.1e) mu=%.1e nu=%.1e dw=%.1e | last a=%.2e nls=%d att=%d soc=%d\n", it, f / sf, E0, e_d, e_p, e_p_unscaled, e_c, mu, nu, dw, last_alpha, last_nls, last_att, (int)last_soc);
