@@ -201,7 +201,10 @@ def huber_fit_batch(Xs, ys, epsilon, alpha=1e-4, max_iter=2000, gtol=1e-7):
         A = np.einsum('bni,bn,bnj->bij', Xa, om, Xa)
         A[:, np.arange(p), np.arange(p)] += alpha
         rhs = np.einsum('bni,bn->bi', Xa, om * Y)
-        sol = np.linalg.solve(A, rhs[..., None])[..., 0]
+        try:
+            sol = np.linalg.solve(A, rhs[..., None])[..., 0]
+        except np.linalg.LinAlgError:             # a degenerate problem (e.g. identical points): it alone gets a least-squares solution
+            sol = np.stack([np.linalg.lstsq(A[b], rhs[b], rcond=None)[0] for b in range(B)])
         w = np.where(active[:, None], sol[:, :p], w); c = np.where(active, sol[:, p], c)
         # scale: n - n_out eps^2 = sum_inliers r^2 / sigma^2 (the inlier set depends on sigma: a few fixed-point steps)
         r = residual()
