@@ -1,6 +1,6 @@
 #!/bin/bash
 # First GPU call of a round (run through gpurun from the repo root; ~2 minutes of box time):
-#   1. pytest -m gpu (23 tests: bench-workload parity against the committed oracle fixture, 600-frame parity, slot independence, kinematic optimisation,
+#   1. pytest -m gpu (26 tests: bench-workload parity against the committed oracle fixture, 600-frame parity, slot independence, kinematic optimisation,
 #      rejection, file interface, CLI, IK, contact-net device ops, OpenPose-JSON -> BVH) and smoke()
 #   2. bench.py as the driver runs it (--steps 20 --warmup 5)              -> bench_driver.json
 #   3. rocprofv3 kernel trace + PMC passes (HBM-side bytes, fp64 MFMA, wave states) on short runs; --gen-workers 1 keeps
