@@ -68,14 +68,25 @@ struct StageDesc {
 };
 
 // cached spline sample used by the cost terms (one per cost spline per data frame)
+// (SC_OME / SC_OMC: d2 p / d(node coefficient j) d(duration) for a duration of an earlier phase / of the current phase -- the derivative of the Hermite weight
+//  itself; SC_CF: d f / d p_i of all cost terms, scaled.  The first SC_LDS fields are what the entry tasks read: they are staged in LDS)
 enum { SC_WP = 0, SC_WV = 4, SC_P = 8, SC_V = 11, SC_DXDT = 14, SC_POLY = 17, SC_PHASE = 18, SC_LAST = 19,
-       SC_QEE = 20, SC_QEC = 23, SC_QCC = 26, SC_STRIDE = 30 };
+       SC_OME = 20, SC_OMC = 24, SC_LDS = 28, SC_QEE = 28, SC_QEC = 31, SC_QCC = 34, SC_CF = 37, SC_STRIDE = 40 };
 // second-order duration tables (stage 3): per end-effector one slot per row sample; 4 doubles = (cur phase, S_ee, S_ec, S_cc)
 enum { D2_STRIDE = 4, X2_STRIDE = 6 };
 // cache of the ee-motion splines at the range-of-motion sample times (exact curvature of the heel-distance rows): per (end-effector,
 // sample) the four position weights at SC_WP, the row's scaled multiplier at RC_MU and the polynomial at SC_POLY (same offsets as the
 // cost-sample cache, so the same weight look-up serves both)
 enum { RC_MU = 4, RC_STRIDE = 18 };
+// Exact node x duration block of the Lagrangian Hessian (duration stage): one record per (row sample, spline whose node values the entry differentiates by,
+// end-effector whose durations it differentiates by).  The entry for coefficient j (dimension dim) of the spline's polynomial XR_POLY and a duration T_k is
+//   w_j A_class[dim] + om_class,j B[dim],  class = earlier phase (k < XR_CUR) / current phase (k == XR_CUR, unless XR_LAST),
+// with w the position weights of the sample (XR_W), om the derivatives of those weights by the duration (XR_OME / XR_OMC).
+enum { XR_POLY = 0, XR_CUR = 1, XR_LAST = 2, XR_W = 3, XR_AE = 7, XR_AC = 10, XR_B = 13, XR_OME = 16, XR_OMC = 20, XR_STRIDE = 24 };
+// record blocks per duration end-effector e, in this order: HEIGHT (n_tdyn, ee-motion spline of e), ROM_M (n_trom, the same spline), HEEL_OWN (n_trom, the same),
+// DYN_P (n_tdyn, the same), HEEL_X (n_trom, the ee-motion spline of the other contact point of e's foot), DYN_F (n_tdyn, ee-force spline of e),
+// ROM_C (n_trom, base-lin), DYN_C (n_tdyn, base-lin), ROM_A (n_trom, base-ang)
+enum { XB_HEIGHT = 0, XB_ROM_M, XB_HEEL_OWN, XB_DYN_P, XB_HEEL_X, XB_DYN_F, XB_ROM_C, XB_DYN_C, XB_ROM_A, XB_COUNT };
 
 struct SeqDesc {
   const GD* cd;       // constant doubles
@@ -103,7 +114,7 @@ struct SeqDesc {
   // wd offsets — state
   int o_node, o_poly_dur, o_pend, o_phase_dur, o_phend, o_ttot;
   // wd offsets — solver vectors (n-, m- and N-sized), see chd_kernels.hpp
-  int o_vec_n, o_vec_m, o_vec_N, o_scache, o_d2tab, o_x2tab, d2_slots, o_rcache;
+  int o_vec_n, o_vec_m, o_vec_N, o_scache, o_d2tab, o_x2tab, d2_slots, o_rcache, o_xtab;
   int max_n, max_m, max_N;
   // wd offsets — KKT storage
   int o_K0b, o_K0x, o_Kfb, o_Kfx;      // full band, border rows (unfactored); lower band, border rows (factor)

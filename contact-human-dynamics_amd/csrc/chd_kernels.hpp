@@ -145,7 +145,7 @@ struct Ctx {
   double tol;           // IPOPT tol of the stage (phys_optim.cpp:578)
   int stall_window;     // 0 = no stall guard (chd_config.stall_window)
   int factor_ll;        // chd_config.factorisation: 0 = right-looking (kfactor_rl), 1 = left-looking (kfactor_ll), 2 = register-resident front (kfactor_rf)
-  int clip_heel;        // 1 while the second model of an iteration is built: heel-distance curvature with max(lam, 0) (solve_stage)
+  int second_model;     // 1 while the second model of an iteration is built: Gauss-Newton, without the exact constraint-curvature blocks (solve_stage)
   int err;              // sticky error flag (band overflow): any thread may set it, read after a barrier
   int n_bad_pivots;     // thread 0 counts
   long long tacc[24];    // cycles per phase (thread 0): 0 eval full, 1 eval values, 2 factor, 3 solve, 4 matvec, 5 total
@@ -322,7 +322,9 @@ CHD_DEV void dur_jac(QP q, int s, double t, const PE& e, DurJac& dj) {
 //   d2p/dT_k dT_l = Q_xy    = h_tautau u_x u_y + h_tauT (u_x v_y + v_x u_y) + h_TT v_x v_y
 // (the reference only needs first derivatives because IPOPT runs with an L-BFGS Hessian, phys_optim.cpp:572;
 //  this solver uses the exact duration block of the Lagrangian Hessian instead — DESIGN.md)
-struct DurJac2 { int cur, last, nvar; double Ge[3], Gc[3], Qee[3], Qec[3], Qcc[3]; };
+// Mixed derivatives: p = sum_j w_j(tau, Tp) x_j over the polynomial's four Hermite coefficients, so d2p / d x_j d T_k is the derivative of the weight,
+//   om_x,j = (d w_j / d tau) u_x + (d w_j / d Tp) v_x  (d w_j / d tau = the velocity weight).
+struct DurJac2 { int cur, last, nvar; double Ge[3], Gc[3], Qee[3], Qec[3], Qcc[3], ome[4], omc[4]; };
 CHD_DEV void dur_jac2(QP q, int s, double t, const PE& e, DurJac2& dj) {
   const auto& sp = q->sp[s];
   const int ee = sp.ee;
@@ -347,6 +349,24 @@ CHD_DEV void dur_jac2(QP q, int s, double t, const PE& e, DurJac2& dj) {
     dj.Qec[k] = dj.last ? 0.0 : htt * ue * uc + htT * (ue * vc + ve * uc) + hTT * ve * vc;
     dj.Qcc[k] = dj.last ? 0.0 : htt * uc * uc + 2 * htT * uc * vc + hTT * vc * vc;
   }
+  const double wT[4] = {-6 * tau3 * iT4 + 6 * tau2 * iT3, 2 * tau2 * iT2 - 2 * tau3 * iT3, -6 * tau2 * iT3 + 6 * tau3 * iT4, -2 * tau3 * iT3 + tau2 * iT2};
+  for (int j = 0; j < 4; ++j) { dj.ome[j] = e.w[1][j] * ue + wT[j] * ve; dj.omc[j] = dj.last ? 0.0 : e.w[1][j] * uc + wT[j] * vc; }
+}
+// one record of the node x duration table (chd_device.hpp, XR_*): block `blk` of duration end-effector `ee`, sample `smp`
+CHD_DEV GD* xrec(QP q, int ee, int blk, int smp) {
+  const int nd_ = q->n_tdyn, nr_ = q->n_trom;
+  // block starts in the order XB_HEIGHT, ROM_M, HEEL_OWN, DYN_P, HEEL_X, DYN_F, ROM_C, DYN_C, ROM_A
+  const int start = blk == XB_HEIGHT ? 0 : blk == XB_ROM_M ? nd_ : blk == XB_HEEL_OWN ? nd_ + nr_ : blk == XB_DYN_P ? nd_ + 2 * nr_ : blk == XB_HEEL_X ? 2 * nd_ + 2 * nr_
+                  : blk == XB_DYN_F ? 2 * nd_ + 3 * nr_ : blk == XB_ROM_C ? 3 * nd_ + 3 * nr_ : blk == XB_DYN_C ? 3 * nd_ + 4 * nr_ : 4 * nd_ + 4 * nr_;
+  return q->wd + q->o_xtab + ((long long)ee * (4 * nd_ + 5 * nr_) + start + smp) * XR_STRIDE;
+}
+CHD_DEV int xblock_len(QP q, int blk) { return (blk == XB_HEIGHT || blk == XB_DYN_P || blk == XB_DYN_F || blk == XB_DYN_C) ? q->n_tdyn : q->n_trom; }
+// (pe: the sample of the spline whose node values the entries differentiate by; dj: the duration derivatives of the end-effector's own spline at the sample --
+//  only its cur / last and, when B is given, its om's are used; Ae / Ac / B may be null = zero)
+CHD_DEV void xrec_store(GD* r, const PE& pe, const DurJac2& dj, const double* Ae, const double* Ac, const double* B) {
+  r[XR_POLY] = pe.poly; r[XR_CUR] = dj.cur; r[XR_LAST] = dj.last;
+  for (int j = 0; j < 4; ++j) { r[XR_W + j] = pe.w[0][j]; r[XR_OME + j] = B ? dj.ome[j] : 0.0; r[XR_OMC + j] = B ? dj.omc[j] : 0.0; }
+  for (int k = 0; k < 3; ++k) { r[XR_AE + k] = Ae ? Ae[k] : 0.0; r[XR_AC + k] = Ac ? Ac[k] : 0.0; r[XR_B + k] = B ? B[k] : 0.0; }
 }
 CHD_DEV double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 CHD_DEV void d2_store(QP q, int ee, int slot, int cur, double see, double sec, double scc) {
@@ -2557,6 +2577,16 @@ CHD_ALWAYS_INLINE CHD_DEV void dyn_unit(LCtx& c, const int ti, const int unit, c
       S3[cls] = v;
     }
     d2_store(q, e, B, dF.cur, S3[0], S3[1], S3[2]);
+    {
+      // node x duration block.  L = La . [ang - sum_e f_e x r_e] + Ll . [m a - sum_e f_e]:  dL/df_e = -(r_e x La) - Ll,  dL/dp_e = La x f_e,  dL/dc = -sum_e La x f_e
+      double AFe[3], AFc[3], BF[3], APe[3], APc[3], BP[3], ACe[3], ACc[3], rxl[3];
+      cross3(La, dP.Ge, AFe); cross3(La, dP.Gc, AFc); cross3(rr, La, rxl);
+      cross3(La, dF.Ge, APe); cross3(La, dF.Gc, APc); cross3(La, pfe.p, BP);
+      for (int k = 0; k < 3; ++k) { AFe[k] = -AFe[k]; AFc[k] = -AFc[k]; BF[k] = -rxl[k] - Ll[k]; ACe[k] = -APe[k]; ACc[k] = -APc[k]; }
+      xrec_store(xrec(q, e, XB_DYN_F, B), pfe, dF, AFe, AFc, BF);
+      xrec_store(xrec(q, e, XB_DYN_P, B), pme, dP, APe, APc, BP);
+      xrec_store(xrec(q, e, XB_DYN_C, B), pl, dP, ACe, ACc, nullptr);
+    }
   }
 }
 
@@ -2572,7 +2602,7 @@ CHD_NOINLINE CHD_DEV void eval_rows(LCtx& c, int mode, GD* cout_, const GD* lam)
   QP q = c.q; SDP S = c.S;
   const GD* sc = VM(c, VM_SC);
   const bool J = mode == EV_FULL;
-  const bool D2 = J && S->opt_dur && lam != nullptr;      // exact duration block of the Lagrangian Hessian
+  const bool D2 = J && S->opt_dur && lam != nullptr && !c.second_model;      // exact duration blocks of the Lagrangian Hessian (first model of an iteration)
   const int slot_height = q->n_tdyn, slot_rom = 2 * q->n_tdyn, slot_heel = 2 * q->n_tdyn + q->n_trom;
   dyn_rows(c, J, D2, cout_, lam, sc);
   PAR_FOR(ti, S->n_tasks) {
@@ -2629,6 +2659,14 @@ CHD_NOINLINE CHD_DEV void eval_rows(LCtx& c, int mode, GD* cout_, const GD* lam)
             const double ls = lam[row0] * sc[row0];
             d2_store(q, e, slot_rom + B, dj.cur, ls * (dot3(dj.Ge, dj.Ge) + dot3(dvec, dj.Qee)), ls * (dot3(dj.Ge, dj.Gc) + dot3(dvec, dj.Qec)),
                      ls * (dot3(dj.Gc, dj.Gc) + dot3(dvec, dj.Qcc)));
+            {      // node x duration block: d = p_ee - R h - c_com
+              double Ae[3], Ac[3], Bv[3], nAe[3], nAc[3], tAe[3], tAc[3];
+              for (int k = 0; k < 3; ++k) { Ae[k] = ls * dj.Ge[k]; Ac[k] = ls * dj.Gc[k]; Bv[k] = ls * dvec[k]; nAe[k] = -Ae[k]; nAc[k] = -Ac[k]; }
+              for (int k = 0; k < 3; ++k) { double dRh[3]; matvec3(dR[k], hip, dRh); tAe[k] = -dot3(dRh, Ae); tAc[k] = -dot3(dRh, Ac); }
+              xrec_store(xrec(q, e, XB_ROM_M, B), pm, dj, Ae, Ac, Bv);
+              xrec_store(xrec(q, e, XB_ROM_C, B), pl, dj, nAe, nAc, nullptr);
+              xrec_store(xrec(q, e, XB_ROM_A, B), pa, dj, tAe, tAc, nullptr);
+            }
           }
         }
       } break;
@@ -2652,6 +2690,17 @@ CHD_NOINLINE CHD_DEV void eval_rows(LCtx& c, int mode, GD* cout_, const GD* lam)
             GD* x2 = q->wd + q->o_x2tab + ((long long)A * q->n_trom + B) * X2_STRIDE;
             x2[0] = da.cur; x2[1] = db.cur;
             x2[2] = -ls * dot3(da.Ge, db.Ge); x2[3] = -ls * dot3(da.Ge, db.Gc); x2[4] = -ls * dot3(da.Gc, db.Ge); x2[5] = -ls * dot3(da.Gc, db.Gc);
+            {      // node x duration block: toe / heel nodes x toe / heel durations
+              double Aae[3], Aac[3], Abe[3], Abc[3], nAae[3], nAac[3], nAbe[3], nAbc[3], Ba[3], Bb[3];
+              for (int k = 0; k < 3; ++k) {
+                Aae[k] = ls * da.Ge[k]; Aac[k] = ls * da.Gc[k]; Abe[k] = ls * db.Ge[k]; Abc[k] = ls * db.Gc[k];
+                nAae[k] = -Aae[k]; nAac[k] = -Aac[k]; nAbe[k] = -Abe[k]; nAbc[k] = -Abc[k]; Ba[k] = ls * dvec[k]; Bb[k] = -ls * dvec[k];
+              }
+              xrec_store(xrec(q, A, XB_HEEL_OWN, B), p1, da, Aae, Aac, Ba);
+              xrec_store(xrec(q, A, XB_HEEL_X, B), p2, da, nAae, nAac, nullptr);
+              xrec_store(xrec(q, A + 2, XB_HEEL_X, B), p1, db, nAbe, nAbc, nullptr);
+              xrec_store(xrec(q, A + 2, XB_HEEL_OWN, B), p2, db, Abe, Abc, Bb);
+            }
           }
         }
       } break;
@@ -2685,6 +2734,7 @@ CHD_NOINLINE CHD_DEV void eval_rows(LCtx& c, int mode, GD* cout_, const GD* lam)
             DurJac2 dj; dur_jac2(q, 2 + A, t, pm, dj);
             const double ls = lam[row0] * sc[row0];
             d2_store(q, A, slot_height + B, dj.cur, ls * dot3(nrm, dj.Qee), ls * dot3(nrm, dj.Qec), ls * dot3(nrm, dj.Qcc));
+            { const double Bv[3] = {ls * nrm[0], ls * nrm[1], ls * nrm[2]}; xrec_store(xrec(q, A, XB_HEIGHT, B), pm, dj, nullptr, nullptr, Bv); }
           }
         }
       } break;
@@ -2720,6 +2770,7 @@ CHD_NOINLINE CHD_DEV void fill_sample_cache(LCtx& c, const bool with_dur) {     
     for (int k = 0; k < 4; ++k) { sc_[SC_WP + k] = e.w[0][k]; sc_[SC_WV + k] = e.w[1][k]; }
     for (int k = 0; k < 3; ++k) { sc_[SC_P + k] = e.p[k]; sc_[SC_V + k] = e.v[k]; sc_[SC_DXDT + k] = 0.0; }
     sc_[SC_POLY] = e.poly; sc_[SC_PHASE] = 0; sc_[SC_LAST] = 0;
+    for (int j = 0; j < 4; ++j) { sc_[SC_OME + j] = 0.0; sc_[SC_OMC + j] = 0.0; }
     if (with_dur && c.S->opt_dur && s >= 2) {
       DurJac dj;
       dur_jac(q, s, t, e, dj);
@@ -2729,6 +2780,7 @@ CHD_NOINLINE CHD_DEV void fill_sample_cache(LCtx& c, const bool with_dur) {     
       DurJac2 d2;
       dur_jac2(q, s, t, e, d2);
       for (int k = 0; k < 3; ++k) { sc_[SC_QEE + k] = d2.Qee[k]; sc_[SC_QEC + k] = d2.Qec[k]; sc_[SC_QCC + k] = d2.Qcc[k]; }
+      for (int j = 0; j < 4; ++j) { sc_[SC_OME + j] = d2.ome[j]; sc_[SC_OMC + j] = d2.omc[j]; }
     }
   }
   CHD_SYNC();
@@ -2792,7 +2844,8 @@ CHD_DEV void supp_add_sample(Supp& sp, const double* sc_, int which, double sign
 // Gauss-Newton model lacks (without it the optimality error hovers just above tol for 100+ iterations on the slow
 // sequences).  grad^2 c = sum_dim g g^T with g = Hermite weights of the toe polynomial (+) and of the heel polynomial (-) at
 // the sample.  This cache holds, per (end-effector, range-of-motion sample): the four position weights, the polynomial and
-// the row's multiplier times its scaling; the entries are then gathered owner-computes like the cost terms.
+// the row's multiplier times its scaling; the entries are then gathered owner-computes like the cost terms.  (First model of an iteration only:
+// the second model is Gauss-Newton, see solve_stage.)
 CHD_DEV const GD* rcache(QP q, int ee, int k) { return q->wd + q->o_rcache + ((long long)ee * q->n_trom + k) * RC_STRIDE; }
 CHD_DEV void fill_rom_cache(LCtx& c, const GD* lam) {
   QP q = c.q; SDP S = c.S;
@@ -2804,7 +2857,7 @@ CHD_DEV void fill_rom_cache(LCtx& c, const GD* lam) {
     GD* r = q->wd + q->o_rcache + (long long)idx * RC_STRIDE;
     for (int j = 0; j < 4; ++j) r[SC_WP + j] = e.w[0][j];
     const int row = S->heel_row0 + (ee % 2) * q->n_trom + k;          // pairs (0, 2) and (1, 3): nlp_formulation.cpp:249-257
-    r[RC_MU] = (c.clip_heel ? fmax(lam[row], 0.0) : lam[row]) * sc[row];
+    r[RC_MU] = lam[row] * sc[row];
     r[SC_POLY] = e.poly;
   }
   CHD_SYNC();
@@ -2828,7 +2881,7 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(LCtx& c, GD* g, const GD* lam) {
     if (i > 0 && pi - pp > gap) gap = pi - pp;
   }
   gap = (int)block_max(c, (double)gap);       // (ends with a barrier)
-  const bool HC = lam != nullptr && S->heel_row0 >= 0;      // exact curvature of the heel-distance rows
+  const bool HC = lam != nullptr && S->heel_row0 >= 0 && !c.second_model;      // exact curvature of the heel-distance rows: first model of an iteration only
   if (HC) fill_rom_cache(c, lam);
   long long tg_ = CHD_CLOCK();
   // ---- node variables.  Every cost residual is linear in the node values for fixed durations,
@@ -2933,8 +2986,8 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(LCtx& c, GD* g, const GD* lam) {
       g[sp.var_off + v1] += c.sf * acc;
     }
   };
-  // the per-sample fields are read ~10^5 times by the entry tasks: keep the first 20 fields of the cache in LDS
-  const int sstride = 20;
+  // the per-sample fields are read ~10^5 times by the entry tasks: keep the first SC_LDS fields of the cache in LDS
+  const int sstride = SC_LDS;
   const bool in_lds = 6 * (F + 2) * sstride <= c.lds_cap - LDS_RED;
   LdsD* ws = c.lds + LDS_RED;
   auto lds_sample = [&](int s, int i) { return (const LdsD*)(ws + ((long long)s * (F + 2) + i) * sstride); };
@@ -2984,7 +3037,7 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(LCtx& c, GD* g, const GD* lam) {
   CHD_SYNC();
   TACC(c, 13, CHD_CLOCK() - tg_); tg_ = CHD_CLOCK();
   // ---- duration variables (stage 3 only)
-  if (S->opt_dur && lam) {
+  if (S->opt_dur && lam && !c.second_model) {
     // residual-weighted curvature of the cost terms, one table slot per data sample:
     //   data  1/2 w |data_i - p_i|^2            -> -w r_i . Q(i)
     //   smooth 1/2 w |p_{i+1} - p_i|^2          -> +w r_i . Q(i+1)  and  -w r_i . Q(i)
@@ -3004,6 +3057,7 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(LCtx& c, GD* g, const GD* lam) {
         cf[k] = c.sf * v;
       }
       d2_store(q, e, slot_cost + i, (int)a[SC_PHASE], dot3(cf, a + SC_QEE), dot3(cf, a + SC_QEC), dot3(cf, a + SC_QCC));
+      { GD* aw = q->wd + q->o_scache + ((long long)s * (q->F + 2) + i) * SC_STRIDE; for (int k = 0; k < 3; ++k) aw[SC_CF + k] = cf[k]; }      // (for the node x duration entries below)
     }
     CHD_SYNC();
     // toe x heel cross blocks of the heel-distance rows: one thread per (pair, k, l)
@@ -3063,7 +3117,7 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(LCtx& c, GD* g, const GD* lam) {
             }
           }
         }
-        if (lam) {     // exact second-order terms collected by the row tasks and the cost pass above
+        if (lam && !c.second_model) {     // exact second-order terms collected by the row tasks and the cost pass above (first model of an iteration)
           const GD* tb = q->wd + q->o_d2tab + (long long)e * q->d2_slots * D2_STRIDE;
           double h2 = 0;
           for (int sl = 0; sl < q->d2_slots; ++sl) h2 += d2_select(tb + sl * D2_STRIDE, k, k2);
@@ -3077,64 +3131,104 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(LCtx& c, GD* g, const GD* lam) {
         if (k2 == k) g[S->dur_off[e] + k] = c.sf * gacc;
       }
     }
-    // ---- (T_k, node variable) entries: one thread per node variable of an ee-motion spline gathers the residuals
-    // that touch the variable's node(s) once and accumulates the entries of up to 8 durations at a time in registers
-    int tot_v = 0;
-    for (int e = 0; e < 4; ++e) tot_v += q->sp[2 + e].n_var;
-    PAR_FOR(idx0, tot_v) {
-      int tar = idx0, e = 0;
-      while (tar >= q->sp[2 + e].n_var) { tar -= q->sp[2 + e].n_var; ++e; }
-      const int s = 2 + e;
+    // ---- (T_k, node variable) entries: one thread per node variable.  Gauss-Newton part (cost terms of the ee-motion splines): the thread gathers the
+    // residuals that touch the variable's node(s) once and accumulates the entries of up to 8 durations at a time in registers.  Exact part (first model
+    // of an iteration, multipliers given): + the residual curvature of the cost terms, sum_i df/dp_i . d2p_i/dx dT, and the records the row tasks left in
+    // the node x duration table (chd_device.hpp, XR_* / XB_*) -- which also couple the durations with force, centre-of-mass and base-angle nodes.
+    const bool DX = lam != nullptr && !c.second_model;
+    const GI* varspl = q->ci + q->o_varspl; const GI* varnode = q->ci + q->o_varnode;
+    PAR_FOR(var, q->n_nodesvars) {
+      const int s = varspl[var];
+      if (!DX && (s < 2 || s > 5)) continue;
       const auto& sp = q->sp[s];
-      const int nv = q->n_phase[e] - 1;
       const double wdat = S->w_data[2], wvel = S->w_vel[2];
-      const int nsm = n_smooth(q, s);
-      const int ent = q->ci[q->o_varnode + sp.var_off + tar];
+      const int ent = varnode[var];
       const int nd = ent / 6, dq0 = (ent % 6) / 3, dm = ent % 3;
       const GI* pinfo = q->ci + q->o_pinfo + sp.poly_off * 4;
       const int nd_hi = (dq0 == 0 && nd < sp.n_polys && pinfo[nd * 4 + 3]) ? nd + 1 : nd;
       const int pa = nd - 1 < 0 ? 0 : nd - 1, pb = nd_hi > sp.n_polys - 1 ? sp.n_polys - 1 : nd_hi;
-      const int i_lo = first[s * fstride + pa];
-      const int i_hi = first[s * fstride + pb + 1] - 1;
-      const int Pv = c.pos_var[sp.var_off + tar];
-      // weight of this variable in p(t_i): the sample's polynomial touches node poly (side 0) and poly + 1 (side 1)
-      auto own_weight = [&](auto a) -> double {
-        const int poly = (int)a[SC_POLY];
+      const int Pv = c.pos_var[var];
+      // weight of this variable in a quantity sum_j W[j] x_j over the coefficients of polynomial `poly` (which touches node poly: side 0, and poly + 1: side 1)
+      auto wsel = [&](const int poly, auto W) -> double {
         double g_ = 0;
-        if (poly >= nd && poly <= nd_hi) g_ += a[SC_WP + dq0];
-        if (poly + 1 >= nd && poly + 1 <= nd_hi) g_ += a[SC_WP + 2 + dq0];
+        if (poly >= nd && poly <= nd_hi) g_ += W[dq0];
+        if (poly + 1 >= nd && poly + 1 <= nd_hi) g_ += W[2 + dq0];
         return g_;
       };
-      for (int k0 = 0; k0 < nv; k0 += 8) {
-        double hk[8];
+      for (int te = 0; te < N_EE; ++te) {      // end-effector whose durations the entries differentiate by
+        int blks[4], nblk = 0;
+        bool own_cost = false;
+        if (s >= 2 && s <= 5) {
+          if (te == s - 2) { own_cost = true; if (DX) { blks[0] = XB_HEIGHT; blks[1] = XB_ROM_M; blks[2] = XB_HEEL_OWN; blks[3] = XB_DYN_P; nblk = 4; } }
+          else if (DX && te == (s - 2 + 2) % 4) { blks[0] = XB_HEEL_X; nblk = 1; }
+          else continue;
+        } else if (s >= 6) {
+          if (te != s - 6) continue;
+          blks[0] = XB_DYN_F; nblk = 1;
+        } else if (s == 0) { blks[0] = XB_ROM_C; blks[1] = XB_DYN_C; nblk = 2; }
+        else { blks[0] = XB_ROM_A; nblk = 1; }
+        const int nv = q->n_phase[te] - 1;
+        const int nsm = own_cost ? n_smooth(q, s) : 0;
+        const int i_lo = own_cost ? first[s * fstride + pa] : 0;
+        const int i_hi = own_cost ? first[s * fstride + pb + 1] - 1 : -1;
+        for (int k0 = 0; k0 < nv; k0 += 8) {
+          double hk[8], hx[8];
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) hk[kk] = 0.0;
-        if (wdat >= 0) {
-          const int r_hi = i_hi > F - 1 ? F - 1 : i_hi;
-          for (int i = i_lo; i <= r_hi; ++i) {
-            auto a = sample(s, i);
-            const double gt = -wdat * own_weight(a);             // r = data - p
+          for (int kk = 0; kk < 8; ++kk) { hk[kk] = 0.0; hx[kk] = 0.0; }
+          if (own_cost && wdat >= 0) {
+            const int r_hi = i_hi > F - 1 ? F - 1 : i_hi;
+            for (int i = i_lo; i <= r_hi; ++i) {
+              auto a = sample(s, i);
+              const double gt = -wdat * wsel((int)a[SC_POLY], a + SC_WP);             // r = data - p
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) if (k0 + kk < nv) hk[kk] += gt * (-cache_djac(a, dm, k0 + kk));
+              for (int kk = 0; kk < 8; ++kk) if (k0 + kk < nv) hk[kk] += gt * (-cache_djac(a, dm, k0 + kk));
+            }
           }
-        }
-        if (wvel >= 0) {
-          const int r_lo = i_lo - 1 < 0 ? 0 : i_lo - 1, r_hi = i_hi > nsm - 1 ? nsm - 1 : i_hi;
-          for (int i = r_lo; i <= r_hi; ++i) {
-            auto a = sample(s, i); auto b = sample(s, i + 1);
-            const double gt = wvel * (own_weight(b) - own_weight(a));      // r = p_{i+1} - p_i
+          if (own_cost && wvel >= 0) {
+            const int r_lo = i_lo - 1 < 0 ? 0 : i_lo - 1, r_hi = i_hi > nsm - 1 ? nsm - 1 : i_hi;
+            for (int i = r_lo; i <= r_hi; ++i) {
+              auto a = sample(s, i); auto b = sample(s, i + 1);
+              const double gt = wvel * (wsel((int)b[SC_POLY], b + SC_WP) - wsel((int)a[SC_POLY], a + SC_WP));      // r = p_{i+1} - p_i
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) if (k0 + kk < nv) hk[kk] += gt * (cache_djac(b, dm, k0 + kk) - cache_djac(a, dm, k0 + kk));
+              for (int kk = 0; kk < 8; ++kk) if (k0 + kk < nv) hk[kk] += gt * (cache_djac(b, dm, k0 + kk) - cache_djac(a, dm, k0 + kk));
+            }
           }
-        }
-        {
-          int pp[8], qv[8]; double vv[8];
+          if (own_cost && DX) {
+            const int r_hi = i_hi > F - 1 ? F - 1 : i_hi;
+            for (int i = i_lo; i <= r_hi; ++i) {
+              auto a = sample(s, i);
+              const double cfd = scache(q, s, i)[SC_CF + dm];
+              const int poly = (int)a[SC_POLY], cur = (int)a[SC_PHASE], last = (int)a[SC_LAST];
+              const double oe = cfd * wsel(poly, a + SC_OME), oc = last ? 0.0 : cfd * wsel(poly, a + SC_OMC);
 #pragma unroll
-          for (int kk = 0; kk < 8; ++kk) {
-            const bool on = k0 + kk < nv && hk[kk] != 0.0;
-            pp[kk] = on ? c.pos_var[S->dur_off[e] + k0 + kk] : -1; qv[kk] = Pv; vv[kk] = c.sf * hk[kk];
+              for (int kk = 0; kk < 8; ++kk) { const int k = k0 + kk; if (k < nv) hx[kk] += k < cur ? oe : (k == cur ? oc : 0.0); }
+            }
           }
-          kadd_batch<8>(c, pp, qv, vv);
+          for (int bi = 0; bi < nblk; ++bi) {
+            const int len = xblock_len(q, blks[bi]);
+            const GD* r = xrec(q, te, blks[bi], 0);
+            for (int smp = 0; smp < len; ++smp, r += XR_STRIDE) {
+              const int poly = (int)r[XR_POLY];
+              if (poly < pa) continue;
+              if (poly > pb) break;            // (the samples of a block are ordered in time; an unused slot reads as polynomial 0 with zero coefficients)
+              const int cur = (int)r[XR_CUR], last = (int)r[XR_LAST];
+              const double g_ = wsel(poly, r + XR_W), bd = r[XR_B + dm];
+              const double ge = g_ * r[XR_AE + dm] + wsel(poly, r + XR_OME) * bd;
+              const double gc = last ? 0.0 : g_ * r[XR_AC + dm] + wsel(poly, r + XR_OMC) * bd;
+#pragma unroll
+              for (int kk = 0; kk < 8; ++kk) { const int k = k0 + kk; if (k < nv) hx[kk] += k < cur ? ge : (k == cur ? gc : 0.0); }
+            }
+          }
+          {
+            int pp[8], qv[8]; double vv[8];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+              vv[kk] = c.sf * hk[kk] + hx[kk];
+              const bool on = k0 + kk < nv && vv[kk] != 0.0;
+              pp[kk] = on ? c.pos_var[S->dur_off[te] + k0 + kk] : -1; qv[kk] = Pv;
+            }
+            kadd_batch<8>(c, pp, qv, vv);
+          }
         }
       }
     }
@@ -3353,18 +3447,21 @@ CHD_NOINLINE CHD_DEV void solve_stage(LCtx& c, StageResult& res) {
     bool ok = false, used_soc = false;
     double alpha = 0, a_du = 1.0;
     int nls = 0, attempt = 0;
-    // Second model of an iteration: when an attempt fails (wrong inertia, or the line search runs out of backtracks) the model is
-    // rebuilt ONCE with the negative part of the heel-distance curvature dropped (lam -> max(lam, 0) in that block) and the attempt
-    // is repeated with the same damping; only if that fails too does the damping grow.  The exact block is what makes the easy
-    // sequences converge in few iterations; its negative part kept the hard ones at dw ~ 10..1e4 for hundreds of iterations.
-    bool clipped = false;
+    // Second model of an iteration: when an attempt with the exact blocks (heel-distance curvature, duration-duration and node x duration blocks)
+    // fails -- wrong inertia, or the line search runs out of backtracks -- the model is rebuilt ONCE without them (plain Gauss-Newton, positive
+    // semi-definite by construction) and the attempt is repeated with the same damping; only if that fails too does the damping grow.  The exact
+    // blocks make the easy sequences converge in few iterations; where they are indefinite, the positive semi-definite model is the fallback.
+    // (Rounds 2-3 kept the positive part of the heel-distance multipliers instead: near-redundant rows -- a sample milliseconds before a
+    //  touch-down next to one in the stance that follows -- carry multipliers of +-1e4 that cancel in the exact block, and the clipped copy
+    //  kept the +1e4: a spurious stiffness under which the kinematic optimisation's clips crawled to the iteration cap.  profiles/r04_curvature_study.md)
+    bool second_used = false;
     auto second_model = [&]() -> bool {
-      if (clipped || it == 0) return false;          // (the first model of a stage has no curvature terms)
-      clipped = true;
-      if (CHD_TID == 0) c.clip_heel = 1;
+      if (second_used || it == 0) return false;          // (the first model of a stage has no curvature terms)
+      second_used = true;
+      if (CHD_TID == 0) c.second_model = 1;
       CHD_SYNC();
       f = eval_nlp(c, x, EV_FULL, cc, g, lam);
-      if (CHD_TID == 0) c.clip_heel = 0;
+      if (CHD_TID == 0) c.second_model = 0;
       CHD_SYNC();
       return true;
     };
@@ -3538,7 +3635,7 @@ CHD_DEV void bind_stage(LCtx& c, QP q, int stage) {
     c.W2 = 2 * c.w + 1; c.LD = c.N;
     c.K0b = q->wd + q->o_K0b; c.K0x = q->wd + q->o_K0x; c.Kfb = q->wd + q->o_Kfb; c.Kfx = q->wd + q->o_Kfx;
     c.pos_var = q->ci + c.S->o_pos_var; c.pos_row = q->ci + c.S->o_pos_row; c.env = q->wi + q->o_envw; c.rcnt = q->wi + q->o_rcntw;
-    c.sf = 1.0; c.err = 0; c.n_bad_pivots = 0; c.clip_heel = 0;
+    c.sf = 1.0; c.err = 0; c.n_bad_pivots = 0; c.second_model = 0;
   }
   CHD_SYNC();
 }

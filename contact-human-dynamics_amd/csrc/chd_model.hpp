@@ -664,6 +664,23 @@ class SeqModel {
             while (pk < h.n_polys && h.ph[pk] < k) ++pk;
             for (int nd = pk; nd < h.n_nodes; ++nd)
               for (int q6 = 0; q6 < 6; ++q6) { int v = h.var_of[nd * 6 + q6]; if (v >= 0) reach(pos_var[S.dur_off[e] + k], pos_var[h.var_off + v]); }
+            // exact node x duration block of the constraint rows (chd_device.hpp, XB_*): the duration also couples with the force nodes of its end-effector
+            // (dynamics rows) and, from the start of its phase on, with the nodes of the foot's other contact point (heel-distance rows) and of the two
+            // base splines (leg-length and dynamics rows)
+            {
+              const HostSpline& hf = hs[6 + e];
+              int pf = 0;
+              while (pf < hf.n_polys && hf.ph[pf] < k) ++pf;
+              for (int nd = pf; nd < hf.n_nodes; ++nd)
+                for (int q6 = 0; q6 < 6; ++q6) { int v = hf.var_of[nd * 6 + q6]; if (v >= 0) reach(pos_var[S.dur_off[e] + k], pos_var[hf.var_off + v]); }
+              const double t0 = std::max(0.0, (k > 0 ? phe[e][k - 1] : 0.0) - kSlack);
+              const int others[3] = {0, 1, 2 + (e + 2) % 4};
+              for (int oi = 0; oi < 3; ++oi) {
+                const HostSpline& ho = hs[others[oi]];
+                for (int nd = locate(pe[others[oi]], t0); nd < ho.n_nodes; ++nd)
+                  for (int q6 = 0; q6 < 6; ++q6) { int v = ho.var_of[nd * 6 + q6]; if (v >= 0) reach(pos_var[S.dur_off[e] + k], pos_var[ho.var_off + v]); }
+              }
+            }
           }
         }
     }
@@ -751,6 +768,7 @@ class SeqModel {
     d.o_d2tab = take(4LL * d.d2_slots * D2_STRIDE);
     d.o_x2tab = take(2LL * d.n_trom * X2_STRIDE);
     d.o_rcache = take(4LL * d.n_trom * RC_STRIDE);
+    d.o_xtab = take(4LL * (4LL * d.n_tdyn + 5LL * d.n_trom) * XR_STRIDE);      // node x duration records (chd_device.hpp: XB_*)
     const long long Nb_cap = N_cap, W2 = 2LL * w_cap + 1, LD = N_cap;
     d.sz_K0b = Nb_cap * W2; d.sz_K0x = (long long)bc_cap * LD;
     d.sz_Kfb = Nb_cap * (w_cap + 1); d.sz_Kfx = (long long)bc_cap * LD;

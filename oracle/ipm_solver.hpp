@@ -20,7 +20,7 @@
 //     adaptive Levenberg damping dw*Dw, instead of L-BFGS(6);
 //   * globalisation: l1 merit function (penalty parameter recomputed per step) with backtracking and a
 //     second-order correction instead of the filter + restoration phase; a failed attempt first retries with the
-//     negative part of the heel-distance curvature dropped, then with more damping;
+//     Gauss-Newton model (no exact constraint-curvature blocks), then with more damping;
 //   * mu_init = 1e-3 and mu-based bound multipliers for the warm-started stages;
 //   * linear algebra: bordered banded LDL^T without pivoting in a time ordering
 //     (stance positions / durations in the border) instead of MA57.
@@ -402,14 +402,14 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
     res.bandwidth = std::max(res.bandwidth, w);
 
     bool ok = false, used_soc = false; double alpha = 0, a_du = 1.0; int nls = 0, attempt = 0;
-    // Second model of an iteration: when an attempt fails (wrong inertia, or the line search runs out of backtracks) the Hessian is
-    // rebuilt ONCE with the negative part of the heel-distance curvature dropped (lam -> max(lam, 0) in that block) and the attempt is
-    // repeated with the same damping; only if that fails too does the damping grow.  The exact block is what makes the easy sequences
-    // converge in few iterations; its negative part is what kept the hard ones at dw ~ 10..1e4 for hundreds of iterations.
-    bool clipped = false;
+    // Second model of an iteration: when an attempt with the exact blocks (heel-distance curvature, node x duration block) fails and the exact duration-duration block fails -- wrong inertia, or the line
+    // search runs out of backtracks -- the Hessian is rebuilt ONCE without them (plain Gauss-Newton, positive semi-definite by construction) and the attempt is repeated
+    // with the same damping; only if that fails too does the damping grow.  (Rounds 2-3 kept max(lam, 0) of the heel-distance block instead; near-redundant
+    // rows carry multipliers of +-1e4 that cancel in the exact block but not in its clipped copy: profiles/r04_curvature_study.md.)
+    bool second_used = false;
     auto second_model = [&]() {
-      if (clipped || it == 0 || opt.lbfgs) return false;          // (the first model of a stage has no curvature terms)
-      clipped = true;
+      if (second_used || it == 0 || opt.lbfgs) return false;          // (the first model of a stage has no curvature terms)
+      second_used = true;
       P.eval(x.data(), &fraw, graw.data(), craw.data(), J.data(), H.data(), lraw.data(), true);
       apply_scaling(true);
       return true;
@@ -430,6 +430,7 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
         K.add(pos_row[i], pos_row[i], -D[i]);
       }
       K.factor(); ++res.n_factor;
+      if (opt.verbose && K.n_bad_pivots > 0) std::printf("   attempt %d: %d bad pivots (dw %.1e, second model %d)\n", attempt, K.n_bad_pivots, dw, (int)second_used);
       if (opt.inertia_retry && K.n_bad_pivots > 0) { if (second_model()) continue; dw *= 10.0; if (dw > opt.delta_w_max) break; continue; }
       const int lk = opt.lbfgs ? (int)lb_S.size() : 0;
       std::vector<double> lbZ, lbC;          // Z = K_sigma^-1 What (N x 2k, column major), C = M - What^T Z (2k x 2k)

@@ -54,6 +54,35 @@ template <int N> inline Dual<N> sin(const Dual<N>& a) { Dual<N> r; r.v = std::si
 template <int N> inline Dual<N> cos(const Dual<N>& a) { Dual<N> r; r.v = std::cos(a.v); double s = -std::sin(a.v); for (int i = 0; i < N; ++i) r.d[i] = s * a.d[i]; return r; }
 
 // ----------------------------------------------------------------------------
+// Second-order forward-mode AD scalar (value, gradient, Hessian over N inputs).
+// Used for the exact constraint curvature lam . grad^2 c of the Euler-angle terms
+// (angular dynamics rows, leg-length rows): the kernel derives the same second
+// derivatives by hand, the oracle gets them by differentiating the very function
+// that produces the row value.
+// ----------------------------------------------------------------------------
+template <int N>
+struct Jet2 {
+  double v;
+  double g[N];
+  double h[N][N];
+  Jet2() : v(0) { for (int i = 0; i < N; ++i) { g[i] = 0; for (int j = 0; j < N; ++j) h[i][j] = 0; } }
+  Jet2(double c) : v(c) { for (int i = 0; i < N; ++i) { g[i] = 0; for (int j = 0; j < N; ++j) h[i][j] = 0; } }
+  static Jet2 var(double c, int k) { Jet2 r(c); r.g[k] = 1.0; return r; }
+};
+template <int N> inline Jet2<N> operator+(const Jet2<N>& a, const Jet2<N>& b) { Jet2<N> r; r.v = a.v + b.v; for (int i = 0; i < N; ++i) { r.g[i] = a.g[i] + b.g[i]; for (int j = 0; j < N; ++j) r.h[i][j] = a.h[i][j] + b.h[i][j]; } return r; }
+template <int N> inline Jet2<N> operator-(const Jet2<N>& a, const Jet2<N>& b) { Jet2<N> r; r.v = a.v - b.v; for (int i = 0; i < N; ++i) { r.g[i] = a.g[i] - b.g[i]; for (int j = 0; j < N; ++j) r.h[i][j] = a.h[i][j] - b.h[i][j]; } return r; }
+template <int N> inline Jet2<N> operator-(const Jet2<N>& a) { Jet2<N> r; r.v = -a.v; for (int i = 0; i < N; ++i) { r.g[i] = -a.g[i]; for (int j = 0; j < N; ++j) r.h[i][j] = -a.h[i][j]; } return r; }
+template <int N> inline Jet2<N> operator*(const Jet2<N>& a, const Jet2<N>& b) {
+  Jet2<N> r; r.v = a.v * b.v;
+  for (int i = 0; i < N; ++i) { r.g[i] = a.g[i] * b.v + a.v * b.g[i]; for (int j = 0; j < N; ++j) r.h[i][j] = a.h[i][j] * b.v + a.g[i] * b.g[j] + a.g[j] * b.g[i] + a.v * b.h[i][j]; }
+  return r;
+}
+template <int N> inline Jet2<N> operator*(double a, const Jet2<N>& b) { Jet2<N> r; r.v = a * b.v; for (int i = 0; i < N; ++i) { r.g[i] = a * b.g[i]; for (int j = 0; j < N; ++j) r.h[i][j] = a * b.h[i][j]; } return r; }
+template <int N> inline Jet2<N> operator*(const Jet2<N>& b, double a) { return a * b; }
+template <int N> inline Jet2<N> sin(const Jet2<N>& a) { Jet2<N> r; const double s = std::sin(a.v), c = std::cos(a.v); r.v = s; for (int i = 0; i < N; ++i) { r.g[i] = c * a.g[i]; for (int j = 0; j < N; ++j) r.h[i][j] = c * a.h[i][j] - s * a.g[i] * a.g[j]; } return r; }
+template <int N> inline Jet2<N> cos(const Jet2<N>& a) { Jet2<N> r; const double s = std::sin(a.v), c = std::cos(a.v); r.v = c; for (int i = 0; i < N; ++i) { r.g[i] = -s * a.g[i]; for (int j = 0; j < N; ++j) r.h[i][j] = -s * a.h[i][j] - c * a.g[i] * a.g[j]; } return r; }
+
+// ----------------------------------------------------------------------------
 // Inputs: exactly the contents of the four phys_optim_in_<char>/*.txt files
 // (reader: phys_optim.cpp:155-267).
 // ----------------------------------------------------------------------------
@@ -264,6 +293,14 @@ class Problem {
   double hx = 0, hy = 0;              // plane height derivatives (ground_plane.cpp:29-41)
   double nrm_n[3], nrm_t1[3], nrm_t2[3];   // [UPSTREAM] HeightMap::GetNormalizedBasis for a plane
 
+  // STUDY SWITCHES (tests/tools only; 0 = the shipped algorithm, which the HIP kernel implements).  profiles/r04_curvature_study.md has the measurements.
+  //   bit 0 / 1 / 2: ADD the exact node-node curvature lam grad^2 c of the dynamics rows' torque term / of their angular term / of the leg-length rows
+  //                  (all three slow the solve down on every family of sequences tried, the kinematic optimisation's clips the most)
+  //   bit 3: keep those blocks in the second model of an iteration
+  //   bit 4: second model = heel-distance curvature with max(lam, 0), capped at clip_cap (rounds 2-3 shipped this without a cap)
+  //   bit 5: no exact node x duration block (round 3's model of the duration stage)
+  int study_mask = 0;
+  double clip_cap = 1e300;
   // --- current stage ---
   int stage = -1;
   StageDef sd{};
@@ -696,6 +733,29 @@ class Problem {
     for (int d = 0; d < 3; ++d) out[d] = e.a[d] * uk * ul + htT[d] * (uk * vl + vk * ul) + hTT[d] * vk * vl;
   }
 
+  // Mixed node x duration derivatives.  p(t) = sum_j w_j(tau, Tp) x_j over the four Hermite coefficients of the active polynomial, and both tau and Tp
+  // are affine in the duration variables (dur_uv), so for a duration T_k of class x in {e: earlier phase, c: current phase}
+  //   d p / d T_k         = G_x   = h_tau u_x + h_T v_x                       (first derivative: d1pos)
+  //   d2 p / d x_j d T_k  = om_x,j = (d w_j / d tau) u_x + (d w_j / d Tp) v_x  (the derivative of the weight itself)
+  // Not in the reference (L-BFGS there); with the duration-duration block this makes the duration stage's Hessian of the Lagrangian exact.
+  struct DurX { int cur, nvar; bool last; double Ge[3], Gc[3], ome[4], omc[4]; };
+  void dur_cross(const Spline& s, double t, const PointEval& e, DurX& dx) const {
+    const int ee = s.ee;
+    dx.cur = segment_id(t, phase_dur[ee]);
+    dx.nvar = (int)phase_dur[ee].size() - 1;
+    dx.last = dx.cur == dx.nvar;
+    const PolyInfo& pi = s.pinfo[e.poly];
+    const double nn = pi.n_in_phase, kin = pi.k_in_phase;
+    const double ue = dx.last ? -1.0 + kin / nn : -1.0, ve = dx.last ? -1.0 / nn : 0.0;
+    const double uc = -kin / nn, vc = 1.0 / nn;
+    const double tau = e.tl, T = e.T, t2 = tau * tau, t3 = t2 * tau, T2 = T * T, T3 = T2 * T, T4 = T3 * T;
+    const double wT[4] = {-6 * t3 / T4 + 6 * t2 / T3, 2 * t2 / T2 - 2 * t3 / T3, -6 * t2 / T3 + 6 * t3 / T4, -2 * t3 / T3 + t2 / T2};
+    double hT[3], htT[3], hTT[3];
+    hermite_T_derivs(s, e, hT, htT, hTT);
+    for (int d = 0; d < 3; ++d) { dx.Ge[d] = e.v[d] * ue + hT[d] * ve; dx.Gc[d] = dx.last ? 0.0 : e.v[d] * uc + hT[d] * vc; }
+    for (int j = 0; j < 4; ++j) { dx.ome[j] = e.w[kVel][j] * ue + wT[j] * ve; dx.omc[j] = dx.last ? 0.0 : e.w[kVel][j] * uc + wT[j] * vc; }
+  }
+
   // [UPSTREAM] EulerConverter::GetRotationMatrixBaseToWorld (ZYX, kindr cheat-sheet)
   template <class S> static void rot_zyx(const S e[3], S R[3][3]) {
     S x = e[0], y = e[1], z = e[2];
@@ -751,15 +811,16 @@ class Problem {
   // H: dense n x n Gauss-Newton Hessian of the (sum-of-squares) objective (may be null).
   // lam (optional, m entries): multipliers of the unscaled rows; when given together with H and the durations are
   // variables, the exact duration-duration block of sum_i lam_i grad^2 c_i + (grad^2 f - Gauss-Newton part) is added to H.
-  // clip_neg_heel: the node-node curvature block of the heel-distance rows takes max(lam, 0) (the solver's second model of an
-  // iteration, ipm_solver.hpp: the negative part of that block is what makes the line search / the inertia fail on the hard sequences).
-  void eval(const double* x, double* f_out, double* grad, double* c, double* J, double* H = nullptr, const double* lam = nullptr, bool clip_neg_heel = false) {
+  // second_model: the solver's second model of an iteration (ipm_solver.hpp) -- plain Gauss-Newton, positive semi-definite by construction, WITHOUT the exact
+  // blocks (heel-distance curvature, duration-duration and node x duration blocks), any of which can be indefinite: it is what is tried when the first model gives
+  // the wrong inertia or no acceptable step.
+  void eval(const double* x, double* f_out, double* grad, double* c, double* J, double* H = nullptr, const double* lam = nullptr, bool second_model = false) {
     set_x(x);
     if (J) std::fill(J, J + (size_t)m * n, 0.0);
     if (grad) std::fill(grad, grad + n, 0.0);
     if (H) std::fill(H, H + (size_t)n * n, 0.0);
     std::vector<double> djac, djac2;
-    const bool D2 = H && lam && sd.opt_durations;
+    const bool D2 = H && lam && sd.opt_durations && !second_model;      // exact duration-duration block (first model of an iteration)
     auto hdd = [&](int ea, int k, int eb, int l, double v) {      // symmetric entry of the duration block
       const int a = dur_off[ea] + k, b = dur_off[eb] + l;
       H[(size_t)a * n + b] += v;
@@ -789,6 +850,42 @@ class Problem {
         Jr[dur_off[s.ee] + k] += coef[0] * djac[0 * nv + k] + coef[1] * djac[1 * nv + k] + coef[2] * djac[2 * nv + k];
     };
 
+    // H[vars of (sa, ea, dim ka)] x [vars of (sb, eb, dim kb)] += val * (weights of `wha` at ea) (weights of `whb` at eb)^T, and the transposed
+    // block when `sym` (two different input groups of a symmetric local Hessian visited once)
+    auto hblock = [&](const Spline& sa, const PointEval& ea, int wha, int ka, const Spline& sb, const PointEval& eb, int whb, int kb, double val, bool sym) {
+      if (val == 0.0) return;
+      for (int q1 = 0; q1 < 4; ++q1) {
+        const int va = sa.vi(ea.poly + q1 / 2, q1 % 2, ka);
+        if (va < 0) continue;
+        for (int q2 = 0; q2 < 4; ++q2) {
+          const int vb = sb.vi(eb.poly + q2 / 2, q2 % 2, kb);
+          if (vb < 0) continue;
+          const double t = val * ea.w[wha][q1] * eb.w[whb][q2];
+          H[(size_t)(sa.var_off + va) * n + sb.var_off + vb] += t;
+          if (sym) H[(size_t)(sb.var_off + vb) * n + sa.var_off + va] += t;
+        }
+      }
+    };
+    // node x duration block: H[(spline sx, coefficient j of the polynomial at ex, dimension dim)][T_k of end-effector dx's] += wts[j] * (k < cur ? ce : k == cur ? cc : 0), both triangles
+    auto xcross = [&](const Spline& sx, const PointEval& ex, int dim, const double* wts, int ee, const DurX& dx, double ce, double cc) {
+      for (int j = 0; j < 4; ++j) {
+        const int v = sx.vi(ex.poly + j / 2, j % 2, dim);
+        if (v < 0 || wts[j] == 0.0) continue;
+        const int xv = sx.var_off + v;
+        const int ne = dx.cur < dx.nvar ? dx.cur : dx.nvar;
+        if (ce != 0.0) for (int k = 0; k < ne; ++k) { const int tv = dur_off[ee] + k; H[(size_t)xv * n + tv] += wts[j] * ce; H[(size_t)tv * n + xv] += wts[j] * ce; }
+        if (cc != 0.0 && !dx.last) { const int tv = dur_off[ee] + dx.cur; H[(size_t)xv * n + tv] += wts[j] * cc; H[(size_t)tv * n + xv] += wts[j] * cc; }
+      }
+    };
+    // one (x-spline, T-end-effector) record of a sample: entry = w_j A_class[dim] + om_class,j B[dim]   (om only when the x-spline belongs to that end-effector)
+    auto xrecord = [&](const Spline& sx, const PointEval& ex, int ee, const DurX& dx, const double* Ae, const double* Ac, const double* B) {
+      for (int dim = 0; dim < 3; ++dim) {
+        if (Ae) xcross(sx, ex, dim, ex.w[kPos], ee, dx, Ae[dim], Ac[dim]);
+        if (B) { xcross(sx, ex, dim, dx.ome, ee, dx, B[dim], 0.0); xcross(sx, ex, dim, dx.omc, ee, dx, 0.0, B[dim]); }
+      }
+    };
+    const bool DX = D2 && !(study_mask & 32);      // exact node x duration block (first model of an iteration)
+    const bool XC = H && lam && (study_mask & 7) && (!second_model || (study_mask & 8));      // study blocks
     PointEval pe, pe2, pl, pa;
     for (const RowBlock& b : blocks) {
       switch (b.family) {
@@ -855,6 +952,29 @@ class Problem {
             add_nodes(row, sp[1], pa, kPos, ca);
             add_nodes(row, sm, pe, kPos, d);
             add_durs(row, sm, t, pe, d);
+            if (XC && (study_mask & 4) && lam[row] != 0.0) {
+              // exact node-node block of lam grad^2 c, c = 1/2 |d|^2, d = p_ee - R(euler) h - c_com (leg_length_constraint.cpp:46-52):
+              //   grad^2 c = sum_i grad d_i grad d_i^T + sum_i d_i grad^2 d_i, the second part living in the Euler angles only
+              Jet2<3> e2[3] = {Jet2<3>::var(pa.p[0], 0), Jet2<3>::var(pa.p[1], 1), Jet2<3>::var(pa.p[2], 2)};
+              Jet2<3> R2[3][3];
+              rot_zyx(e2, R2);
+              double Hth[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+              for (int i = 0; i < 3; ++i) {
+                Jet2<3> rh = R2[i][0] * h[0] + R2[i][1] * h[1] + R2[i][2] * h[2];
+                for (int a = 0; a < 3; ++a) for (int b2 = 0; b2 < 3; ++b2) Hth[a][b2] += dRh[i][a] * dRh[i][b2] - d[i] * rh.h[a][b2];
+              }
+              const double lm = lam[row];
+              for (int a = 0; a < 3; ++a) {
+                hblock(sp[0], pl, kPos, a, sp[0], pl, kPos, a, lm, false);            // com x com: I
+                hblock(sm, pe, kPos, a, sm, pe, kPos, a, lm, false);                  // ee x ee: I
+                hblock(sm, pe, kPos, a, sp[0], pl, kPos, a, -lm, true);               // ee x com: -I
+                for (int b2 = 0; b2 < 3; ++b2) {
+                  hblock(sp[1], pa, kPos, a, sp[1], pa, kPos, b2, lm * Hth[a][b2], false);
+                  hblock(sp[0], pl, kPos, a, sp[1], pa, kPos, b2, lm * dRh[a][b2], true);       // (-e_a) . (-dRh[a][b])
+                  hblock(sm, pe, kPos, a, sp[1], pa, kPos, b2, -lm * dRh[a][b2], true);
+                }
+              }
+            }
             if (D2)
               for (int k2 = 0; k2 < nvar_of(e); ++k2)
                 for (int l2 = 0; l2 <= k2; ++l2) {
@@ -862,6 +982,16 @@ class Problem {
                   d1pos(sm, t, pe, k2, gk); d1pos(sm, t, pe, l2, gl); d2pos(sm, t, pe, k2, l2, q2);
                   hdd(e, k2, e, l2, lam[row] * (gk[0] * gl[0] + gk[1] * gl[1] + gk[2] * gl[2] + d[0] * q2[0] + d[1] * q2[1] + d[2] * q2[2]));
                 }
+            if (DX && lam[row] != 0.0) {
+              DurX dx; dur_cross(sm, t, pe, dx);
+              const double lm = lam[row];
+              double Ae[3], Ac[3], Bv[3], nAe[3], nAc[3], tAe[3], tAc[3];
+              for (int i = 0; i < 3; ++i) { Ae[i] = lm * dx.Ge[i]; Ac[i] = lm * dx.Gc[i]; Bv[i] = lm * d[i]; nAe[i] = -Ae[i]; nAc[i] = -Ac[i]; }
+              for (int kk = 0; kk < 3; ++kk) { tAe[kk] = -(dRh[0][kk] * Ae[0] + dRh[1][kk] * Ae[1] + dRh[2][kk] * Ae[2]); tAc[kk] = -(dRh[0][kk] * Ac[0] + dRh[1][kk] * Ac[1] + dRh[2][kk] * Ac[2]); }
+              xrecord(sm, pe, e, dx, Ae, Ac, Bv);
+              xrecord(sp[0], pl, e, dx, nAe, nAc, nullptr);
+              xrecord(sp[1], pa, e, dx, tAe, tAc, nullptr);
+            }
           }
         } break;
         case FAM_HEELDIST: {  // ee_dist_constraint.cpp:29-94 ; pairs nlp_formulation.cpp:249-257
@@ -899,7 +1029,7 @@ class Problem {
                 };
                 push(sp[2 + e1], pe, 1.0); push(sp[2 + e2], pe2, -1.0);
                 for (int a = 0; a < ng; ++a)
-                  for (int b2 = 0; b2 < ng; ++b2) H[(size_t)gv[a] * n + gv[b2]] += (clip_neg_heel ? std::max(lam[row], 0.0) : lam[row]) * gw[a] * gw[b2];
+                  for (int b2 = 0; b2 < ng; ++b2) H[(size_t)gv[a] * n + gv[b2]] += (second_model ? ((study_mask & 16) ? std::min(std::max(lam[row], 0.0), clip_cap) : 0.0) : lam[row]) * gw[a] * gw[b2];
               }
             }
             if (D2) {
@@ -922,6 +1052,19 @@ class Problem {
                   d1pos(sp[2 + e1], t, pe, k2, ga); d1pos(sp[2 + e2], t, pe2, l2, gb);
                   hdd(e1, k2, e2, l2, -lam[row] * dot(ga, gb));
                 }
+            }
+            if (DX && lam[row] != 0.0) {
+              DurX da, db; dur_cross(sp[2 + e1], t, pe, da); dur_cross(sp[2 + e2], t, pe2, db);
+              const double lm = lam[row];
+              double Aae[3], Aac[3], Abe[3], Abc[3], nAae[3], nAac[3], nAbe[3], nAbc[3], Ba[3], Bb[3];
+              for (int i = 0; i < 3; ++i) {
+                Aae[i] = lm * da.Ge[i]; Aac[i] = lm * da.Gc[i]; Abe[i] = lm * db.Ge[i]; Abc[i] = lm * db.Gc[i];
+                nAae[i] = -Aae[i]; nAac[i] = -Aac[i]; nAbe[i] = -Abe[i]; nAbc[i] = -Abc[i]; Ba[i] = lm * d[i]; Bb[i] = -lm * d[i];
+              }
+              xrecord(sp[2 + e1], pe, e1, da, Aae, Aac, Ba);            // toe nodes x toe durations
+              xrecord(sp[2 + e2], pe2, e1, da, nAae, nAac, nullptr);    // heel nodes x toe durations
+              xrecord(sp[2 + e1], pe, e2, db, nAbe, nAbc, nullptr);     // toe nodes x heel durations
+              xrecord(sp[2 + e2], pe2, e2, db, Abe, Abc, Bb);           // heel nodes x heel durations
             }
           }
         } break;
@@ -989,6 +1132,32 @@ class Problem {
                 add_durs(row0 + i, sp[2 + e], t, pm[e], Xf[i]);
               }
             }
+            if (XC && (study_mask & 3)) {
+              const double* la = lam + row0;
+              if (study_mask & 1)
+                for (int e = 0; e < 4; ++e)
+                  for (int j = 0; j < 3; ++j)
+                    for (int k2 = 0; k2 < 3; ++k2) {
+                      if (j == k2) continue;
+                      // rows ang_i - sum_e (f_e x r_e)_i, r_e = c - p_e (humanoid_rigid_body_dynamics.cpp:97-99): d2 L / d f_j d r_k = -sum_i lam_i eps_ijk
+                      const int i = 3 - j - k2;
+                      const double eps = ((j + 1) % 3 == k2) ? 1.0 : -1.0;         // eps_ijk with (i, j, k) a permutation of (0, 1, 2): +1 when k follows j cyclically
+                      const double mjk = -la[i] * eps;
+                      hblock(sp[6 + e], pf[e], kPos, j, sp[0], pl, kPos, k2, mjk, true);
+                      hblock(sp[6 + e], pf[e], kPos, j, sp[2 + e], pm[e], kPos, k2, -mjk, true);
+                    }
+              if (study_mask & 2) {
+                // angular term I_w wd + w x I_w w as a function of (euler, euler', euler''): second derivatives by second-order AD
+                Jet2<9> e2[3], ed2[3], edd2[3], ang2[3];
+                for (int i = 0; i < 3; ++i) { e2[i] = Jet2<9>::var(pa.p[i], i); ed2[i] = Jet2<9>::var(pa.v[i], 3 + i); edd2[i] = Jet2<9>::var(pa.a[i], 6 + i); }
+                angular_term(e2, ed2, edd2, Ib, ang2);
+                for (int a = 0; a < 9; ++a)
+                  for (int b2 = 0; b2 < 9; ++b2) {
+                    const double v = la[0] * ang2[0].h[a][b2] + la[1] * ang2[1].h[a][b2] + la[2] * ang2[2].h[a][b2];
+                    hblock(sp[1], pa, a / 3, a % 3, sp[1], pa, b2 / 3, b2 % 3, v, false);
+                  }
+              }
+            }
             if (D2) {
               auto cross = [](const double* a, const double* b2, double* o) { o[0] = a[1] * b2[2] - a[2] * b2[1]; o[1] = a[2] * b2[0] - a[0] * b2[2]; o[2] = a[0] * b2[1] - a[1] * b2[0]; };
               for (int e = 0; e < 4; ++e) {
@@ -1005,6 +1174,23 @@ class Problem {
                     for (int i = 0; i < 3; ++i) v += -lam[row0 + i] * (a1[i] - a2[i] - a3[i] - a4[i]) - lam[row0 + 3 + i] * qF[i];
                     hdd(e, k2, e, l2, v);
                   }
+              }
+            }
+            if (DX) {
+              auto cross = [](const double* a, const double* b2, double* o) { o[0] = a[1] * b2[2] - a[2] * b2[1]; o[1] = a[2] * b2[0] - a[0] * b2[2]; o[2] = a[0] * b2[1] - a[1] * b2[0]; };
+              const double* la = lam + row0; const double* ll = lam + row0 + 3;
+              for (int e = 0; e < 4; ++e) {
+                // L = la . [ang - sum_e f_e x r_e] + ll . [m a - sum_e f_e], r_e = c - p_e:
+                //   dL/df_e = -(r_e x la) - ll,  dL/dp_e = la x f_e,  dL/dc = -sum_e la x f_e
+                DurX dF, dP; dur_cross(sp[6 + e], t, pf[e], dF); dur_cross(sp[2 + e], t, pm[e], dP);
+                const double r[3] = {pl.p[0] - pm[e].p[0], pl.p[1] - pm[e].p[1], pl.p[2] - pm[e].p[2]};
+                double rxl[3], lxf[3], lxGPe[3], lxGPc[3], lxGFe[3], lxGFc[3], BF[3], AFe[3], AFc[3], nlxGFe[3], nlxGFc[3];
+                cross(r, la, rxl); cross(la, pf[e].p, lxf);
+                cross(la, dP.Ge, lxGPe); cross(la, dP.Gc, lxGPc); cross(la, dF.Ge, lxGFe); cross(la, dF.Gc, lxGFc);
+                for (int i = 0; i < 3; ++i) { BF[i] = -rxl[i] - ll[i]; AFe[i] = -lxGPe[i]; AFc[i] = -lxGPc[i]; nlxGFe[i] = -lxGFe[i]; nlxGFc[i] = -lxGFc[i]; }
+                xrecord(sp[6 + e], pf[e], e, dF, AFe, AFc, BF);              // force nodes
+                xrecord(sp[2 + e], pm[e], e, dP, lxGFe, lxGFc, lxf);         // position nodes
+                xrecord(sp[0], pl, e, dP, nlxGFe, nlxGFc, nullptr);          // centre-of-mass nodes
               }
             }
           }
@@ -1051,6 +1237,11 @@ class Problem {
                   d2pos(s, t, pe, k2, l2, q2);
                   hdd(b.ee, k2, b.ee, l2, lam[row] * (in.normal[0] * q2[0] + in.normal[1] * q2[1] + in.normal[2] * q2[2]));
                 }
+            if (DX && lam[row] != 0.0) {
+              DurX dx; dur_cross(s, t, pe, dx);
+              const double Bv[3] = {lam[row] * in.normal[0], lam[row] * in.normal[1], lam[row] * in.normal[2]};
+              xrecord(s, pe, b.ee, dx, nullptr, nullptr, Bv);
+            }
           }
         } break;
         case FAM_TOTALTIME: { // total_duration_constraint.cpp:60-82
@@ -1111,6 +1302,10 @@ class Problem {
           if (D2 && s.phase_based)
             for (int k2 = 0; k2 < nvar_of(s.ee); ++k2)
               for (int l2 = 0; l2 <= k2; ++l2) { double q2[3]; d2pos(s, t, pe, k2, l2, q2); hdd(s.ee, k2, s.ee, l2, -w * r * q2[d]); }
+          if (DX && s.phase_based) {      // residual curvature of the node x duration block: -w r d2p/dx dT (the product of first derivatives is the Gauss-Newton part)
+            DurX dx; dur_cross(s, t, pe, dx);
+            xcross(s, pe, d, dx.ome, s.ee, dx, -w * r, 0.0); xcross(s, pe, d, dx.omc, s.ee, dx, 0.0, -w * r);
+          }
         }
         t += in.dt;                                                   // :48
       }
@@ -1141,6 +1336,11 @@ class Problem {
                   d2pos(s, t + in.dt, pe2, k2, l2, qb); d2pos(s, t, pe, k2, l2, qa);
                   hdd(s.ee, k2, s.ee, l2, w * r * (qb[d] - qa[d]));
                 }
+            if (DX && s.phase_based && which == kPos) {
+              DurX da, db; dur_cross(s, t, pe, da); dur_cross(s, t + in.dt, pe2, db);
+              xcross(s, pe2, d, db.ome, s.ee, db, w * r, 0.0); xcross(s, pe2, d, db.omc, s.ee, db, 0.0, w * r);
+              xcross(s, pe, d, da.ome, s.ee, da, -w * r, 0.0); xcross(s, pe, d, da.omc, s.ee, da, 0.0, -w * r);
+            }
           }
         }
       }

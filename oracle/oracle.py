@@ -58,6 +58,9 @@ def lib():
         L.orc_sample_solution.restype = C.c_int
         L.orc_solve_stage.argtypes = [C.c_void_p, C.c_int, C.c_int, PD]
         L.orc_solve_stage.restype = C.c_int
+        L.orc_set_study_mask.argtypes = [C.c_int, C.c_double]
+        if os.environ.get('ORC_STUDY_MASK'):          # study runs only (tests/tools): 0 = the shipped algorithm
+            L.orc_set_study_mask(int(os.environ['ORC_STUDY_MASK']), float(os.environ.get('ORC_CLIP_CAP', '0')))
         _LIB = L
     return _LIB
 

@@ -6,11 +6,13 @@
 
 using namespace orc;
 
-static int g_verbose = 0, g_inertia_retry = 1, g_stall_window = 0, g_lbfgs = 0;
+static int g_verbose = 0, g_inertia_retry = 1, g_stall_window = 0, g_lbfgs = 0, g_study_mask = 0;
 extern "C" {
 void orc_set_verbose(int v) { g_verbose = v; }
 void orc_set_inertia_retry(int v) { g_inertia_retry = v; }
 void orc_set_stall_window(int v) { g_stall_window = v; }
+static double g_clip_cap = 1e300;
+void orc_set_study_mask(int v, double clip_cap) { g_study_mask = v; g_clip_cap = clip_cap > 0 ? clip_cap : 1e300; }      // Problem::study_mask (0 = the shipped algorithm)
 void orc_set_ipopt_like(int v) { g_lbfgs = v; }      // L-BFGS(6) + mu_init 0.1 on every stage: see IpmOptions::lbfgs (oracle-only study mode)
 
 struct orc_seq_in {
@@ -81,6 +83,7 @@ void orc_eval(void* h, const double* x, double* f, double* grad, double* c, doub
   ((Problem*)h)->eval(x, f, grad, c, J, H);
 }
 void orc_eval_lam(void* h, const double* x, const double* lam, double* f, double* grad, double* c, double* J, double* H) {
+  ((Problem*)h)->study_mask = g_study_mask; ((Problem*)h)->clip_cap = g_clip_cap;
   ((Problem*)h)->eval(x, f, grad, c, J, H, lam);
 }
 void orc_bounds(void* h, double* cl, double* cu) {
@@ -121,6 +124,7 @@ int orc_sample_solution(void* h, int cap, int* num_frames_header, double* base_l
 int orc_solve_stage(void* h, int stage, int max_iter, double* stats /*8*/) {
   Problem* p = (Problem*)h;
   p->set_stage(stage);
+  p->study_mask = g_study_mask; p->clip_cap = g_clip_cap;
   IpmOptions opt;
   opt.max_iter = max_iter > 0 ? max_iter : p->cfg.max_iter[stage];
   opt.ref_tol = p->cfg.tol;
