@@ -34,7 +34,7 @@ CAPS = [7000, 7000, 7000, 2500, 2000, 7000]
 
 def kernel_sources_sha256():
     """Hash of the solver kernel's sources: profiles/traffic.json carries the one its PMC passes were measured with (tools/pmc_summary.py)."""
-    return _sources_sha256(('chd_kernels.hpp', 'chd_phys.hip', 'chd_model.hpp', 'chd_device.hpp'))
+    return _sources_sha256(('chd_kernels.hpp', 'chd_kfront.hpp', 'chd_phys.hip', 'chd_model.hpp', 'chd_device.hpp', 'chd_io.hpp'))      # = phys_optim.SOURCES
 
 
 def _sources_sha256(files):
@@ -165,7 +165,12 @@ def contact_net_rate(device, n_videos=128, frames=FRAMES, reps=20):
             model(x)
         sync(); t_fwd = (time.perf_counter() - t0) / reps
     nfr = n_videos * frames
+    wbytes = sum(p.numel() * p.element_size() for p in model.parameters()) + sum(b.numel() * b.element_size() for b in model.buffers())
+    abytes = wbytes + int(x.numel()) * 4 + int(x.shape[0]) * 20 * 4      # weights once per launch sequence + 351 floats in, 20 out per window
     out = {'fps': nfr / t_fwd, 'fps_end_to_end': nfr / t_all, 'unit': 'frames/s', 'videos': n_videos, 'frames': frames,
+           'roofline': {'bound': 'hbm', 'achieved': abytes / t_fwd / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': abytes / t_fwd / 1e9 / HBM_PEAK_GBS,
+                        'algorithmic_bytes_per_forward': abytes, 'weight_bytes': wbytes, 'flops_per_forward': 2 * 0.954e6 * int(x.shape[0]),
+                        'note': 'forward pass of all windows of all videos (library GEMMs of PyTorch-ROCm); 5 small layers: launch-latency bound at this size'},
            'windows': int(x.shape[0]), 'dtype': 'f32', 'device': str(device),
            'note': 'fps: forward pass, windows resident on the device; fps_end_to_end: NumPy pre-processing + upload + forward + vote merge; '
                    'fps_end_to_end_device_ops: the same with gap interpolation, windowing and vote merge as tensor ops on the device'}
@@ -219,7 +224,7 @@ def kinematic_optimisation_rate(device_index, n_clips=256, frames=100):
         tj = json.load(open(os.path.join(ROOT, 'profiles', 'kinopt_traffic.json')))
         if (tj['clips'], tj['frames']) == (n_clips, frames):
             traffic = tj['hbm_bytes_per_batch']; tnote = tj.get('note', '')
-            if tj.get('sources_sha256') != _sources_sha256(('chd_kinopt_kernels.hpp',)):
+            if tj.get('sources_sha256') != _sources_sha256(('chd_kinopt.hip', 'chd_kinopt_kernels.hpp')) or tj.get('lds_doubles') != 18432:      # kernel AND launch (tile size, launch bounds)
                 tnote = 'STALE (kernel source changed since the PMC passes): ' + tnote
     except Exception:
         pass
@@ -249,6 +254,7 @@ def main(argv=None, solver_factory=None):
     ap.add_argument('--towr_phys_optim_path', default=os.environ.get('TOWR_PHYS_OPTIM_PATH', ''),
                     help='directory of a REFERENCE phys_optim binary (scripts/run_phys_mocap.py:26): if one is found there it is run on the first sequences of the workload, '
                          'compared with the HIP results and timed as the CPU baseline (kind "reference")')
+    ap.add_argument('--all-factorisations', action='store_true', help='also time the two alternative factorisations on the same workload (side runs)')
     ap.add_argument('--no-cpu-baseline', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--no-side-metrics', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--worker', action='store_true', help=argparse.SUPPRESS)        # (accepted for old command lines; no effect)
@@ -315,9 +321,14 @@ def main(argv=None, solver_factory=None):
     res = batch.fetch()
     n_ok = sum(1 for r in res if r.dynamics_succeed and r.durations_succeed)
     sizes = res[0].sizes
+    total_value_hint = B * steps / elapsed          # (solve-only sequences/s of this rank)
 
-    # side runs (one GPU, outside the timed region of `value`): the same workload with the stall guard, with the other factorisation,
-    # and BASELINE configs[2]'s per-GPU slice (4 000 sequences / 8 GPUs = 500 in one call)
+    def np_eq(a, b_):
+        import numpy as _np
+        return _np.array_equal(_np.asarray(a), _np.asarray(b_))
+
+    # side runs (one GPU, outside the timed region of `value`): the whole call a user makes on the same sequences (set-up + upload + solve + fetch,
+    # pipelined; and file to file), the stall guard, BASELINE configs[2]'s per-GPU slice (4 000 sequences / 8 GPUs = 500 in one call), configs[4] (600 frames)
     side = {}
     if world == 1 and not args.no_side_metrics:
         def timed_solve(sq, **kw):
@@ -329,15 +340,60 @@ def main(argv=None, solver_factory=None):
             b2.free(); s2.close()
             return len(sq) / dt2, st2
         try:
+            # (a) chd_phys_solve_batch: what the reference does inside the process it would be timed as (phys_optim.cpp:428-540 set-up + solve + SaveSolution arrays)
+            t1 = time.perf_counter(); res_incl, cs = solver.solve_batch(seqs); dt_incl = time.perf_counter() - t1
+            side['value_including_setup'] = len(seqs) / dt_incl
+            side['setup_ms_per_sequence'] = cs['setup_cpu_ms'] / max(1, cs['n_sequences'])
+            side['including_setup'] = {'seconds': dt_incl, 'host_threads': cs['host_threads'], 'chunks': cs['n_chunks'], 'chunk': cs['chunk'],
+                                       'setup_wall_ms': cs['setup_wall_ms'], 'upload_ms': cs['upload_ms'], 'host_waited_for_device_ms': cs['wait_for_pool_ms'],
+                                       'kernel_ms_sum_over_chunks': cs['kernel_ms'], 'iterations': cs['total_iters'], 'fallbacks': cs['n_fallback'],
+                                       'identical_to_split_interface': bool(all(a.stage_iters == b_.stage_iters and all(np_eq(x.base_lin, y.base_lin) for x, y in zip(a.snapshots, b_.snapshots))
+                                                                               for a, b_ in zip(res_incl, res))),
+                                       'host_cores_to_keep_one_gpu_busy': cs['setup_cpu_ms'] / max(1e-9, 1e3 * len(seqs) / (total_value_hint or 1.0)),
+                                       'note': 'chd_phys_solve_batch on the SAME %d sequences: table build on the host threads, upload, persistent launches (up to 3 chunks in flight), '
+                                               'stage-4 fallbacks, fetch -- one call, wall clock; host_cores_to_keep_one_gpu_busy = set-up thread-seconds per second of solve-only rate' % len(seqs)}
+            # (b) the same file to file ("I/O-inclusive figure reported separately"): chd_phys_solve_dirs on 1 024 directories of the workload
+            import tempfile
+            import shutil
+            from chd_amd import io_formats as iof
+            nd = min(1024, len(seqs))
+            root = tempfile.mkdtemp(prefix='chd_bench_dirs_')
+            try:
+                ins, outs_ = [], []
+                for i in range(nd):
+                    d_in = os.path.join(root, 'v%05d' % i, 'phys_optim_in_ybot'); d_out = os.path.join(root, 'v%05d' % i, 'phys_optim_out_ybot')
+                    iof.write_inputs(seqs[i], d_in); os.makedirs(d_out)
+                    ins.append(d_in); outs_.append(d_out)
+                t1 = time.perf_counter(); stt = solver.solve_dirs(ins, outs_, [args.frames] * nd); dt_io = time.perf_counter() - t1
+                cs2 = solver.call_stats()
+                side['value_including_file_io'] = nd / dt_io
+                side['including_file_io'] = {'directories': nd, 'seconds': dt_io, 'failures': int(sum(1 for v in stt if v != 0)), 'read_ms': cs2['prep_ms'], 'write_ms_overlapped': cs2['finish_ms'],
+                                             'note': 'chd_phys_solve_dirs: 4 input files parsed + set-up + solve + 4 output files written per directory (tmpfs/page cache), one call'}
+            finally:
+                shutil.rmtree(root, ignore_errors=True)
+        except Exception as exc:
+            side['inclusive_run_error'] = '%s: %s' % (type(exc).__name__, exc)
+        try:
             v, st2 = timed_solve(seqs, stall_window=150)
             side['value_with_stall_guard_150'] = v; side['stall_guard_150_hits'] = st2['n_stalled']; side['stall_guard_150_fallbacks'] = st2['n_fallback']
-            for kind, name in ((0, 'right_looking'), (1, 'left_looking'), (2, 'register_front')):      # the other factorisations on the same workload
-                if kind != args.factorisation:
-                    v, st2 = timed_solve(seqs, factorisation=kind)
-                    side['value_%s_factorisation' % name] = v
+            if args.all_factorisations:                                                       # (the two alternatives nobody defaults: behind a flag)
+                for kind, name in ((0, 'right_looking'), (1, 'left_looking'), (2, 'register_front')):
+                    if kind != args.factorisation:
+                        v, st2 = timed_solve(seqs, factorisation=kind)
+                        side['value_%s_factorisation' % name] = v
             v, st2 = timed_solve(seqs[:500])
             side['value_500_sequences_in_one_call'] = v
             side['kernel_busy_fraction_500_sequences'] = st2['phase_ms'][5] / max(1e-9, st2['n_workgroups'] * (st2['kernel_ms'][0] + st2['kernel_ms'][1]))
+            # BASELINE configs[4]: one 600-frame sequence on a 10-degree floor, alone in a launch
+            sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+            import make_bench_parity_golden as mk
+            long_seq = mk.make_case(0, 600, 10.0)
+            s3 = PhysOptim(device=local, config=default_config())
+            t1 = time.perf_counter(); b3 = s3.upload([long_seq]); t_up = time.perf_counter() - t1
+            st3 = b3.solve(); r3 = b3.fetch()[0]; b3.free(); s3.close()
+            side['long_600_frames'] = {'upload_seconds_incl_table_build': t_up, 'kernel_ms': st3['kernel_ms'][0] + st3['kernel_ms'][1], 'iterations': st3['total_iters'],
+                                       'kkt_dim': r3.sizes['kkt_dim'], 'halfband': r3.sizes['halfband'], 'border': r3.sizes['border'], 'stage_status': list(r3.stage_status),
+                                       'time_share': {k: st3['phase_ms'][i] / max(1e-9, st3['phase_ms'][5]) for k, i in (('evaluation_full', 0), ('evaluation_values', 1), ('factorisation', 2), ('substitution', 3), ('kkt_matvec', 4))}}
         except Exception as exc:
             side['side_run_error'] = '%s: %s' % (type(exc).__name__, exc)
 

@@ -6,9 +6,13 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -84,21 +88,28 @@ __global__ __launch_bounds__(CHD_MAX_THREADS) void chd_debug_linsolve_kernel(con
   debug_linsolve((QP)&s_desc, *(LCtx*)&s_ctx, stage, (LdsD*)lds, lds_doubles, dw, dval, which, reps, (const GD*)rhs, (GD*)x, out);
 }
 
+// A handle owns CHD_N_POOLS workspace pools (one workspace per resident workgroup each) with a stream of their own: a launch uses one pool, so up to
+// CHD_N_POOLS persistent launches can be in flight -- chunk k + 1 of a pipelined call starts filling the compute units that chunk k's last
+// sequences leave idle, while the host builds the tables of chunk k + 2.  The split interface (chd_batch_solve) uses pool 0 only; the other
+// pools are allocated when a pipelined call first needs them.
+#define CHD_N_POOLS 3
 struct chd_handle {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream[CHD_N_POOLS] = {nullptr, nullptr, nullptr};
   chd_config cfg;
   std::string err;
   int lds_bytes = 0;
   int threads = CHD_MAX_THREADS;
   int n_wg = 0;                        // resident workgroups of a launch
-  // workgroup workspaces (grow-only) and the queue counter
-  double* d_wd = nullptr; int* d_wi = nullptr; int* d_counter = nullptr;
+  // workgroup workspaces (grow-only)
+  double* d_wd[CHD_N_POOLS] = {nullptr, nullptr, nullptr}; int* d_wi[CHD_N_POOLS] = {nullptr, nullptr, nullptr};
   long long wd_stride = 0, wi_stride = 0;
+  chd_call_stats call{};               // accounting of the last chd_phys_solve_batch / chd_phys_solve_dirs
 };
 
 struct chd_batch {
   int B = 0;
+  int pool = 0;                          // workspace pool / stream of this batch's launches
   std::vector<SeqModel> models;
   std::vector<SeqDesc> descs;            // host copy with DEVICE pointers
   std::vector<char> ok;                  // 0: rejected at set-up (build_err), never queued
@@ -108,12 +119,13 @@ struct chd_batch {
   long long tot_cd = 0, tot_ci = 0, od_stride = 0, oi_stride = 0;      // results: one fixed-size slot per sequence (strided copies of the statistics)
   long long wd_need = 0, wi_need = 0;
   double *d_cd = nullptr, *d_od = nullptr, *d_f = nullptr, *d_x = nullptr;
-  int *d_ci = nullptr, *d_oi = nullptr, *d_order = nullptr;
+  int *d_ci = nullptr, *d_oi = nullptr, *d_order = nullptr, *d_counter = nullptr;
   long long x_cap = 0;
   SeqDesc* d_descs = nullptr;
   std::vector<double> h_od;
   std::vector<int> h_oi;
   bool solved = false, fetched = false;
+  double build_cpu_ms = 0;               // host time of the table builder, summed over the sequences (thread time, not wall)
   chd_batch_stats stats{};
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
@@ -136,135 +148,77 @@ static void host_parallel_for(int n, F fn) {
   for (auto& th : pool) th.join();
 }
 
-extern "C" {
-
-int chd_phys_version(void) { return CHD_PHYS_ABI_VERSION; }
-
-void chd_config_default(chd_config* c) {
-  c->w_com_lin = 0.4; c->w_com_ang = 1.7; c->w_ee = 0.3; c->w_smooth = 0.1; c->w_dur = 0.1;     // phys_optim.cpp:27-31
-  const int mi[CHD_N_STAGES] = {7000, 7000, 7000, 2500, 2000, 7000};                              // :571, :640, :652, :706, :743
-  for (int i = 0; i < CHD_N_STAGES; ++i) c->max_iter[i] = mi[i];
-  c->tol = 1e-3;                                                                                   // :578
-  c->threads_per_sequence = 0;
-  c->stall_window = 0;
-  c->max_workgroups = 0;
-  c->lds_kilobytes = 0;
-  c->factorisation = 0;
-  for (int i = 0; i < 3; ++i) c->reserved[i] = 0;
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static unsigned host_threads(int n) {
+  unsigned nt = std::thread::hardware_concurrency();
+  if (nt == 0) nt = 4;
+  if (nt > 32) nt = 32;
+  if ((int)nt > n) nt = (unsigned)(n > 0 ? n : 1);
+  return nt;
 }
 
-int chd_phys_create(const chd_config* cfg, int device_id, chd_handle** out) {
-  if (!out) return -1;
-  *out = nullptr;
-  chd_handle* h = new chd_handle();
-  if (cfg) h->cfg = *cfg; else chd_config_default(&h->cfg);
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
-    std::fprintf(stderr, "chd_phys_create: no HIP device available (this library has no CPU path)\n");
-    delete h; return -2;
-  }
-  if (device_id < 0 || device_id >= ndev) { std::fprintf(stderr, "chd_phys_create: bad device id %d (have %d)\n", device_id, ndev); delete h; return -3; }
-  h->device = device_id;
-  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return -4; }
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { delete h; return -5; }
-  size_t lds = prop.maxSharedMemoryPerMultiProcessor;
-  if (lds > 160 * 1024) lds = 160 * 1024;
-  if (lds < 64 * 1024) lds = 64 * 1024;
-  h->lds_bytes = (int)lds - 12288;    // the 12 KB hold the kernel's static LDS: sequence descriptor + solver context (2.4 KB), cumulative-time tables (5.6 KB)
-  if (h->cfg.lds_kilobytes > 0 && h->cfg.lds_kilobytes * 1024 < h->lds_bytes) h->lds_bytes = std::max(32, h->cfg.lds_kilobytes) * 1024;
-  hipFuncSetAttribute((const void*)chd_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
-  hipFuncSetAttribute((const void*)chd_debug_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
-  hipFuncSetAttribute((const void*)chd_debug_linsolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
-  // the factorisation / substitution phases are written for eight wavefronts (wave-specialised look-ahead, register prefetch
-  // by lane group): other workgroup sizes are refused rather than silently mis-solved
-  // (experiment, profiles/r02k_final/two_workgroups.md: with CHD_EXPERIMENTAL_256 set, 256-thread workgroups -- two per compute unit with
-  //  76 KB of LDS each -- solve correctly through the generic substitution, at 0.8x the throughput)
-  const bool exp256 = h->cfg.threads_per_sequence == 256 && std::getenv("CHD_EXPERIMENTAL_256") != nullptr;
-  if (h->cfg.threads_per_sequence != 0 && h->cfg.threads_per_sequence != CHD_MAX_THREADS && !exp256) {
-    std::fprintf(stderr, "chd_phys_create: threads_per_sequence must be 0 or %d\n", CHD_MAX_THREADS);
-    (void)hipStreamDestroy(h->stream); delete h; return -7;
-  }
-  h->threads = exp256 ? 256 : CHD_MAX_THREADS;
-  h->n_wg = h->cfg.max_workgroups > 0 ? h->cfg.max_workgroups : prop.multiProcessorCount;
-  if (h->n_wg < 1) h->n_wg = 1;
-  if (hipMalloc((void**)&h->d_counter, 64) != hipSuccess) { (void)hipStreamDestroy(h->stream); delete h; return -6; }
-  *out = h;
-  return 0;
-}
-
-void chd_phys_destroy(chd_handle* h) {
-  if (!h) return;
-  (void)hipSetDevice(h->device);
-  (void)hipFree(h->d_wd); (void)hipFree(h->d_wi); (void)hipFree(h->d_counter);
-  if (h->stream) (void)hipStreamDestroy(h->stream);
-  delete h;
-}
-
-const char* chd_phys_last_error(const chd_handle* h) { return h ? h->err.c_str() : "null handle"; }
-
-// workspaces for `n_wg` resident workgroups of at least (wd_need, wi_need) elements each
-static int ensure_workspace(chd_handle* h, long long wd_need, long long wi_need) {
-  if (h->d_wd && wd_need <= h->wd_stride && wi_need <= h->wi_stride) return 0;
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
-  (void)hipFree(h->d_wd); (void)hipFree(h->d_wi);
-  h->d_wd = nullptr; h->d_wi = nullptr;
+// workspaces of pool `pool` for `n_wg` resident workgroups of at least (wd_need, wi_need) elements each.  The stride is common to all pools: when it
+// has to grow, every pool that exists is reallocated (the caller makes sure no launch is in flight).
+static int ensure_workspace(chd_handle* h, int pool, long long wd_need, long long wi_need) {
   auto al = [](long long v) { return (v + 63) & ~63LL; };
-  h->wd_stride = std::max(h->wd_stride, al(wd_need)); h->wi_stride = std::max(h->wi_stride, al(wi_need));
-  hipError_t e = hipMalloc((void**)&h->d_wd, (size_t)h->wd_stride * 8 * h->n_wg);
-  if (e == hipSuccess) e = hipMalloc((void**)&h->d_wi, (size_t)h->wi_stride * 4 * h->n_wg);
+  const bool grow = al(wd_need) > h->wd_stride || al(wi_need) > h->wi_stride;
+  if (!grow && h->d_wd[pool]) return 0;
+  if (grow) {
+    for (int p = 0; p < CHD_N_POOLS; ++p) {
+      if (!h->d_wd[p]) continue;
+      HIP_TRY(h, hipStreamSynchronize(h->stream[p]));
+      (void)hipFree(h->d_wd[p]); (void)hipFree(h->d_wi[p]);
+      h->d_wd[p] = nullptr; h->d_wi[p] = nullptr;
+    }
+    h->wd_stride = std::max(h->wd_stride, al(wd_need)); h->wi_stride = std::max(h->wi_stride, al(wi_need));
+  }
+  hipError_t e = hipMalloc((void**)&h->d_wd[pool], (size_t)h->wd_stride * 8 * h->n_wg);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_wi[pool], (size_t)h->wi_stride * 4 * h->n_wg);
   if (e != hipSuccess) {
-    (void)hipFree(h->d_wd); h->d_wd = nullptr; h->wd_stride = h->wi_stride = 0;
+    (void)hipFree(h->d_wd[pool]); h->d_wd[pool] = nullptr; h->d_wi[pool] = nullptr;
     return fail(h, std::string("workspace allocation (") + std::to_string((h->wd_stride * 8 + h->wi_stride * 4) * h->n_wg >> 20) + " MiB): " + hipGetErrorString(e));
   }
   // (no clearing needed for correctness: a workgroup zeroes / initialises what it reads, sequence by sequence and stage by stage)
-  HIP_TRY(h, hipMemsetAsync(h->d_wd, 0, (size_t)h->wd_stride * 8 * h->n_wg, h->stream));
-  HIP_TRY(h, hipMemsetAsync(h->d_wi, 0, (size_t)h->wi_stride * 4 * h->n_wg, h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->d_wd[pool], 0, (size_t)h->wd_stride * 8 * h->n_wg, h->stream[pool]));
+  HIP_TRY(h, hipMemsetAsync(h->d_wi[pool], 0, (size_t)h->wi_stride * 4 * h->n_wg, h->stream[pool]));
   return 0;
 }
 
-void chd_batch_free(chd_handle* h, chd_batch* b) {
-  if (!b) return;
-  if (h) (void)hipSetDevice(h->device);
-  (void)hipFree(b->d_cd); (void)hipFree(b->d_ci); (void)hipFree(b->d_od); (void)hipFree(b->d_oi);
-  (void)hipFree(b->d_descs); (void)hipFree(b->d_order); (void)hipFree(b->d_f); (void)hipFree(b->d_x);
-  for (int k = 0; k < 4; ++k) if (b->ev[k]) (void)hipEventDestroy(b->ev[k]);
-  delete b;
-}
-
-int chd_batch_upload(chd_handle* h, int B, const chd_seq_in* in, chd_batch** out) {
-  if (!h || !in || !out || B <= 0) return fail(h, "chd_batch_upload: bad arguments");
-  *out = nullptr;
-  HIP_TRY(h, hipSetDevice(h->device));
+// ---- host half of an upload: the per-sequence NLP structure tables (phys_optim.cpp:428-540, nlp_formulation.cpp:79-203), on `nt` threads.  A sequence
+// whose set-up fails (too short, inconsistent contact schedule, degenerate floor normal ...) is rejected on its own -- the reference runs one process per
+// video, so a bad video only loses itself (run_phys_mocap.py:159-174) -- and the rest of the batch is solved.  No HIP call in here.
+static chd_batch* batch_build(const chd_config& cfg, int B, const chd_seq_in* in, unsigned nt) {
   chd_batch* b = new chd_batch();
   b->B = B;
   b->models.resize(B);
   b->ok.assign(B, 1); b->build_err.assign(B, std::string());
-  // ---- structure tables on the host, in parallel.  A sequence whose set-up fails (too short, inconsistent contact
-  // schedule, degenerate floor normal ...) is rejected on its own -- the reference runs one process per video, so a bad
-  // video only loses itself (run_phys_mocap.py:159-174) -- and the rest of the batch is solved.
-  {
-    unsigned nt = std::thread::hardware_concurrency();
-    if (nt == 0) nt = 4;
-    if (nt > 32) nt = 32;
-    if ((int)nt > B) nt = B;
+  if (nt < 1) nt = 1;
+  if ((int)nt > B) nt = (unsigned)B;
+  std::vector<double> cpu(nt, 0.0);
+  auto body = [&](unsigned t) {
+    const double t0 = now_ms();
+    for (int i = (int)t; i < B; i += (int)nt) {
+      try { b->models[i].build(in[i], cfg); }
+      catch (const std::exception& e) { b->ok[i] = 0; b->build_err[i] = e.what(); }
+      catch (...) { b->ok[i] = 0; b->build_err[i] = "set-up failed"; }
+    }
+    cpu[t] = now_ms() - t0;
+  };
+  if (nt == 1) body(0);
+  else {
     std::vector<std::thread> pool;
-    for (unsigned t = 0; t < nt; ++t)
-      pool.emplace_back([&, t]() {
-        for (int i = t; i < B; i += nt) {
-          try { b->models[i].build(in[i], h->cfg); }
-          catch (const std::exception& e) { b->ok[i] = 0; b->build_err[i] = e.what(); }
-          catch (...) { b->ok[i] = 0; b->build_err[i] = "set-up failed"; }
-        }
-      });
+    for (unsigned t = 0; t < nt; ++t) pool.emplace_back(body, t);
     for (auto& th : pool) th.join();
   }
+  for (double v : cpu) b->build_cpu_ms += v;
   for (int i = 0; i < B; ++i) if (b->ok[i]) b->order.push_back(i);
-  if (b->order.empty()) { std::string m = "no solvable sequence in the batch (sequence 0: " + b->build_err[0] + ")"; chd_batch_free(h, b); return fail(h, m); }
-  for (int i = 0; i < B; ++i) if (!b->ok[i]) h->err = "sequence " + std::to_string(i) + " rejected: " + b->build_err[i];
-  // longest sequences first (cost ~ frames x iterations: the queue's tail is made of the short ones)
-  std::stable_sort(b->order.begin(), b->order.end(), [&](int a, int c2) { return b->models[a].d.F > b->models[c2].d.F; });
-  // ---- pool layout
+  // queue order: longest sequences first, and among equal lengths the ones with the most contact phases first (a launch lasts as long as its last
+  // sequence: the expensive ones must not start last.  Iterations of the duration stage grow with the number of duration variables.)
+  std::stable_sort(b->order.begin(), b->order.end(), [&](int a, int c2) {
+    const SeqDesc& da = b->models[a].d; const SeqDesc& dc = b->models[c2].d;
+    if (da.F != dc.F) return da.F > dc.F;
+    return da.tot_phases > dc.tot_phases;
+  });
   auto al = [](long long v) { return (v + 31) & ~31LL; };
   b->off_cd.assign(B, 0); b->off_ci.assign(B, 0);
   for (int i = 0; i < B; ++i) {
@@ -276,17 +230,26 @@ int chd_batch_upload(chd_handle* h, int B, const chd_seq_in* in, chd_batch** out
     b->od_stride = std::max(b->od_stride, al(out_d_size(M.d.cap, M.d.tot_entries + M.d.tot_phases)));
     b->oi_stride = std::max(b->oi_stride, al(out_i_size(M.d.cap)));
   }
-  auto bail = [&](const char* what, hipError_t e) { std::string m = std::string(what) + ": " + hipGetErrorString(e); chd_batch_free(h, b); return fail(h, m); };
+  return b;
+}
+
+// ---- device half of an upload: pools, descriptors, result slots (on the stream of the batch's pool)
+static int batch_to_device(chd_handle* h, chd_batch* b, int pool) {
+  const int B = b->B;
+  b->pool = pool;
+  hipStream_t st = h->stream[pool];
+  auto bail = [&](const char* what, hipError_t e) { return fail(h, std::string(what) + ": " + hipGetErrorString(e)); };
   hipError_t e;
-  if ((e = hipMalloc((void**)&b->d_cd, b->tot_cd * 8)) != hipSuccess) return bail("hipMalloc cd", e);
-  if ((e = hipMalloc((void**)&b->d_ci, b->tot_ci * 4)) != hipSuccess) return bail("hipMalloc ci", e);
+  if ((e = hipMalloc((void**)&b->d_cd, std::max<long long>(b->tot_cd, 1) * 8)) != hipSuccess) return bail("hipMalloc cd", e);
+  if ((e = hipMalloc((void**)&b->d_ci, std::max<long long>(b->tot_ci, 1) * 4)) != hipSuccess) return bail("hipMalloc ci", e);
   if ((e = hipMalloc((void**)&b->d_od, b->od_stride * 8 * B)) != hipSuccess) return bail("hipMalloc od", e);
   if ((e = hipMalloc((void**)&b->d_oi, b->oi_stride * 4 * B)) != hipSuccess) return bail("hipMalloc oi", e);
   if ((e = hipMalloc((void**)&b->d_descs, sizeof(SeqDesc) * B)) != hipSuccess) return bail("hipMalloc descs", e);
   if ((e = hipMalloc((void**)&b->d_order, sizeof(int) * B)) != hipSuccess) return bail("hipMalloc order", e);
+  if ((e = hipMalloc((void**)&b->d_counter, 64)) != hipSuccess) return bail("hipMalloc counter", e);
   if ((e = hipMalloc((void**)&b->d_f, 64)) != hipSuccess) return bail("hipMalloc f", e);
-  if ((e = hipMemsetAsync(b->d_od, 0, b->od_stride * 8 * B, h->stream)) != hipSuccess) return bail("memset od", e);
-  if ((e = hipMemsetAsync(b->d_oi, 0, b->oi_stride * 4 * B, h->stream)) != hipSuccess) return bail("memset oi", e);
+  if ((e = hipMemsetAsync(b->d_od, 0, b->od_stride * 8 * B, st)) != hipSuccess) return bail("memset od", e);
+  if ((e = hipMemsetAsync(b->d_oi, 0, b->oi_stride * 4 * B, st)) != hipSuccess) return bail("memset oi", e);
   // ---- stage pools through one staging buffer each
   {
     std::vector<double> hcd(b->tot_cd, 0.0);
@@ -296,36 +259,35 @@ int chd_batch_upload(chd_handle* h, int B, const chd_seq_in* in, chd_batch** out
       std::copy(b->models[i].cd.begin(), b->models[i].cd.end(), hcd.begin() + b->off_cd[i]);
       std::copy(b->models[i].ci.begin(), b->models[i].ci.end(), hci.begin() + b->off_ci[i]);
     }
-    if ((e = hipMemcpy(b->d_cd, hcd.data(), b->tot_cd * 8, hipMemcpyHostToDevice)) != hipSuccess) return bail("copy cd", e);
-    if ((e = hipMemcpy(b->d_ci, hci.data(), b->tot_ci * 4, hipMemcpyHostToDevice)) != hipSuccess) return bail("copy ci", e);
+    if ((e = hipMemcpyAsync(b->d_cd, hcd.data(), b->tot_cd * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return bail("copy cd", e);
+    if ((e = hipMemcpyAsync(b->d_ci, hci.data(), b->tot_ci * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return bail("copy ci", e);
+    b->descs.resize(B);
+    for (int i = 0; i < B; ++i) {
+      SeqDesc dd = b->models[i].d;
+      dd.cd = (const GD*)(b->d_cd + b->off_cd[i]); dd.ci = (const GI*)(b->d_ci + b->off_ci[i]);
+      dd.wd = nullptr; dd.wi = nullptr;            // the workgroup that takes the sequence fills in its own workspace
+      dd.out_d = (GD*)(b->d_od + b->od_stride * i); dd.out_i = (GI*)(b->d_oi + b->oi_stride * i);
+      b->descs[i] = dd;
+    }
+    if ((e = hipMemcpyAsync(b->d_descs, b->descs.data(), sizeof(SeqDesc) * B, hipMemcpyHostToDevice, st)) != hipSuccess) return bail("copy descs", e);
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return bail("sync", e);          // (the staging buffers go out of scope)
   }
-  b->descs.resize(B);
-  for (int i = 0; i < B; ++i) {
-    SeqDesc dd = b->models[i].d;
-    dd.cd = (const GD*)(b->d_cd + b->off_cd[i]); dd.ci = (const GI*)(b->d_ci + b->off_ci[i]);
-    dd.wd = nullptr; dd.wi = nullptr;            // the workgroup that takes the sequence fills in its own workspace
-    dd.out_d = (GD*)(b->d_od + b->od_stride * i); dd.out_i = (GI*)(b->d_oi + b->oi_stride * i);
-    b->descs[i] = dd;
-  }
-  if ((e = hipMemcpy(b->d_descs, b->descs.data(), sizeof(SeqDesc) * B, hipMemcpyHostToDevice)) != hipSuccess) return bail("copy descs", e);
   for (int k = 0; k < 4; ++k) if ((e = hipEventCreate(&b->ev[k])) != hipSuccess) return bail("hipEventCreate", e);
-  if (ensure_workspace(h, b->wd_need, b->wi_need) != 0) { std::string m = h->err; chd_batch_free(h, b); return fail(h, m); }
-  if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return bail("sync", e);
-  *out = b;
   return 0;
 }
 
-// one persistent launch over `items` (indices into the batch)
+// one persistent launch over `items` (indices into the batch), asynchronous: e1 is recorded behind the kernel
 static int launch_queue(chd_handle* h, chd_batch* b, const std::vector<int>& items, int stage_first, int stage_last, hipEvent_t e0, hipEvent_t e1) {
-  HIP_TRY(h, hipMemcpyAsync(b->d_order, items.data(), items.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipMemsetAsync(h->d_counter, 0, sizeof(int), h->stream));
+  hipStream_t st = h->stream[b->pool];
+  HIP_TRY(h, hipMemcpyAsync(b->d_order, items.data(), items.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  HIP_TRY(h, hipMemsetAsync(b->d_counter, 0, sizeof(int), st));
   const unsigned grid = (unsigned)std::min<size_t>(items.size(), (size_t)h->n_wg);
-  HIP_TRY(h, hipEventRecord(e0, h->stream));
-  hipLaunchKernelGGL(chd_solve_kernel, dim3(grid), dim3(h->threads), h->lds_bytes, h->stream, b->d_descs, (const int*)b->d_order, (int)items.size(),
-                     h->d_counter, h->d_wd, h->wd_stride, h->d_wi, h->wi_stride, h->lds_bytes / 8, h->cfg.tol, h->cfg.stall_window, stage_first, stage_last, (h->cfg.factorisation == 1 || h->cfg.factorisation == 2) ? h->cfg.factorisation : 0);
+  HIP_TRY(h, hipEventRecord(e0, st));
+  hipLaunchKernelGGL(chd_solve_kernel, dim3(grid), dim3(h->threads), h->lds_bytes, st, b->d_descs, (const int*)b->d_order, (int)items.size(),
+                     b->d_counter, h->d_wd[b->pool], h->wd_stride, h->d_wi[b->pool], h->wi_stride, h->lds_bytes / 8, h->cfg.tol, h->cfg.stall_window, stage_first, stage_last, (h->cfg.factorisation == 1 || h->cfg.factorisation == 2) ? h->cfg.factorisation : 0);
   HIP_TRY(h, hipGetLastError());
-  HIP_TRY(h, hipEventRecord(e1, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipEventRecord(e1, st));
+  HIP_TRY(h, hipStreamSynchronize(st));          // (the pageable `items` buffer: the copy has left it once this returns; the kernel is waited for through e1)
   return 0;
 }
 
@@ -337,19 +299,20 @@ static int fetch_stats(chd_handle* h, chd_batch* b, std::vector<double>& st) {
   return 0;
 }
 
-int chd_batch_solve(chd_handle* h, chd_batch* b) {
-  if (!h || !b) return fail(h, "chd_batch_solve: bad arguments");
-  HIP_TRY(h, hipSetDevice(h->device));
-  if (ensure_workspace(h, b->wd_need, b->wi_need) != 0) return -1;
+// ---- launch 1: stages 1.1, 1.2, 2.1, 2.2, 3 for every sequence
+static int solve_launch_main(chd_handle* h, chd_batch* b) {
   b->stats = chd_batch_stats{};
-  b->fetched = false;
-  HIP_TRY(h, hipMemsetAsync(b->d_od, 0, b->od_stride * 8 * b->B, h->stream));
-  // ---- launch 1: stages 1.1, 1.2, 2.1, 2.2, 3 for every sequence
-  if (launch_queue(h, b, b->order, 0, 4, b->ev[0], b->ev[1]) != 0) return -1;
+  b->fetched = false; b->solved = false;
+  HIP_TRY(h, hipMemsetAsync(b->d_od, 0, b->od_stride * 8 * b->B, h->stream[b->pool]));
+  return launch_queue(h, b, b->order, 0, 4, b->ev[0], b->ev[1]);
+}
+
+// ---- waits for launch 1, runs the stage-4 fallback where stage 3 failed (phys_optim.cpp:714), accounting
+static int solve_finish(chd_handle* h, chd_batch* b) {
+  HIP_TRY(h, hipEventSynchronize(b->ev[1]));
   float ms = 0;
   HIP_TRY(h, hipEventElapsedTime(&ms, b->ev[0], b->ev[1]));
   b->stats.kernel_ms[0] = ms;
-  // ---- which sequences need the stage-4 fallback (phys_optim.cpp:714)
   auto t0 = std::chrono::steady_clock::now();
   std::vector<double> st;
   if (fetch_stats(h, b, st) != 0) return -1;
@@ -366,10 +329,7 @@ int chd_batch_solve(chd_handle* h, chd_batch* b) {
       ph[k].resize(M.d.tot_phases);
       HIP_TRY(h, hipMemcpy(ph[k].data(), b->d_od + b->od_stride * idx[k] + out_d_state_off(M.d.cap) + M.d.tot_entries, ph[k].size() * 8, hipMemcpyDeviceToHost));
     }
-    unsigned nt = std::thread::hardware_concurrency();
-    if (nt == 0) nt = 4;
-    if (nt > 32) nt = 32;
-    if (nt > idx.size()) nt = (unsigned)idx.size();
+    const unsigned nt = host_threads((int)idx.size());
     std::vector<std::thread> pool;
     for (unsigned t = 0; t < nt; ++t)
       pool.emplace_back([&, t]() {
@@ -397,6 +357,7 @@ int chd_batch_solve(chd_handle* h, chd_batch* b) {
     }
     b->stats.host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (launch_queue(h, b, idx, 5, 5, b->ev[2], b->ev[3]) != 0) return -1;
+    HIP_TRY(h, hipEventSynchronize(b->ev[3]));
     HIP_TRY(h, hipEventElapsedTime(&ms, b->ev[2], b->ev[3]));
     b->stats.kernel_ms[1] = ms;
     if (fetch_stats(h, b, st) != 0) return -1;
@@ -437,16 +398,8 @@ int chd_batch_solve(chd_handle* h, chd_batch* b) {
   return 0;
 }
 
-int chd_batch_get_stats(chd_handle* h, chd_batch* b, chd_batch_stats* out) {
-  if (!h || !b || !out) return fail(h, "chd_batch_get_stats: bad arguments");
-  *out = b->stats;
-  return 0;
-}
-
-int chd_batch_fetch(chd_handle* h, chd_batch* b, chd_seq_out* out) {
-  if (!h || !b || !out) return fail(h, "chd_batch_fetch: bad arguments");
-  if (!b->solved) return fail(h, "chd_batch_fetch: batch not solved");
-  HIP_TRY(h, hipSetDevice(h->device));
+// results of a solved batch -> caller arrays
+static int batch_fetch(chd_handle* h, chd_batch* b, chd_seq_out* out) {
   if (!b->fetched) {
     b->h_od.resize((size_t)b->od_stride * b->B); b->h_oi.resize((size_t)b->oi_stride * b->B);
     HIP_TRY(h, hipMemcpy(b->h_od.data(), b->d_od, b->h_od.size() * 8, hipMemcpyDeviceToHost));
@@ -501,22 +454,252 @@ int chd_batch_fetch(chd_handle* h, chd_batch* b, chd_seq_out* out) {
   return 0;
 }
 
-int chd_phys_solve_batch(chd_handle* h, int B, const chd_seq_in* in, chd_seq_out* out) {
+// ---- the pipelined whole-call path (chd_phys_solve_batch, chd_phys_solve_dirs).
+// The B sequences are cut into chunks.  For chunk k, in this order: `prep` (e.g. parse the input files) and the table builder on all host cores;
+// upload + persistent launch on pool k mod CHD_N_POOLS, behind the launch of chunk k - CHD_N_POOLS; a finisher thread that waits for the launch, runs the
+// stage-4 fallback, fetches the results and calls `fin` (e.g. write the output files).  While the device works on chunks k and k - 1, the host
+// prepares chunk k + 1: the set-up (4.5 ms per 90-frame sequence and core) and the file I/O disappear behind the solve, and a chunk's last sequences
+// share the device with the next chunk's first ones.
+struct PipeChunk {
+  int c0 = 0, c1 = 0;
   chd_batch* b = nullptr;
-  int rc = chd_batch_upload(h, B, in, &b);
-  if (rc != 0) return rc;
-  rc = chd_batch_solve(h, b);
-  if (rc == 0) rc = chd_batch_fetch(h, b, out);
-  chd_batch_free(h, b);
-  return rc;
+  int rc = 0;
+  std::string err;
+  std::thread fin;
+  std::mutex mu; std::condition_variable cv; bool device_done = false;
+};
+template <class Prep, class Fin>
+static int solve_pipelined(chd_handle* h, int B, const chd_seq_in* in, chd_seq_out* out, Prep prep, Fin fin) {
+  HIP_TRY(h, hipSetDevice(h->device));
+  const double t_begin = now_ms();
+  h->call = chd_call_stats{};
+  int chunk = h->cfg.pipeline_chunk;
+  if (chunk == 0) { chunk = B / 8; if (chunk < 128) chunk = 128; if (chunk > 512) chunk = 512; }      // automatic
+  if (chunk < 0 || chunk > B) chunk = B;                                                                // < 0: one chunk, i.e. upload, solve, fetch in turn
+  const int K = (B + chunk - 1) / chunk;
+  std::vector<std::unique_ptr<PipeChunk>> ch;
+  for (int k = 0; k < K; ++k) { ch.emplace_back(new PipeChunk()); ch[k]->c0 = k * chunk; ch[k]->c1 = std::min(B, (k + 1) * chunk); }
+  const unsigned nt = host_threads(B);
+  std::string first_err;
+  int n_solved_chunks = 0;
+  std::mutex agg_mu;
+  double prep_ms = 0, build_wall_ms = 0, upload_ms = 0, wait_ms = 0;
+  for (int k = 0; k < K; ++k) {
+    PipeChunk& c = *ch[k];
+    const int n = c.c1 - c.c0;
+    double t0 = now_ms();
+    prep(c.c0, c.c1);
+    prep_ms += now_ms() - t0; t0 = now_ms();
+    c.b = batch_build(h->cfg, n, in + c.c0, nt);
+    build_wall_ms += now_ms() - t0;
+    h->call.setup_cpu_ms += c.b->build_cpu_ms;
+    for (int i = 0; i < n; ++i) if (!c.b->ok[i]) { std::lock_guard<std::mutex> lk(agg_mu); first_err = "sequence " + std::to_string(c.c0 + i) + " rejected: " + c.b->build_err[i]; }
+    const int pool = k % CHD_N_POOLS;
+    t0 = now_ms();
+    if (k >= CHD_N_POOLS) {            // the pool's previous launch (and its fallback) must be over
+      PipeChunk& p = *ch[k - CHD_N_POOLS];
+      std::unique_lock<std::mutex> lk(p.mu);
+      p.cv.wait(lk, [&] { return p.device_done; });
+    }
+    if (c.b->order.empty()) {            // nothing solvable in this chunk: results are the rejection marks
+      wait_ms += now_ms() - t0;
+      c.rc = 1;
+      { std::lock_guard<std::mutex> lk(c.mu); c.device_done = true; }
+      c.cv.notify_all();
+      c.b->fetched = true;               // (nothing on the device: the results are the rejection marks)
+      batch_fetch(h, c.b, out + c.c0);
+      fin(c.c0, c.c1);
+      continue;
+    }
+    if (c.b->wd_need > h->wd_stride || c.b->wi_need > h->wi_stride) {          // the workspaces have to grow: no launch may be in flight
+      for (int j = 0; j < k; ++j) { PipeChunk& p = *ch[j]; std::unique_lock<std::mutex> lk(p.mu); p.cv.wait(lk, [&] { return p.device_done; }); }
+    }
+    wait_ms += now_ms() - t0; t0 = now_ms();
+    int rc = ensure_workspace(h, pool, c.b->wd_need, c.b->wi_need);
+    if (rc == 0) rc = batch_to_device(h, c.b, pool);
+    if (rc == 0) rc = solve_launch_main(h, c.b);
+    upload_ms += now_ms() - t0;
+    if (rc != 0) {
+      c.rc = -1; c.err = h->err;
+      { std::lock_guard<std::mutex> lk(c.mu); c.device_done = true; }
+      c.cv.notify_all();
+      continue;
+    }
+    c.fin = std::thread([h, &c, out, &fin, &agg_mu, &n_solved_chunks]() {
+      (void)hipSetDevice(h->device);
+      chd_handle local = *h;              // (error text of this thread's calls; the device resources are shared, read-only here)
+      int rc2 = solve_finish(&local, c.b);
+      { std::lock_guard<std::mutex> lk(c.mu); c.device_done = true; }
+      c.cv.notify_all();
+      if (rc2 == 0) rc2 = batch_fetch(&local, c.b, out + c.c0);
+      if (rc2 != 0) { c.rc = -1; c.err = local.err; return; }
+      fin(c.c0, c.c1);
+      std::lock_guard<std::mutex> lk(agg_mu);
+      ++n_solved_chunks;
+    });
+  }
+  for (auto& c : ch) if (c->fin.joinable()) c->fin.join();
+  // ---- accounting over the chunks, then the device memory goes back
+  chd_call_stats& cs = h->call;
+  cs.n_chunks = K; cs.chunk = chunk; cs.host_threads = (int)nt; cs.n_sequences = B;
+  cs.prep_ms = prep_ms; cs.setup_wall_ms = build_wall_ms; cs.upload_ms = upload_ms; cs.wait_for_pool_ms = wait_ms;
+  std::string err;
+  for (auto& c : ch) {
+    if (c->rc < 0 && err.empty()) err = c->err;
+    if (c->b) {
+      const chd_batch_stats& s = c->b->stats;
+      cs.kernel_ms += s.kernel_ms[0] + s.kernel_ms[1]; cs.total_iters += s.total_iters; cs.total_factorizations += s.total_factorizations; cs.alg_bytes += s.alg_bytes;
+      cs.n_fallback += s.n_fallback; cs.n_stalled += s.n_stalled; cs.n_rejected += c->b->B - (int)c->b->order.size();
+      cs.sequence_ms += s.phase_ms[5]; if (s.max_seq_ms > cs.max_seq_ms) cs.max_seq_ms = s.max_seq_ms;
+      chd_batch_free(h, c->b);
+    }
+  }
+  cs.wall_ms = now_ms() - t_begin;
+  if (!err.empty()) return fail(h, err);
+  if (n_solved_chunks == 0) return fail(h, "no solvable sequence in the batch (" + first_err + ")");
+  h->err = first_err;          // (a rejected sequence: the rest was solved)
+  return 0;
+}
+
+extern "C" {
+
+int chd_phys_version(void) { return CHD_PHYS_ABI_VERSION; }
+
+void chd_config_default(chd_config* c) {
+  c->w_com_lin = 0.4; c->w_com_ang = 1.7; c->w_ee = 0.3; c->w_smooth = 0.1; c->w_dur = 0.1;     // phys_optim.cpp:27-31
+  const int mi[CHD_N_STAGES] = {7000, 7000, 7000, 2500, 2000, 7000};                              // :571, :640, :652, :706, :743
+  for (int i = 0; i < CHD_N_STAGES; ++i) c->max_iter[i] = mi[i];
+  c->tol = 1e-3;                                                                                   // :578
+  c->threads_per_sequence = 0;
+  c->stall_window = 0;
+  c->max_workgroups = 0;
+  c->lds_kilobytes = 0;
+  c->factorisation = 0;
+  c->pipeline_chunk = 0;
+  for (int i = 0; i < 2; ++i) c->reserved[i] = 0;
+}
+
+int chd_phys_create(const chd_config* cfg, int device_id, chd_handle** out) {
+  if (!out) return -1;
+  *out = nullptr;
+  chd_handle* h = new chd_handle();
+  if (cfg) h->cfg = *cfg; else chd_config_default(&h->cfg);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    std::fprintf(stderr, "chd_phys_create: no HIP device available (this library has no CPU path)\n");
+    delete h; return -2;
+  }
+  if (device_id < 0 || device_id >= ndev) { std::fprintf(stderr, "chd_phys_create: bad device id %d (have %d)\n", device_id, ndev); delete h; return -3; }
+  h->device = device_id;
+  if (hipSetDevice(device_id) != hipSuccess) { delete h; return -4; }
+  for (int p = 0; p < CHD_N_POOLS; ++p)
+    if (hipStreamCreateWithFlags(&h->stream[p], hipStreamNonBlocking) != hipSuccess) { for (int q = 0; q < p; ++q) (void)hipStreamDestroy(h->stream[q]); delete h; return -4; }
+  auto drop = [&]() { for (int p = 0; p < CHD_N_POOLS; ++p) (void)hipStreamDestroy(h->stream[p]); delete h; };
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { drop(); return -5; }
+  size_t lds = prop.maxSharedMemoryPerMultiProcessor;
+  if (lds > 160 * 1024) lds = 160 * 1024;
+  if (lds < 64 * 1024) lds = 64 * 1024;
+  h->lds_bytes = (int)lds - 12288;    // the 12 KB hold the kernel's static LDS: sequence descriptor + solver context (2.4 KB), cumulative-time tables (5.6 KB)
+  if (h->cfg.lds_kilobytes > 0 && h->cfg.lds_kilobytes * 1024 < h->lds_bytes) h->lds_bytes = std::max(32, h->cfg.lds_kilobytes) * 1024;
+  hipFuncSetAttribute((const void*)chd_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
+  hipFuncSetAttribute((const void*)chd_debug_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
+  hipFuncSetAttribute((const void*)chd_debug_linsolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
+  // the factorisation / substitution phases are written for eight wavefronts (wave-specialised look-ahead, register prefetch
+  // by lane group): other workgroup sizes are refused rather than silently mis-solved
+  // (experiment, profiles/r02k_final/two_workgroups.md: with CHD_EXPERIMENTAL_256 set, 256-thread workgroups -- two per compute unit with
+  //  76 KB of LDS each -- solve correctly through the generic substitution, at 0.8x the throughput)
+  const bool exp256 = h->cfg.threads_per_sequence == 256 && std::getenv("CHD_EXPERIMENTAL_256") != nullptr;
+  if (h->cfg.threads_per_sequence != 0 && h->cfg.threads_per_sequence != CHD_MAX_THREADS && !exp256) {
+    std::fprintf(stderr, "chd_phys_create: threads_per_sequence must be 0 or %d\n", CHD_MAX_THREADS);
+    drop(); return -7;
+  }
+  h->threads = exp256 ? 256 : CHD_MAX_THREADS;
+  h->n_wg = h->cfg.max_workgroups > 0 ? h->cfg.max_workgroups : prop.multiProcessorCount;
+  if (h->n_wg < 1) h->n_wg = 1;
+  *out = h;
+  return 0;
+}
+
+void chd_phys_destroy(chd_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  for (int p = 0; p < CHD_N_POOLS; ++p) {
+    (void)hipFree(h->d_wd[p]); (void)hipFree(h->d_wi[p]);
+    if (h->stream[p]) (void)hipStreamDestroy(h->stream[p]);
+  }
+  delete h;
+}
+
+const char* chd_phys_last_error(const chd_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+void chd_batch_free(chd_handle* h, chd_batch* b) {
+  if (!b) return;
+  if (h) (void)hipSetDevice(h->device);
+  (void)hipFree(b->d_cd); (void)hipFree(b->d_ci); (void)hipFree(b->d_od); (void)hipFree(b->d_oi);
+  (void)hipFree(b->d_descs); (void)hipFree(b->d_order); (void)hipFree(b->d_counter); (void)hipFree(b->d_f); (void)hipFree(b->d_x);
+  for (int k = 0; k < 4; ++k) if (b->ev[k]) (void)hipEventDestroy(b->ev[k]);
+  delete b;
+}
+
+int chd_batch_upload(chd_handle* h, int B, const chd_seq_in* in, chd_batch** out) {
+  if (!h || !in || !out || B <= 0) return fail(h, "chd_batch_upload: bad arguments");
+  *out = nullptr;
+  HIP_TRY(h, hipSetDevice(h->device));
+  chd_batch* b = batch_build(h->cfg, B, in, host_threads(B));
+  if (b->order.empty()) { std::string m = "no solvable sequence in the batch (sequence 0: " + b->build_err[0] + ")"; chd_batch_free(h, b); return fail(h, m); }
+  for (int i = 0; i < B; ++i) if (!b->ok[i]) h->err = "sequence " + std::to_string(i) + " rejected: " + b->build_err[i];
+  if (batch_to_device(h, b, 0) != 0 || ensure_workspace(h, 0, b->wd_need, b->wi_need) != 0) { std::string m = h->err; chd_batch_free(h, b); return fail(h, m); }
+  hipError_t e = hipStreamSynchronize(h->stream[0]);
+  if (e != hipSuccess) { chd_batch_free(h, b); return fail(h, std::string("sync: ") + hipGetErrorString(e)); }
+  *out = b;
+  return 0;
+}
+
+int chd_batch_solve(chd_handle* h, chd_batch* b) {
+  if (!h || !b) return fail(h, "chd_batch_solve: bad arguments");
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (ensure_workspace(h, b->pool, b->wd_need, b->wi_need) != 0) return -1;
+  if (solve_launch_main(h, b) != 0) return -1;
+  return solve_finish(h, b);
+}
+
+int chd_batch_get_stats(chd_handle* h, chd_batch* b, chd_batch_stats* out) {
+  if (!h || !b || !out) return fail(h, "chd_batch_get_stats: bad arguments");
+  *out = b->stats;
+  return 0;
+}
+
+int chd_batch_fetch(chd_handle* h, chd_batch* b, chd_seq_out* out) {
+  if (!h || !b || !out) return fail(h, "chd_batch_fetch: bad arguments");
+  if (!b->solved) return fail(h, "chd_batch_fetch: batch not solved");
+  HIP_TRY(h, hipSetDevice(h->device));
+  return batch_fetch(h, b, out);
+}
+
+int chd_phys_solve_batch(chd_handle* h, int B, const chd_seq_in* in, chd_seq_out* out) {
+  if (!h || !in || !out || B <= 0) return fail(h, "chd_phys_solve_batch: bad arguments");
+  return solve_pipelined(h, B, in, out, [](int, int) {}, [](int, int) {});
+}
+
+int chd_phys_get_call_stats(chd_handle* h, chd_call_stats* out) {
+  if (!h || !out) return fail(h, "chd_phys_get_call_stats: bad arguments");
+  *out = h->call;
+  return 0;
 }
 
 int chd_phys_solve_dirs(chd_handle* h, int B, const char* const* in_dirs, const char* const* out_dirs, const int* nframes, int* status) {
   if (!h || B <= 0 || !in_dirs || !out_dirs || !nframes) return fail(h, "chd_phys_solve_dirs: bad arguments");
+  // Unreadable directories drop out before the batch is formed (the reference's child process would have died on that video alone); the readable ones are
+  // parsed, solved and written chunk by chunk: reading chunk k + 1 and writing chunk k - 1 run on the host while the device solves chunk k.
   std::vector<io::SeqFiles> files(B);
   std::vector<std::string> errs(B);
   std::vector<char> readable(B, 0);
+  // (the token count of the four files is not known before they are parsed: every directory is read once, here, in parallel -- ~1 ms each -- and the
+  //  pipeline below starts with the table builder.  Reading is `prep` for the accounting.)
+  const double t_read0 = now_ms();
   host_parallel_for(B, [&](int i) { readable[i] = io::read_inputs(in_dirs[i], nframes[i], files[i], errs[i]) ? 1 : 0; });
+  const double read_ms = now_ms() - t_read0;
   std::vector<int> good;
   std::string first_err;
   for (int i = 0; i < B; ++i) {
@@ -532,15 +715,22 @@ int chd_phys_solve_dirs(chd_handle* h, int B, const char* const* in_dirs, const 
     store[k].bind(out[k], nframes[good[k]] + 4);
   }
   h->err.clear();
-  int rc = chd_phys_solve_batch(h, (int)good.size(), in.data(), out.data());
-  if (rc != 0) return rc;
-  if (first_err.empty()) first_err = h->err;           // a sequence rejected at set-up (the rest was solved)
   std::vector<std::string> werr(good.size());
   std::vector<int> wst(good.size(), 0);
-  host_parallel_for((int)good.size(), [&](int k) {
-    if (out[k].stage_status[0] == -4) { wst[k] = -3; return; }      // rejected at set-up: no output files, as when the reference's child process dies
-    if (!io::write_outputs(out_dirs[good[k]], files[good[k]].dt, out[k], werr[k])) wst[k] = -2;
-  });
+  std::atomic<long long> write_us{0};
+  auto fin = [&](int c0, int c1) {          // the chunk's output files (called from the chunk's finisher thread)
+    const double t0 = now_ms();
+    host_parallel_for(c1 - c0, [&](int j) {
+      const int k = c0 + j;
+      if (out[k].stage_status[0] == -4) { wst[k] = -3; return; }      // rejected at set-up: no output files, as when the reference's child process dies
+      if (!io::write_outputs(out_dirs[good[k]], files[good[k]].dt, out[k], werr[k])) wst[k] = -2;
+    });
+    write_us += (long long)((now_ms() - t0) * 1e3);
+  };
+  int rc = solve_pipelined(h, (int)good.size(), in.data(), out.data(), [](int, int) {}, fin);
+  h->call.prep_ms += read_ms; h->call.wall_ms += read_ms; h->call.finish_ms = write_us.load() * 1e-3;
+  if (rc != 0) return rc;
+  if (first_err.empty()) first_err = h->err;           // a sequence rejected at set-up (the rest was solved)
   for (size_t k = 0; k < good.size(); ++k) {
     if (wst[k] != 0 && status) status[good[k]] = wst[k];
     if (wst[k] == -2 && first_err.empty()) first_err = werr[k];
@@ -560,7 +750,7 @@ int chd_debug_eval(chd_handle* h, chd_batch* b, int seq, int stage, const double
                    double* J, double* H) {
   if (!h || !b || seq < 0 || seq >= b->B || stage < 0 || stage >= N_STAGES || !b->ok[seq]) return fail(h, "chd_debug_eval: bad arguments");
   HIP_TRY(h, hipSetDevice(h->device));
-  if (ensure_workspace(h, b->wd_need, b->wi_need) != 0) return -1;
+  if (ensure_workspace(h, 0, b->wd_need, b->wi_need) != 0) return -1;
   const SeqModel& M = b->models[seq];
   const SeqDesc& dd = b->descs[seq];
   const StageDesc& S = M.d.st[stage];
@@ -569,16 +759,16 @@ int chd_debug_eval(chd_handle* h, chd_batch* b, int seq, int stage, const double
     if (b->x_cap < n) { (void)hipFree(b->d_x); b->d_x = nullptr; HIP_TRY(h, hipMalloc((void**)&b->d_x, (size_t)dd.max_n * 8)); b->x_cap = dd.max_n; }
     HIP_TRY(h, hipMemcpy(b->d_x, x, n * 8, hipMemcpyHostToDevice));
   }
-  HIP_TRY(h, hipMemcpyAsync(b->d_order, &seq, sizeof(int), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipMemsetAsync(h->d_counter, 0, sizeof(int), h->stream));
-  hipLaunchKernelGGL(chd_debug_eval_kernel, dim3(1), dim3(h->threads), h->lds_bytes, h->stream, b->d_descs, (const int*)b->d_order, h->d_counter, h->d_wd, h->d_wi,
+  HIP_TRY(h, hipMemcpyAsync(b->d_order, &seq, sizeof(int), hipMemcpyHostToDevice, h->stream[0]));
+  HIP_TRY(h, hipMemsetAsync(b->d_counter, 0, sizeof(int), h->stream[0]));
+  hipLaunchKernelGGL(chd_debug_eval_kernel, dim3(1), dim3(h->threads), h->lds_bytes, h->stream[0], b->d_descs, (const int*)b->d_order, b->d_counter, h->d_wd[0], h->d_wi[0],
                      stage, x ? (const double*)b->d_x : (const double*)nullptr, h->lds_bytes / 8, b->d_f);
   HIP_TRY(h, hipGetLastError());
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream[0]));
   double fo[2];
   HIP_TRY(h, hipMemcpy(fo, b->d_f, 16, hipMemcpyDeviceToHost));
   if (f) *f = fo[0];
-  const double* wd = h->d_wd;          // workgroup 0's workspace
+  const double* wd = h->d_wd[0];          // workgroup 0's workspace
   if (x_out) HIP_TRY(h, hipMemcpy(x_out, wd + dd.o_vec_n + (long long)VN_X * dd.max_n, n * 8, hipMemcpyDeviceToHost));
   if (grad) HIP_TRY(h, hipMemcpy(grad, wd + dd.o_vec_n + (long long)VN_G * dd.max_n, n * 8, hipMemcpyDeviceToHost));
   if (cvals) HIP_TRY(h, hipMemcpy(cvals, wd + dd.o_vec_m + (long long)VM_C * dd.max_m, m * 8, hipMemcpyDeviceToHost));
@@ -600,23 +790,25 @@ int chd_debug_eval(chd_handle* h, chd_batch* b, int seq, int stage, const double
 }
 
 // Factor / solve self test of one sequence's KKT matrix (stage `stage` at the initial state, diagonal dw Dw / -dval):
-// which = 0 the left-looking factorisation (what the solver runs), 1 the right-looking one.  info: [0] replaced pivots,
+// which = 0 the left-looking factorisation, 1 the right-looking one (what the solver runs by default), 2 the register-resident frontal one.  info: [0] replaced pivots,
 // [1] / [2] clock ticks (100 MHz) of `reps` factorisations / of the solve, [3] the factorisation that actually ran.
 int chd_debug_linsolve(chd_handle* h, chd_batch* b, int seq, int stage, double dw, double dval, int which, int reps, const double* rhs, double* x, double* info) {
   if (!h || !b || seq < 0 || seq >= b->B || stage < 0 || stage >= N_STAGES || !b->ok[seq] || !rhs || !x) return fail(h, "chd_debug_linsolve: bad arguments");
   HIP_TRY(h, hipSetDevice(h->device));
-  if (ensure_workspace(h, b->wd_need, b->wi_need) != 0) return -1;
+  if (ensure_workspace(h, 0, b->wd_need, b->wi_need) != 0) return -1;
   const StageDesc& S = b->models[seq].d.st[stage];
   const int N = S.n + S.m;
   double* d_buf = nullptr;
   HIP_TRY(h, hipMalloc((void**)&d_buf, (size_t)(2 * N + 16) * 8));
-  HIP_TRY(h, hipMemcpy(d_buf, rhs, (size_t)N * 8, hipMemcpyHostToDevice));
-  HIP_TRY(h, hipMemcpyAsync(b->d_order, &seq, sizeof(int), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipMemsetAsync(h->d_counter, 0, sizeof(int), h->stream));
-  hipLaunchKernelGGL(chd_debug_linsolve_kernel, dim3(1), dim3(h->threads), h->lds_bytes, h->stream, b->d_descs, (const int*)b->d_order, h->d_counter, h->d_wd, h->d_wi,
-                     stage, h->lds_bytes / 8, dw, dval, which, reps < 1 ? 1 : reps, (const double*)d_buf, d_buf + N, d_buf + 2 * N);
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  hipError_t e = hipMemcpy(d_buf, rhs, (size_t)N * 8, hipMemcpyHostToDevice);          // (every later error path frees d_buf)
+  if (e == hipSuccess) e = hipMemcpyAsync(b->d_order, &seq, sizeof(int), hipMemcpyHostToDevice, h->stream[0]);
+  if (e == hipSuccess) e = hipMemsetAsync(b->d_counter, 0, sizeof(int), h->stream[0]);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(chd_debug_linsolve_kernel, dim3(1), dim3(h->threads), h->lds_bytes, h->stream[0], b->d_descs, (const int*)b->d_order, b->d_counter, h->d_wd[0], h->d_wi[0],
+                       stage, h->lds_bytes / 8, dw, dval, which, reps < 1 ? 1 : reps, (const double*)d_buf, d_buf + N, d_buf + 2 * N);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream[0]);
   if (e == hipSuccess) e = hipMemcpy(x, d_buf + N, (size_t)N * 8, hipMemcpyDeviceToHost);
   if (e == hipSuccess && info) e = hipMemcpy(info, d_buf + 2 * N, 14 * 8, hipMemcpyDeviceToHost);
   (void)hipFree(d_buf);

@@ -12,7 +12,7 @@ class ChdConfig(C.Structure):
     _fields_ = [('w_com_lin', C.c_double), ('w_com_ang', C.c_double), ('w_ee', C.c_double),
                 ('w_smooth', C.c_double), ('w_dur', C.c_double), ('max_iter', C.c_int * N_STAGES),
                 ('tol', C.c_double), ('threads_per_sequence', C.c_int), ('stall_window', C.c_int), ('max_workgroups', C.c_int),
-                ('lds_kilobytes', C.c_int), ('factorisation', C.c_int), ('reserved', C.c_int * 3)]
+                ('lds_kilobytes', C.c_int), ('factorisation', C.c_int), ('pipeline_chunk', C.c_int), ('reserved', C.c_int * 2)]
 
 
 class ChdSeqIn(C.Structure):
@@ -44,6 +44,14 @@ class ChdBatchStats(C.Structure):
                 ('total_factorizations', C.c_longlong), ('alg_bytes', C.c_double), ('n_fallback', C.c_int),
                 ('phase_ms', C.c_double * 24), ('max_seq_ms', C.c_double), ('n_stalled', C.c_int), ('n_rejected', C.c_int),
                 ('n_workgroups', C.c_int)]
+
+
+class ChdCallStats(C.Structure):
+    _fields_ = [('wall_ms', C.c_double), ('prep_ms', C.c_double), ('setup_cpu_ms', C.c_double), ('setup_wall_ms', C.c_double), ('upload_ms', C.c_double),
+                ('wait_for_pool_ms', C.c_double), ('finish_ms', C.c_double), ('kernel_ms', C.c_double), ('sequence_ms', C.c_double), ('max_seq_ms', C.c_double),
+                ('alg_bytes', C.c_double), ('total_iters', C.c_longlong), ('total_factorizations', C.c_longlong),
+                ('n_sequences', C.c_int), ('n_chunks', C.c_int), ('chunk', C.c_int), ('host_threads', C.c_int), ('n_fallback', C.c_int), ('n_stalled', C.c_int),
+                ('n_rejected', C.c_int)]
 
 
 def default_config(**kw):

@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 
 from .io_formats import Solution
-from .phys_capi import (ChdBatchStats, ChdConfig, ChdSeqIn, ChdSeqOut, N_SNAPSHOTS, N_STAGES, PD, default_config,
+from .phys_capi import (ChdBatchStats, ChdCallStats, ChdConfig, ChdSeqIn, ChdSeqOut, N_SNAPSHOTS, N_STAGES, PD, default_config,
                         seq_to_c)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -24,7 +24,7 @@ SNAPSHOT_FILES = ('sol_out_no_dynamics.txt', 'sol_out_dynamics.txt', 'sol_out_du
 
 EXPORTS = ['chd_phys_version', 'chd_config_default', 'chd_phys_create', 'chd_phys_destroy', 'chd_phys_last_error',
            'chd_batch_upload', 'chd_batch_solve', 'chd_batch_fetch', 'chd_batch_free', 'chd_batch_get_stats',
-           'chd_phys_solve_batch', 'chd_phys_solve_dirs', 'chd_debug_sizes', 'chd_debug_eval', 'chd_debug_linsolve']
+           'chd_phys_solve_batch', 'chd_phys_get_call_stats', 'chd_phys_solve_dirs', 'chd_debug_sizes', 'chd_debug_eval', 'chd_debug_linsolve']
 
 
 def build_library(force=False, verbose=False):
@@ -81,6 +81,7 @@ def load_library():
     L.chd_batch_free.argtypes = [vp, vp]
     L.chd_batch_get_stats.argtypes = [vp, vp, C.POINTER(ChdBatchStats)]
     L.chd_phys_solve_batch.argtypes = [vp, C.c_int, C.POINTER(ChdSeqIn), C.POINTER(ChdSeqOut)]
+    L.chd_phys_get_call_stats.argtypes = [vp, C.POINTER(ChdCallStats)]
     L.chd_phys_solve_dirs.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.chd_debug_sizes.argtypes = [vp, vp, C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 5
     L.chd_debug_eval.argtypes = [vp, vp, C.c_int, C.c_int, PD, PD, PD, PD, PD, PD, PD]
@@ -122,6 +123,27 @@ class SeqResult:
         return sum(self.stage_iters)
 
 
+def alloc_outputs(seqs):
+    """Caller-owned result arrays of ``chd_seq_out`` for a list of sequences: (ctypes array, per-sequence NumPy buffers)."""
+    B = len(seqs)
+    outs = (ChdSeqOut * B)()
+    bufs = []
+    for i, s in enumerate(seqs):
+        cap = s.F + 4
+        per = []
+        for k in range(N_SNAPSHOTS):
+            bl = np.zeros((cap, 3)); ba = np.zeros((cap, 3)); ep = np.zeros((4, cap, 3)); ef = np.zeros((4, cap, 3))
+            ct = np.zeros((4, cap), dtype=np.uint8)
+            sn = outs[i].snap[k]
+            sn.capacity = cap
+            sn.base_lin = bl.ctypes.data_as(PD); sn.base_ang_deg = ba.ctypes.data_as(PD)
+            sn.ee_pos = ep.ctypes.data_as(PD); sn.ee_force = ef.ctypes.data_as(PD)
+            sn.contact = ct.ctypes.data_as(C.POINTER(C.c_ubyte))
+            per.append((bl, ba, ep, ef, ct))
+        bufs.append(per)
+    return outs, bufs
+
+
 class Batch:
     """Device-resident batch (``chd_batch``): upload once, solve (the timed part), fetch."""
 
@@ -145,21 +167,7 @@ class Batch:
 
     def fetch(self):
         B = len(self.seqs)
-        outs = (ChdSeqOut * B)()
-        bufs = []
-        for i, s in enumerate(self.seqs):
-            cap = s.F + 4
-            per = []
-            for k in range(N_SNAPSHOTS):
-                bl = np.zeros((cap, 3)); ba = np.zeros((cap, 3)); ep = np.zeros((4, cap, 3)); ef = np.zeros((4, cap, 3))
-                ct = np.zeros((4, cap), dtype=np.uint8)
-                sn = outs[i].snap[k]
-                sn.capacity = cap
-                sn.base_lin = bl.ctypes.data_as(PD); sn.base_ang_deg = ba.ctypes.data_as(PD)
-                sn.ee_pos = ep.ctypes.data_as(PD); sn.ee_force = ef.ctypes.data_as(PD)
-                sn.contact = ct.ctypes.data_as(C.POINTER(C.c_ubyte))
-                per.append((bl, ba, ep, ef, ct))
-            bufs.append(per)
+        outs, bufs = alloc_outputs(self.seqs)
         self.solver._check(self.solver.L.chd_batch_fetch(self.solver.h, self.h, outs), 'chd_batch_fetch')
         return [SeqResult(self.seqs[i].dt, outs[i], bufs[i]) for i in range(B)]
 
@@ -233,6 +241,21 @@ class PhysOptim:
             return b.fetch(), st
         finally:
             b.free()
+
+    def solve_batch(self, seqs):
+        """The whole call (``chd_phys_solve_batch``): set-up, upload, solve and fetch, pipelined over chunks of the batch so that the host work hides
+        behind the device's.  Returns (results, call statistics)."""
+        seqs = list(seqs)
+        keep = []
+        cin = (ChdSeqIn * len(seqs))(*[seq_to_c(s, keep) for s in seqs])
+        outs, bufs = alloc_outputs(seqs)
+        self._check(self.L.chd_phys_solve_batch(self.h, len(seqs), cin, outs), 'chd_phys_solve_batch')
+        return [SeqResult(seqs[i].dt, outs[i], bufs[i]) for i in range(len(seqs))], self.call_stats()
+
+    def call_stats(self):
+        st = ChdCallStats()
+        self._check(self.L.chd_phys_get_call_stats(self.h, C.byref(st)), 'chd_phys_get_call_stats')
+        return {k: getattr(st, k) for k, _ in ChdCallStats._fields_}
 
     def solve_dirs(self, in_dirs, out_dirs, nframes):
         """Batched drop-in for ``./phys_optim --in_dir D_in --nframes F --out_dir D_out`` run once per directory."""

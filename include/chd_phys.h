@@ -52,7 +52,11 @@ typedef struct chd_config {
                                  * read-modify-write; measured slower and with more HBM traffic: csrc/chd_kernels.hpp kfactor_ll);
                                  * 2 = frontal, the front held in the accumulator registers by slot (no HBM access on a panel's critical
                                  * path; correct, instruction-bound and slower: csrc/chd_kfront.hpp) */
-  int reserved[3];
+  int pipeline_chunk;           /* chd_phys_solve_batch / chd_phys_solve_dirs cut their B sequences into chunks of this many: the host builds the
+                                 * tables of chunk k + 1 (and reads / writes the files of its neighbours) while the device solves chunk k, and up to
+                                 * three chunks' launches share the device.  0 = automatic (B / 8, between 128 and 512); < 0 = one chunk: set-up,
+                                 * solve and fetch in turn, as rounds 1-3 did */
+  int reserved[2];
 } chd_config;
 
 /* One sequence = the content of phys_optim_in_<char>/{skel,motion,terrain,contact}_info.txt
@@ -154,8 +158,27 @@ typedef struct chd_batch_stats {
 } chd_batch_stats;
 int chd_batch_get_stats(chd_handle* h, chd_batch* b, chd_batch_stats* out);
 
-/* Convenience: upload + solve + fetch. */
+/* The whole call a user makes -- what replaces the loop `for video: subprocess.run(['./phys_optim', ...])` of run_phys_mocap.py:80-174 when the
+ * inputs are already in memory: set-up (the reference does it inside the child process: phys_optim.cpp:428-540, nlp_formulation.cpp:79-203), upload,
+ * solve, fetch -- pipelined over chunks of the batch (chd_config.pipeline_chunk), so that the host work hides behind the device's. */
 int chd_phys_solve_batch(chd_handle* h, int B, const chd_seq_in* in, chd_seq_out* out);
+/* Accounting of the last chd_phys_solve_batch / chd_phys_solve_dirs on this handle (wall-clock milliseconds unless stated). */
+typedef struct chd_call_stats {
+  double wall_ms;              /* the whole call */
+  double prep_ms;              /* reading the input files (solve_dirs) */
+  double setup_cpu_ms;         /* table builder, thread time summed over all sequences: / n_sequences = set-up cost of one sequence on one core */
+  double setup_wall_ms;        /* table builder, wall time on host_threads threads (overlaps the device's work from the second chunk on) */
+  double upload_ms;            /* allocation, host-to-device copies, launches */
+  double wait_for_pool_ms;     /* the host had the next chunk ready and waited for a workspace pool: the device is the bottleneck */
+  double finish_ms;            /* writing the output files (solve_dirs; overlaps the device's work) */
+  double kernel_ms;            /* sum of the chunks' kernel times (launches overlap: this can exceed wall_ms) */
+  double sequence_ms;          /* in-kernel wall clock summed over the sequences */
+  double max_seq_ms;
+  double alg_bytes;
+  long long total_iters, total_factorizations;
+  int n_sequences, n_chunks, chunk, host_threads, n_fallback, n_stalled, n_rejected;
+} chd_call_stats;
+int chd_phys_get_call_stats(chd_handle* h, chd_call_stats* out);
 
 /* Drop-in for B invocations of ./phys_optim: reads the four input files of every in_dirs[i],
  * solves the batch, writes sol_out_no_dynamics.txt, sol_out_dynamics.txt, sol_out_durations.txt

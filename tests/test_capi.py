@@ -134,13 +134,13 @@ def test_struct_mirrors_match_the_header_sizes(lib, tmp_path):
     """sizeof of every struct of include/chd_phys.h as compiled by the C compiler == the ctypes mirror."""
     import subprocess
     src = tmp_path / 's.c'
-    src.write_text('#include <stdio.h>\n#include "chd_phys.h"\nint main(void){printf("%zu %zu %zu %zu %zu\\n", sizeof(chd_config), sizeof(chd_seq_in), '
-                   'sizeof(chd_snapshot), sizeof(chd_seq_out), sizeof(chd_batch_stats)); return 0;}\n')
+    src.write_text('#include <stdio.h>\n#include "chd_phys.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(chd_config), sizeof(chd_seq_in), '
+                   'sizeof(chd_snapshot), sizeof(chd_seq_out), sizeof(chd_batch_stats), sizeof(chd_call_stats)); return 0;}\n')
     exe = tmp_path / 's'
     subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
     sizes = [int(v) for v in subprocess.check_output([str(exe)], text=True).split()]
     assert sizes == [C.sizeof(phys_capi.ChdConfig), C.sizeof(phys_capi.ChdSeqIn), C.sizeof(phys_capi.ChdSnapshot), C.sizeof(phys_capi.ChdSeqOut),
-                     C.sizeof(phys_capi.ChdBatchStats)]
+                     C.sizeof(phys_capi.ChdBatchStats), C.sizeof(phys_capi.ChdCallStats)]
     c = phys_capi.ChdConfig()
     lib.chd_config_default(C.byref(c))
     assert c.stall_window == 0 and c.max_workgroups == 0 and c.threads_per_sequence == 0       # no stall guard unless asked for
