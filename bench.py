@@ -250,11 +250,9 @@ def main(argv=None, solver_factory=None):
     ap.add_argument('--max-workgroups', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--threads', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--lds-kb', type=int, default=0, help=argparse.SUPPRESS)
-    ap.add_argument('--factorisation', type=int, default=0, help=argparse.SUPPRESS)        # chd_config.factorisation (1 = left-looking)
     ap.add_argument('--towr_phys_optim_path', default=os.environ.get('TOWR_PHYS_OPTIM_PATH', ''),
                     help='directory of a REFERENCE phys_optim binary (scripts/run_phys_mocap.py:26): if one is found there it is run on the first sequences of the workload, '
                          'compared with the HIP results and timed as the CPU baseline (kind "reference")')
-    ap.add_argument('--all-factorisations', action='store_true', help='also time the two alternative factorisations on the same workload (side runs)')
     ap.add_argument('--no-cpu-baseline', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--no-side-metrics', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--worker', action='store_true', help=argparse.SUPPRESS)        # (accepted for old command lines; no effect)
@@ -294,8 +292,7 @@ def main(argv=None, solver_factory=None):
         if on_gpu:
             torch.cuda.synchronize()
 
-    cfg = default_config(stall_window=args.stall_window, max_workgroups=args.max_workgroups, threads_per_sequence=args.threads, lds_kilobytes=args.lds_kb,
-                         factorisation=args.factorisation)   # reference caps and tol
+    cfg = default_config(stall_window=args.stall_window, max_workgroups=args.max_workgroups, threads_per_sequence=args.threads, lds_kilobytes=args.lds_kb)   # reference caps and tol
     solver = (PhysOptim if on_gpu else solver_factory)(device=local, config=cfg)
     batch = solver.upload(seqs)                                           # inputs + tables -> HBM (not timed)
     if args.warmup > 0:                                                   # W untimed steps: the first W batches
@@ -333,7 +330,7 @@ def main(argv=None, solver_factory=None):
     if world == 1 and not args.no_side_metrics:
         def timed_solve(sq, **kw):
             c2 = default_config(max_workgroups=args.max_workgroups, threads_per_sequence=args.threads, lds_kilobytes=args.lds_kb,
-                                **{**dict(stall_window=args.stall_window, factorisation=args.factorisation), **kw})
+                                **{**dict(stall_window=args.stall_window), **kw})
             s2 = PhysOptim(device=local, config=c2)
             b2 = s2.upload(sq)
             torch.cuda.synchronize(); t1 = time.perf_counter(); st2 = b2.solve(); torch.cuda.synchronize(); dt2 = time.perf_counter() - t1
@@ -376,11 +373,6 @@ def main(argv=None, solver_factory=None):
         try:
             v, st2 = timed_solve(seqs, stall_window=150)
             side['value_with_stall_guard_150'] = v; side['stall_guard_150_hits'] = st2['n_stalled']; side['stall_guard_150_fallbacks'] = st2['n_fallback']
-            if args.all_factorisations:                                                       # (the two alternatives nobody defaults: behind a flag)
-                for kind, name in ((0, 'right_looking'), (1, 'left_looking'), (2, 'register_front')):
-                    if kind != args.factorisation:
-                        v, st2 = timed_solve(seqs, factorisation=kind)
-                        side['value_%s_factorisation' % name] = v
             v, st2 = timed_solve(seqs[:500])
             side['value_500_sequences_in_one_call'] = v
             side['kernel_busy_fraction_500_sequences'] = st2['phase_ms'][5] / max(1e-9, st2['n_workgroups'] * (st2['kernel_ms'][0] + st2['kernel_ms'][1]))
@@ -437,16 +429,13 @@ def main(argv=None, solver_factory=None):
                        'ipm_iterations_per_sequence': tot_iters_all / total_seqs,
                        'ipm_iterations_rank0': {'p50': float(np.percentile(it_seq, 50)), 'p90': float(np.percentile(it_seq, 90)), 'max': float(it_seq.max())},
                        'factorizations_rank0': nfact, 'stage4_fallbacks_rank0': st['n_fallback'], 'stall_guard_hits_rank0': st['n_stalled'],
-                       'converged_rank0': '%d/%d' % (n_ok, len(res)), 'factorisation': ('right-looking', 'left-looking', 'register-front')[args.factorisation] if 0 <= args.factorisation <= 2 else str(args.factorisation), **side,
+                       'converged_rank0': '%d/%d' % (n_ok, len(res)), 'factorisation': 'right-looking bordered band L D L^T, matrix-core trailing update', **side,
                        'slowest_sequence_ms': st['max_seq_ms'], 'mean_sequence_ms': st['phase_ms'][5] / max(1, len(res)),
                        'in_kernel_phase_ms_per_sequence': [round(v / max(1, len(res)), 3) for v in st['phase_ms']],
                        'in_kernel_time_share': {k: st['phase_ms'][i] / max(1e-9, st['phase_ms'][5]) for k, i in
                                                 (('evaluation_full', 0), ('evaluation_values', 1), ('factorisation', 2), ('substitution', 3), ('kkt_matvec', 4),
                                                  ('factor_copy', 6), ('factor_panel_load', 8), ('factor_row_solve', 9), ('factor_lookahead_wavefront', 11),
-                                                 ('factor_store_and_wait_for_trailing_tiles', 10), ('factor_border', 12))} if args.factorisation == 0 else
-                                                {k: st['phase_ms'][i] / max(1e-9, st['phase_ms'][5]) for k, i in
-                                                 (('evaluation_full', 0), ('evaluation_values', 1), ('factorisation', 2), ('substitution', 3), ('kkt_matvec', 4),
-                                                  ('factor_tiles', 8), ('factor_diagonal_block', 9), ('factor_row_solve', 10), ('factor_store', 11), ('factor_border', 12))}},
+                                                 ('factor_store_and_wait_for_trailing_tiles', 10), ('factor_border', 12))}},
             'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS * world, 'unit': 'GB/s', 'frac': ach / (HBM_PEAK_GBS * world),
                          'definition': 'sum over sequences of SURVEY 8(d) bytes_iter x IPM iterations / wall time of the timed region / (8 TB/s x GPUs)',
                          'algorithmic_bytes_per_step': alg_bytes_all / steps / world, 'algorithmic_bytes_per_iteration': alg_bytes / max(1, iters),

@@ -21,6 +21,10 @@
 // infrastructure; libchd_phys.so contains only the HIP build.
 #pragma once
 #include <math.h>
+#ifdef CHD_HOST_EMU
+#include <cstdio>
+#include <cstdlib>
+#endif
 
 #include "chd_device.hpp"
 
@@ -81,14 +85,14 @@ namespace chd {
 #define CHD_DELTA_W0 1e-4
 #define CHD_DELTA_W_MIN 1e-9
 #define CHD_DELTA_W_MAX 1e8
-// Inertia handling.  When the no-pivot LDL^T meets a pivot of unexpected sign it substitutes +-1e-10 (pivot_fix) so that
-// the factorisation can finish; a step computed from that modified matrix is garbage.  The line search rejects it almost
-// always, but on 2 % (flat floor) to 15 % (tilted floor) of sequences it accepted one, and since the garbage differs
-// between implementations (finite in the oracle, NaN here), kernel and oracle parted ways in the duration stage (found with
-// the host emulation: seeds 31, 73, 77, 105, 107, 113).  With CHD_INERTIA_RETRY such a factorisation counts
-// as a failed attempt (dw x 10, no solve, no trial evaluations), as IPOPT's inertia correction does.  The oracle has the
-// same switch (IpmOptions::inertia_retry); tests/test_host_emu.py checks the pair in lockstep.  Added after round 1's last
-// GPU run: validated through the host emulation only (0 = the code that ran on the MI355X in round 1).
+// Inertia handling.  The factorisation is L D L^T without pivoting in a fixed elimination order; every pivot is compared with the sign EXPECTED AT ITS
+// POSITION (+ at a variable, - at a constraint row).  A pivot of the wrong sign (or below 1e-14 in magnitude) is replaced by +-1e-10 so that the
+// factorisation can finish, and the attempt counts as failed (second model, then more damping; solve_stage) without a solve or trial evaluations -- the
+// role of IPOPT's inertia correction.  The test is stricter than the inertia (n, m, 0): a negative pivot at a variable's position can be balanced by a positive
+// one at a row's.  Measured on the fixture's 200 sequences + the kinematic optimisation's four hard clips (tests/tools/emu_sweep.py), the plain inertia count
+// costs robustness: 3 failed stages instead of 1, slowest sequence 915 iterations instead of 231 -- steps from factorisations with pivots of the "wrong" sign
+// are poor ones without pivoting.  Unlike the inertia, the positional test depends on the elimination order: the oracle uses the SAME order (band by node
+// time, border variables by the start time of their phase: chd_model.hpp / ipm_solver.hpp), which is what keeps the two in lockstep.
 #ifndef CHD_INERTIA_RETRY
 #define CHD_INERTIA_RETRY 1
 #endif
@@ -144,10 +148,9 @@ struct Ctx {
   double sf;            // objective scaling
   double tol;           // IPOPT tol of the stage (phys_optim.cpp:578)
   int stall_window;     // 0 = no stall guard (chd_config.stall_window)
-  int factor_ll;        // chd_config.factorisation: 0 = right-looking (kfactor_rl), 1 = left-looking (kfactor_ll), 2 = register-resident front (kfactor_rf)
   int second_model;     // 1 while the second model of an iteration is built: Gauss-Newton, without the exact constraint-curvature blocks (solve_stage)
   int err;              // sticky error flag (band overflow): any thread may set it, read after a barrier
-  int n_bad_pivots;     // thread 0 counts
+  int n_bad_pivots;     // pivots that did not have the sign expected at their position and were replaced (thread 0 counts)
   long long tacc[24];    // cycles per phase (thread 0): 0 eval full, 1 eval values, 2 factor, 3 solve, 4 matvec, 5 total
 };
 #ifdef CHD_HOST_EMU
@@ -704,6 +707,8 @@ CHD_DEV double pivot_fix(LCtx& c, double d, int sg) {
   if (!(d * sg > 1e-14)) { d = sg * 1e-10; if (CHD_TID == 0) c.n_bad_pivots++; }
   return d;
 }
+// the factorisation just made is unusable: a pivot did not have the expected sign
+CHD_DEV bool factor_failed(LCtx& c) { return block_sum(c, CHD_TID == 0 ? (double)c.n_bad_pivots : 0.0) > 0.0; }
 
 // wave-0-only sections: one wavefront works through a short dependent chain in LDS while the
 // other waves wait at the next workgroup barrier
@@ -1199,9 +1204,9 @@ CHD_DEV void kfactor_band(LCtx& c, const GI* sign, LdsD* dv, LdsD* DL, LdsD* dv2
   CHD_SYNC();
   for (int c0 = 0; c0 < Nb; c0 += NB) {
 #if CHD_INERTIA_RETRY && CHD_ABORT_BAD_FACTOR
-    // A diagonal block met a pivot of unexpected sign: the factorisation is going to be discarded (inertia retry), so it stops
-    // here -- before the block's columns (multipliers of order 1e10 after the pivot was replaced) are stored and can overflow into
-    // NaNs that would stay in the factor storage outside the envelope.  (The count lives in the LDS context: uniform after the barrier.)
+    // A diagonal block met a pivot of unexpected sign: the factorisation is going to be discarded (inertia retry), so it stops here -- before the block's
+    // columns (multipliers of order 1e10 after the pivot was replaced) are stored and can overflow into NaNs that would stay in the factor storage
+    // outside the envelope.  (The count lives in the LDS context: uniform after the barrier.)
     if (c.n_bad_pivots > 0) return;
 #endif
     Panel P; panel_geometry<NB>(c, P, c0, ldp);
@@ -1368,477 +1373,10 @@ CHD_NOINLINE CHD_DEV void kfactor_rl(LCtx& c, const GD* diag, const GI* sign) {
 }
 
 
-// ------------------------------------------------------------------------------------------
-// Left-looking blocked L D L^T of the bordered band -- the ALTERNATIVE factorisation (chd_config.factorisation = 1); the
-// right-looking kfactor_rl above is the default because it is the faster one on the MI355X (profiles/r03a_merit_clip:
-// 512 against 444 sequences/s on the bench workload).
-//
-// Right-looking, every 32-column panel read-modify-writes its trailing window in HBM / L2 (the window, ~100-200 active rows,
-// fits neither LDS nor -- as a sliding structure -- the register file).  Left-looking, a panel's columns are formed ONCE, in
-// registers, from the finished part of the factor:
-//     S(i, J) = K0(i, J) + diag - sum_{k < c0} L(i, k) d_k L(J, k)^T            i in {panel rows} + {active rows below}
-// as 16 x 16 fp64 matrix-core tiles whose operands are gathered straight from the factor storage in the MFMA register layout
-// (lane = (row, k)), read-only and independent of each other -- no copy K0 -> Kf, no window, no read-modify-write; then the
-// diagonal block is factored by one wavefront, the rows below are solved against it and stored.  The border's Schur complement
-// is formed the same way at the end (tiles of border rows x border rows over all band columns) and factored densely in LDS.
-// What the MI355X measurement says (PMC passes of the same profile): the gathers re-read every row of L once per panel it is
-// active in (~9 MB per factorisation; the 1.2 MB factor of 256 resident sequences does not stay in L2 / MALL), so the HBM-side
-// traffic is HIGHER than right-looking (17.5 x against 13.3 x the algorithmic bytes), the tile phase waits for one batch of
-// gathers per 32 columns of depth (22 % of the kernel time), and the diagonal block -- hidden behind the trailing update by
-// the right-looking version's look-ahead -- is on the critical path here (8.5 %).  Making it win needs the far part of a
-// panel's tiles computed during the previous panel's diagonal block / row solve (two panel buffers: 16-column panels) with the
-// near part from LDS; not done.
-// The factor storage has the same layout as before (unit-lower L in the band / border rows, pivots on the diagonal), and
-// every entry inside a row's envelope is rewritten by each factorisation; left of the envelope it stays zero.
-// ------------------------------------------------------------------------------------------
-#define CHD_LL_RING 512            // pivots of the last CHD_LL_RING band columns, in LDS (w + panel width must stay below it)
-struct LLPanel {
-  int c0, jb, nrows;               // first column, columns, rows of the panel's list (NB panel slots + active rows)
-  int pf;                          // first band column any row of the panel reaches (min of their envelope starts)
-};
-// the row list of a panel: slots [0, NB) = the panel's own rows c0 + a (-1 beyond jb), then the active rows below in ascending
-// order (band rows i, then border rows as Nb + r); `cnt[0]` = length, `cnt[1]` = pf.  Built by one wavefront.
-#ifdef CHD_HOST_EMU
-template <int NB>
-CHD_DEV void ll_build_rows(LCtx& c, int* rows, int* cnt, const int c0, const int jb) {
-  const int Nb = c.Nb, w = c.w, bc = c.bc, last = c0 + jb - 1;
-  int n = 0, pf = c0;
-  for (int a = 0; a < NB; ++a) { rows[n++] = a < jb ? c0 + a : -1; if (a < jb && c.env[2 * (c0 + a)] < pf) pf = c.env[2 * (c0 + a)]; }
-  const int iend = c0 + jb + w < Nb ? c0 + jb + w : Nb;
-  for (int i = c0 + jb; i < iend; ++i) if (c.env[2 * i] <= last) rows[n++] = i;
-  for (int r = 0; r < bc; ++r) if (c.env[2 * (Nb + r)] <= last) rows[n++] = Nb + r;
-  cnt[0] = n; cnt[1] = pf;
-}
-#else
-template <int NB>
-CHD_DEV void ll_build_rows(LCtx& c, int* rows_, int* cnt_, const int c0, const int jb) {
-  LdsI* rows = (LdsI*)rows_; LdsI* cnt = (LdsI*)cnt_;
-  const int Nb = c.Nb, w = c.w, bc = c.bc, last = c0 + jb - 1;
-  const int ln = threadIdx.x & 63;
-  int pf = c0;
-  if (ln < NB) { rows[ln] = ln < jb ? c0 + ln : -1; if (ln < jb) pf = c.env[2 * (c0 + ln)]; }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(pf, o); pf = t < pf ? t : pf; }
-  const int nbelow = (c0 + jb + w < Nb ? c0 + jb + w : Nb) - (c0 + jb);
-  const int wr = nbelow + bc;
-  int base = NB;
-  for (int u0 = 0; u0 < wr; u0 += 256) {         // four 64-row groups per pass: their envelope starts are fetched together
-    int ef[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { const int u = u0 + 64 * r + ln; ef[r] = c.env[u < wr ? 2 * (u < nbelow ? c0 + jb + u : Nb + u - nbelow) : 0]; }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int u = u0 + 64 * r + ln;
-      const bool on = u < wr && ef[r] <= last;
-      const unsigned long long m = __ballot(on);
-      if (on) rows[base + __popcll(m & ((1ull << ln) - 1ull))] = u < nbelow ? c0 + jb + u : Nb + u - nbelow;
-      base += __popcll(m);
-    }
-  }
-  if (ln == 0) { cnt[0] = base; cnt[1] = pf; }
-}
-#endif
-
-// S tiles of one panel -> PT (column-major, PT[j * ldp + t] for list slot t), NB = 16 NC columns
-#ifdef CHD_HOST_EMU
-template <int NC>
-CHD_DEV void ll_tiles(LCtx& c, const GD* diag, const int* rows, const int nrows, const int pf, const int c0, const int jb, LdsD* PT, const int ldp, const LdsD* dring) {
-  constexpr int NB = 16 * NC;
-  const int Nb = c.Nb, w = c.w, W1 = c.w + 1, W2 = c.W2, LD = c.LD;
-  auto Lf = [&](int p, int k) -> double {          // L(p, k), k < c0 <= p or p in the panel
-    if (p < Nb) return (p - k <= w) ? c.Kfb[(long long)p * W1 + (k - p + w)] : 0.0;
-    return c.Kfx[(long long)(p - Nb) * LD + k];
-  };
-  for (int t = 0; t < nrows; ++t)
-    for (int j = 0; j < NB; ++j) {
-      const int p = rows[t], kc = c0 + j;
-      double v;
-      if (p < 0 || j >= jb) v = (t == j) ? 1.0 : 0.0;          // padding of a short last panel: identity
-      else {
-        if (p < Nb) v = (p - kc <= w && kc - p <= w) ? c.K0b[(long long)p * W2 + (kc - p + w)] : 0.0;
-        else v = c.K0x[(long long)(p - Nb) * LD + kc];
-        if (p == kc) v += diag[p];
-        int klo = c.env[2 * p] > pf ? c.env[2 * p] : pf;
-        for (int k = klo; k < c0; ++k) v -= Lf(p, k) * dring[k & (CHD_LL_RING - 1)] * Lf(kc, k);
-      }
-      PT[j * ldp + t] = v;
-    }
-}
-#else
-template <int NC>
-CHD_NOINLINE CHD_DEV void ll_tiles(LCtx& c, const GD* diag, const int* rows_, const int nrows, const int pf, const int c0, const int jb, LdsD* PT, const int ldp, const LdsD* dring) {
-  constexpr int NB = 16 * NC;
-  const LdsI* rows = (const LdsI*)rows_;
-  const int Nb = c.Nb, w = c.w, W1 = c.w + 1, W2 = c.W2, LD = c.LD;
-  const int wave = threadIdx.x >> 6, nwv = blockDim.x >> 6, lane = threadIdx.x & 63;
-  const int lr = lane & 15, lk = lane >> 4;
-  const GD* Kfb = c.Kfb; const GD* Kfx = c.Kfx;
-  const GD* safe = c.Kfb + w;
-  const int nblk = (nrows + 15) >> 4;
-  // B operand rows: the panel's own rows (same for every block of this wavefront)
-  const GD* pB[NC]; int kminB[NC]; bool okB[NC];
-#pragma unroll
-  for (int cb = 0; cb < NC; ++cb) {
-    const int j = 16 * cb + lr, p = c0 + j;
-    okB[cb] = j < jb;
-    pB[cb] = Kfb + (long long)(okB[cb] ? p : 0) * W1 + (w - (okB[cb] ? p : 0));
-    kminB[cb] = okB[cb] ? (p - w > 0 ? p - w : 0) : 0x3fffffff;
-  }
-  for (int blk = wave; blk < nblk; blk += nwv) {
-    // A operand row of this lane, and the block's first column
-    const int ta = 16 * blk + lr;
-    const int pa = ta < nrows ? rows[ta] : -1;
-    const bool okA = pa >= 0;
-    const bool bandA = pa < Nb;
-    const GD* pA = okA ? (bandA ? Kfb + (long long)pa * W1 + (w - pa) : Kfx + (long long)(pa - Nb) * LD) : safe;
-    const int kminA = okA ? (bandA ? (pa - w > 0 ? pa - w : 0) : 0) : 0x3fffffff;
-    int ef = okA ? c.env[2 * pa] : 0x3fffffff;
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) { const int t = __shfl_xor(ef, o); ef = t < ef ? t : ef; }
-    const int klo = ef > pf ? ef : pf;
-    const int nst = klo < c0 ? (c0 - klo + 3) >> 2 : 0;          // steps of four columns, ending at c0
-    const int kstart = c0 - 4 * nst;
-    // accumulators <- K0 (+ diagonal shift); D layout: rows lk + 4 q, column lr
-    chd_f64x4 acc[NC];
-    {
-      int pq[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { const int t = 16 * blk + lk + 4 * q; pq[q] = t < nrows ? rows[t] : -1; }
-#pragma unroll
-      for (int cb = 0; cb < NC; ++cb) {
-        const int j = 16 * cb + lr, kc = c0 + j;
-        double v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int p = pq[q];
-          const bool real = p >= 0 && j < jb;
-          const bool inb = real && (p >= Nb || (p - kc <= w && kc - p <= w));
-          const GD* src = !inb ? safe : (p < Nb ? c.K0b + (long long)p * W2 + (kc - p + w) : c.K0x + (long long)(p - Nb) * LD + kc);
-          const double t = *src;
-          const double dg = (real && p == kc) ? diag[p] : 0.0;
-          v[q] = real ? (inb ? t : 0.0) + dg : ((16 * blk + lk + 4 * q == j) ? 1.0 : 0.0);
-        }
-        acc[cb] = chd_f64x4{v[0], v[1], v[2], v[3]};
-      }
-    }
-    // - sum_k L(rows, k) d_k L(panel rows, k)^T, eight steps of four columns per pass, all loads of a pass issued together
-    constexpr int U = 8;
-    for (int k0 = kstart; k0 < c0; k0 += 4 * U) {
-      double a[U], b[NC][U], dk[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int k = k0 + 4 * u + lk;
-        const bool in = k < c0;
-        a[u] = *((in && k >= kminA) ? pA + k : safe);
-#pragma unroll
-        for (int cb = 0; cb < NC; ++cb) b[cb][u] = *((in && k >= kminB[cb]) ? pB[cb] + k : safe);
-        dk[u] = (in && k >= 0) ? dring[k & (CHD_LL_RING - 1)] : 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int k = k0 + 4 * u + lk;
-        const bool in = k < c0;
-        const double av = (in && k >= kminA) ? a[u] : 0.0;
-#pragma unroll
-        for (int cb = 0; cb < NC; ++cb) {
-          const double bv = (in && k >= kminB[cb]) ? -dk[u] * b[cb][u] : 0.0;
-          acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[cb], 0, 0, 0);
-        }
-      }
-    }
-#pragma unroll
-    for (int cb = 0; cb < NC; ++cb)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { const int t = 16 * blk + lk + 4 * q; if (t < nrows) PT[(16 * cb + lr) * ldp + t] = acc[cb][q]; }
-  }
-}
-#endif
-
-// diagonal block of the panel from PT slots [0, NB) -> unit-lower DL, pivots dv (+ reciprocals at dv[32 ..]), the pivot ring, and the
-// block's rows of the factor storage.  One wavefront.
-#ifdef CHD_HOST_EMU
-template <int NB>
-CHD_DEV void ll_diag(LCtx& c, const GI* sign, LdsD* dv, LdsD* DL, const LdsD* PT, const int ldp, LdsD* dring, const int c0, const int jb) {
-  const int W1 = c.w + 1, w = c.w;
-  double A[NB][NB];
-  for (int a = 0; a < NB; ++a) for (int j = 0; j < NB; ++j) A[a][j] = j <= a ? PT[j * ldp + a] : 0.0;
-  for (int j = 0; j < NB; ++j) {
-    double d = A[j][j];
-    if (j < jb) d = pivot_fix(c, d, sign[c0 + j]);
-    const double inv = 1.0 / d;
-    for (int a = j + 1; a < NB; ++a) { A[a][j] *= inv; DL[j * NB + a] = A[a][j]; }
-    dv[j] = d; dv[32 + j] = inv;
-    for (int jj = j + 1; jj < NB; ++jj) for (int a = jj; a < NB; ++a) A[a][jj] -= A[a][j] * d * A[jj][j];
-  }
-  for (int a = 0; a < jb; ++a) {
-    dring[(c0 + a) & (CHD_LL_RING - 1)] = dv[a];
-    GD* dst = c.Kfb + (long long)(c0 + a) * W1 + (w - a);
-    for (int j = 0; j < a; ++j) dst[j] = DL[j * NB + a];
-    dst[a] = dv[a];
-  }
-}
-#else
-template <int NB>
-CHD_NOINLINE CHD_DEV void ll_diag(LCtx& c, const GI* sign, LdsD* dv, LdsD* DL, const LdsD* PT, const int ldp, LdsD* dring, const int c0, const int jb) {
-  if (threadIdx.x < 64) {
-    const int W1 = c.w + 1, w = c.w;
-    const int a = threadIdx.x;
-    const bool act = a < NB;
-    const int sg_a = a < jb ? sign[c0 + a] : 1;
-    double ar[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) ar[j] = (act && j <= a) ? PT[j * ldp + a] : (a == j ? 1.0 : 0.0);
-    const unsigned long long sg_pos = __ballot(sg_a > 0);
-    double u[NB], row[NB];
-#pragma unroll
-    for (int k = 0; k < NB; ++k) { u[k] = 0.0; row[k] = 0.0; }
-    double lprev = 0.0;
-    int bad = 0;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      if (j > 0) row[j - 1] = readlane_f64(lprev, j);
-      double s0 = ar[j], s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-      for (int k = 0; k + 3 < j; k += 4) { s0 -= u[k] * row[k]; s1 -= u[k + 1] * row[k + 1]; s2 -= u[k + 2] * row[k + 2]; s3 -= u[k + 3] * row[k + 3]; }
-#pragma unroll
-      for (int k = j & ~3; k < j; ++k) s0 -= u[k] * row[k];
-      const double v = (s0 + s1) + (s2 + s3);
-      if (j + 1 < NB) {
-#pragma unroll
-        for (int k = 0; k < j; ++k) row[k] = DL[k * NB + (j + 1)];
-      }
-      double d = readlane_f64(v, j);
-      if (j < jb) { const double sg = ((sg_pos >> j) & 1ull) ? 1.0 : -1.0; if (!(d * sg > 1e-14)) { d = sg * 1e-10; ++bad; } }
-      const double inv = rcp_f64(d);
-      const double lj = v * inv;
-      u[j] = v; lprev = lj;
-      if (act && a > j) DL[j * NB + a] = lj;
-      if (a == j) { dv[j] = d; dv[32 + j] = inv; if (j < jb) dring[(c0 + j) & (CHD_LL_RING - 1)] = d; }
-      // this lane's row of the factor storage: L(a, j) for j < a, the pivot at j == a
-      if (a < jb && j <= a) c.Kfb[(long long)(c0 + a) * W1 + (w - a + j)] = (j == a) ? d : lj;
-    }
-    if (threadIdx.x == 0) c.n_bad_pivots += bad;
-  }
-}
-#endif
-
-// rows below the diagonal block: y_j = S(t, j) - sum_{k<j} y_k L(j, k);  L(t, j) = y_j / d_j, in place in PT (one list row per
-// thread; column k + 1 of the diagonal block's L is requested while column k's multiply-adds run)
-template <int NB>
-CHD_NOINLINE CHD_DEV void ll_rows(const int nrows, LdsD* PT, const int ldp, const LdsD* DL, const LdsD* dv) {
-  PAR_FOR(t2, nrows - NB) {
-    const int t = NB + t2;
-    double y0[NB], cur[NB], nx[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) { y0[j] = PT[j * ldp + t]; cur[j] = j > 0 ? DL[j] : 0.0; nx[j] = 0.0; }
-#pragma unroll
-    for (int k = 0; k < NB - 1; ++k) {
-#pragma unroll
-      for (int j = k + 2; j < NB; ++j) nx[j] = DL[(k + 1) * NB + j];
-      CHD_SCHED_FENCE();
-#pragma unroll
-      for (int j = k + 1; j < NB; ++j) y0[j] -= y0[k] * cur[j];
-      CHD_SCHED_FENCE();
-#pragma unroll
-      for (int j = k + 2; j < NB; ++j) cur[j] = nx[j];
-    }
-#pragma unroll
-    for (int j = 0; j < NB; ++j) PT[j * ldp + t] = y0[j] * dv[32 + j];
-  }
-}
-// the solved rows -> factor storage: one task = 8 consecutive columns of one list row
-template <int NB>
-CHD_NOINLINE CHD_DEV void ll_store(LCtx& c, const int* rows_, const int nrows, const int c0, const int jb, const LdsD* PT, const int ldp) {
-  const int Nb = c.Nb, w = c.w, W1 = c.w + 1, LD = c.LD;
-#ifdef CHD_HOST_EMU
-  const int* rows = rows_;
-#else
-  const LdsI* rows = (const LdsI*)rows_;
-#endif
-  PAR_FOR(idx, (nrows - NB) * (NB / 8)) {
-    const int t = NB + idx / (NB / 8), j0 = (idx % (NB / 8)) * 8;
-    const int p = rows[t];
-    const bool band = p < Nb;
-    GD* dst = band ? c.Kfb + (long long)p * W1 + (c0 + j0 - p + w) : c.Kfx + (long long)(p - Nb) * LD + c0 + j0;
-    double v[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = PT[(j0 + q) * ldp + t];
-#pragma unroll
-    for (int q = 0; q < 8; ++q)
-      if (j0 + q < jb && (!band || p - (c0 + j0 + q) <= w)) dst[q] = v[q];
-  }
-}
-
-// Schur complement of the border: S(r, q) = K0(r, q) + diag - sum_{k < Nb} L(r, k) d_k L(q, k), r >= q border rows, as 16 x 16 tiles
-// (one wavefront per tile, operands gathered from the border rows of the factor storage, pivots from its diagonal) -> SL (dense bc x bc, lower)
-#ifdef CHD_HOST_EMU
-CHD_DEV void ll_border_schur(LCtx& c, const GD* diag, LdsD* SL, const int lds_) {
-  const int Nb = c.Nb, W1 = c.w + 1, w = c.w, LD = c.LD, bc = c.bc;
-  for (int r = 0; r < bc; ++r)
-    for (int q = 0; q <= r; ++q) {
-      double v = c.K0x[(long long)r * LD + Nb + q] + (r == q ? diag[Nb + r] : 0.0);
-      const int fr = c.env[2 * (Nb + r)], fq = c.env[2 * (Nb + q)];
-      for (int k = fr > fq ? fr : fq; k < Nb; ++k) v -= c.Kfx[(long long)r * LD + k] * c.Kfb[(long long)k * W1 + w] * c.Kfx[(long long)q * LD + k];
-      SL[(long long)r * lds_ + q] = v;
-    }
-}
-#else
-template <class SP>
-CHD_NOINLINE CHD_DEV void ll_border_schur(LCtx& c, const GD* diag, SP SL, const int lds_) {
-  const int Nb = c.Nb, W1 = c.w + 1, w = c.w, LD = c.LD, bc = c.bc;
-  const int wave = threadIdx.x >> 6, nwv = blockDim.x >> 6, lane = threadIdx.x & 63;
-  const int lr = lane & 15, lk = lane >> 4;
-  const GD* Kfx = c.Kfx; const GD* Kfb = c.Kfb;
-  const GD* safe = c.Kfb + w;
-  const int nt = (bc + 15) >> 4, ntri = nt * (nt + 1) / 2;
-  for (int t = wave; t < ntri; t += nwv) {
-    int tr = (int)((__fsqrt_rn(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-    while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
-    while (tr * (tr + 1) / 2 > t) --tr;
-    const int tc = t - tr * (tr + 1) / 2;
-    const int ra = 16 * tr + lr, rb = 16 * tc + lr;
-    const bool okA = ra < bc, okB = rb < bc;
-    const GD* pA = Kfx + (long long)(okA ? ra : 0) * LD;
-    const GD* pB = Kfx + (long long)(okB ? rb : 0) * LD;
-    int fa = okA ? c.env[2 * (Nb + ra)] : 0x3fffffff, fb = okB ? c.env[2 * (Nb + rb)] : 0x3fffffff;
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) { int u = __shfl_xor(fa, o); fa = u < fa ? u : fa; u = __shfl_xor(fb, o); fb = u < fb ? u : fb; }
-    const int klo = fa > fb ? fa : fb;
-    const int nst = klo < Nb ? (Nb - klo + 3) >> 2 : 0;
-    const int kstart = Nb - 4 * nst;
-    chd_f64x4 acc;
-    {
-      double v[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int r = 16 * tr + lk + 4 * q, col = 16 * tc + lr;
-        const bool real = r < bc && col < bc;
-        const double t0 = *(real ? c.K0x + (long long)r * LD + Nb + col : safe);
-        v[q] = real ? t0 + (r == col ? diag[Nb + r] : 0.0) : 0.0;
-      }
-      acc = chd_f64x4{v[0], v[1], v[2], v[3]};
-    }
-    constexpr int U = 8;
-    for (int k0 = kstart; k0 < Nb; k0 += 4 * U) {
-      double a[U], b[U], dk[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int k = k0 + 4 * u + lk;
-        const bool in = k < Nb && k >= 0;
-        a[u] = *((in && okA) ? pA + k : safe);
-        b[u] = *((in && okB) ? pB + k : safe);
-        dk[u] = *(in ? Kfb + (long long)k * W1 + w : safe);
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int k = k0 + 4 * u + lk;
-        const bool in = k < Nb && k >= 0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((in && okA) ? a[u] : 0.0, (in && okB) ? -dk[u] * b[u] : 0.0, acc, 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int r = 16 * tr + lk + 4 * q, col = 16 * tc + lr;
-      if (r < bc && col <= r) SL[(long long)r * lds_ + col] = acc[q];
-    }
-  }
-}
-#endif
-
-template <int NC>
-CHD_DEV void kfactor_ll_band(LCtx& c, const GD* diag, const GI* sign, LdsD* dv, LdsD* DL, LdsD* dring, LdsD* PT, const int ldp, int* rowsA, int* rowsB, const int lsz) {
-  constexpr int NB = 16 * NC;
-  const int Nb = c.Nb;
-  // the list of panel J + 1 is built by the second wavefront while the first one factors panel J's diagonal block
-#ifdef CHD_HOST_EMU
-  ll_build_rows<NB>(c, rowsA, rowsA + lsz - 2, 0, Nb < NB ? Nb : NB);
-#else
-  if (CHD_WAVE_ID == 1) ll_build_rows<NB>(c, rowsA, rowsA + lsz - 2, 0, Nb < NB ? Nb : NB);
-#endif
-  CHD_SYNC();
-  for (int c0 = 0; c0 < Nb; c0 += NB) {
-    const int jb = Nb - c0 < NB ? Nb - c0 : NB;
-#ifdef CHD_HOST_EMU
-    const int nrows = rowsA[lsz - 2], pf = rowsA[lsz - 1];
-#else
-    const int nrows = ((const LdsI*)rowsA)[lsz - 2], pf = ((const LdsI*)rowsA)[lsz - 1];
-#endif
-    long long tp_ = CHD_CLOCK();
-    ll_tiles<NC>(c, diag, rowsA, nrows, pf, c0, jb, PT, ldp, dring);
-    CHD_SYNC();
-    TACC(c, 8, CHD_CLOCK() - tp_); tp_ = CHD_CLOCK();
-    ll_diag<NB>(c, sign, dv, DL, PT, ldp, dring, c0, jb);
-    const int c0n = c0 + NB;
-#ifdef CHD_HOST_EMU
-    if (c0n < Nb) ll_build_rows<NB>(c, rowsB, rowsB + lsz - 2, c0n, Nb - c0n < NB ? Nb - c0n : NB);
-#else
-    if (c0n < Nb && CHD_WAVE_ID == 1) ll_build_rows<NB>(c, rowsB, rowsB + lsz - 2, c0n, Nb - c0n < NB ? Nb - c0n : NB);
-#endif
-    CHD_SYNC();
-    TACC(c, 9, CHD_CLOCK() - tp_); tp_ = CHD_CLOCK();
-#if CHD_INERTIA_RETRY && CHD_ABORT_BAD_FACTOR
-    if (c.n_bad_pivots > 0) return;          // the factorisation is going to be discarded (inertia retry)
-#endif
-    ll_rows<NB>(nrows, PT, ldp, DL, dv);
-    CHD_SYNC();
-    TACC(c, 10, CHD_CLOCK() - tp_); tp_ = CHD_CLOCK();
-    ll_store<NB>(c, rowsA, nrows, c0, jb, PT, ldp);
-    CHD_SYNC();                              // (the stores above are operands of the next panel's tiles)
-    TACC(c, 11, CHD_CLOCK() - tp_);
-    int* t_ = rowsA; rowsA = rowsB; rowsB = t_;
-  }
-}
-
-// returns false when the shape does not fit (the caller then runs the right-looking version)
-CHD_DEV bool kfactor_ll(LCtx& c, const GD* diag, const GI* sign) {
-  const int Nb = c.Nb, w = c.w, LD = c.LD, bc = c.bc;
-  const int lsz = 32 + w + bc + 2;                     // ints per row list (+ count, + pf)
-  const int fixed = LDS_RED + 64 + 32 * 32 + CHD_LL_RING + (2 * lsz + 1) / 2 + 8;
-  int nc = 2;
-  while (nc >= 1 && (long long)(16 * nc + w + bc + 18) * (16 * nc) > c.lds_cap - fixed) --nc;
-  if (nc < 1 || w + 32 >= CHD_LL_RING) return false;
-  if (CHD_TID == 0) c.n_bad_pivots = 0;
-  LdsD* dv = c.lds + LDS_RED;
-  LdsD* DL = dv + 64;
-  LdsD* dring = DL + 32 * 32;
-  LdsD* PT = dring + CHD_LL_RING;
-  const int NB = 16 * nc;
-  const int ldp = (NB + w + bc + 17) | 1;
-  int* rowsA = (int*)(PT + (long long)ldp * NB); int* rowsB = rowsA + lsz;
-  CHD_SYNC();
-  if (nc == 2) kfactor_ll_band<2>(c, diag, sign, dv, DL, dring, PT, ldp, rowsA, rowsB, lsz);
-  else kfactor_ll_band<1>(c, diag, sign, dv, DL, dring, PT, ldp, rowsA, rowsB, lsz);
-  CHD_SYNC();
-  // ---- border: Schur complement from the finished band factor, dense L D L^T in LDS
-  const long long td_ = CHD_CLOCK();
-  if (bc > 0 && !(CHD_INERTIA_RETRY && CHD_ABORT_BAD_FACTOR && c.n_bad_pivots > 0)) {
-    LdsD* SL = c.lds + LDS_RED;
-    const bool in_lds = (long long)bc * bc <= c.lds_cap - LDS_RED;
-    if (in_lds) {
-      ll_border_schur(c, diag, SL, bc);
-      CHD_SYNC();
-      dense_ldlt(c, SL, bc, bc, sign + Nb);
-      PAR_FOR(idx, bc * bc) { const int r = idx / bc, k = idx % bc; if (k <= r) c.Kfx[(long long)r * LD + Nb + k] = SL[idx]; }
-      CHD_SYNC();
-    } else {
-      ll_border_schur(c, diag, c.Kfx + Nb, LD);
-      CHD_SYNC();
-      dense_ldlt(c, c.Kfx + Nb, LD, bc, sign + Nb);
-    }
-  }
-  TACC(c, 12, CHD_CLOCK() - td_);
-  return true;
-}
-
-#include "chd_kfront.hpp"
-
-CHD_NOINLINE CHD_DEV void kfactor(LCtx& c, const GD* diag, const GI* sign) {
-  if (c.factor_ll) {      // chd_config.factorisation: 1 = left-looking tiles from the factor storage, 2 = frontal with the front in the accumulator registers
-    TIC();
-    if (c.factor_ll == 2 ? kfactor_rf(c, diag, sign) : kfactor_ll(c, diag, sign)) { TOC(c, 2); return; }
-  }
-  kfactor_rl(c, diag, sign);
-}
+// (Rounds 2-3 carried two alternative factorisations -- left-looking matrix-core tiles gathered from the factor storage, and a frontal one with the front in the
+//  accumulator registers; both correct, both measured slower on the MI355X (482 and 409 against 629 sequences/s, profiles/r03a_merit_clip, r03b_register_front)
+//  and removed in round 4.  chd_config.factorisation is kept in the ABI and ignored.)
+CHD_NOINLINE CHD_DEV void kfactor(LCtx& c, const GD* diag, const GI* sign) { kfactor_rl(c, diag, sign); }
 
 // in-block triangular solves for the substitution (wave-cooperative on the device)
 #define CHD_SOLVE_NB 64
@@ -3471,8 +3009,8 @@ CHD_NOINLINE CHD_DEV void solve_stage(LCtx& c, StageResult& res) {
       CHD_SYNC();
       kfactor(c, diag, sign); ++n_factor;
 #if CHD_INERTIA_RETRY
-      // a pivot of unexpected sign was replaced (wrong inertia): more damping instead of a step from the modified matrix
-      if (block_sum(c, CHD_TID == 0 ? (double)c.n_bad_pivots : 0.0) > 0.0) { if (second_model()) continue; dw *= 10.0; if (dw > CHD_DELTA_W_MAX) break; continue; }
+      // a pivot of unexpected sign was replaced: second model / more damping instead of a step from the modified matrix
+      if (factor_failed(c)) { if (second_model()) continue; dw *= 10.0; if (dw > CHD_DELTA_W_MAX) break; continue; }
 #endif
       ksolve(c, rhs, sol, diag, 1);
       PAR_FOR(j, n) dx[j] = sol[pos_var[j]];
@@ -3568,6 +3106,9 @@ CHD_NOINLINE CHD_DEV void solve_stage(LCtx& c, StageResult& res) {
       dw *= 10.0;
       if (dw > CHD_DELTA_W_MAX) break;
     }
+#ifdef CHD_HOST_EMU
+    if (std::getenv("CHD_EMU_TRACE")) std::fprintf(stderr, "TRACE stage %d it %d E0 %.17g ed %.17g f %.17g mu %g dw %g att %d nls %d soc %d alpha %.17g nfact %d\n", S->stage, it, E0, e_d, f, mu, dw, attempt, nls, (int)used_soc, alpha, n_factor);
+#endif
     if (!ok) { status = -2; break; }
     if (attempt == 0 && nls == 0) dw = fmax(CHD_DELTA_W_MIN, dw / 2.0);
     else if (nls >= 1) dw *= 4.0;
@@ -3674,16 +3215,16 @@ CHD_DEV void load_state(QP q) {
   refresh_durations(q);
 }
 
-CHD_DEV void reset_context(LCtx& c, LdsD* lds, int lds_cap, double tol, int stall_window, int factor_ll = 0) {
+CHD_DEV void reset_context(LCtx& c, LdsD* lds, int lds_cap, double tol, int stall_window) {
   if (CHD_TID == 0) {
-    c.lds = lds; c.lds_cap = lds_cap; c.tol = tol; c.stall_window = stall_window; c.factor_ll = factor_ll;
+    c.lds = lds; c.lds_cap = lds_cap; c.tol = tol; c.stall_window = stall_window;
     for (int k = 0; k < 24; ++k) c.tacc[k] = 0;
   }
   CHD_SYNC();
 }
 
-CHD_DEV void run_sequence(QP q, LCtx& c, LdsD* lds, int lds_cap, double tol, int stall_window, int stage_first, int stage_last, int factor_ll = 0) {
-  reset_context(c, lds, lds_cap, tol, stall_window, factor_ll);
+CHD_DEV void run_sequence(QP q, LCtx& c, LdsD* lds, int lds_cap, double tol, int stall_window, int stage_first, int stage_last) {
+  reset_context(c, lds, lds_cap, tol, stall_window);
   const long long t_begin = CHD_CLOCK();
   // the workgroup's workspace still holds the previous sequence: everything below the KKT storage (state, solver
   // vectors, tables) starts from zero; the KKT storage is cleared stage by stage (kreset)
@@ -3735,9 +3276,8 @@ CHD_DEV void debug_eval(QP q, LCtx& c, int stage, int use_x, LdsD* lds, int lds_
   CHD_SYNC();
 }
 
-// Debug entry: K0 of `stage` at the initial state, + (dw Dw, -dval) on the diagonal, factored `reps` times by the left-looking
-// (which = 0) or the right-looking (1) factorisation and solved for `rhs` (one refinement step).  out: [0] replaced pivots,
-// [1] clock ticks (100 MHz) of the factorisations, [2] of the solve, [3] which one ran (0 / 1 / 2), [4..11] the factorisation's phase timers 6..13.
+// Debug entry: K0 of `stage` at the initial state, + (dw Dw, -dval) on the diagonal, factored `reps` times and solved for `rhs` (one refinement step).
+// out: [0] replaced pivots, [1] clock ticks (100 MHz) of the factorisations, [2] of the solve, [3] 1, [4..11] the factorisation's phase timers 6..13.
 CHD_DEV void debug_linsolve(QP q, LCtx& c, int stage, LdsD* lds, int lds_cap, double dw, double dval, int which, int reps, const GD* rhs_in, GD* x_out, double* out) {
   double fo[2];
   debug_eval(q, c, stage, 0, lds, lds_cap, nullptr, nullptr, fo);
@@ -3746,14 +3286,9 @@ CHD_DEV void debug_linsolve(QP q, LCtx& c, int stage, LdsD* lds, int lds_cap, do
   PAR_FOR(j, c.n) { diag[c.pos_var[j]] = dw * Dw[j]; sign[c.pos_var[j]] = 1; }
   PAR_FOR(i, c.m) { diag[c.pos_row[i]] = -dval; sign[c.pos_row[i]] = -1; }
   CHD_SYNC();
-  int ran = which;
+  int ran = 1; (void)which;
   const long long t0 = CHD_CLOCK();
-  for (int r = 0; r < reps; ++r) {
-    if (which == 0) { if (!kfactor_ll(c, diag, sign)) { kfactor_rl(c, diag, sign); ran = 1; } }
-    else if (which == 2) { ran = 2; if (!kfactor_rf(c, diag, sign)) { kfactor_rl(c, diag, sign); ran = 1; } }
-    else kfactor_rl(c, diag, sign);
-    CHD_SYNC();
-  }
+  for (int r = 0; r < reps; ++r) { kfactor_rl(c, diag, sign); CHD_SYNC(); }
   const long long t1 = CHD_CLOCK();
   GD* rhs = VK(c, VK_RHS); GD* sol = VK(c, VK_SOL);
   PAR_FOR(i, c.N) rhs[i] = rhs_in[i];

@@ -514,11 +514,19 @@ class SeqModel {
           int v = h.var_of[nd * 6 + q];
           if (v < 0) continue;
           const int g = h.var_off + v;
-          if (h.phase_based && s < 6 && h.const_node(nd)) border[g] = 1; else vtime[g] = tn[nd];
+          if (h.phase_based && s < 6 && h.const_node(nd)) {      // shared stance position: border; its time = start of the stance polynomial (first node of the pair)
+            border[g] = 1;
+            if (nd < h.n_polys && h.isc[nd]) vtime[g] = tn[nd];
+          } else vtime[g] = tn[nd];
           if (s >= 6) Dw[g] = 1.0 / (fscale * fscale);
         }
     }
     for (int g = d.n_nodesvars; g < n; ++g) border[g] = 1;
+    if (S.opt_dur)
+      for (int e = 0; e < N_EE; ++e) {      // a duration variable: the start time of its phase
+        double t0 = 0;
+        for (int k = 0; k + 1 < d.n_phase[e]; ++k) { vtime[S.dur_off[e] + k] = t0; t0 += phase_dur[e][k]; }
+      }
     std::vector<int> band;
     for (int j = 0; j < n; ++j) if (!border[j]) band.push_back(j);
     std::stable_sort(band.begin(), band.end(), [&](int a, int b) { return vtime[a] < vtime[b]; });
@@ -684,12 +692,14 @@ class SeqModel {
           }
         }
     }
-    // ---- sort the border variables by their first coupled band position: the border rows that reach a band column k are
-    // then a prefix [0, rcnt[k]) of the border, which the column passes of the substitution / mat-vec stop at
+    // ---- order of the border variables: by the start time of their phase (stance position: its stance phase, duration: its own phase), ties by index.
+    // The oracle uses the same rule (ipm_solver.hpp): the positional pivot test of the factorisation depends on the elimination order.  The border rows that
+    // reach a band column k are then (almost) a prefix [0, rcnt[k]) of the border, which the column passes of the substitution / mat-vec stop at -- a row inside
+    // the prefix that does not reach the column holds zeros there.
     {
       std::vector<int> bvars;
       for (int j = 0; j < n; ++j) if (pos_var[j] >= Nb) bvars.push_back(j);
-      std::stable_sort(bvars.begin(), bvars.end(), [&](int a, int b) { return bfirst[pos_var[a] - Nb] < bfirst[pos_var[b] - Nb]; });
+      std::stable_sort(bvars.begin(), bvars.end(), [&](int a, int b) { return vtime[a] < vtime[b]; });
       std::vector<int> nb_first(bc, Nb);
       std::vector<int> newpos(n, -1);
       for (size_t r = 0; r < bvars.size(); ++r) { newpos[bvars[r]] = Nb + (int)r; nb_first[r] = bfirst[pos_var[bvars[r]] - Nb]; }

@@ -56,14 +56,14 @@ __device__ inline bool take_sequence(SeqDesc* s_desc, int* s_item, const SeqDesc
 
 __global__ __launch_bounds__(CHD_MAX_THREADS) void chd_solve_kernel(const SeqDesc* descs, const int* order, int n_items, int* counter,
                                                                     double* wd_pool, long long wd_stride, int* wi_pool, long long wi_stride,
-                                                                    int lds_doubles, double tol, int stall_window, int stage_first, int stage_last, int factor_ll) {
+                                                                    int lds_doubles, double tol, int stall_window, int stage_first, int stage_last) {
   extern __shared__ double lds[];
   __shared__ SeqDesc s_desc;
   __shared__ Ctx s_ctx;
   __shared__ int s_item;
   for (;;) {
     if (!take_sequence(&s_desc, &s_item, descs, order, n_items, counter, wd_pool, wd_stride, wi_pool, wi_stride)) break;
-    run_sequence((QP)&s_desc, *(LCtx*)&s_ctx, (LdsD*)lds, lds_doubles, tol, stall_window, stage_first, stage_last, factor_ll);
+    run_sequence((QP)&s_desc, *(LCtx*)&s_ctx, (LdsD*)lds, lds_doubles, tol, stall_window, stage_first, stage_last);
   }
 }
 
@@ -115,6 +115,7 @@ struct chd_batch {
   std::vector<char> ok;                  // 0: rejected at set-up (build_err), never queued
   std::vector<std::string> build_err;
   std::vector<int> order;                // queue order of the solvable sequences (longest first)
+  std::vector<int> fallback;             // the sequences of the stage-4 launch (kept here: the copy to the device is asynchronous)
   std::vector<long long> off_cd, off_ci;
   long long tot_cd = 0, tot_ci = 0, od_stride = 0, oi_stride = 0;      // results: one fixed-size slot per sequence (strided copies of the statistics)
   long long wd_need = 0, wi_need = 0;
@@ -284,11 +285,10 @@ static int launch_queue(chd_handle* h, chd_batch* b, const std::vector<int>& ite
   const unsigned grid = (unsigned)std::min<size_t>(items.size(), (size_t)h->n_wg);
   HIP_TRY(h, hipEventRecord(e0, st));
   hipLaunchKernelGGL(chd_solve_kernel, dim3(grid), dim3(h->threads), h->lds_bytes, st, b->d_descs, (const int*)b->d_order, (int)items.size(),
-                     b->d_counter, h->d_wd[b->pool], h->wd_stride, h->d_wi[b->pool], h->wi_stride, h->lds_bytes / 8, h->cfg.tol, h->cfg.stall_window, stage_first, stage_last, (h->cfg.factorisation == 1 || h->cfg.factorisation == 2) ? h->cfg.factorisation : 0);
+                     b->d_counter, h->d_wd[b->pool], h->wd_stride, h->d_wi[b->pool], h->wi_stride, h->lds_bytes / 8, h->cfg.tol, h->cfg.stall_window, stage_first, stage_last);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipEventRecord(e1, st));
-  HIP_TRY(h, hipStreamSynchronize(st));          // (the pageable `items` buffer: the copy has left it once this returns; the kernel is waited for through e1)
-  return 0;
+  return 0;          // (asynchronous: the kernel is waited for through e1; `items` must stay alive until then -- the callers pass vectors owned by the batch)
 }
 
 // per-sequence statistics block (stages + phase timers are fetched with two strided copies)
@@ -317,7 +317,8 @@ static int solve_finish(chd_handle* h, chd_batch* b) {
   std::vector<double> st;
   if (fetch_stats(h, b, st) != 0) return -1;
   const size_t sw = (size_t)N_STAGES * RS_STRIDE;
-  std::vector<int> idx;
+  std::vector<int>& idx = b->fallback;
+  idx.clear();
   for (int i : b->order) if ((int)st[sw * i + 4 * RS_STRIDE + RS_STATUS] != 0) idx.push_back(i);
   std::sort(idx.begin(), idx.end());
   b->stats.n_fallback = (int)idx.size();
@@ -790,7 +791,7 @@ int chd_debug_eval(chd_handle* h, chd_batch* b, int seq, int stage, const double
 }
 
 // Factor / solve self test of one sequence's KKT matrix (stage `stage` at the initial state, diagonal dw Dw / -dval):
-// which = 0 the left-looking factorisation, 1 the right-looking one (what the solver runs by default), 2 the register-resident frontal one.  info: [0] replaced pivots,
+// (`which` is ignored since round 4: one factorisation is left.)  info: [0] replaced pivots,
 // [1] / [2] clock ticks (100 MHz) of `reps` factorisations / of the solve, [3] the factorisation that actually ran.
 int chd_debug_linsolve(chd_handle* h, chd_batch* b, int seq, int stage, double dw, double dval, int which, int reps, const double* rhs, double* x, double* info) {
   if (!h || !b || seq < 0 || seq >= b->B || stage < 0 || stage >= N_STAGES || !b->ok[seq] || !rhs || !x) return fail(h, "chd_debug_linsolve: bad arguments");

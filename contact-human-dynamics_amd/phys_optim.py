@@ -19,7 +19,7 @@ from .phys_capi import (ChdBatchStats, ChdCallStats, ChdConfig, ChdSeqIn, ChdSeq
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.environ.get('CHD_PHYS_LIB') or os.path.join(_CSRC, 'libchd_phys.so')      # (override: kernel experiments with variant builds)
-SOURCES = ['chd_phys.hip', 'chd_kernels.hpp', 'chd_kfront.hpp', 'chd_model.hpp', 'chd_device.hpp', 'chd_io.hpp']
+SOURCES = ['chd_phys.hip', 'chd_kernels.hpp', 'chd_model.hpp', 'chd_device.hpp', 'chd_io.hpp']
 SNAPSHOT_FILES = ('sol_out_no_dynamics.txt', 'sol_out_dynamics.txt', 'sol_out_durations.txt')
 
 EXPORTS = ['chd_phys_version', 'chd_config_default', 'chd_phys_create', 'chd_phys_destroy', 'chd_phys_last_error',
@@ -189,8 +189,8 @@ class Batch:
         return dict(x=xo, f=f.value, g=g, c=c, J=J, H=H, err=rc)
 
     def debug_linsolve(self, seq, stage, rhs, dw=1e-4, dval=1e-3, which=0, reps=1):
-        """Factor / solve self test of the KKT matrix of (seq, stage) at the initial state: which = 0 the left-looking factorisation (what
-        the solver runs), 1 the right-looking one.  Returns (x, info) with info = dict(bad_pivots, factor_us, solve_us, ran)."""
+        """Factor / solve self test of the KKT matrix of (seq, stage) at the initial state (`which` is ignored since round 4: one factorisation is left).
+        Returns (x, info) with info = dict(bad_pivots, factor_us, solve_us, ran, phase_us)."""
         sz = self.sizes(seq, stage)
         rhs = np.ascontiguousarray(rhs, dtype=np.float64)
         assert rhs.size == sz['kkt_dim']

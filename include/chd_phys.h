@@ -47,11 +47,9 @@ typedef struct chd_config {
   int max_workgroups;           /* resident workgroups of the solver launch; 0 = one per compute unit */
   int lds_kilobytes;            /* dynamic LDS per workgroup; 0 = all of a compute unit's (156 KB); smaller values narrow the
                                    factorisation panels (tuning / test knob) */
-  int factorisation;            /* 0 = right-looking panels with a matrix-core trailing update (default: the faster one on the MI355X);
-                                 * 1 = left-looking matrix-core tiles gathered from the factor storage (no K0 -> Kf copy, no window
-                                 * read-modify-write; measured slower and with more HBM traffic: csrc/chd_kernels.hpp kfactor_ll);
-                                 * 2 = frontal, the front held in the accumulator registers by slot (no HBM access on a panel's critical
-                                 * path; correct, instruction-bound and slower: csrc/chd_kfront.hpp) */
+  int factorisation;            /* ignored since round 4 (kept for the ABI).  Rounds 2-3 carried two alternatives to the right-looking panel
+                                 * factorisation -- left-looking matrix-core tiles gathered from the factor storage (1), a front held in the
+                                 * accumulator registers (2); both were correct and measured slower on the MI355X, and were removed */
   int pipeline_chunk;           /* chd_phys_solve_batch / chd_phys_solve_dirs cut their B sequences into chunks of this many: the host builds the
                                  * tables of chunk k + 1 (and reads / writes the files of its neighbours) while the device solves chunk k, and up to
                                  * three chunks' launches share the device.  0 = automatic (B / 8, between 128 and 512); < 0 = one chunk: set-up,
@@ -196,8 +194,7 @@ int chd_phys_solve_dirs(chd_handle* h, int B, const char* const* in_dirs, const 
  *   sequence `seq` of an uploaded batch, on the device.  Any output pointer may be NULL. */
 int chd_debug_sizes(chd_handle* h, chd_batch* b, int seq, int stage, int* n, int* m, int* kkt_dim, int* halfband, int* border);
 /* chd_debug_linsolve: factor / solve self test of the sequence's KKT matrix of `stage` at the initial state, with dw * Dw on the
- * variable diagonal and -dval on the row diagonal: which = 0 the left-looking factorisation, 1 the right-looking one (the default), 2 the
- * register-resident frontal one; `reps` factorisations are timed.  rhs, x: kkt_dim doubles (KKT ordering).  info (14 doubles): replaced
+ * variable diagonal and -dval on the row diagonal (`which` is ignored since round 4: one factorisation is left); `reps` factorisations are timed.  rhs, x: kkt_dim doubles (KKT ordering).  info (14 doubles): replaced
  * pivots, clock ticks (100 MHz) of the factorisations, of the solve, the factorisation that ran, ten in-kernel phase timers. */
 int chd_debug_linsolve(chd_handle* h, chd_batch* b, int seq, int stage, double dw, double dval, int which, int reps,
                        const double* rhs, double* x, double* info);

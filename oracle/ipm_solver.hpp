@@ -103,6 +103,8 @@ struct BorderedBandLDL {
       for (int k = k0; k < i; ++k) r[k] -= Li[k - k0] * xi;
     }
   }
+  // every pivot is compared with the sign expected at its position; a pivot of the wrong sign (or below 1e-14) is replaced and counted (chd_kernels.hpp,
+  // "Inertia handling": stricter than the inertia, and dependent on the elimination order -- which is the kernel's)
   bool fix_pivot(double& d, int pos) {
     double sg = sign[pos];
     if (!(d * sg > 1e-14)) { d = sg * 1e-10; ++n_bad_pivots; return false; }
@@ -264,13 +266,16 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
   // ---- KKT ordering (time-banded, border = long-range variables) ------------
   // structural pattern: union of |J| at x0 and at a deterministic perturbation
   std::vector<char> pat((size_t)m * n, 0);
-  for (size_t k = 0; k < pat.size(); ++k) pat[k] = J[k] != 0.0;
   {
     std::vector<double> xp(x), cp(m), Jp((size_t)m * n);
+    P.pattern_mode = true;          // (structure, not values: nlp_model.hpp)
+    P.eval(x.data(), nullptr, nullptr, cp.data(), Jp.data(), nullptr);
+    for (size_t k = 0; k < pat.size(); ++k) pat[k] = Jp[k] != 0.0;
     unsigned s_ = 12345u;
     for (int j = 0; j < n; ++j) { s_ = s_ * 1664525u + 1013904223u; double r = ((s_ >> 8) & 0xFFFF) / 65535.0 - 0.5; xp[j] += (vkind[j] == 1 ? 10.0 : vkind[j] == 2 ? 0.0 : 1e-2) * r; }
     P.eval(xp.data(), nullptr, nullptr, cp.data(), Jp.data(), nullptr);
     for (size_t k = 0; k < pat.size(); ++k) pat[k] |= (Jp[k] != 0.0);
+    P.pattern_mode = false;
     P.set_x(x.data());
   }
   std::vector<int> band_vars;
@@ -287,8 +292,15 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
   std::vector<int> pos_var(n, -1), pos_row(m, -1);
   int Nb = 0;
   for (size_t r = 0; r < band_vars.size(); ++r) { pos_var[band_vars[r]] = Nb++; for (int i : rows_after[r]) pos_row[i] = Nb++; }
+  // border variables in the order of the start time of their phase (a shared stance position: its stance phase; a duration: its own phase), ties by index --
+  // the same rule as the kernel's table builder (chd_model.hpp), because the pivot test of BorderedBandLDL depends on the elimination order
   int bcount = 0;
-  for (int j = 0; j < n; ++j) if (vborder[j]) pos_var[j] = Nb + bcount++;
+  {
+    std::vector<int> bvars;
+    for (int j = 0; j < n; ++j) if (vborder[j]) bvars.push_back(j);
+    std::stable_sort(bvars.begin(), bvars.end(), [&](int a, int b2) { return vtime[a] < vtime[b2]; });
+    for (int j : bvars) pos_var[j] = Nb + bcount++;
+  }
   for (int i : border_rows) pos_row[i] = Nb + bcount++;
   const int N = Nb + bcount;
   BorderedBandLDL K;

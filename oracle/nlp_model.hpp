@@ -301,6 +301,10 @@ class Problem {
   //   bit 5: no exact node x duration block (round 3's model of the duration stage)
   int study_mask = 0;
   double clip_cap = 1e300;
+  // structure mode of eval(): a Jacobian entry of a spline sample is marked 1 for EVERY coefficient of the active polynomial in a dimension with a non-zero
+  // factor, whatever its Hermite weight (a sample on a node has weight exactly 0 on the polynomial's other node).  The solver takes the KKT ordering from it,
+  // so that it is the ordering the kernel's table builder derives from the structure (chd_model.hpp: at_time / poly_vars).
+  bool pattern_mode = false;
   // --- current stage ---
   int stage = -1;
   StageDef sd{};
@@ -597,7 +601,12 @@ class Problem {
           kind[g] = (i >= 6) ? 1 : 0;
         }
     }
-    for (int g = n_nodesvars; g < n; ++g) { border[g] = 1; kind[g] = 2; time[g] = 0.0; }
+    for (int g = n_nodesvars; g < n; ++g) { border[g] = 1; kind[g] = 2; }
+    if (sd.opt_durations)
+      for (int e = 0; e < 4; ++e) {          // a duration variable: the start time of its phase (orders the border, ipm_solver.hpp)
+        double t0 = 0;
+        for (size_t k = 0; k + 1 < phase_dur[e].size(); ++k) { time[dur_off[e] + k] = t0; t0 += phase_dur[e][k]; }
+      }
   }
 
   // Constraint-row layout (order is irrelevant to the NLP; chosen once here).
@@ -829,7 +838,9 @@ class Problem {
     auto nvar_of = [&](int e) { return (int)phase_dur[e].size() - 1; };
 
     // J[row, vars of spline s touched at e] += coef[dim] * w[which][j]
-    auto add_nodes = [&](int row, const Spline& s, const PointEval& e, int which, const double coef[3]) {
+    // (`mask`: in structure mode, the dimensions that are structurally non-zero -- given where a coefficient can be identically zero although the entry is
+    //  structural, e.g. the position entries of a foot whose force is pinned to zero in a swing phase; default: the dimensions with a non-zero coefficient)
+    auto add_nodes = [&](int row, const Spline& s, const PointEval& e, int which, const double coef[3], int mask = -1) {
       if (!J) return;
       double* Jr = J + (size_t)row * n;
       for (int side = 0; side < 2; ++side)
@@ -837,7 +848,7 @@ class Problem {
           double w = e.w[which][side * 2 + deriv];
           for (int dim = 0; dim < 3; ++dim) {
             int v = s.vi(e.poly + side, deriv, dim);
-            if (v >= 0) Jr[s.var_off + v] += coef[dim] * w;
+            if (v >= 0) Jr[s.var_off + v] += pattern_mode ? ((mask >= 0 ? ((mask >> dim) & 1) != 0 : coef[dim] != 0.0) ? 1.0 : 0.0) : coef[dim] * w;
           }
         }
     };
@@ -946,11 +957,11 @@ class Problem {
             c[row] = 0.5 * (d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
             cl[row] = 0.0; cu[row] = 0.5 * L * L;                       // :59
             double cf[3] = {-d[0], -d[1], -d[2]};
-            add_nodes(row, sp[0], pl, kPos, cf);
+            add_nodes(row, sp[0], pl, kPos, cf, 7);
             double ca[3];
             for (int kk = 0; kk < 3; ++kk) ca[kk] = -(d[0] * dRh[0][kk] + d[1] * dRh[1][kk] + d[2] * dRh[2][kk]);
-            add_nodes(row, sp[1], pa, kPos, ca);
-            add_nodes(row, sm, pe, kPos, d);
+            add_nodes(row, sp[1], pa, kPos, ca, 7);
+            add_nodes(row, sm, pe, kPos, d, 7);
             add_durs(row, sm, t, pe, d);
             if (XC && (study_mask & 4) && lam[row] != 0.0) {
               // exact node-node block of lam grad^2 c, c = 1/2 |d|^2, d = p_ee - R(euler) h - c_com (leg_length_constraint.cpp:46-52):
@@ -1004,8 +1015,8 @@ class Problem {
             double md[3] = {-d[0], -d[1], -d[2]};
             c[row] = 0.5 * (d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
             cl[row] = cu[row] = 0.5 * in.heel_dist * in.heel_dist;     // :39
-            add_nodes(row, sp[2 + e1], pe, kPos, d);
-            add_nodes(row, sp[2 + e2], pe2, kPos, md);
+            add_nodes(row, sp[2 + e1], pe, kPos, d, 7);
+            add_nodes(row, sp[2 + e2], pe2, kPos, md, 7);
             add_durs(row, sp[2 + e1], t, pe, d);
             add_durs(row, sp[2 + e2], t, pe2, md);
             if (H && lam) {
@@ -1106,26 +1117,26 @@ class Problem {
               // base-lin: angular rows -sum_e cross(f_e) dc ; linear rows m * d(acc)
               double cf[3] = {0, 0, 0};
               for (int e = 0; e < 4; ++e) { double X[3][3]; crossmat(pf[e].p, X); for (int j = 0; j < 3; ++j) cf[j] -= X[i][j]; }
-              add_nodes(row0 + i, sp[0], pl, kPos, cf);
+              add_nodes(row0 + i, sp[0], pl, kPos, cf, 7 & ~(1 << i));
               double cm[3] = {0, 0, 0}; cm[i] = in.mass;
-              add_nodes(row0 + 3 + i, sp[0], pl, kAcc, cm);
+              add_nodes(row0 + 3 + i, sp[0], pl, kAcc, cm, 1 << i);
               // base-ang: chain rule through (e, e', e'')
               double c0[3] = {ang[i].d[0], ang[i].d[1], ang[i].d[2]};
               double c1[3] = {ang[i].d[3], ang[i].d[4], ang[i].d[5]};
               double c2[3] = {ang[i].d[6], ang[i].d[7], ang[i].d[8]};
-              add_nodes(row0 + i, sp[1], pa, kPos, c0);
-              add_nodes(row0 + i, sp[1], pa, kVel, c1);
-              add_nodes(row0 + i, sp[1], pa, kAcc, c2);
+              add_nodes(row0 + i, sp[1], pa, kPos, c0, 7);
+              add_nodes(row0 + i, sp[1], pa, kVel, c1, 7);
+              add_nodes(row0 + i, sp[1], pa, kAcc, c2, 7);
               for (int e = 0; e < 4; ++e) {
                 double r[3] = {pl.p[0] - pm[e].p[0], pl.p[1] - pm[e].p[1], pl.p[2] - pm[e].p[2]};
                 double Xr[3][3], Xf[3][3];
                 crossmat(r, Xr); crossmat(pf[e].p, Xf);
                 // force: angular +cross(r) df ; linear -df
-                add_nodes(row0 + i, sp[6 + e], pf[e], kPos, Xr[i]);
+                add_nodes(row0 + i, sp[6 + e], pf[e], kPos, Xr[i], 7 & ~(1 << i));
                 double ml[3] = {0, 0, 0}; ml[i] = -1.0;
-                add_nodes(row0 + 3 + i, sp[6 + e], pf[e], kPos, ml);
+                add_nodes(row0 + 3 + i, sp[6 + e], pf[e], kPos, ml, 1 << i);
                 // ee position: angular +cross(f) dp
-                add_nodes(row0 + i, sp[2 + e], pm[e], kPos, Xf[i]);
+                add_nodes(row0 + i, sp[2 + e], pm[e], kPos, Xf[i], 7 & ~(1 << i));
                 // schedule: force spline then motion spline (humanoid_dynamic_constraint.cpp:112-118)
                 add_durs(row0 + i, sp[6 + e], t, pf[e], Xr[i]);
                 add_durs(row0 + 3 + i, sp[6 + e], t, pf[e], ml);

@@ -76,7 +76,6 @@ int emu_linsolve(void* h, int stage, double dw, double dval, const double* b, do
   const double* Dw = e->M.d.cd + c.S->o_Dw;
   for (int j = 0; j < c.n; ++j) { diag[c.pos_var[j]] = dw * Dw[j]; sign[c.pos_var[j]] = 1; }
   for (int i = 0; i < c.m; ++i) { diag[c.pos_row[i]] = -dval; sign[c.pos_row[i]] = -1; }
-  c.factor_ll = e->cfg.factorisation;
   kfactor(c, diag, sign);
   double* rhs = VK(c, VK_RHS); double* sol = VK(c, VK_SOL);
   for (int i = 0; i < c.N; ++i) rhs[i] = b[i];
@@ -91,7 +90,7 @@ int emu_linsolve(void* h, int stage, double dw, double dval, const double* b, do
 }
 int emu_solve(void* h, int stage_first, int stage_last, int lds_doubles) {
   Emu* e = (Emu*)h; e->bind();
-  run_sequence(&e->M.d, e->ctx, e->lds.data(), lds_doubles > 0 ? lds_doubles : 18432, e->cfg.tol, e->cfg.stall_window, stage_first, stage_last, e->cfg.factorisation);
+  run_sequence(&e->M.d, e->ctx, e->lds.data(), lds_doubles > 0 ? lds_doubles : 18432, e->cfg.tol, e->cfg.stall_window, stage_first, stage_last);
   return 0;
 }
 // stage-4 fallback: rebuild the tables of stage index 5 with the durations stage 3 left
@@ -191,5 +190,3 @@ extern "C" int emu_front_profile(void* h, int stage, int nb, int* out, int cap) 
   return np;
 }
 
-// how many factorisations the register-front emulation completed / refused (fell back to the right-looking one) since the library was loaded
-extern "C" void emu_rf_counts(long long* out) { out[0] = chd::chd_rf_completed; out[1] = chd::chd_rf_refused; }

@@ -23,7 +23,7 @@ _VARIANT = os.environ.get('CHD_EMU_VARIANT', '')
 def build(force=False):
     so = os.path.join(_HERE, 'libchd_emu%s.so' % ('_' + _VARIANT if _VARIANT else ''))
     csrc = os.path.join(_ROOT, 'contact-human-dynamics_amd', 'csrc')
-    srcs = [os.path.join(_HERE, 'emu.cpp')] + [os.path.join(csrc, f) for f in ('chd_kernels.hpp', 'chd_kfront.hpp', 'chd_model.hpp', 'chd_device.hpp')]
+    srcs = [os.path.join(_HERE, 'emu.cpp')] + [os.path.join(csrc, f) for f in ('chd_kernels.hpp', 'chd_model.hpp', 'chd_device.hpp')]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         flags = ['-DCHD_INERTIA_RETRY=0'] if _VARIANT == 'noinertia' else []
         subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-Wno-unused-variable'] + flags + ['-o', so, srcs[0]])

@@ -257,35 +257,6 @@ def test_long_sequence_matches_oracle():
     assert worst < 1e-3
 
 
-def test_alternative_factorisations_match_right_looking():
-    """The left-looking factorisation (matrix-core tiles gathered from the factor storage: kfactor_ll) and the frontal one with the front in the
-    accumulator registers (kfactor_rf) against the right-looking one (kfactor_rl) on the KKT matrices of all stages: same solution of K x = b to
-    1e-8 (each with one refinement step), no replaced pivots, and no silent fall-back."""
-    from chd_amd.phys_optim import PhysOptim, default_config
-    s = PhysOptim(device=0, config=default_config())
-    seqs = [make_walk(seed=3, F=90, randomize=True), make_walk(seed=11, F=60, randomize=True, tilt_deg=5.0)]
-    b = s.upload(seqs)
-    rng = np.random.default_rng(0)
-    try:
-        for q in range(len(seqs)):
-            for stage in range(5):
-                N = b.sizes(q, stage)['kkt_dim']
-                rhs = rng.normal(size=N)
-                x0, i0 = b.debug_linsolve(q, stage, rhs, dw=1e-2, dval=1e-3, which=0)
-                x1, i1 = b.debug_linsolve(q, stage, rhs, dw=1e-2, dval=1e-3, which=1)
-                x2, i2 = b.debug_linsolve(q, stage, rhs, dw=1e-2, dval=1e-3, which=2)
-                assert i0['ran'] == 0 and i1['ran'] == 1 and i2['ran'] == 2
-                assert i0['bad_pivots'] == 0 and i1['bad_pivots'] == 0 and i2['bad_pivots'] == 0
-                assert np.isfinite(x0).all() and np.isfinite(x2).all()
-                err = np.linalg.norm(x0 - x1) / np.linalg.norm(x1)
-                assert err < 1e-8, (q, stage, err)
-                err2 = np.linalg.norm(x2 - x1) / np.linalg.norm(x1)
-                assert err2 < 1e-8, (q, stage, err2)
-    finally:
-        b.free(); s.close()
-
-
-@pytest.mark.gpu
 def test_narrow_panels_match_the_default_width():
     """chd_config.lds_kilobytes narrows the factorisation's panels (32 -> 16 -> 8 columns: the look-ahead wavefront, its hand-over buffer and the
     tile passes are written for any of them).  K x = b on the KKT matrices of all stages with 80 KB and 44 KB of LDS against the default: the same

@@ -50,11 +50,10 @@ def test_eval_parity_all_stages(emu, oracle_lib):
         o.set_x(x0 if st != 4 else np.concatenate([x0, o.get_x()[x0.size:]]))
 
 
-@pytest.mark.parametrize('kind', [0, 1, 2])
-def test_bordered_band_factorisation(emu, kind):
-    """The three factorisations of the kernel source (chd_config.factorisation: 0 right-looking, 1 left-looking, 2 frontal with slot bookkeeping) solve K x = b."""
+def test_bordered_band_factorisation(emu):
+    """The factorisation of the kernel source (right-looking bordered band L D L^T) solves K x = b."""
     seq = make_walk(seed=0, F=40, randomize=True)
-    e = emu.EmuProblem(seq, default_config(factorisation=kind))
+    e = emu.EmuProblem(seq, default_config())
     for st in (1, 4):
         sz = e.sizes(st)
         b = np.random.default_rng(st).normal(size=sz['n'] + sz['m'])
@@ -62,13 +61,14 @@ def test_bordered_band_factorisation(emu, kind):
         assert bad == 0 and np.isfinite(x).all()
 
 
-@pytest.mark.parametrize('seed,F,tilt,kind', [(2, 40, 0.0, 0), (6, 60, 5.0, 0), (9, 90, 0.0, 0), (6, 60, 5.0, 1), (2, 40, 0.0, 2)])
-def test_staged_solve_parity(emu, oracle_lib, seed, F, tilt, kind):
+@pytest.mark.parametrize('seed,F,tilt', [(2, 40, 0.0), (6, 60, 5.0), (9, 90, 0.0), (103, 90, 0.0), (67, 90, 0.0)])
+def test_staged_solve_parity(emu, oracle_lib, seed, F, tilt):
     """Kernel source (host emulation) vs oracle through all stages: same statuses, same iteration counts, snapshots to
-    1e-8 -- flat and tilted floors, 40 / 60 / 90 frames; the last two cases with the left-looking and the frontal factorisation."""
+    1e-8 -- flat and tilted floors, 40 / 60 / 90 frames; the last two are the sequences on which oracle and kernel parted ways in round 4 until the
+    oracle took its KKT ordering from the structure like the kernel's table builder (the positional pivot test depends on the elimination order)."""
     seq = make_walk(seed=seed, F=F, randomize=True, tilt_deg=tilt)
     caps = [300] * 6
-    e = emu.EmuProblem(seq, default_config(max_iter=caps, factorisation=kind))
+    e = emu.EmuProblem(seq, default_config(max_iter=caps))
     e.solve(0, 4)
     stats, snaps = e.results()
     if stats[4, 0] != 0:

@@ -81,5 +81,6 @@ if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--videos', type=int, default=32)
     ap.add_argument('--frames', type=int, default=60)
+    ap.add_argument('--keep', default=None, help='keep the generated directory tree here (a fresh directory)')
     a = ap.parse_args()
-    print(json.dumps(run(a.videos, a.frames)))
+    print(json.dumps(run(a.videos, a.frames, keep=a.keep)))
