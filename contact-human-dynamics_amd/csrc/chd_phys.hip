@@ -105,6 +105,12 @@ struct chd_handle {
   double* d_wd[CHD_N_POOLS] = {nullptr, nullptr, nullptr}; int* d_wi[CHD_N_POOLS] = {nullptr, nullptr, nullptr};
   long long wd_stride = 0, wi_stride = 0;
   chd_call_stats call{};               // accounting of the last chd_phys_solve_batch / chd_phys_solve_dirs
+  // device buffers of the pipelined path, one set per pool, grow-only and reused chunk after chunk: no hipMalloc / hipFree while launches are in flight
+  // (measured, round 4: allocating per chunk serialised the chunks -- 214 ms of "upload" per chunk, the whole call at 0.72 of the solve-only rate)
+  struct PoolBufs {
+    double* d_cd = nullptr; int* d_ci = nullptr; double* d_od = nullptr; int* d_oi = nullptr; SeqDesc* d_descs = nullptr; int* d_order = nullptr; int* d_counter = nullptr; double* d_f = nullptr;
+    long long cap_cd = 0, cap_ci = 0, cap_od = 0, cap_oi = 0, cap_seq = 0;
+  } pb[CHD_N_POOLS];
 };
 
 struct chd_batch {
@@ -126,6 +132,7 @@ struct chd_batch {
   std::vector<double> h_od;
   std::vector<int> h_oi;
   bool solved = false, fetched = false;
+  bool owns_device = true;               // false: the device buffers belong to the handle's pool (pipelined path)
   double build_cpu_ms = 0;               // host time of the table builder, summed over the sequences (thread time, not wall)
   chd_batch_stats stats{};
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -235,12 +242,43 @@ static chd_batch* batch_build(const chd_config& cfg, int B, const chd_seq_in* in
 }
 
 // ---- device half of an upload: pools, descriptors, result slots (on the stream of the batch's pool)
-static int batch_to_device(chd_handle* h, chd_batch* b, int pool) {
+// make sure pool `pool`'s reusable buffers hold a batch of these sizes (grow-only, 1/8 head-room; reallocation only while nothing runs on the pool)
+static int ensure_pool_bufs(chd_handle* h, int pool, long long n_cd, long long n_ci, long long n_od, long long n_oi, long long n_seq) {
+  chd_handle::PoolBufs& P = h->pb[pool];
+  auto grow = [&](void** p, long long& cap, long long need, size_t elem) -> hipError_t {
+    if (need <= cap && *p) return hipSuccess;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    cap = need + need / 8 + 64;
+    return hipMalloc(p, (size_t)cap * elem);
+  };
+  hipError_t e;
+  if ((e = grow((void**)&P.d_cd, P.cap_cd, n_cd, 8)) != hipSuccess || (e = grow((void**)&P.d_ci, P.cap_ci, n_ci, 4)) != hipSuccess ||
+      (e = grow((void**)&P.d_od, P.cap_od, n_od, 8)) != hipSuccess || (e = grow((void**)&P.d_oi, P.cap_oi, n_oi, 4)) != hipSuccess)
+    return fail(h, std::string("pool buffers: ") + hipGetErrorString(e));
+  if (n_seq > P.cap_seq || !P.d_descs) {
+    (void)hipFree(P.d_descs); (void)hipFree(P.d_order); P.d_descs = nullptr; P.d_order = nullptr;
+    P.cap_seq = n_seq + n_seq / 8 + 8;
+    if ((e = hipMalloc((void**)&P.d_descs, sizeof(SeqDesc) * (size_t)P.cap_seq)) != hipSuccess || (e = hipMalloc((void**)&P.d_order, sizeof(int) * (size_t)P.cap_seq)) != hipSuccess)
+      return fail(h, std::string("pool buffers: ") + hipGetErrorString(e));
+  }
+  if (!P.d_counter && ((e = hipMalloc((void**)&P.d_counter, 64)) != hipSuccess || (e = hipMalloc((void**)&P.d_f, 64)) != hipSuccess)) return fail(h, std::string("pool buffers: ") + hipGetErrorString(e));
+  return 0;
+}
+
+// ---- device half of an upload: pools, descriptors, result slots (on the stream of the batch's pool).  `pooled`: the buffers are the handle's reusable ones
+static int batch_to_device(chd_handle* h, chd_batch* b, int pool, bool pooled = false) {
   const int B = b->B;
   b->pool = pool;
   hipStream_t st = h->stream[pool];
   auto bail = [&](const char* what, hipError_t e) { return fail(h, std::string(what) + ": " + hipGetErrorString(e)); };
   hipError_t e;
+  if (pooled) {
+    if (ensure_pool_bufs(h, pool, std::max<long long>(b->tot_cd, 1), std::max<long long>(b->tot_ci, 1), b->od_stride * B, b->oi_stride * B, B) != 0) return -1;
+    const chd_handle::PoolBufs& P = h->pb[pool];
+    b->owns_device = false;
+    b->d_cd = P.d_cd; b->d_ci = P.d_ci; b->d_od = P.d_od; b->d_oi = P.d_oi; b->d_descs = P.d_descs; b->d_order = P.d_order; b->d_counter = P.d_counter; b->d_f = P.d_f;
+  } else {
   if ((e = hipMalloc((void**)&b->d_cd, std::max<long long>(b->tot_cd, 1) * 8)) != hipSuccess) return bail("hipMalloc cd", e);
   if ((e = hipMalloc((void**)&b->d_ci, std::max<long long>(b->tot_ci, 1) * 4)) != hipSuccess) return bail("hipMalloc ci", e);
   if ((e = hipMalloc((void**)&b->d_od, b->od_stride * 8 * B)) != hipSuccess) return bail("hipMalloc od", e);
@@ -249,6 +287,7 @@ static int batch_to_device(chd_handle* h, chd_batch* b, int pool) {
   if ((e = hipMalloc((void**)&b->d_order, sizeof(int) * B)) != hipSuccess) return bail("hipMalloc order", e);
   if ((e = hipMalloc((void**)&b->d_counter, 64)) != hipSuccess) return bail("hipMalloc counter", e);
   if ((e = hipMalloc((void**)&b->d_f, 64)) != hipSuccess) return bail("hipMalloc f", e);
+  }
   if ((e = hipMemsetAsync(b->d_od, 0, b->od_stride * 8 * B, st)) != hipSuccess) return bail("memset od", e);
   if ((e = hipMemsetAsync(b->d_oi, 0, b->oi_stride * 4 * B, st)) != hipSuccess) return bail("memset oi", e);
   // ---- stage pools through one staging buffer each
@@ -468,6 +507,7 @@ struct PipeChunk {
   std::string err;
   std::thread fin;
   std::mutex mu; std::condition_variable cv; bool device_done = false;
+  double t_built = 0, t_launched = 0, t_solved = 0, t_fetched = 0, t_finished = 0, kernel_ms0 = 0, kernel_ms1 = 0;      // ms since the start of the call (CHD_PIPE_TRACE)
 };
 template <class Prep, class Fin>
 static int solve_pipelined(chd_handle* h, int B, const chd_seq_in* in, chd_seq_out* out, Prep prep, Fin fin) {
@@ -493,6 +533,7 @@ static int solve_pipelined(chd_handle* h, int B, const chd_seq_in* in, chd_seq_o
     prep_ms += now_ms() - t0; t0 = now_ms();
     c.b = batch_build(h->cfg, n, in + c.c0, nt);
     build_wall_ms += now_ms() - t0;
+    c.t_built = now_ms() - t_begin;
     h->call.setup_cpu_ms += c.b->build_cpu_ms;
     for (int i = 0; i < n; ++i) if (!c.b->ok[i]) { std::lock_guard<std::mutex> lk(agg_mu); first_err = "sequence " + std::to_string(c.c0 + i) + " rejected: " + c.b->build_err[i]; }
     const int pool = k % CHD_N_POOLS;
@@ -516,25 +557,35 @@ static int solve_pipelined(chd_handle* h, int B, const chd_seq_in* in, chd_seq_o
       for (int j = 0; j < k; ++j) { PipeChunk& p = *ch[j]; std::unique_lock<std::mutex> lk(p.mu); p.cv.wait(lk, [&] { return p.device_done; }); }
     }
     wait_ms += now_ms() - t0; t0 = now_ms();
-    int rc = ensure_workspace(h, pool, c.b->wd_need, c.b->wi_need);
-    if (rc == 0) rc = batch_to_device(h, c.b, pool);
+    int rc = 0;
+    if (k == 0)          // before the first launch: workspaces and reusable buffers of every pool this call will use, sized by this chunk (+ head-room)
+      for (int p = 0; p < CHD_N_POOLS && p < K && rc == 0; ++p) {
+        rc = ensure_workspace(h, p, c.b->wd_need, c.b->wi_need);
+        if (rc == 0) rc = ensure_pool_bufs(h, p, std::max<long long>(c.b->tot_cd, 1), std::max<long long>(c.b->tot_ci, 1), c.b->od_stride * chunk, c.b->oi_stride * chunk, chunk);
+      }
+    if (rc == 0) rc = ensure_workspace(h, pool, c.b->wd_need, c.b->wi_need);
+    if (rc == 0) rc = batch_to_device(h, c.b, pool, true);
     if (rc == 0) rc = solve_launch_main(h, c.b);
     upload_ms += now_ms() - t0;
+    c.t_launched = now_ms() - t_begin;
     if (rc != 0) {
       c.rc = -1; c.err = h->err;
       { std::lock_guard<std::mutex> lk(c.mu); c.device_done = true; }
       c.cv.notify_all();
       continue;
     }
-    c.fin = std::thread([h, &c, out, &fin, &agg_mu, &n_solved_chunks]() {
+    c.fin = std::thread([h, &c, out, &fin, &agg_mu, &n_solved_chunks, t_begin]() {
       (void)hipSetDevice(h->device);
       chd_handle local = *h;              // (error text of this thread's calls; the device resources are shared, read-only here)
       int rc2 = solve_finish(&local, c.b);
-      { std::lock_guard<std::mutex> lk(c.mu); c.device_done = true; }
-      c.cv.notify_all();
+      c.t_solved = now_ms() - t_begin;
       if (rc2 == 0) rc2 = batch_fetch(&local, c.b, out + c.c0);
+      c.t_fetched = now_ms() - t_begin;
+      { std::lock_guard<std::mutex> lk(c.mu); c.device_done = true; }          // (the pool's buffers are free again: the results are on the host)
+      c.cv.notify_all();
       if (rc2 != 0) { c.rc = -1; c.err = local.err; return; }
       fin(c.c0, c.c1);
+      c.t_finished = now_ms() - t_begin;
       std::lock_guard<std::mutex> lk(agg_mu);
       ++n_solved_chunks;
     });
@@ -549,6 +600,7 @@ static int solve_pipelined(chd_handle* h, int B, const chd_seq_in* in, chd_seq_o
     if (c->rc < 0 && err.empty()) err = c->err;
     if (c->b) {
       const chd_batch_stats& s = c->b->stats;
+      c->kernel_ms0 = s.kernel_ms[0]; c->kernel_ms1 = s.kernel_ms[1];
       cs.kernel_ms += s.kernel_ms[0] + s.kernel_ms[1]; cs.total_iters += s.total_iters; cs.total_factorizations += s.total_factorizations; cs.alg_bytes += s.alg_bytes;
       cs.n_fallback += s.n_fallback; cs.n_stalled += s.n_stalled; cs.n_rejected += c->b->B - (int)c->b->order.size();
       cs.sequence_ms += s.phase_ms[5]; if (s.max_seq_ms > cs.max_seq_ms) cs.max_seq_ms = s.max_seq_ms;
@@ -556,6 +608,10 @@ static int solve_pipelined(chd_handle* h, int B, const chd_seq_in* in, chd_seq_o
     }
   }
   cs.wall_ms = now_ms() - t_begin;
+  if (std::getenv("CHD_PIPE_TRACE"))
+    for (int k = 0; k < K; ++k)
+      std::fprintf(stderr, "[chd pipeline] chunk %d (%d sequences, pool %d): built %.0f ms, launched %.0f, solved %.0f (kernel %.0f + %.0f ms), fetched %.0f, finished %.0f\n", k, ch[k]->c1 - ch[k]->c0, k % CHD_N_POOLS,
+                   ch[k]->t_built, ch[k]->t_launched, ch[k]->t_solved, ch[k]->kernel_ms0, ch[k]->kernel_ms1, ch[k]->t_fetched, ch[k]->t_finished);
   if (!err.empty()) return fail(h, err);
   if (n_solved_chunks == 0) return fail(h, "no solvable sequence in the batch (" + first_err + ")");
   h->err = first_err;          // (a rejected sequence: the rest was solved)
@@ -627,6 +683,8 @@ void chd_phys_destroy(chd_handle* h) {
   (void)hipSetDevice(h->device);
   for (int p = 0; p < CHD_N_POOLS; ++p) {
     (void)hipFree(h->d_wd[p]); (void)hipFree(h->d_wi[p]);
+    chd_handle::PoolBufs& P = h->pb[p];
+    (void)hipFree(P.d_cd); (void)hipFree(P.d_ci); (void)hipFree(P.d_od); (void)hipFree(P.d_oi); (void)hipFree(P.d_descs); (void)hipFree(P.d_order); (void)hipFree(P.d_counter); (void)hipFree(P.d_f);
     if (h->stream[p]) (void)hipStreamDestroy(h->stream[p]);
   }
   delete h;
@@ -637,8 +695,11 @@ const char* chd_phys_last_error(const chd_handle* h) { return h ? h->err.c_str()
 void chd_batch_free(chd_handle* h, chd_batch* b) {
   if (!b) return;
   if (h) (void)hipSetDevice(h->device);
-  (void)hipFree(b->d_cd); (void)hipFree(b->d_ci); (void)hipFree(b->d_od); (void)hipFree(b->d_oi);
-  (void)hipFree(b->d_descs); (void)hipFree(b->d_order); (void)hipFree(b->d_counter); (void)hipFree(b->d_f); (void)hipFree(b->d_x);
+  if (b->owns_device) {
+    (void)hipFree(b->d_cd); (void)hipFree(b->d_ci); (void)hipFree(b->d_od); (void)hipFree(b->d_oi);
+    (void)hipFree(b->d_descs); (void)hipFree(b->d_order); (void)hipFree(b->d_counter); (void)hipFree(b->d_f);
+  }
+  (void)hipFree(b->d_x);
   for (int k = 0; k < 4; ++k) if (b->ev[k]) (void)hipEventDestroy(b->ev[k]);
   delete b;
 }
