@@ -11,6 +11,7 @@
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -110,6 +111,9 @@ struct chd_handle {
   struct PoolBufs {
     double* d_cd = nullptr; int* d_ci = nullptr; double* d_od = nullptr; int* d_oi = nullptr; SeqDesc* d_descs = nullptr; int* d_order = nullptr; int* d_counter = nullptr; double* d_f = nullptr;
     long long cap_cd = 0, cap_ci = 0, cap_od = 0, cap_oi = 0, cap_seq = 0;
+    // page-locked host staging: copies from / to it run on the DMA engines.  (A copy from pageable memory is done by a copy KERNEL, and the persistent
+    // workgroups hold every register of every compute unit: measured in round 4, the upload of chunk k + 1 then waits until chunk k's queue drains.)
+    void* pin[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; size_t pin_cap[6] = {0, 0, 0, 0, 0, 0};      // 0 cd, 1 ci, 2 descs + order, 3 od, 4 oi, 5 scratch
   } pb[CHD_N_POOLS];
 };
 
@@ -266,6 +270,43 @@ static int ensure_pool_bufs(chd_handle* h, int pool, long long n_cd, long long n
   return 0;
 }
 
+static void* pin_get(chd_handle* h, int pool, int which, size_t bytes) {
+  chd_handle::PoolBufs& P = h->pb[pool];
+  if (bytes <= P.pin_cap[which] && P.pin[which]) return P.pin[which];
+  if (P.pin[which]) (void)hipHostFree(P.pin[which]);
+  P.pin[which] = nullptr; P.pin_cap[which] = bytes + bytes / 8 + 4096;
+  if (hipHostMalloc(&P.pin[which], P.pin_cap[which], hipHostMallocDefault) != hipSuccess) { P.pin[which] = nullptr; P.pin_cap[which] = 0; }
+  return P.pin[which];
+}
+// small copies of a batch's finisher / fallback path: through the pool's page-locked scratch when the batch lives in a pool (DMA engine, see above)
+static hipError_t copy_d2h(chd_handle* h, chd_batch* b, void* dst, const void* src, size_t bytes) {
+  if (b->owns_device) return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
+  void* sc = pin_get(h, b->pool, 5, bytes);
+  if (!sc) return hipErrorOutOfMemory;
+  hipError_t e = hipMemcpyAsync(sc, src, bytes, hipMemcpyDeviceToHost, h->stream[b->pool]);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream[b->pool]);
+  if (e == hipSuccess) std::memcpy(dst, sc, bytes);
+  return e;
+}
+static hipError_t copy_d2h_2d(chd_handle* h, chd_batch* b, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height) {
+  if (b->owns_device) return hipMemcpy2D(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToHost);
+  void* sc = pin_get(h, b->pool, 5, width * height);
+  if (!sc) return hipErrorOutOfMemory;
+  hipError_t e = hipMemcpy2DAsync(sc, width, src, spitch, width, height, hipMemcpyDeviceToHost, h->stream[b->pool]);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream[b->pool]);
+  if (e == hipSuccess) for (size_t r = 0; r < height; ++r) std::memcpy((char*)dst + r * dpitch, (char*)sc + r * width, width);
+  return e;
+}
+static hipError_t copy_h2d(chd_handle* h, chd_batch* b, void* dst, const void* src, size_t bytes) {
+  if (b->owns_device) return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+  void* sc = pin_get(h, b->pool, 5, bytes);
+  if (!sc) return hipErrorOutOfMemory;
+  std::memcpy(sc, src, bytes);
+  hipError_t e = hipMemcpyAsync(dst, sc, bytes, hipMemcpyHostToDevice, h->stream[b->pool]);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream[b->pool]);
+  return e;
+}
+
 // ---- device half of an upload: pools, descriptors, result slots (on the stream of the batch's pool).  `pooled`: the buffers are the handle's reusable ones
 static int batch_to_device(chd_handle* h, chd_batch* b, int pool, bool pooled = false) {
   const int B = b->B;
@@ -290,17 +331,22 @@ static int batch_to_device(chd_handle* h, chd_batch* b, int pool, bool pooled = 
   }
   if ((e = hipMemsetAsync(b->d_od, 0, b->od_stride * 8 * B, st)) != hipSuccess) return bail("memset od", e);
   if ((e = hipMemsetAsync(b->d_oi, 0, b->oi_stride * 4 * B, st)) != hipSuccess) return bail("memset oi", e);
-  // ---- stage pools through one staging buffer each
+  // ---- stage pools through one staging buffer each (page-locked and owned by the pool when `pooled`: the copies are then asynchronous)
   {
-    std::vector<double> hcd(b->tot_cd, 0.0);
-    std::vector<int> hci(b->tot_ci, 0);
+    std::vector<double> hcd_v; std::vector<int> hci_v;
+    double* hcd; int* hci; SeqDesc* hdesc;
+    if (pooled) {
+      hcd = (double*)pin_get(h, pool, 0, (size_t)std::max<long long>(b->tot_cd, 1) * 8); hci = (int*)pin_get(h, pool, 1, (size_t)std::max<long long>(b->tot_ci, 1) * 4);
+      hdesc = (SeqDesc*)pin_get(h, pool, 2, sizeof(SeqDesc) * (size_t)B + sizeof(int) * (size_t)B);
+      if (!hcd || !hci || !hdesc) return fail(h, "page-locked staging buffers: allocation failed");
+    } else { hcd_v.assign(b->tot_cd, 0.0); hci_v.assign(b->tot_ci, 0); hcd = hcd_v.data(); hci = hci_v.data(); hdesc = nullptr; }
     for (int i = 0; i < B; ++i) {
       if (!b->ok[i]) continue;
-      std::copy(b->models[i].cd.begin(), b->models[i].cd.end(), hcd.begin() + b->off_cd[i]);
-      std::copy(b->models[i].ci.begin(), b->models[i].ci.end(), hci.begin() + b->off_ci[i]);
+      std::copy(b->models[i].cd.begin(), b->models[i].cd.end(), hcd + b->off_cd[i]);
+      std::copy(b->models[i].ci.begin(), b->models[i].ci.end(), hci + b->off_ci[i]);
     }
-    if ((e = hipMemcpyAsync(b->d_cd, hcd.data(), b->tot_cd * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return bail("copy cd", e);
-    if ((e = hipMemcpyAsync(b->d_ci, hci.data(), b->tot_ci * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return bail("copy ci", e);
+    if ((e = hipMemcpyAsync(b->d_cd, hcd, b->tot_cd * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return bail("copy cd", e);
+    if ((e = hipMemcpyAsync(b->d_ci, hci, b->tot_ci * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return bail("copy ci", e);
     b->descs.resize(B);
     for (int i = 0; i < B; ++i) {
       SeqDesc dd = b->models[i].d;
@@ -309,8 +355,10 @@ static int batch_to_device(chd_handle* h, chd_batch* b, int pool, bool pooled = 
       dd.out_d = (GD*)(b->d_od + b->od_stride * i); dd.out_i = (GI*)(b->d_oi + b->oi_stride * i);
       b->descs[i] = dd;
     }
-    if ((e = hipMemcpyAsync(b->d_descs, b->descs.data(), sizeof(SeqDesc) * B, hipMemcpyHostToDevice, st)) != hipSuccess) return bail("copy descs", e);
-    if ((e = hipStreamSynchronize(st)) != hipSuccess) return bail("sync", e);          // (the staging buffers go out of scope)
+    const SeqDesc* dsrc = b->descs.data();
+    if (pooled) { std::memcpy(hdesc, b->descs.data(), sizeof(SeqDesc) * (size_t)B); dsrc = hdesc; }
+    if ((e = hipMemcpyAsync(b->d_descs, dsrc, sizeof(SeqDesc) * B, hipMemcpyHostToDevice, st)) != hipSuccess) return bail("copy descs", e);
+    if (!pooled && (e = hipStreamSynchronize(st)) != hipSuccess) return bail("sync", e);          // (the pageable staging buffers go out of scope)
   }
   for (int k = 0; k < 4; ++k) if ((e = hipEventCreate(&b->ev[k])) != hipSuccess) return bail("hipEventCreate", e);
   return 0;
@@ -319,7 +367,12 @@ static int batch_to_device(chd_handle* h, chd_batch* b, int pool, bool pooled = 
 // one persistent launch over `items` (indices into the batch), asynchronous: e1 is recorded behind the kernel
 static int launch_queue(chd_handle* h, chd_batch* b, const std::vector<int>& items, int stage_first, int stage_last, hipEvent_t e0, hipEvent_t e1) {
   hipStream_t st = h->stream[b->pool];
-  HIP_TRY(h, hipMemcpyAsync(b->d_order, items.data(), items.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  const int* isrc = items.data();
+  if (!b->owns_device) {            // (behind the descriptors in the pool's page-locked staging buffer 2)
+    int* po = (int*)((char*)pin_get(h, b->pool, 2, sizeof(SeqDesc) * (size_t)b->B + sizeof(int) * (size_t)b->B) + sizeof(SeqDesc) * (size_t)b->B);
+    std::memcpy(po, items.data(), items.size() * sizeof(int)); isrc = po;
+  }
+  HIP_TRY(h, hipMemcpyAsync(b->d_order, isrc, items.size() * sizeof(int), hipMemcpyHostToDevice, st));
   HIP_TRY(h, hipMemsetAsync(b->d_counter, 0, sizeof(int), st));
   const unsigned grid = (unsigned)std::min<size_t>(items.size(), (size_t)h->n_wg);
   HIP_TRY(h, hipEventRecord(e0, st));
@@ -334,7 +387,7 @@ static int launch_queue(chd_handle* h, chd_batch* b, const std::vector<int>& ite
 static int fetch_stats(chd_handle* h, chd_batch* b, std::vector<double>& st) {
   const size_t w = (size_t)N_STAGES * RS_STRIDE;
   st.resize(w * b->B);
-  HIP_TRY(h, hipMemcpy2D(st.data(), w * 8, b->d_od, (size_t)b->od_stride * 8, w * 8, (size_t)b->B, hipMemcpyDeviceToHost));
+  HIP_TRY(h, copy_d2h_2d(h, b, st.data(), w * 8, b->d_od, (size_t)b->od_stride * 8, w * 8, (size_t)b->B));
   return 0;
 }
 
@@ -367,7 +420,7 @@ static int solve_finish(chd_handle* h, chd_batch* b) {
     for (size_t k = 0; k < idx.size(); ++k) {
       const SeqModel& M = b->models[idx[k]];
       ph[k].resize(M.d.tot_phases);
-      HIP_TRY(h, hipMemcpy(ph[k].data(), b->d_od + b->od_stride * idx[k] + out_d_state_off(M.d.cap) + M.d.tot_entries, ph[k].size() * 8, hipMemcpyDeviceToHost));
+      HIP_TRY(h, copy_d2h(h, b, ph[k].data(), b->d_od + b->od_stride * idx[k] + out_d_state_off(M.d.cap) + M.d.tot_entries, ph[k].size() * 8));
     }
     const unsigned nt = host_threads((int)idx.size());
     std::vector<std::thread> pool;
@@ -390,10 +443,10 @@ static int solve_finish(chd_handle* h, chd_batch* b) {
         // the stage's regions are contiguous in the pools: [o_pos_var, o_env + 2*(n + m_cap)) and [o_cl, o_task_t + task_cap)
         const long long i0 = S.o_pos_var, i1 = S.o_rcnt + (S.n + M.stage_m_cap[5]);
         const long long d0 = S.o_cl, d1 = S.o_task_t + (long long)M.stage_task_cap[5];
-        HIP_TRY(h, hipMemcpy(b->d_ci + b->off_ci[i] + i0, M.ci.data() + i0, (i1 - i0) * 4, hipMemcpyHostToDevice));
-        HIP_TRY(h, hipMemcpy(b->d_cd + b->off_cd[i] + d0, M.cd.data() + d0, (d1 - d0) * 8, hipMemcpyHostToDevice));
+        HIP_TRY(h, copy_h2d(h, b, b->d_ci + b->off_ci[i] + i0, M.ci.data() + i0, (i1 - i0) * 4));
+        HIP_TRY(h, copy_h2d(h, b, b->d_cd + b->off_cd[i] + d0, M.cd.data() + d0, (d1 - d0) * 8));
       }
-      HIP_TRY(h, hipMemcpy(b->d_descs + i, &b->descs[i], sizeof(SeqDesc), hipMemcpyHostToDevice));
+      HIP_TRY(h, copy_h2d(h, b, b->d_descs + i, &b->descs[i], sizeof(SeqDesc)));
     }
     b->stats.host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (launch_queue(h, b, idx, 5, 5, b->ev[2], b->ev[3]) != 0) return -1;
@@ -413,10 +466,10 @@ static int solve_finish(chd_handle* h, chd_batch* b) {
     for (int i : b->order) same = same && b->models[i].d.cap == b->models[b->order[0]].d.cap;
     if (same) {
       const long long off = N_STAGES * RS_STRIDE + 3LL * 10 * b->models[b->order[0]].d.cap * 3;
-      HIP_TRY(h, hipMemcpy2D(tm.data(), 24 * 8, b->d_od + off, (size_t)b->od_stride * 8, 24 * 8, (size_t)b->B, hipMemcpyDeviceToHost));
+      HIP_TRY(h, copy_d2h_2d(h, b, tm.data(), 24 * 8, b->d_od + off, (size_t)b->od_stride * 8, 24 * 8, (size_t)b->B));
     } else {
       for (int i : b->order)
-        HIP_TRY(h, hipMemcpy(tm.data() + 24 * (size_t)i, b->d_od + b->od_stride * i + N_STAGES * RS_STRIDE + 3LL * 10 * b->models[i].d.cap * 3, 24 * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(h, copy_d2h(h, b, tm.data() + 24 * (size_t)i, b->d_od + b->od_stride * i + N_STAGES * RS_STRIDE + 3LL * 10 * b->models[i].d.cap * 3, 24 * 8));
     }
   }
   for (int i : b->order) {
@@ -440,11 +493,22 @@ static int solve_finish(chd_handle* h, chd_batch* b) {
 
 // results of a solved batch -> caller arrays
 static int batch_fetch(chd_handle* h, chd_batch* b, chd_seq_out* out) {
-  if (!b->fetched) {
-    b->h_od.resize((size_t)b->od_stride * b->B); b->h_oi.resize((size_t)b->oi_stride * b->B);
-    HIP_TRY(h, hipMemcpy(b->h_od.data(), b->d_od, b->h_od.size() * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemcpy(b->h_oi.data(), b->d_oi, b->h_oi.size() * 4, hipMemcpyDeviceToHost));
-    b->fetched = true;
+  const double* h_od = nullptr; const int* h_oi = nullptr;
+  if (!b->fetched && !b->owns_device) {            // pool: straight into the page-locked buffers (read below before the pool is handed on)
+    double* pod = (double*)pin_get(h, b->pool, 3, (size_t)b->od_stride * b->B * 8); int* poi = (int*)pin_get(h, b->pool, 4, (size_t)b->oi_stride * b->B * 4);
+    if (!pod || !poi) return fail(h, "page-locked result buffers: allocation failed");
+    HIP_TRY(h, hipMemcpyAsync(pod, b->d_od, (size_t)b->od_stride * b->B * 8, hipMemcpyDeviceToHost, h->stream[b->pool]));
+    HIP_TRY(h, hipMemcpyAsync(poi, b->d_oi, (size_t)b->oi_stride * b->B * 4, hipMemcpyDeviceToHost, h->stream[b->pool]));
+    HIP_TRY(h, hipStreamSynchronize(h->stream[b->pool]));
+    h_od = pod; h_oi = poi;
+  } else {
+    if (!b->fetched) {
+      b->h_od.resize((size_t)b->od_stride * b->B); b->h_oi.resize((size_t)b->oi_stride * b->B);
+      HIP_TRY(h, hipMemcpy(b->h_od.data(), b->d_od, b->h_od.size() * 8, hipMemcpyDeviceToHost));
+      HIP_TRY(h, hipMemcpy(b->h_oi.data(), b->d_oi, b->h_oi.size() * 4, hipMemcpyDeviceToHost));
+      b->fetched = true;
+    }
+    h_od = b->h_od.data(); h_oi = b->h_oi.data();
   }
   for (int i = 0; i < b->B; ++i) {
     chd_seq_out& o = out[i];
@@ -457,8 +521,8 @@ static int batch_fetch(chd_handle* h, chd_batch* b, chd_seq_out* out) {
     }
     const SeqModel& M = b->models[i];
     const int cap = M.d.cap;
-    const double* od = b->h_od.data() + b->od_stride * i;
-    const int* oi = b->h_oi.data() + b->oi_stride * i;
+    const double* od = h_od + b->od_stride * i;
+    const int* oi = h_oi + b->oi_stride * i;
     const bool fb = (int)od[4 * RS_STRIDE + RS_STATUS] != 0;
     for (int s = 0; s < N_STAGES; ++s) {
       const double* r = od + s * RS_STRIDE;
@@ -562,6 +626,10 @@ static int solve_pipelined(chd_handle* h, int B, const chd_seq_in* in, chd_seq_o
       for (int p = 0; p < CHD_N_POOLS && p < K && rc == 0; ++p) {
         rc = ensure_workspace(h, p, c.b->wd_need, c.b->wi_need);
         if (rc == 0) rc = ensure_pool_bufs(h, p, std::max<long long>(c.b->tot_cd, 1), std::max<long long>(c.b->tot_ci, 1), c.b->od_stride * chunk, c.b->oi_stride * chunk, chunk);
+        if (rc == 0) {
+          const size_t need[6] = {(size_t)c.b->tot_cd * 8, (size_t)c.b->tot_ci * 4, (sizeof(SeqDesc) + sizeof(int)) * (size_t)chunk, (size_t)c.b->od_stride * chunk * 8, (size_t)c.b->oi_stride * chunk * 4, (size_t)chunk * 1024};
+          for (int q = 0; q < 6; ++q) if (!pin_get(h, p, q, need[q] + need[q] / 8)) rc = fail(h, "page-locked staging buffers: allocation failed");
+        }
       }
     if (rc == 0) rc = ensure_workspace(h, pool, c.b->wd_need, c.b->wi_need);
     if (rc == 0) rc = batch_to_device(h, c.b, pool, true);
@@ -685,6 +753,7 @@ void chd_phys_destroy(chd_handle* h) {
     (void)hipFree(h->d_wd[p]); (void)hipFree(h->d_wi[p]);
     chd_handle::PoolBufs& P = h->pb[p];
     (void)hipFree(P.d_cd); (void)hipFree(P.d_ci); (void)hipFree(P.d_od); (void)hipFree(P.d_oi); (void)hipFree(P.d_descs); (void)hipFree(P.d_order); (void)hipFree(P.d_counter); (void)hipFree(P.d_f);
+    for (int q = 0; q < 6; ++q) if (P.pin[q]) (void)hipHostFree(P.pin[q]);
     if (h->stream[p]) (void)hipStreamDestroy(h->stream[p]);
   }
   delete h;
