@@ -93,17 +93,17 @@ __global__ __launch_bounds__(CHD_MAX_THREADS) void chd_debug_linsolve_kernel(con
 // CHD_N_POOLS persistent launches can be in flight -- chunk k + 1 of a pipelined call starts filling the compute units that chunk k's last
 // sequences leave idle, while the host builds the tables of chunk k + 2.  The split interface (chd_batch_solve) uses pool 0 only; the other
 // pools are allocated when a pipelined call first needs them.
-#define CHD_N_POOLS 3
+#define CHD_N_POOLS 4
 struct chd_handle {
   int device = 0;
-  hipStream_t stream[CHD_N_POOLS] = {nullptr, nullptr, nullptr};
+  hipStream_t stream[CHD_N_POOLS] = {};
   chd_config cfg;
   std::string err;
   int lds_bytes = 0;
   int threads = CHD_MAX_THREADS;
   int n_wg = 0;                        // resident workgroups of a launch
   // workgroup workspaces (grow-only)
-  double* d_wd[CHD_N_POOLS] = {nullptr, nullptr, nullptr}; int* d_wi[CHD_N_POOLS] = {nullptr, nullptr, nullptr};
+  double* d_wd[CHD_N_POOLS] = {}; int* d_wi[CHD_N_POOLS] = {};
   long long wd_stride = 0, wi_stride = 0;
   chd_call_stats call{};               // accounting of the last chd_phys_solve_batch / chd_phys_solve_dirs
   // device buffers of the pipelined path, one set per pool, grow-only and reused chunk after chunk: no hipMalloc / hipFree while launches are in flight
@@ -571,19 +571,28 @@ struct PipeChunk {
   std::string err;
   std::thread fin;
   std::mutex mu; std::condition_variable cv; bool device_done = false;
-  double t_built = 0, t_launched = 0, t_solved = 0, t_fetched = 0, t_finished = 0, kernel_ms0 = 0, kernel_ms1 = 0;      // ms since the start of the call (CHD_PIPE_TRACE)
+  double t_built = 0, t_launched = 0, t_solved = 0, t_fetched = 0, t_finished = 0, kernel_ms0 = 0, kernel_ms1 = 0, t_step[3] = {0, 0, 0};      // ms since the start of the call (CHD_PIPE_TRACE)
 };
 template <class Prep, class Fin>
 static int solve_pipelined(chd_handle* h, int B, const chd_seq_in* in, chd_seq_out* out, Prep prep, Fin fin) {
   HIP_TRY(h, hipSetDevice(h->device));
   const double t_begin = now_ms();
   h->call = chd_call_stats{};
+  // chunk plan: a small first chunk (the device starts after ~50 ms of host work instead of after the set-up of a full chunk), then chunks of `chunk`
   int chunk = h->cfg.pipeline_chunk;
-  if (chunk == 0) { chunk = B / 8; if (chunk < 128) chunk = 128; if (chunk > 512) chunk = 512; }      // automatic
+  if (chunk == 0) { chunk = (B + CHD_N_POOLS - 1) / CHD_N_POOLS; if (chunk < 256) chunk = 256; if (chunk > 1024) chunk = 1024; }      // automatic
   if (chunk < 0 || chunk > B) chunk = B;                                                                // < 0: one chunk, i.e. upload, solve, fetch in turn
-  const int K = (B + chunk - 1) / chunk;
   std::vector<std::unique_ptr<PipeChunk>> ch;
-  for (int k = 0; k < K; ++k) { ch.emplace_back(new PipeChunk()); ch[k]->c0 = k * chunk; ch[k]->c1 = std::min(B, (k + 1) * chunk); }
+  {
+    int c0 = 0;
+    const int first = (h->cfg.pipeline_chunk >= 0 && B > 2 * 128 && chunk > 128) ? 128 : chunk;
+    while (c0 < B) {
+      int n = ch.empty() ? first : chunk;
+      if (B - c0 - n < 64) n = B - c0;            // (no crumbs at the end)
+      ch.emplace_back(new PipeChunk()); ch.back()->c0 = c0; ch.back()->c1 = std::min(B, c0 + n); c0 = ch.back()->c1;
+    }
+  }
+  const int K = (int)ch.size();
   const unsigned nt = host_threads(B);
   std::string first_err;
   int n_solved_chunks = 0;
@@ -622,17 +631,21 @@ static int solve_pipelined(chd_handle* h, int B, const chd_seq_in* in, chd_seq_o
     }
     wait_ms += now_ms() - t0; t0 = now_ms();
     int rc = 0;
+    const long long scale_ = (chunk + n - 1) / n;          // (the first chunk is the small one: the pools are sized for a full chunk of sequences like its own)
     if (k == 0)          // before the first launch: workspaces and reusable buffers of every pool this call will use, sized by this chunk (+ head-room)
       for (int p = 0; p < CHD_N_POOLS && p < K && rc == 0; ++p) {
         rc = ensure_workspace(h, p, c.b->wd_need, c.b->wi_need);
-        if (rc == 0) rc = ensure_pool_bufs(h, p, std::max<long long>(c.b->tot_cd, 1), std::max<long long>(c.b->tot_ci, 1), c.b->od_stride * chunk, c.b->oi_stride * chunk, chunk);
+        if (rc == 0) rc = ensure_pool_bufs(h, p, std::max<long long>(c.b->tot_cd, 1) * scale_, std::max<long long>(c.b->tot_ci, 1) * scale_, c.b->od_stride * chunk, c.b->oi_stride * chunk, chunk);
         if (rc == 0) {
-          const size_t need[6] = {(size_t)c.b->tot_cd * 8, (size_t)c.b->tot_ci * 4, (sizeof(SeqDesc) + sizeof(int)) * (size_t)chunk, (size_t)c.b->od_stride * chunk * 8, (size_t)c.b->oi_stride * chunk * 4, (size_t)chunk * 1024};
+          const size_t need[6] = {(size_t)c.b->tot_cd * 8 * scale_, (size_t)c.b->tot_ci * 4 * scale_, (sizeof(SeqDesc) + sizeof(int)) * (size_t)chunk, (size_t)c.b->od_stride * chunk * 8, (size_t)c.b->oi_stride * chunk * 4, (size_t)chunk * 1024};
           for (int q = 0; q < 6; ++q) if (!pin_get(h, p, q, need[q] + need[q] / 8)) rc = fail(h, "page-locked staging buffers: allocation failed");
         }
       }
+    c.t_step[0] = now_ms() - t_begin;
     if (rc == 0) rc = ensure_workspace(h, pool, c.b->wd_need, c.b->wi_need);
+    c.t_step[1] = now_ms() - t_begin;
     if (rc == 0) rc = batch_to_device(h, c.b, pool, true);
+    c.t_step[2] = now_ms() - t_begin;
     if (rc == 0) rc = solve_launch_main(h, c.b);
     upload_ms += now_ms() - t0;
     c.t_launched = now_ms() - t_begin;
@@ -678,8 +691,8 @@ static int solve_pipelined(chd_handle* h, int B, const chd_seq_in* in, chd_seq_o
   cs.wall_ms = now_ms() - t_begin;
   if (std::getenv("CHD_PIPE_TRACE"))
     for (int k = 0; k < K; ++k)
-      std::fprintf(stderr, "[chd pipeline] chunk %d (%d sequences, pool %d): built %.0f ms, launched %.0f, solved %.0f (kernel %.0f + %.0f ms), fetched %.0f, finished %.0f\n", k, ch[k]->c1 - ch[k]->c0, k % CHD_N_POOLS,
-                   ch[k]->t_built, ch[k]->t_launched, ch[k]->t_solved, ch[k]->kernel_ms0, ch[k]->kernel_ms1, ch[k]->t_fetched, ch[k]->t_finished);
+      std::fprintf(stderr, "[chd pipeline] chunk %d (%d sequences, pool %d): built %.0f ms (pool ready %.0f, workspace %.0f, uploaded %.0f), launched %.0f, solved %.0f (kernel %.0f + %.0f ms), fetched %.0f, finished %.0f\n", k, ch[k]->c1 - ch[k]->c0, k % CHD_N_POOLS,
+                   ch[k]->t_built, ch[k]->t_step[0], ch[k]->t_step[1], ch[k]->t_step[2], ch[k]->t_launched, ch[k]->t_solved, ch[k]->kernel_ms0, ch[k]->kernel_ms1, ch[k]->t_fetched, ch[k]->t_finished);
   if (!err.empty()) return fail(h, err);
   if (n_solved_chunks == 0) return fail(h, "no solvable sequence in the batch (" + first_err + ")");
   h->err = first_err;          // (a rejected sequence: the rest was solved)

@@ -27,6 +27,6 @@ for ch in chunks:
     s.solve_batch(seqs[:256])                      # warm-up: kernel load, pools
     t0 = time.perf_counter(); r2, cs = s.solve_batch(seqs); dt = time.perf_counter() - t0
     same = all(a.stage_iters == b_.stage_iters for a, b_ in zip(res, r2))
-    print('chd_phys_solve_batch, chunk %d: %.2f s = %.1f sequences/s (%.2f of solve-only); chunks %d, set-up %.0f ms wall on %d threads (%.2f ms per sequence and thread), upload %.0f ms, waited for the device %.0f ms; same results %s'
-          % (ch, dt, n / dt, (n / dt) / (n / (t2 - t1)), cs['n_chunks'], cs['setup_wall_ms'], cs['host_threads'], cs['setup_cpu_ms'] / n, cs['upload_ms'], cs['wait_for_pool_ms'], same), flush=True)
+    print('chd_phys_solve_batch, chunk %d: %.2f s in Python, %.2f s in the library = %.1f sequences/s (%.2f of solve-only); chunks %d, set-up %.0f ms wall on %d threads (%.2f ms per sequence and thread), upload %.0f ms, waited for the device %.0f ms; same results %s'
+          % (ch, dt, cs['wall_ms'] * 1e-3, n / (cs['wall_ms'] * 1e-3), (n / (cs['wall_ms'] * 1e-3)) / (n / (t2 - t1)), cs['n_chunks'], cs['setup_wall_ms'], cs['host_threads'], cs['setup_cpu_ms'] / n, cs['upload_ms'], cs['wait_for_pool_ms'], same), flush=True)
     s.close()
