@@ -104,7 +104,7 @@ struct chd_handle {
   int n_wg = 0;                        // resident workgroups of a launch
   // workgroup workspaces (grow-only)
   double* d_wd[CHD_N_POOLS] = {}; int* d_wi[CHD_N_POOLS] = {};
-  long long wd_stride = 0, wi_stride = 0;
+  long long wd_stride[CHD_N_POOLS] = {}, wi_stride[CHD_N_POOLS] = {};          // per pool: a pool that has to grow is reallocated alone, while it is idle
   chd_call_stats call{};               // accounting of the last chd_phys_solve_batch / chd_phys_solve_dirs
   // device buffers of the pipelined path, one set per pool, grow-only and reused chunk after chunk: no hipMalloc / hipFree while launches are in flight
   // (measured, round 4: allocating per chunk serialised the chunks -- 214 ms of "upload" per chunk, the whole call at 0.72 of the solve-only rate)
@@ -169,30 +169,35 @@ static unsigned host_threads(int n) {
   return nt;
 }
 
-// workspaces of pool `pool` for `n_wg` resident workgroups of at least (wd_need, wi_need) elements each.  The stride is common to all pools: when it
-// has to grow, every pool that exists is reallocated (the caller makes sure no launch is in flight).
-static int ensure_workspace(chd_handle* h, int pool, long long wd_need, long long wi_need) {
+// workspaces of pool `pool` for `n_wg` resident workgroups of at least (wd_need, wi_need) elements each (+ `headroom` eighths when the pool has to be
+// (re)allocated: the pipelined path asks for 2/8, because a sequence that needs a few per cent more than its predecessors must not stall the pipeline --
+// measured in round 4: every new maximum drained all launches and reallocated every pool, 1.2 s each time).  The caller makes sure the pool is idle.
+static int ensure_workspace(chd_handle* h, int pool, long long wd_need, long long wi_need, int headroom = 0) {
   auto al = [](long long v) { return (v + 63) & ~63LL; };
-  const bool grow = al(wd_need) > h->wd_stride || al(wi_need) > h->wi_stride;
-  if (!grow && h->d_wd[pool]) return 0;
-  if (grow) {
-    for (int p = 0; p < CHD_N_POOLS; ++p) {
-      if (!h->d_wd[p]) continue;
-      HIP_TRY(h, hipStreamSynchronize(h->stream[p]));
-      (void)hipFree(h->d_wd[p]); (void)hipFree(h->d_wi[p]);
-      h->d_wd[p] = nullptr; h->d_wi[p] = nullptr;
-    }
-    h->wd_stride = std::max(h->wd_stride, al(wd_need)); h->wi_stride = std::max(h->wi_stride, al(wi_need));
+  if (h->d_wd[pool] && al(wd_need) <= h->wd_stride[pool] && al(wi_need) <= h->wi_stride[pool]) return 0;
+  if (h->d_wd[pool]) {
+    HIP_TRY(h, hipStreamSynchronize(h->stream[pool]));
+    (void)hipFree(h->d_wd[pool]); (void)hipFree(h->d_wi[pool]);
+    h->d_wd[pool] = nullptr; h->d_wi[pool] = nullptr;
   }
-  hipError_t e = hipMalloc((void**)&h->d_wd[pool], (size_t)h->wd_stride * 8 * h->n_wg);
-  if (e == hipSuccess) e = hipMalloc((void**)&h->d_wi[pool], (size_t)h->wi_stride * 4 * h->n_wg);
+  h->wd_stride[pool] = std::max(h->wd_stride[pool], al(wd_need + wd_need / 8 * headroom)); h->wi_stride[pool] = std::max(h->wi_stride[pool], al(wi_need + wi_need / 8 * headroom));
+  hipError_t e = hipMalloc((void**)&h->d_wd[pool], (size_t)h->wd_stride[pool] * 8 * h->n_wg);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_wi[pool], (size_t)h->wi_stride[pool] * 4 * h->n_wg);
+  if (e != hipSuccess && headroom > 0) {          // not with head-room: exactly what is needed
+    (void)hipFree(h->d_wd[pool]); h->d_wd[pool] = nullptr; h->d_wi[pool] = nullptr;
+    h->wd_stride[pool] = al(wd_need); h->wi_stride[pool] = al(wi_need);
+    e = hipMalloc((void**)&h->d_wd[pool], (size_t)h->wd_stride[pool] * 8 * h->n_wg);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_wi[pool], (size_t)h->wi_stride[pool] * 4 * h->n_wg);
+  }
   if (e != hipSuccess) {
     (void)hipFree(h->d_wd[pool]); h->d_wd[pool] = nullptr; h->d_wi[pool] = nullptr;
-    return fail(h, std::string("workspace allocation (") + std::to_string((h->wd_stride * 8 + h->wi_stride * 4) * h->n_wg >> 20) + " MiB): " + hipGetErrorString(e));
+    const long long mib = (h->wd_stride[pool] * 8 + h->wi_stride[pool] * 4) * h->n_wg >> 20;
+    h->wd_stride[pool] = h->wi_stride[pool] = 0;
+    return fail(h, std::string("workspace allocation (") + std::to_string(mib) + " MiB): " + hipGetErrorString(e));
   }
   // (no clearing needed for correctness: a workgroup zeroes / initialises what it reads, sequence by sequence and stage by stage)
-  HIP_TRY(h, hipMemsetAsync(h->d_wd[pool], 0, (size_t)h->wd_stride * 8 * h->n_wg, h->stream[pool]));
-  HIP_TRY(h, hipMemsetAsync(h->d_wi[pool], 0, (size_t)h->wi_stride * 4 * h->n_wg, h->stream[pool]));
+  HIP_TRY(h, hipMemsetAsync(h->d_wd[pool], 0, (size_t)h->wd_stride[pool] * 8 * h->n_wg, h->stream[pool]));
+  HIP_TRY(h, hipMemsetAsync(h->d_wi[pool], 0, (size_t)h->wi_stride[pool] * 4 * h->n_wg, h->stream[pool]));
   return 0;
 }
 
@@ -377,7 +382,7 @@ static int launch_queue(chd_handle* h, chd_batch* b, const std::vector<int>& ite
   const unsigned grid = (unsigned)std::min<size_t>(items.size(), (size_t)h->n_wg);
   HIP_TRY(h, hipEventRecord(e0, st));
   hipLaunchKernelGGL(chd_solve_kernel, dim3(grid), dim3(h->threads), h->lds_bytes, st, b->d_descs, (const int*)b->d_order, (int)items.size(),
-                     b->d_counter, h->d_wd[b->pool], h->wd_stride, h->d_wi[b->pool], h->wi_stride, h->lds_bytes / 8, h->cfg.tol, h->cfg.stall_window, stage_first, stage_last);
+                     b->d_counter, h->d_wd[b->pool], h->wd_stride[b->pool], h->d_wi[b->pool], h->wi_stride[b->pool], h->lds_bytes / 8, h->cfg.tol, h->cfg.stall_window, stage_first, stage_last);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipEventRecord(e1, st));
   return 0;          // (asynchronous: the kernel is waited for through e1; `items` must stay alive until then -- the callers pass vectors owned by the batch)
@@ -593,6 +598,7 @@ static int solve_pipelined(chd_handle* h, int B, const chd_seq_in* in, chd_seq_o
     }
   }
   const int K = (int)ch.size();
+  int n_pools = std::min(CHD_N_POOLS, K);
   const unsigned nt = host_threads(B);
   std::string first_err;
   int n_solved_chunks = 0;
@@ -609,10 +615,10 @@ static int solve_pipelined(chd_handle* h, int B, const chd_seq_in* in, chd_seq_o
     c.t_built = now_ms() - t_begin;
     h->call.setup_cpu_ms += c.b->build_cpu_ms;
     for (int i = 0; i < n; ++i) if (!c.b->ok[i]) { std::lock_guard<std::mutex> lk(agg_mu); first_err = "sequence " + std::to_string(c.c0 + i) + " rejected: " + c.b->build_err[i]; }
-    const int pool = k % CHD_N_POOLS;
+    const int pool = k % n_pools;
     t0 = now_ms();
-    if (k >= CHD_N_POOLS) {            // the pool's previous launch (and its fallback) must be over
-      PipeChunk& p = *ch[k - CHD_N_POOLS];
+    if (k >= n_pools) {            // the pool's previous launch (and its fallback) must be over
+      PipeChunk& p = *ch[k - n_pools];
       std::unique_lock<std::mutex> lk(p.mu);
       p.cv.wait(lk, [&] { return p.device_done; });
     }
@@ -626,23 +632,21 @@ static int solve_pipelined(chd_handle* h, int B, const chd_seq_in* in, chd_seq_o
       fin(c.c0, c.c1);
       continue;
     }
-    if (c.b->wd_need > h->wd_stride || c.b->wi_need > h->wi_stride) {          // the workspaces have to grow: no launch may be in flight
-      for (int j = 0; j < k; ++j) { PipeChunk& p = *ch[j]; std::unique_lock<std::mutex> lk(p.mu); p.cv.wait(lk, [&] { return p.device_done; }); }
-    }
     wait_ms += now_ms() - t0; t0 = now_ms();
     int rc = 0;
     const long long scale_ = (chunk + n - 1) / n;          // (the first chunk is the small one: the pools are sized for a full chunk of sequences like its own)
     if (k == 0)          // before the first launch: workspaces and reusable buffers of every pool this call will use, sized by this chunk (+ head-room)
-      for (int p = 0; p < CHD_N_POOLS && p < K && rc == 0; ++p) {
-        rc = ensure_workspace(h, p, c.b->wd_need, c.b->wi_need);
+      for (int p = 0; p < n_pools && rc == 0; ++p) {
+        rc = ensure_workspace(h, p, c.b->wd_need, c.b->wi_need, 2);
         if (rc == 0) rc = ensure_pool_bufs(h, p, std::max<long long>(c.b->tot_cd, 1) * scale_, std::max<long long>(c.b->tot_ci, 1) * scale_, c.b->od_stride * chunk, c.b->oi_stride * chunk, chunk);
         if (rc == 0) {
           const size_t need[6] = {(size_t)c.b->tot_cd * 8 * scale_, (size_t)c.b->tot_ci * 4 * scale_, (sizeof(SeqDesc) + sizeof(int)) * (size_t)chunk, (size_t)c.b->od_stride * chunk * 8, (size_t)c.b->oi_stride * chunk * 4, (size_t)chunk * 1024};
           for (int q = 0; q < 6; ++q) if (!pin_get(h, p, q, need[q] + need[q] / 8)) rc = fail(h, "page-locked staging buffers: allocation failed");
         }
+        if (rc != 0 && p >= 1) { n_pools = p; rc = 0; h->err.clear(); break; }          // (long sequences: the memory holds fewer pools -- fewer launches in flight)
       }
     c.t_step[0] = now_ms() - t_begin;
-    if (rc == 0) rc = ensure_workspace(h, pool, c.b->wd_need, c.b->wi_need);
+    if (rc == 0) rc = ensure_workspace(h, pool, c.b->wd_need, c.b->wi_need, 2);          // (this pool is idle; grows alone if this chunk holds a larger sequence than any before)
     c.t_step[1] = now_ms() - t_begin;
     if (rc == 0) rc = batch_to_device(h, c.b, pool, true);
     c.t_step[2] = now_ms() - t_begin;
@@ -691,7 +695,7 @@ static int solve_pipelined(chd_handle* h, int B, const chd_seq_in* in, chd_seq_o
   cs.wall_ms = now_ms() - t_begin;
   if (std::getenv("CHD_PIPE_TRACE"))
     for (int k = 0; k < K; ++k)
-      std::fprintf(stderr, "[chd pipeline] chunk %d (%d sequences, pool %d): built %.0f ms (pool ready %.0f, workspace %.0f, uploaded %.0f), launched %.0f, solved %.0f (kernel %.0f + %.0f ms), fetched %.0f, finished %.0f\n", k, ch[k]->c1 - ch[k]->c0, k % CHD_N_POOLS,
+      std::fprintf(stderr, "[chd pipeline] chunk %d (%d sequences, pool %d): built %.0f ms (pool ready %.0f, workspace %.0f, uploaded %.0f), launched %.0f, solved %.0f (kernel %.0f + %.0f ms), fetched %.0f, finished %.0f\n", k, ch[k]->c1 - ch[k]->c0, k % n_pools,
                    ch[k]->t_built, ch[k]->t_step[0], ch[k]->t_step[1], ch[k]->t_step[2], ch[k]->t_launched, ch[k]->t_solved, ch[k]->kernel_ms0, ch[k]->kernel_ms1, ch[k]->t_fetched, ch[k]->t_finished);
   if (!err.empty()) return fail(h, err);
   if (n_solved_chunks == 0) return fail(h, "no solvable sequence in the batch (" + first_err + ")");
