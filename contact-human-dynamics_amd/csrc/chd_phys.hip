@@ -93,7 +93,7 @@ __global__ __launch_bounds__(CHD_MAX_THREADS) void chd_debug_linsolve_kernel(con
 // CHD_N_POOLS persistent launches can be in flight -- chunk k + 1 of a pipelined call starts filling the compute units that chunk k's last
 // sequences leave idle, while the host builds the tables of chunk k + 2.  The split interface (chd_batch_solve) uses pool 0 only; the other
 // pools are allocated when a pipelined call first needs them.
-#define CHD_N_POOLS 4
+#define CHD_N_POOLS 8
 struct chd_handle {
   int device = 0;
   hipStream_t stream[CHD_N_POOLS] = {};
@@ -113,7 +113,7 @@ struct chd_handle {
     long long cap_cd = 0, cap_ci = 0, cap_od = 0, cap_oi = 0, cap_seq = 0;
     // page-locked host staging: copies from / to it run on the DMA engines.  (A copy from pageable memory is done by a copy KERNEL, and the persistent
     // workgroups hold every register of every compute unit: measured in round 4, the upload of chunk k + 1 then waits until chunk k's queue drains.)
-    void* pin[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; size_t pin_cap[6] = {0, 0, 0, 0, 0, 0};      // 0 cd, 1 ci, 2 descs + order, 3 od, 4 oi, 5 scratch
+    void* pin[6] = {}; size_t pin_cap[6] = {};      // 0 cd, 1 ci, 2 descs + order, 3 od, 4 oi, 5 scratch
   } pb[CHD_N_POOLS];
 };
 
@@ -585,7 +585,7 @@ static int solve_pipelined(chd_handle* h, int B, const chd_seq_in* in, chd_seq_o
   h->call = chd_call_stats{};
   // chunk plan: a small first chunk (the device starts after ~50 ms of host work instead of after the set-up of a full chunk), then chunks of `chunk`
   int chunk = h->cfg.pipeline_chunk;
-  if (chunk == 0) { chunk = (B + CHD_N_POOLS - 1) / CHD_N_POOLS; if (chunk < 256) chunk = 256; if (chunk > 1024) chunk = 1024; }      // automatic
+  if (chunk == 0) { chunk = (B + CHD_N_POOLS - 2) / (CHD_N_POOLS - 1); if (chunk < 256) chunk = 256; if (chunk > 1024) chunk = 1024; }      // automatic: every chunk queued at once when B <= ~7 000
   if (chunk < 0 || chunk > B) chunk = B;                                                                // < 0: one chunk, i.e. upload, solve, fetch in turn
   std::vector<std::unique_ptr<PipeChunk>> ch;
   {
