@@ -349,7 +349,7 @@ def main(argv=None, solver_factory=None):
                                        'identical_to_split_interface': bool(all(a.stage_iters == b_.stage_iters and all(np_eq(x.base_lin, y.base_lin) for x, y in zip(a.snapshots, b_.snapshots))
                                                                                for a, b_ in zip(res_incl, res))),
                                        'host_cores_to_keep_one_gpu_busy': cs['setup_cpu_ms'] / max(1e-9, 1e3 * len(seqs) / (total_value_hint or 1.0)),
-                                       'note': 'chd_phys_solve_batch on the SAME %d sequences: table build on the host threads, upload, persistent launches (up to 8 chunks in flight), '
+                                       'note': 'chd_phys_solve_batch on the SAME %d sequences: table build on the host threads, upload, persistent launches (up to 4 chunks in flight), '
                                                'stage-4 fallbacks, fetch -- one call, wall clock; host_cores_to_keep_one_gpu_busy = set-up thread-seconds per second of solve-only rate' % len(seqs)}
             # (b) the same file to file ("I/O-inclusive figure reported separately"): chd_phys_solve_dirs on 1 024 directories of the workload
             import tempfile

@@ -92,8 +92,10 @@ __global__ __launch_bounds__(CHD_MAX_THREADS) void chd_debug_linsolve_kernel(con
 // A handle owns CHD_N_POOLS workspace pools (one workspace per resident workgroup each) with a stream of their own: a launch uses one pool, so up to
 // CHD_N_POOLS persistent launches can be in flight -- chunk k + 1 of a pipelined call starts filling the compute units that chunk k's last
 // sequences leave idle, while the host builds the tables of chunk k + 2.  The split interface (chd_batch_solve) uses pool 0 only; the other
-// pools are allocated when a pipelined call first needs them.
-#define CHD_N_POOLS 8
+// pools are allocated when a pipelined call first needs them.  Measured on the MI355X (profiles/r04_pipeline.md, 2 560 sequences, ~8 chunks): four pools
+// 0.90 of the solve-only rate, eight pools 0.79 (a launch's workgroups keep their compute units until ITS queue is drained: many launches in flight split
+// the units unevenly), caps on the grid of a launch 0.75-0.88.
+#define CHD_N_POOLS 4
 struct chd_handle {
   int device = 0;
   hipStream_t stream[CHD_N_POOLS] = {};
@@ -585,7 +587,7 @@ static int solve_pipelined(chd_handle* h, int B, const chd_seq_in* in, chd_seq_o
   h->call = chd_call_stats{};
   // chunk plan: a small first chunk (the device starts after ~50 ms of host work instead of after the set-up of a full chunk), then chunks of `chunk`
   int chunk = h->cfg.pipeline_chunk;
-  if (chunk == 0) { chunk = (B + CHD_N_POOLS - 2) / (CHD_N_POOLS - 1); if (chunk < 256) chunk = 256; if (chunk > 1024) chunk = 1024; }      // automatic: every chunk queued at once when B <= ~7 000
+  if (chunk == 0) { chunk = (B + 6) / 7; if (chunk < 256) chunk = 256; if (chunk > 1024) chunk = 1024; }      // automatic: about eight chunks, four of them in flight
   if (chunk < 0 || chunk > B) chunk = B;                                                                // < 0: one chunk, i.e. upload, solve, fetch in turn
   std::vector<std::unique_ptr<PipeChunk>> ch;
   {

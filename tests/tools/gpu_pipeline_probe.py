@@ -24,7 +24,9 @@ print('split interface: upload (table build + copies) %.2f s, solve %.2f s = %.1
 s.close()
 for ch in chunks:
     s = PhysOptim(0, default_config(pipeline_chunk=ch))
-    s.solve_batch(seqs[:256])                      # warm-up: kernel load, pools
+    os.environ.pop('CHD_PIPE_TRACE', None)
+    s.solve_batch(seqs)                            # warm-up with the same plan: kernel load, pools
+    os.environ['CHD_PIPE_TRACE'] = '1'
     t0 = time.perf_counter(); r2, cs = s.solve_batch(seqs); dt = time.perf_counter() - t0
     same = all(a.stage_iters == b_.stage_iters for a, b_ in zip(res, r2))
     print('chd_phys_solve_batch, chunk %d: %.2f s in Python, %.2f s in the library = %.1f sequences/s (%.2f of solve-only); chunks %d, set-up %.0f ms wall on %d threads (%.2f ms per sequence and thread), upload %.0f ms, waited for the device %.0f ms; same results %s'
