@@ -34,7 +34,7 @@ CAPS = [7000, 7000, 7000, 2500, 2000, 7000]
 
 def kernel_sources_sha256():
     """Hash of the solver kernel's sources: profiles/traffic.json carries the one its PMC passes were measured with (tools/pmc_summary.py)."""
-    return _sources_sha256(('chd_kernels.hpp', 'chd_kfront.hpp', 'chd_phys.hip', 'chd_model.hpp', 'chd_device.hpp', 'chd_io.hpp'))      # = phys_optim.SOURCES
+    return _sources_sha256(('chd_kernels.hpp', 'chd_phys.hip', 'chd_model.hpp', 'chd_device.hpp', 'chd_io.hpp'))      # = phys_optim.SOURCES (tests/test_capi.py checks that)
 
 
 def _sources_sha256(files):

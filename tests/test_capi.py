@@ -144,3 +144,15 @@ def test_struct_mirrors_match_the_header_sizes(lib, tmp_path):
     c = phys_capi.ChdConfig()
     lib.chd_config_default(C.byref(c))
     assert c.stall_window == 0 and c.max_workgroups == 0 and c.threads_per_sequence == 0       # no stall guard unless asked for
+
+
+def test_bench_hashes_the_sources_the_build_uses():
+    """bench.py marks profiles/traffic.json STALE by a hash of the kernel sources: the list must be the one build_library compiles."""
+    import re
+    from chd_amd import phys_optim
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    m = re.search(r"def kernel_sources_sha256\(\):.*?_sources_sha256\(\((.*?)\)\)", src, re.S)
+    listed = set(re.findall(r"'([^']+)'", m.group(1)))
+    assert listed == set(phys_optim.SOURCES), (listed, phys_optim.SOURCES)
+    for f in listed:
+        assert os.path.exists(os.path.join(ROOT, 'contact-human-dynamics_amd', 'csrc', f)), f
