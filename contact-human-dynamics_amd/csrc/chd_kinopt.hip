@@ -50,10 +50,12 @@ int chd_kin_solve_batch(const chd_kin_config* cfg, int device, int B, chd_kin_se
   if (device < 0 || device >= ndev) return fail("device index out of range");
   hipError_t e;
   if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
-  if (cfg->reserved[1] > 0) {   // LDS doubles per workgroup: the product passes address 3 * 84 * (TF + 2) doubles with TF >= 1 (kin_jv) and 336 (kin_jtu)
+  {   // LDS doubles per workgroup (default 18 432 = 144 KB, or reserved[1]): the product passes address 3 * 84 * (TF + 2) doubles with TF >= 1 (kin_jv) and 336 (kin_jtu).
+      // The default is checked against the device like an explicit value: a device / partition mode with less LDS fails here with a message, not in the launch.
     int lds_max = 0;
     if ((e = hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device)) != hipSuccess) return fail("hipDeviceGetAttribute", e);
-    if (cfg->reserved[1] < 756 || (long long)cfg->reserved[1] * 8 > lds_max) return fail("reserved[1] (LDS doubles per workgroup) out of range: 756 .. device limit");
+    const long long want = cfg->reserved[1] > 0 ? cfg->reserved[1] : 18432;
+    if (want < 756 || want * 8 > lds_max) return fail(cfg->reserved[1] > 0 ? "reserved[1] (LDS doubles per workgroup) out of range: 756 .. device limit" : "the device offers less than the 144 KB of LDS per workgroup the default frame tiles need: set reserved[1] (LDS doubles per workgroup, >= 756)");
   }
   KinBatch bt;
   if (!bt.build(cfg, B, in)) return fail(bt.err);

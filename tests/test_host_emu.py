@@ -116,6 +116,16 @@ def test_duration_block_of_lagrangian_hessian_vs_finite_differences(emu, oracle_
     o = OracleProblem(seq); o.set_stage(4)
     Ho = o.eval(x, jac=True, hess=True, lam=lam)[4]
     assert np.abs(Ho[nd:, nd:] - A).max() <= 1e-11 * np.abs(A).max()
+    # the node x duration block (round 4): kernel source (records of the row tasks + sample cache, gathered per node variable) against the oracle's (per-family
+    # scatter) and against the same finite differences; it also holds force / centre-of-mass / base-angle x duration entries
+    Hk = e.eval(4, x, lam=lam)['H']
+    FDx = np.zeros((nd, n - nd))
+    for k in range(nd, n):
+        xp = x.copy(); xm = x.copy(); xp[k] += h; xm[k] -= h
+        FDx[:, k - nd] = ((grad_lagrangian(xp) - grad_lagrangian(xm)) / (2 * h))[:nd]
+    assert np.abs(Hk[:nd, nd:] - FDx).max() <= 1e-6 * np.abs(FDx).max()
+    assert np.abs(Hk[:nd, nd:] - Ho[:nd, nd:]).max() <= 1e-11 * np.abs(Ho[:nd, nd:]).max()
+    assert np.abs(Hk[:nd, :nd] - Ho[:nd, :nd]).max() <= 1e-11 * np.abs(Ho[:nd, :nd]).max()
 
 
 def test_kkt_structure_tables(emu):

