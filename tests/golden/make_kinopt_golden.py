@@ -15,6 +15,7 @@ not used on this path).  Run in the build container only (it reads /root/referen
 
     python tests/golden/make_kinopt_golden.py                      # the three short clips (10 / 16 / 12 frames)
     python tests/golden/make_kinopt_golden.py --long 40 60         # kinopt_golden_long.npz: clips of 40 and 60 frames (tens of minutes: the reference's dense Jacobians)
+    python tests/golden/make_kinopt_golden.py --long 100 --out=kinopt_golden_100.npz      # one clip of the bench's length (crosses the kernel's default frame tiles)
 """
 import contextlib
 import io
@@ -108,8 +109,9 @@ if __name__ == '__main__':
              dict(seed=3, F=12, floor='refit')]
     out_name = 'kinopt_golden.npz'
     if len(sys.argv) > 1 and sys.argv[1] == '--long':          # clips of a realistic length: kinopt_golden_long.npz, frames from the command line
-        cases = [dict(seed=10 + i, F=int(f), floor=None) for i, f in enumerate(sys.argv[2:] or ['40', '60'])]
-        out_name = 'kinopt_golden_long.npz'
+        frames_ = [a for a in sys.argv[2:] if not a.startswith('--out=')] or ['40', '60']
+        cases = [dict(seed=10 + i + (0 if len(frames_) > 1 else int(frames_[0])), F=int(f), floor=None) for i, f in enumerate(frames_)]
+        out_name = ([a[6:] for a in sys.argv[2:] if a.startswith('--out=')] or ['kinopt_golden_long.npz'])[0]
     out = {'n_cases': np.array(len(cases)), 'scipy_version': np.array(scipy.__version__), 'sklearn_version': np.array(sklearn.__version__),
            'forward_mapping': np.array([ot.FORWARD_MAPPING[j] for j in range(28)]), 'backward_mapping': np.array([ot.BACKWARD_MAPPING[j] for j in range(28)])}
     real_lsq = ot.least_squares
