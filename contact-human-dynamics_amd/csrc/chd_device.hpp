@@ -14,9 +14,11 @@ namespace chd {
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(1))) double GD;
 typedef __attribute__((address_space(1))) int GI;
+typedef __attribute__((address_space(1))) unsigned long long GU;
 #else
 typedef double GD;
 typedef int GI;
+typedef unsigned long long GU;
 #endif
 
 enum { N_SPLINES = 10, N_EE = 4, N_STAGES = 6 };
@@ -118,11 +120,14 @@ struct SeqDesc {
   int max_n, max_m, max_N;
   // wd offsets — KKT storage
   int o_K0b, o_K0x, o_Kfb, o_Kfx;      // full band, border rows (unfactored); lower band, border rows (factor)
+  int o_pmb, o_pmx, o_pmt;             // occupancy masks of the unfactored matrix (64-bit words, one bit per stored entry; chd_kernels.hpp "KKT storage"):
+                                       // band rows, border rows, and the border transposed (per band column: which border rows hold an entry in it)
   long long sz_K0b, sz_K0x, sz_Kfb, sz_Kfx;
   // wi offsets
   int o_flags, o_first, o_sign;
   int o_envw;           // working copy of the stage's envelope (2 ints per KKT position): widened when an entry lands outside it
   int o_rcntw;          // working copy of StageDesc::o_rcnt
+  int o_csr_rp, o_csr_col, o_csr_row, csr_cap;      // the marked entries of the unfactored matrix as a row-sorted list (chd_kernels.hpp "KKT storage"): N + 1 row starts, csr_cap (column, row) pairs
   StageDesc st[N_STAGES];
 };
 

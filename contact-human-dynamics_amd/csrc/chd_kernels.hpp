@@ -142,6 +142,11 @@ struct Ctx {
   int lds_cap;          // doubles available in lds
   int n, m, N, Nb, bc, w, W2, LD;
   GD* K0b; GD* K0x; GD* Kfb; GD* Kfx;
+  GU* pmb; GU* pmx; GU* pmt;      // occupancy masks of K0 (band rows, border rows, border transposed): one bit per stored entry that has ever been written in this stage
+  int MW, LW, CW;                 // 64-bit words per band row / border row / band column of the three masks
+  GI* csr_rp; GI* csr_col; GI* csr_row;      // the marked entries as a row-sorted list, rebuilt from the masks when an evaluation has added bits
+  int csr_nnz, csr_cap;
+  int pm_dirty;                   // an entry was marked since the list was built (any thread sets it; read after a barrier)
   const GI* pos_var; const GI* pos_row;
   GI* env;              // [2p] first, [2p+1] last band position coupled to p (envelope): the stage's working copy
   GI* rcnt;             // [k]: the border rows [0, rcnt[k]) are the ones that can reach band column k (working copy)
@@ -504,6 +509,18 @@ CHD_DEV void angular_term(const double e[3], const double ed[3], const double ed
 // durations can carry a sample into a polynomial that structure did not foresee.  An entry (row hi, column lo < hi)
 // left of row hi's envelope start widens the working copy: the row starts at lo, and the columns in between are
 // reached by row hi.  (min / max updates: the result does not depend on the order the threads arrive in.)
+//
+// Occupancy.  The band envelope holds ~18 x as many entries as the matrix has non-zeros (537 k against 30 k for a 90-frame walk; the border: 79 k
+// against 1.5 k), so everything that READS K0 -- the two KKT products of an iteration, the copy into the factor, clearing it for the next evaluation -- goes
+// through bit masks of the entries that have ever been written in this stage: one bit per stored entry of a band row (pmb), of a border row (pmx), and
+// the border transposed (pmt: per band column, the border rows with an entry in it).  The masks maintain themselves at no cost in traffic: kzero
+// stores -0.0 in the marked entries and everything else is +0.0 since kreset, so a writer whose read-modify-write finds the bit pattern of +0.0 knows the
+// entry may be unmarked and sets its bits (atomic OR: idempotent, order independent).  -0.0 + v == v for every v != 0, so values are unchanged; an entry that
+// cancels to +0.0 exactly is marked again by its next writer, harmlessly.  In the duration stage the pattern moves with the iterate (a sample changes
+// polynomial): bits are only ever added within a stage.  The readers do not walk the masks themselves (a dependent load and a divergent bit loop per word)
+// but a row-sorted list of the marked entries, (column, row) pairs + row starts, rebuilt from the masks after an evaluation that added bits
+// (csr_rebuild: the first evaluation of a stage, and in the duration stage whenever the pattern moved).  A band row's list holds its band entries and
+// then the border rows coupled to its column, so one pass gives the whole product.
 #ifdef CHD_HOST_EMU
 CHD_DEV void env_min(GI* p, int v) { if (v < *p) *p = v; }
 CHD_DEV void env_max(GI* p, int v) { if (v > *p) *p = v; }
@@ -518,20 +535,51 @@ CHD_DEV void env_cover(LCtx& c, const int hi, const int lo) {
   if (hi < c.Nb) for (int k = lo; k < first && k < hi; ++k) env_max(c.env + 2 * k + 1, hi);
   else for (int k = lo; k < first && k < c.Nb; ++k) env_max(c.rcnt + k, hi - c.Nb + 1);      // border row hi - Nb now reaches columns lo ..
 }
+#ifdef CHD_HOST_EMU
+CHD_DEV unsigned long long dbits(double v) { unsigned long long u; __builtin_memcpy(&u, &v, 8); return u; }
+CHD_DEV bool mask_or(GU* p, unsigned long long b) { const bool was = (*p & b) != 0; *p |= b; return !was; }      // true: the bit is new
+#else
+CHD_DEV unsigned long long dbits(double v) { return (unsigned long long)__double_as_longlong(v); }
+CHD_DEV bool mask_or(GU* p, unsigned long long b) { return (__hip_atomic_fetch_or(p, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & b) == 0; }
+#endif
+// the entry stored at `p` (inside K0b or K0x) becomes a marked one
+CHD_NOINLINE CHD_DEV void kmark(LCtx& c, const GD* p) {
+  bool fresh;
+  if (p < c.K0x) {
+    const long long off = p - c.K0b;
+    const int i = (int)(off / c.W2), o = (int)(off - (long long)i * c.W2);
+    fresh = mask_or(c.pmb + (long long)i * c.MW + (o >> 6), 1ull << (o & 63));
+  } else {
+    const long long off = p - c.K0x;
+    const int r = (int)(off / c.LD), k = (int)(off - (long long)r * c.LD);
+    fresh = mask_or(c.pmx + (long long)r * c.LW + (k >> 6), 1ull << (k & 63));
+    if (k < c.Nb) mask_or(c.pmt + (long long)k * c.CW + (r >> 6), 1ull << (r & 63));
+  }
+  if (fresh) c.pm_dirty = 1;      // (an entry of the list that cancelled to +0.0 exactly comes here too, and changes nothing)
+}
+// *p += val for a slot of K0 whose previous content `old` the caller has loaded
+#define K0_ADD(c, p, old, val) do { const double o__ = (old), v__ = (val); if (v__ != 0.0) { if (dbits(o__) == 0ull) kmark(c, p); *(p) = o__ + v__; } } while (0)      // (a zero contribution must not turn the -0.0 marker into +0.0)
 CHD_DEV void kadd(LCtx& c, int p, int qq, double val) {
   if (p < c.Nb && qq < c.Nb) {
     int dlt = qq - p;
     if (dlt > c.w || dlt < -c.w) { c.err = 1; return; }
     const int hi_ = dlt < 0 ? p : qq, lo_ = dlt < 0 ? qq : p;
     const int first_ = c.env[2 * hi_];                  // (looked up alongside the K0 accesses; the widening itself is rare)
-    c.K0b[(long long)p * c.W2 + (dlt + c.w)] += val;
-    if (dlt != 0) c.K0b[(long long)qq * c.W2 + (c.w - dlt)] += val;
+    GD* a = c.K0b + (long long)p * c.W2 + (dlt + c.w);
+    GD* b = c.K0b + (long long)qq * c.W2 + (c.w - dlt);
+    const double oa = *a, ob = *b;
+    K0_ADD(c, a, oa, val);
+    if (dlt != 0) K0_ADD(c, b, ob, val);
     if (lo_ < first_) env_cover(c, hi_, lo_);
   } else {
     const int hi = p > qq ? p : qq, lo = p > qq ? qq : p;
     const int first_ = c.env[2 * hi];
-    c.K0x[(long long)(hi - c.Nb) * c.LD + lo] += val;
-    if (lo >= c.Nb && lo != hi) c.K0x[(long long)(lo - c.Nb) * c.LD + hi] += val;
+    GD* a = c.K0x + (long long)(hi - c.Nb) * c.LD + lo;
+    const bool two = lo >= c.Nb && lo != hi;
+    GD* b = two ? c.K0x + (long long)(lo - c.Nb) * c.LD + hi : a;
+    const double oa = *a, ob = *b;
+    K0_ADD(c, a, oa, val);
+    if (two) K0_ADD(c, b, ob, val);
     if (lo < c.Nb && lo < first_) env_cover(c, hi, lo);
   }
 }
@@ -565,7 +613,7 @@ CHD_DEV void kadd_batch(LCtx& c, const int* p, const int* qq, const double* val)
 #pragma unroll
   for (int i = 0; i < N; ++i) { oa[i] = *(sl[i].a ? sl[i].a : c.K0b); ob[i] = *(sl[i].b ? sl[i].b : c.K0b); }
 #pragma unroll
-  for (int i = 0; i < N; ++i) { if (sl[i].a) *sl[i].a = oa[i] + val[i]; if (sl[i].b) *sl[i].b = ob[i] + val[i]; }
+  for (int i = 0; i < N; ++i) { if (sl[i].a) K0_ADD(c, sl[i].a, oa[i], val[i]); if (sl[i].b) K0_ADD(c, sl[i].b, ob[i], val[i]); }
 }
 CHD_DEV double kget(const LCtx& c, int p, int qq) {
   if (p < c.Nb && qq < c.Nb) {
@@ -577,27 +625,71 @@ CHD_DEV double kget(const LCtx& c, int p, int qq) {
   return c.K0x[(long long)(hi - c.Nb) * c.LD + lo];
 }
 
+// where the entry (row, col) of the list lives in K0
+CHD_DEV GD* k0_at(const LCtx& c, const int row, const int col) {
+  if (row < c.Nb) return col < c.Nb ? c.K0b + (long long)row * c.W2 + (col - row + c.w) : c.K0x + (long long)(col - c.Nb) * c.LD + row;
+  return c.K0x + (long long)(row - c.Nb) * c.LD + col;
+}
+// every marked entry <- -0.0 (the writers' "seen before" marker, see above): ~30 k scattered stores instead of the envelope's ~600 k
 CHD_DEV void kzero(LCtx& c) {
-  const long long nx_ = (long long)c.bc * c.LD;
-  // band rows: only the envelope [efirst_i, clast_i] (what the mat-vec and the factor copy read; kadd widens it first
-  // if an entry ever lands outside), one wavefront per row
-  for (int i0 = CHD_WAVE_ID * 8; i0 < c.Nb; i0 += CHD_NWAVES * 8) {       // eight rows per pass: their envelope bounds are fetched together
-    int lo[8], hi[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) { const int i = i0 + r < c.Nb ? i0 + r : c.Nb - 1; lo[r] = c.env[2 * i]; hi[r] = c.env[2 * i + 1]; }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      if (i0 + r >= c.Nb) break;
-      GD* row = c.K0b + (long long)(i0 + r) * c.W2 + (c.w - (i0 + r));
-      for (int k = lo[r] + CHD_LANE; k <= hi[r]; k += CHD_WAVE_SZ) row[k] = 0.0;
+  const double mz = -0.0;
+  PAR_FOR(e, c.csr_nnz) *k0_at(c, c.csr_row[e], c.csr_col[e]) = mz;
+}
+CHD_DEV int popc64(unsigned long long m) { return __builtin_popcountll(m); }
+// the list of marked entries from the masks: count per row, exclusive scan, fill
+CHD_NOINLINE CHD_DEV void csr_rebuild(LCtx& c) {
+  const int N = c.N, Nb = c.Nb, MW = c.MW, LW = c.LW, CW = c.CW, w = c.w;
+#ifdef CHD_HOST_EMU
+  if (std::getenv("CHD_EMU_TRACE_CSR")) std::fprintf(stderr, "csr_rebuild stage %d nnz before %d\n", c.S->stage, c.csr_nnz);
+#endif
+  PAR_FOR(i, N) {
+    int cnt = 0;
+    if (i < Nb) {
+      for (int k = 0; k < MW; ++k) cnt += popc64(c.pmb[(long long)i * MW + k]);
+      for (int k = 0; k < CW; ++k) cnt += popc64(c.pmt[(long long)i * CW + k]);
+    } else for (int k = 0; k < LW; ++k) cnt += popc64(c.pmx[(long long)(i - Nb) * LW + k]);
+    c.csr_rp[i] = cnt;
+  }
+  CHD_SYNC();
+  // exclusive scan: every thread scans a contiguous chunk of rows, the chunk totals go through LDS
+  LdsI* part = (LdsI*)(c.lds + LDS_RED);
+  const int chunk = (N + CHD_NT - 1) / CHD_NT;
+  const int r0 = CHD_TID * chunk < N ? CHD_TID * chunk : N, r1 = r0 + chunk < N ? r0 + chunk : N;
+  int tot = 0;
+  for (int i = r0; i < r1; ++i) tot += c.csr_rp[i];
+  part[CHD_TID] = tot;
+  CHD_SYNC();
+  int off = 0, total = 0;
+  for (int t = 0; t < CHD_NT; ++t) { const int v = part[t]; if (t < CHD_TID) off += v; total += v; }
+  CHD_SYNC();
+  if (total > c.csr_cap) {           // (does not happen for borders up to half dense: chd_model.hpp csr_cap)
+    if (CHD_TID == 0) { c.err = 1; c.csr_nnz = 0; c.pm_dirty = 0; }
+    PAR_FOR(i, N + 1) c.csr_rp[i] = 0;
+    CHD_SYNC();
+    return;
+  }
+  for (int i = r0; i < r1; ++i) { const int v = c.csr_rp[i]; c.csr_rp[i] = off; off += v; }
+  if (CHD_TID == 0) { c.csr_rp[N] = total; c.csr_nnz = total; c.pm_dirty = 0; }
+  CHD_SYNC();
+  PAR_FOR(i, N) {
+    int e = c.csr_rp[i];
+    if (i < Nb) {
+      for (int k = 0; k < MW; ++k) {
+        unsigned long long m = c.pmb[(long long)i * MW + k];
+        while (m) { c.csr_col[e] = i - w + k * 64 + __builtin_ctzll(m); c.csr_row[e] = i; ++e; m &= m - 1; }
+      }
+      for (int k = 0; k < CW; ++k) {
+        unsigned long long m = c.pmt[(long long)i * CW + k];
+        while (m) { c.csr_col[e] = Nb + k * 64 + __builtin_ctzll(m); c.csr_row[e] = i; ++e; m &= m - 1; }
+      }
+    } else {
+      for (int k = 0; k < LW; ++k) {
+        unsigned long long m = c.pmx[(long long)(i - Nb) * LW + k];
+        while (m) { c.csr_col[e] = k * 64 + __builtin_ctzll(m); c.csr_row[e] = i; ++e; m &= m - 1; }
+      }
     }
   }
-  // border rows: nothing is ever stored left of the row's first coupled band position (env[2 (Nb + r)])
-  for (int r = CHD_WAVE_ID; r < c.bc; r += CHD_NWAVES) {
-    GD* row = c.K0x + (long long)r * c.LD;
-    for (int k = c.env[2 * (c.Nb + r)] + CHD_LANE; k < c.LD; k += CHD_WAVE_SZ) row[k] = 0.0;
-  }
-  (void)nx_;
+  CHD_SYNC();
 }
 // start of a stage: the border blocks are reused with a new layout, and their structurally-zero left parts are
 // neither cleared nor copied again afterwards
@@ -609,7 +701,12 @@ CHD_DEV void kreset(LCtx& c) {
   const long long nf_ = (long long)c.Nb * (c.w + 1);
   for (long long i = CHD_TID; i < nf_; i += CHD_NT) c.Kfb[i] = 0.0;       // the copy into the factor only covers each row's envelope
   const long long n0_ = (long long)c.Nb * c.W2;
-  for (long long i = CHD_TID; i < n0_; i += CHD_NT) c.K0b[i] = 0.0;       // kzero only clears the envelope
+  for (long long i = CHD_TID; i < n0_; i += CHD_NT) c.K0b[i] = 0.0;       // kzero only touches marked entries
+  PAR_FOR(i, c.Nb * c.MW) c.pmb[i] = 0ull;
+  PAR_FOR(i, c.bc * c.LW) c.pmx[i] = 0ull;
+  PAR_FOR(i, c.Nb * c.CW) c.pmt[i] = 0ull;
+  PAR_FOR(i, c.N + 1) c.csr_rp[i] = 0;
+  if (CHD_TID == 0) { c.csr_nnz = 0; c.pm_dirty = 0; }
   CHD_SYNC();
 }
 
@@ -652,42 +749,34 @@ CHD_DEV double dot_column(AP col, const long long ld, BP b, int r, const int ren
   for (; r < rend; ++r) s0 += col[r * ld] * b[r];
   return (s0 + s1) + (s2 + s3);
 }
-// y = K0 x (+ diag .* x)
+// sum over the list entries e0, e0 + st, ... < e1 of row `row`: K0(row, col_e) x[col_e], eight value loads in flight per lane
+template <class XP>
+CHD_DEV double list_dot(const LCtx& c, const int row, XP x, int e, const int e1, const int st) {
+  double s0 = 0, s1 = 0;
+  for (; e < e1; e += 8 * st) {
+    int col[8]; double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) col[q] = e + q * st < e1 ? c.csr_col[e + q * st] : -1;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = col[q] >= 0 ? *k0_at(c, row, col[q]) : 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) { if (col[q] >= 0) s0 += v[q] * x[col[q]]; if (col[q + 1] >= 0) s1 += v[q + 1] * x[col[q + 1]]; }
+  }
+  return s0 + s1;
+}
+// y = K0 x (+ diag .* x), over the marked entries only
 // `only` (optional): rows whose entry is <= 0 are skipped (their y is left untouched)
 template <class XP>
 CHD_DEV void kmatvec_impl(LCtx& c, XP x, GD* y, const GD* diag, const GI* only) {
-  const int Nb = c.Nb, w = c.w, W2 = c.W2, LD = c.LD, bc = c.bc;
-  {
-    // 8 lanes per band row (an envelope holds ~100-200 entries: 16 requests in flight per lane), 64 rows per pass
-    const int gl = CHD_NT >= 8 ? 8 : 1;
-    const int step = CHD_NT / gl, lane_ = CHD_TID % gl;
-    int i = CHD_TID / gl;
-    int lo = i < Nb ? c.env[2 * i] : 0, hi = i < Nb ? c.env[2 * i + 1] : 0;      // nothing is stored outside the envelope
-    for (; i < Nb; i += step) {
-      const int in = i + step;
-      const int nlo = in < Nb ? c.env[2 * in] : 0, nhi = in < Nb ? c.env[2 * in + 1] : 0;      // next row's envelope, one pass ahead
-      if (!(only && only[i] <= 0)) {
-        const double dterm = diag ? diag[i] * x[i] : 0.0;
-        const GD* row = c.K0b + (long long)i * W2 + (w - i);
-        double acc = dot_strided(row, x, lo + lane_, hi + 1, gl);      // (16-byte requests were tried: same rate, the limit is lines in flight)
-#ifndef CHD_HOST_EMU
-        acc += __shfl_xor(acc, 4); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 1);
-#endif
-        if (lane_ == 0) y[i] = acc + dterm;
-      }
-      lo = nlo; hi = nhi;
-    }
-  }
-  GROUP_FOR(r, bc) {
-    if (only && only[Nb + r] <= 0) continue;
-    const GD* row = c.K0x + (long long)r * LD;
-    const double acc = group_sum(dot_strided(row, x, c.env[2 * (Nb + r)] + lane_, LD, CHD_GL));
-    if (lane_ == 0) y[Nb + r] = acc + (diag ? diag[Nb + r] * x[Nb + r] : 0.0);
-  }
-  CHD_SYNC();
-  PAR_FOR(i, Nb) {
+  const int Nb = c.Nb, bc = c.bc;
+  PAR_FOR(i, Nb) {             // a lane per band row (~12 band entries + the border rows coupled to the column)
     if (only && only[i] <= 0) continue;
-    y[i] += dot_column(c.K0x + i, LD, x + Nb, 0, c.rcnt[i]);
+    y[i] = list_dot(c, i, x, c.csr_rp[i], c.csr_rp[i + 1], 1) + (diag ? diag[i] * x[i] : 0.0);
+  }
+  GROUP_FOR(r, bc) {           // a lane group per border row (tens to thousands of entries)
+    if (only && only[Nb + r] <= 0) continue;
+    const double acc = group_sum(list_dot(c, Nb + r, x, c.csr_rp[Nb + r] + lane_, c.csr_rp[Nb + r + 1], CHD_GL));
+    if (lane_ == 0) y[Nb + r] = acc + (diag ? diag[Nb + r] * x[Nb + r] : 0.0);
   }
   CHD_SYNC();
 }
@@ -1278,63 +1367,41 @@ CHD_NOINLINE CHD_DEV void kfactor_rl(LCtx& c, const GD* diag, const GI* sign) {
   TIC();
   const int Nb = c.Nb, w = c.w, W2 = c.W2, W1 = c.w + 1, LD = c.LD, bc = c.bc;
   if (CHD_TID == 0) c.n_bad_pivots = 0;
-  // copy the lower triangle (+ diagonal shift) into the factor storage: eight rows per wavefront pass, all loads
-  // of a pass issued before the first store (the copy is latency bound, not bandwidth bound)
+  // K0 + diag -> the factor storage, lower triangle: the factor's envelope [efirst_i, i] of each row is written in full (the factorisation fills it in), but
+  // only the marked entries of K0 are read: zeros (the shift on the diagonal) first, then the list's entries on top
   {
-    constexpr int RP = 8, QP = 6;                      // QP * wave size covers W1 <= 384; wider bands take the tail loop
-    int cnext[RP];                                     // envelope starts of the next pass's rows (fetched one pass ahead)
-#pragma unroll
-    for (int r = 0; r < RP; ++r) { const int i = CHD_WAVE_ID * RP + r < Nb ? CHD_WAVE_ID * RP + r : Nb - 1; cnext[r] = c.env[2 * i] - i + w; }
-    for (int i0 = CHD_WAVE_ID * RP; i0 < Nb; i0 += CHD_NWAVES * RP) {
-      // only the envelope [efirst_i, i] of each row: the rest of the factor storage is zero since the start of the stage
-      double v[RP][QP];
-      int clo[RP];
-#pragma unroll
-      for (int r = 0; r < RP; ++r) {
-        clo[r] = cnext[r];
-        const int in = i0 + CHD_NWAVES * RP + r < Nb ? i0 + CHD_NWAVES * RP + r : Nb - 1;
-        cnext[r] = c.env[2 * in] - in + w;
-      }
+    int cnext = 0;
+    { const int i = CHD_WAVE_ID < Nb ? CHD_WAVE_ID : Nb - 1; cnext = c.env[2 * i] - i + w; }
+    for (int i = CHD_WAVE_ID; i < Nb; i += CHD_NWAVES) {
+      const int clo = cnext;
+      const int in = i + CHD_NWAVES < Nb ? i + CHD_NWAVES : Nb - 1;
+      cnext = c.env[2 * in] - in + w;                  // the next row's envelope start, fetched a row ahead
 #ifdef CHD_HOST_EMU
-      for (int r = 0; r < RP; ++r)
-        for (int cc = 0; cc < clo[r] && i0 + r < Nb; ++cc)
-          if (c.K0b[(long long)(i0 + r) * W2 + cc] != 0.0 || c.Kfb[(long long)(i0 + r) * W1 + cc] != 0.0) { c.err = 2; std::fprintf(stderr, "band envelope violated: row %d col offset %d first %d (K0 %g Kf %g)\n", i0 + r, cc, clo[r], c.K0b[(long long)(i0 + r) * W2 + cc], c.Kfb[(long long)(i0 + r) * W1 + cc]); break; }      // structure check
+      for (int cc = 0; cc < clo; ++cc)
+        if (c.K0b[(long long)i * W2 + cc] != 0.0 || c.Kfb[(long long)i * W1 + cc] != 0.0) { c.err = 2; std::fprintf(stderr, "band envelope violated: row %d col offset %d first %d (K0 %g Kf %g)\n", i, cc, clo, c.K0b[(long long)i * W2 + cc], c.Kfb[(long long)i * W1 + cc]); break; }      // structural-envelope self check (host only)
 #endif
-#pragma unroll
-      for (int r = 0; r < RP; ++r)
-#pragma unroll
-        for (int q = 0; q < QP; ++q) {
-          const int i = i0 + r, cc = clo[r] + CHD_LANE + q * CHD_WAVE_SZ;
-          if (i < Nb && clo[r] + q * CHD_WAVE_SZ < W1)      // (uniform over the wavefront: whole requests beyond the row's envelope are skipped)
-            v[r][q] = *(cc < W1 ? c.K0b + (long long)i * W2 + cc : c.K0b + w);      // predicated-off lanes re-read one valid address
-        }
-#pragma unroll
-      for (int r = 0; r < RP; ++r)
-#pragma unroll
-        for (int q = 0; q < QP; ++q) {
-          const int i = i0 + r, cc = clo[r] + CHD_LANE + q * CHD_WAVE_SZ;
-          if (i < Nb && cc < W1) c.Kfb[(long long)i * W1 + cc] = v[r][q] + (cc == w ? diag[i] : 0.0);
-        }
-      for (int r = 0; r < RP; ++r)
-        for (int cc = clo[r] + CHD_LANE + QP * CHD_WAVE_SZ; cc < W1 && i0 + r < Nb; cc += CHD_WAVE_SZ)
-          c.Kfb[(long long)(i0 + r) * W1 + cc] = c.K0b[(long long)(i0 + r) * W2 + cc] + (cc == w ? diag[i0 + r] : 0.0);
+      GD* dst = c.Kfb + (long long)i * W1;
+      const double dg = diag[i];
+      for (int cc = clo + CHD_LANE; cc < W1; cc += CHD_WAVE_SZ) dst[cc] = cc == w ? dg : 0.0;
     }
   }
   for (int r = CHD_WAVE_ID; r < bc; r += CHD_NWAVES) {
-    const GD* src = c.K0x + (long long)r * LD;
     GD* dst = c.Kfx + (long long)r * LD;
-    int k = c.env[2 * (Nb + r)] + CHD_LANE;         // zero (in both) left of the first coupled band position
+    const double dg = diag[Nb + r];
 #ifdef CHD_HOST_EMU
-    for (int kk = 0; kk < c.env[2 * (Nb + r)]; ++kk) if (src[kk] != 0.0 || dst[kk] != 0.0) { c.err = 2; std::fprintf(stderr, "border structure violated: row %d col %d first %d\n", r, kk, c.env[2 * (Nb + r)]); break; }      // structure check
+    const GD* src = c.K0x + (long long)r * LD;
+    for (int kk = 0; kk < c.env[2 * (Nb + r)]; ++kk) if (src[kk] != 0.0 || dst[kk] != 0.0) { c.err = 2; std::fprintf(stderr, "border structure violated: row %d col %d first %d\n", r, kk, c.env[2 * (Nb + r)]); break; }      // structural self check (host only)
 #endif
-    for (; k + 7 * CHD_WAVE_SZ < LD; k += 8 * CHD_WAVE_SZ) {
-      double v[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = src[k + q * CHD_WAVE_SZ];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) dst[k + q * CHD_WAVE_SZ] = v[q] + (k + q * CHD_WAVE_SZ == Nb + r ? diag[Nb + r] : 0.0);
+    for (int k = c.env[2 * (Nb + r)] + CHD_LANE; k < LD; k += CHD_WAVE_SZ) dst[k] = k == Nb + r ? dg : 0.0;      // zero (in both) left of the first coupled band position
+  }
+  CHD_SYNC();
+  PAR_FOR(e, c.csr_nnz) {
+    const int row = c.csr_row[e], col = c.csr_col[e];
+    if (row < Nb) {
+      if (col <= row) c.Kfb[(long long)row * W1 + (col - row + w)] = c.K0b[(long long)row * W2 + (col - row + w)] + (col == row ? diag[row] : 0.0);
+    } else {
+      c.Kfx[(long long)(row - Nb) * LD + col] = c.K0x[(long long)(row - Nb) * LD + col] + (col == row ? diag[row] : 0.0);
     }
-    for (; k < LD; k += CHD_WAVE_SZ) dst[k] = src[k] + (k == Nb + r ? diag[Nb + r] : 0.0);
   }
   CHD_SYNC();
   TACC(c, 6, CHD_CLOCK() - tic_);
@@ -1979,7 +2046,7 @@ CHD_NOINLINE CHD_DEV void row_nodes_nv(LCtx& c, const int pr, const double sc, c
 #pragma unroll
   for (int i = 0; i < 12; ++i) { oa[i] = *(sl[i].a ? sl[i].a : c.K0b); ob[i] = *(sl[i].b ? sl[i].b : c.K0b); }
 #pragma unroll
-  for (int i = 0; i < 12; ++i) { if (sl[i].a) *sl[i].a = oa[i] + val[i]; if (sl[i].b) *sl[i].b = ob[i] + val[i]; }
+  for (int i = 0; i < 12; ++i) { if (sl[i].a) K0_ADD(c, sl[i].a, oa[i], val[i]); if (sl[i].b) K0_ADD(c, sl[i].b, ob[i], val[i]); }
 }
 CHD_DEV void row_nodes(const RowW& r, int s, const PE& e, int which, const double coef[3], int dimmask) {
   if (!r.on) return;
@@ -2010,8 +2077,8 @@ CHD_DEV void row_durs(const RowW& r, int s, double t, const PE& e, const double 
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const double val = r.sc * (k0 + i < n_early ? ve : vo);
-      if (sl[i].a) *sl[i].a = oa[i] + val;
-      if (sl[i].b) *sl[i].b = ob[i] + val;
+      if (sl[i].a) K0_ADD(c, sl[i].a, oa[i], val);
+      if (sl[i].b) K0_ADD(c, sl[i].b, ob[i], val);
     }
   }
 }
@@ -2800,6 +2867,7 @@ CHD_DEV double eval_nlp(LCtx& c, const GD* x, int mode, GD* c_out, GD* g, const 
     TACC(c, 22, CHD_CLOCK() - te_); te_ = CHD_CLOCK();
     eval_cost_grad_hess(c, g, lam);
     c.err = block_max(c, (double)c.err) > 0.5 ? 1 : 0;     // a band overflow seen by any thread
+    if (c.pm_dirty) csr_rebuild(c);                        // (uniform: the flag is read behind the reduction's barriers) the evaluation wrote entries the readers' list does not hold yet
     TACC(c, 23, CHD_CLOCK() - te_);
   }
   CHD_SYNC();
@@ -3174,6 +3242,9 @@ CHD_DEV void bind_stage(LCtx& c, QP q, int stage) {
     c.q = q; c.S = &q->st[stage];
     c.n = c.S->n; c.m = c.S->m; c.N = c.n + c.m; c.Nb = c.S->Nb; c.bc = c.S->bc; c.w = c.S->w;
     c.W2 = 2 * c.w + 1; c.LD = c.N;
+    c.MW = (c.W2 + 63) >> 6; c.LW = (c.LD + 63) >> 6; c.CW = (c.bc + 63) >> 6;
+    c.pmb = (GU*)(q->wd + q->o_pmb); c.pmx = (GU*)(q->wd + q->o_pmx); c.pmt = (GU*)(q->wd + q->o_pmt);
+    c.csr_rp = q->wi + q->o_csr_rp; c.csr_col = q->wi + q->o_csr_col; c.csr_row = q->wi + q->o_csr_row; c.csr_cap = q->csr_cap; c.csr_nnz = 0; c.pm_dirty = 0;
     c.K0b = q->wd + q->o_K0b; c.K0x = q->wd + q->o_K0x; c.Kfb = q->wd + q->o_Kfb; c.Kfx = q->wd + q->o_Kfx;
     c.pos_var = q->ci + c.S->o_pos_var; c.pos_row = q->ci + c.S->o_pos_row; c.env = q->wi + q->o_envw; c.rcnt = q->wi + q->o_rcntw;
     c.sf = 1.0; c.err = 0; c.n_bad_pivots = 0; c.second_model = 0;

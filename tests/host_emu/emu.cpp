@@ -190,3 +190,29 @@ extern "C" int emu_front_profile(void* h, int stage, int nb, int* out, int cap) 
   return np;
 }
 
+
+// non-zero counts of the unfactored KKT matrix of `stage` at the initial point (analysis helper): out = band envelope entries (both triangles),
+// band non-zeros, 64-byte lines of the band rows holding a non-zero, border entries right of each row's first position, border non-zeros, border lines
+extern "C" void emu_nnz_stats(void* h, int stage, double* out) {
+  Emu* e = (Emu*)h; e->bind();
+  double fo[2];
+  std::vector<double> lam(e->M.d.st[stage].m, 0.5);
+  debug_eval(&e->M.d, e->ctx, stage, 0, e->lds.data(), (int)e->lds.size(), nullptr, lam.data(), fo);
+  Ctx c; c.lds = e->lds.data(); c.lds_cap = (int)e->lds.size();
+  bind_stage(c, &e->M.d, stage);
+  long long env = 0, nz = 0, lines = 0, benv = 0, bnz = 0, blines = 0;
+  for (int i = 0; i < c.Nb; ++i) {
+    env += c.env[2 * i + 1] - c.env[2 * i] + 1;
+    long long lastline = -1;
+    for (int k = c.env[2 * i]; k <= c.env[2 * i + 1]; ++k) {
+      const long long a = (long long)i * c.W2 + (k - i + c.w);
+      if (c.K0b[a] != 0.0) { nz++; if (a / 8 != lastline) { lines++; lastline = a / 8; } }
+    }
+  }
+  for (int r = 0; r < c.bc; ++r) {
+    benv += c.LD - c.env[2 * (c.Nb + r)];
+    long long lastline = -1;
+    for (int k = 0; k < c.LD; ++k) { const long long a = (long long)r * c.LD + k; if (c.K0x[a] != 0.0) { bnz++; if (a / 8 != lastline) { blines++; lastline = a / 8; } } }
+  }
+  out[0] = (double)env; out[1] = (double)nz; out[2] = (double)lines; out[3] = (double)benv; out[4] = (double)bnz; out[5] = (double)blines; out[6] = c.Nb; out[7] = c.bc;
+}
