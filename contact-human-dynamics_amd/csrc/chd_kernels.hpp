@@ -1370,19 +1370,29 @@ CHD_NOINLINE CHD_DEV void kfactor_rl(LCtx& c, const GD* diag, const GI* sign) {
   // K0 + diag -> the factor storage, lower triangle: the factor's envelope [efirst_i, i] of each row is written in full (the factorisation fills it in), but
   // only the marked entries of K0 are read: zeros (the shift on the diagonal) first, then the list's entries on top
   {
-    int cnext = 0;
-    { const int i = CHD_WAVE_ID < Nb ? CHD_WAVE_ID : Nb - 1; cnext = c.env[2 * i] - i + w; }
-    for (int i = CHD_WAVE_ID; i < Nb; i += CHD_NWAVES) {
-      const int clo = cnext;
-      const int in = i + CHD_NWAVES < Nb ? i + CHD_NWAVES : Nb - 1;
-      cnext = c.env[2 * in] - in + w;                  // the next row's envelope start, fetched a row ahead
+    constexpr int RP = 8;                              // rows per wavefront pass: their envelope starts and shifts are fetched a pass ahead, the stores of a pass are independent
+    int cnext[RP]; double dnext[RP];
+#pragma unroll
+    for (int r = 0; r < RP; ++r) { const int i = CHD_WAVE_ID * RP + r < Nb ? CHD_WAVE_ID * RP + r : Nb - 1; cnext[r] = c.env[2 * i] - i + w; dnext[r] = diag[i]; }
+    for (int i0 = CHD_WAVE_ID * RP; i0 < Nb; i0 += CHD_NWAVES * RP) {
+      int clo[RP]; double dg[RP];
+#pragma unroll
+      for (int r = 0; r < RP; ++r) {
+        clo[r] = cnext[r]; dg[r] = dnext[r];
+        const int in = i0 + CHD_NWAVES * RP + r < Nb ? i0 + CHD_NWAVES * RP + r : Nb - 1;
+        cnext[r] = c.env[2 * in] - in + w; dnext[r] = diag[in];
+      }
 #ifdef CHD_HOST_EMU
-      for (int cc = 0; cc < clo; ++cc)
-        if (c.K0b[(long long)i * W2 + cc] != 0.0 || c.Kfb[(long long)i * W1 + cc] != 0.0) { c.err = 2; std::fprintf(stderr, "band envelope violated: row %d col offset %d first %d (K0 %g Kf %g)\n", i, cc, clo, c.K0b[(long long)i * W2 + cc], c.Kfb[(long long)i * W1 + cc]); break; }      // structural-envelope self check (host only)
+      for (int r = 0; r < RP && i0 + r < Nb; ++r)
+        for (int cc = 0; cc < clo[r]; ++cc)
+          if (c.K0b[(long long)(i0 + r) * W2 + cc] != 0.0 || c.Kfb[(long long)(i0 + r) * W1 + cc] != 0.0) { c.err = 2; std::fprintf(stderr, "band envelope violated: row %d col offset %d first %d (K0 %g Kf %g)\n", i0 + r, cc, clo[r], c.K0b[(long long)(i0 + r) * W2 + cc], c.Kfb[(long long)(i0 + r) * W1 + cc]); break; }      // structural-envelope self check (host only)
 #endif
-      GD* dst = c.Kfb + (long long)i * W1;
-      const double dg = diag[i];
-      for (int cc = clo + CHD_LANE; cc < W1; cc += CHD_WAVE_SZ) dst[cc] = cc == w ? dg : 0.0;
+#pragma unroll
+      for (int r = 0; r < RP; ++r) {
+        if (i0 + r >= Nb) break;
+        GD* dst = c.Kfb + (long long)(i0 + r) * W1;
+        for (int cc = clo[r] + CHD_LANE; cc < W1; cc += CHD_WAVE_SZ) dst[cc] = cc == w ? dg[r] : 0.0;
+      }
     }
   }
   for (int r = CHD_WAVE_ID; r < bc; r += CHD_NWAVES) {
