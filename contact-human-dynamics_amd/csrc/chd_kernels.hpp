@@ -293,6 +293,19 @@ CHD_DEV void dpos_dT(QP q, int s, const PE& e, double* out) {
   }
 }
 
+// The samples of a uniform time table (tab[k] = k * step, then T; SeqModel::sample_times) that can lie in the polynomials pa .. pb of spline s at the current
+// durations: [k_lo, k_hi], a superset by a sample on either side -- the loops that gather per-sample records by polynomial keep their own test and only start
+// and stop closer
+CHD_DEV void sample_range(QP q, int s, int pa, int pb, const GD* tab, int len, int& k_lo, int& k_hi) {
+  const auto& sp = q->sp[s];
+  double t_lo, t_hi;
+  if (chd_tab_ok) { const LdsD* pend = (const LdsD*)chd_pend_l + sp.poly_off; t_lo = pa > 0 ? pend[pa - 1] : 0.0; t_hi = pend[pb]; }
+  else { const GD* pend = q->wd + q->o_pend + sp.poly_off; t_lo = pa > 0 ? pend[pa - 1] : 0.0; t_hi = pend[pb]; }
+  const double step = tab[1] - tab[0];
+  const double idt = step > 0.0 ? 1.0 / step : 0.0;
+  k_lo = (int)(t_lo * idt) - 1; if (k_lo < 0) k_lo = 0;
+  k_hi = step > 0.0 ? (int)(t_hi * idt) + 2 : len - 1; if (k_hi > len - 1) k_hi = len - 1;
+}
 // phase of end-effector e at time t, and whether it is the last one
 CHD_DEV int phase_lookup(QP q, int e, double t) {
   if (chd_tab_ok) return seg_lookup((const LdsD*)chd_phend_l + q->phase_off[e], q->n_phase[e], t);
@@ -368,6 +381,7 @@ CHD_DEV GD* xrec(QP q, int ee, int blk, int smp) {
                   : blk == XB_DYN_F ? 2 * nd_ + 3 * nr_ : blk == XB_ROM_C ? 3 * nd_ + 3 * nr_ : blk == XB_DYN_C ? 3 * nd_ + 4 * nr_ : 4 * nd_ + 4 * nr_;
   return q->wd + q->o_xtab + ((long long)ee * (4 * nd_ + 5 * nr_) + start + smp) * XR_STRIDE;
 }
+CHD_DEV int xblock_times(QP q, int blk) { return (blk == XB_HEIGHT || blk == XB_DYN_P || blk == XB_DYN_F || blk == XB_DYN_C) ? q->o_tdyn : q->o_trom; }      // the block's sample times (offset in cd)
 CHD_DEV int xblock_len(QP q, int blk) { return (blk == XB_HEIGHT || blk == XB_DYN_P || blk == XB_DYN_F || blk == XB_DYN_C) ? q->n_tdyn : q->n_trom; }
 // (pe: the sample of the spline whose node values the entries differentiate by; dj: the duration derivatives of the end-effector's own spline at the sample --
 //  only its cur / last and, when B is given, its om's are used; Ae / Ac / B may be null = zero)
@@ -2551,13 +2565,16 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(LCtx& c, GD* g, const GD* lam) {
           if (wacc >= 0) acc += wacc * (wgt(b, 1, n1, h1, dq1) - wgt(a, 1, n1, h1, dq1)) * (wgt(b, 1, n2, h2, dq2) - wgt(a, 1, n2, h2, dq2));
         }
       double acch = 0.0;                   // + sum over the range-of-motion samples in these polynomials of lam sc w w (heel-distance rows)
-      if (HC && s >= 2)
-        for (int k = 0; k < q->n_trom; ++k) {
+      if (HC && s >= 2) {
+        int k_lo, k_hi;
+        sample_range(q, s, pa, pb, q->cd + q->o_trom, q->n_trom, k_lo, k_hi);
+        for (int k = k_lo; k <= k_hi; ++k) {
           const GD* a = rcache(q, s - 2, k);
           const int p = (int)a[SC_POLY];
           if (p < pa || p > pb) continue;
           acch += a[RC_MU] * wgt(a, 0, n1, h1, dq1) * wgt(a, 0, n2, h2, dq2);
         }
+      }
       if (acc == 0.0 && acch == 0.0) continue;
       {
         int pp[3], qv[3]; double vv[3];
@@ -2631,7 +2648,9 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(LCtx& c, GD* g, const GD* lam) {
       if (!any) continue;
       const int h1 = group_end(sa, pia, n1), h2 = group_end(sb, pib, n2);
       double acc = 0.0;
-      for (int k = 0; k < q->n_trom; ++k) {
+      int k_lo, k_hi;
+      sample_range(q, 2 + pr, n1 - 1 < 0 ? 0 : n1 - 1, h1 > sa.n_polys - 1 ? sa.n_polys - 1 : h1, q->cd + q->o_trom, q->n_trom, k_lo, k_hi);
+      for (int k = k_lo; k <= k_hi; ++k) {
         const GD* a = rcache(q, pr, k);
         const int p = (int)a[SC_POLY];
         if (p + 1 < n1 || p > h1) continue;                 // the toe polynomial of this sample does not touch the coefficient
@@ -2821,8 +2840,10 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(LCtx& c, GD* g, const GD* lam) {
           }
           for (int bi = 0; bi < nblk; ++bi) {
             const int len = xblock_len(q, blks[bi]);
-            const GD* r = xrec(q, te, blks[bi], 0);
-            for (int smp = 0; smp < len; ++smp, r += XR_STRIDE) {
+            int k_lo, k_hi;
+            sample_range(q, s, pa, pb, q->cd + xblock_times(q, blks[bi]), len, k_lo, k_hi);
+            const GD* r = xrec(q, te, blks[bi], k_lo);
+            for (int smp = k_lo; smp <= k_hi; ++smp, r += XR_STRIDE) {
               const int poly = (int)r[XR_POLY];
               if (poly < pa) continue;
               if (poly > pb) break;            // (the samples of a block are ordered in time; an unused slot reads as polynomial 0 with zero coefficients)
