@@ -106,16 +106,17 @@ def test_batch_driver_on_gpu(gold, tmp_path):
         assert m.n_frames == F and m.n_joints == 28
 
 
-@pytest.mark.parametrize('lds_doubles', [0, 9216])
-def test_realistic_clip_lengths_match_the_reference(lds_doubles):
+@pytest.mark.parametrize('fixture,lds_doubles', [('kinopt_golden_long.npz', 0), ('kinopt_golden_long.npz', 9216), ('kinopt_golden_100.npz', 0)])
+def test_realistic_clip_lengths_match_the_reference(fixture, lds_doubles):
     """Clips of 40 and 60 frames (tests/golden/kinopt_golden_long.npz: the reference's own `optimize_trajectory` run on them,
     make_kinopt_golden.py --long) through the kernel: every least-squares solve within 5e-4 of the reference's solution, the relabelled contacts exact
     (VERDICT r02 item 5).  Twice: at the DEFAULT frame tiles (144 KB of LDS: 71 frames for J v, 54 for J^T u -- the 40-frame clip crosses no tile boundary,
     the 60-frame one only that of J^T u) and at 72 KB tiles (34 / 27 frames: both clips cross both boundaries, as the 100-frame clips of the bench do at the
-    default) -- VERDICT r03 "weak" 3."""
-    path = os.path.join(HERE, 'golden', 'kinopt_golden_long.npz')
+    default) -- VERDICT r03 "weak" 3.  And one 100-frame clip (kinopt_golden_100.npz, make_kinopt_golden.py --long 100 --out=...: the bench's clip length), which
+    crosses both boundaries of the default tiles."""
+    path = os.path.join(HERE, 'golden', fixture)
     if not os.path.exists(path):
-        pytest.skip('kinopt_golden_long.npz not generated')
+        pytest.skip(fixture + ' not generated')
     torch = pytest.importorskip('torch')
     if not torch.cuda.is_available():
         pytest.skip('needs an MI355X')
