@@ -95,6 +95,7 @@ int chd_ik_solve_batch(const chd_ik_config* cfg, int device, int B, const chd_ik
   const unsigned nthreads = bt.max_T > 16 ? 512u : 128u;
   double* cur = d_x0; double* nxt = d_x1;
   IK_TRY(hipEventRecord(ev0, st), "hipEventRecord");
+  (void)hipGetLastError();      // an error another library of the process left behind in this thread (hipBLASLt's kernel look-ups do) is not this launch's
   for (int it = 0; it < P.iterations; ++it) {
     hipLaunchKernelGGL(chd_ik_step_kernel, dim3((unsigned)nwg), dim3(nthreads), lds, st, d_seqs, d_fs, d_fi, P, d_ip, d_dp, cur, nxt, bt.max_J, bt.max_T);
     IK_TRY(hipGetLastError(), "launch");

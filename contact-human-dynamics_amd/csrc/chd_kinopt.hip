@@ -103,6 +103,7 @@ int chd_kin_solve_batch(const chd_kin_config* cfg, int device, int B, chd_kin_se
   // least-squares kernels for 256 clips x 100 frames.  A 128-VGPR build with two resident workgroups was measured too: 3.45 s.)
   const int lds_doubles = cfg->reserved[1] > 0 ? cfg->reserved[1] : 18432;
   KIN_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chd_kin_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * lds_doubles)), "hipFuncSetAttribute");
+  (void)hipGetLastError();      // an error another library of the process left behind in this thread is not this launch's
   hipLaunchKernelGGL(chd_kin_solve_kernel, dim3((unsigned)B), dim3((unsigned)nthreads), sizeof(double) * (size_t)lds_doubles, st, d_seqs, bt.P, d_dp, d_ip, d_work, d_state, d_stats, lds_doubles);
   KIN_TRY(hipGetLastError(), "launch");
   KIN_TRY(hipEventRecord(ev1, st), "hipEventRecord");

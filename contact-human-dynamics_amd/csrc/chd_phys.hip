@@ -383,6 +383,7 @@ static int launch_queue(chd_handle* h, chd_batch* b, const std::vector<int>& ite
   HIP_TRY(h, hipMemsetAsync(b->d_counter, 0, sizeof(int), st));
   const unsigned grid = (unsigned)std::min<size_t>(items.size(), (size_t)h->n_wg);
   HIP_TRY(h, hipEventRecord(e0, st));
+  (void)hipGetLastError();      // an error another library of the process left behind in this thread is not this launch's
   hipLaunchKernelGGL(chd_solve_kernel, dim3(grid), dim3(h->threads), h->lds_bytes, st, b->d_descs, (const int*)b->d_order, (int)items.size(),
                      b->d_counter, h->d_wd[b->pool], h->wd_stride[b->pool], h->d_wi[b->pool], h->wi_stride[b->pool], h->lds_bytes / 8, h->cfg.tol, h->cfg.stall_window, stage_first, stage_last);
   HIP_TRY(h, hipGetLastError());
@@ -911,6 +912,7 @@ int chd_debug_eval(chd_handle* h, chd_batch* b, int seq, int stage, const double
   }
   HIP_TRY(h, hipMemcpyAsync(b->d_order, &seq, sizeof(int), hipMemcpyHostToDevice, h->stream[0]));
   HIP_TRY(h, hipMemsetAsync(b->d_counter, 0, sizeof(int), h->stream[0]));
+  (void)hipGetLastError();
   hipLaunchKernelGGL(chd_debug_eval_kernel, dim3(1), dim3(h->threads), h->lds_bytes, h->stream[0], b->d_descs, (const int*)b->d_order, b->d_counter, h->d_wd[0], h->d_wi[0],
                      stage, x ? (const double*)b->d_x : (const double*)nullptr, h->lds_bytes / 8, b->d_f);
   HIP_TRY(h, hipGetLastError());
@@ -954,6 +956,7 @@ int chd_debug_linsolve(chd_handle* h, chd_batch* b, int seq, int stage, double d
   if (e == hipSuccess) e = hipMemcpyAsync(b->d_order, &seq, sizeof(int), hipMemcpyHostToDevice, h->stream[0]);
   if (e == hipSuccess) e = hipMemsetAsync(b->d_counter, 0, sizeof(int), h->stream[0]);
   if (e == hipSuccess) {
+    (void)hipGetLastError();
     hipLaunchKernelGGL(chd_debug_linsolve_kernel, dim3(1), dim3(h->threads), h->lds_bytes, h->stream[0], b->d_descs, (const int*)b->d_order, b->d_counter, h->d_wd[0], h->d_wi[0],
                        stage, h->lds_bytes / 8, dw, dval, which, reps < 1 ? 1 : reps, (const double*)d_buf, d_buf + N, d_buf + 2 * N);
     e = hipGetLastError();
