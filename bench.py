@@ -442,7 +442,7 @@ def main(argv=None, solver_factory=None):
                          'definition': 'sum over sequences of SURVEY 8(d) bytes_iter x IPM iterations / wall time of the timed region / (8 TB/s x GPUs)',
                          'algorithmic_bytes_per_step': alg_bytes_all / steps / world, 'algorithmic_bytes_per_iteration': alg_bytes / max(1, iters),
                          'traffic': traffic, 'traffic_note': traffic_note, 'kernel': 'chd_solve_kernel',
-                         'launches': 1 + (1 if st['kernel_ms'][1] > 0 else 0), 'kernel_ms_rank0': kernel_ms,
+                         'launches': 1 + (1 if st['kernel_ms'][1] > 0 else 0), 'kernel_ms_rank0': kernel_ms, 'fallback_launch_ms_rank0': st['kernel_ms'][1],
                          'kernel_busy_fraction': st['phase_ms'][5] / max(1e-9, st['n_workgroups'] * kernel_ms),
                          'fp64': {'achieved': flops / elapsed / 1e12, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': flops / elapsed / 1e12 / FP64_PEAK_TFLOPS,
                                   'note': 'rank 0, by formula: band LDL^T + substitutions + products at the mean problem size; MFMA counters: profiles/'}},

@@ -166,6 +166,13 @@ typedef __attribute__((address_space(3))) Ctx LCtx;
 #define CHD_CLOCK() ((long long)wall_clock64())
 #endif
 #define TACC(c, k, v) do { if (CHD_TID == 0) (c).tacc[k] += (v); } while (0)
+#ifdef CHD_EVAL_TIMING      // study build: the substitution's sub-phase slots 16..20 time parts of the evaluation instead (with a barrier in front of every reading)
+#define EVT_BEGIN() CHD_SYNC(); long long evt_ = CHD_CLOCK()
+#define EVT(c, k) do { CHD_SYNC(); TACC(c, k, CHD_CLOCK() - evt_); evt_ = CHD_CLOCK(); } while (0)
+#else
+#define EVT_BEGIN() ((void)0)
+#define EVT(c, k) ((void)0)
+#endif
 #define TIC() const long long tic_ = CHD_CLOCK()
 #define TOC(c, k) TACC(c, k, CHD_CLOCK() - tic_)
 
@@ -1666,7 +1673,9 @@ CHD_DEV void ksolve_impl(LCtx& c, const GD* rhs, GD* x, YP y, SP Sp, const int l
   }
   if (tile) load_diag_tile(c, tile, (nblk - 1) * nb, Nb - (nblk - 1) * nb);
   CHD_SYNC();
+#ifndef CHD_EVAL_TIMING
   TACC(c, 18, CHD_CLOCK() - ts_);
+#endif
   // backward, band
   tri_backward(c, y, (nblk - 1) * nb, Nb - (nblk - 1) * nb, tile);
   CHD_SYNC();
@@ -1875,7 +1884,9 @@ CHD_DEV void ksolve_fast(LCtx& c, const GD* rhs, GD* x, LdsD* y, LdsD* Sp, LdsD*
   }
   CHD_WRITE_TILE();
   CHD_SYNC();
+#ifndef CHD_EVAL_TIMING
   TACC(c, 18, CHD_CLOCK() - ts_);
+#endif
   // backward, band
   CHD_LOAD_TILE(nblk - 2);
   if (wv == 0) tri_chain_bwd(y, tile, (nblk - 1) * nb, Nb - (nblk - 1) * nb);
@@ -1897,7 +1908,9 @@ CHD_DEV void ksolve_fast(LCtx& c, const GD* rhs, GD* x, LdsD* y, LdsD* Sp, LdsD*
   }
   PAR_FOR(i, N) x[i] = y[i];
   CHD_SYNC();
+#ifndef CHD_EVAL_TIMING
   TACC(c, 16, t16_); TACC(c, 17, t17_); TACC(c, 19, t19_); TACC(c, 20, t20_);
+#endif
 #undef CHD_LOAD_TILE
 #undef CHD_WRITE_TILE
 #undef CHD_LOAD_FAR
@@ -2533,6 +2546,7 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(LCtx& c, GD* g, const GD* lam) {
     return v;
   };
   auto node_terms = [&](auto sample) {
+    EVT_BEGIN();
     PAR_FOR(idx, tot_nodes * 2 * ncol) {
       const int col = idx % ncol, row = idx / ncol;
       const int dq1 = row % 2, back = col / 2, dq2 = col % 2;
@@ -2587,6 +2601,7 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(LCtx& c, GD* g, const GD* lam) {
         kadd_batch<3>(c, pp, qv, vv);      // the three dimensions are three different entries
       }
     }
+    EVT(c, 16);
     // gradient: one thread per (coefficient, dimension)
     PAR_FOR(idx, tot_nodes * 2 * 3) {
       const int dim = idx % 3, row = idx / 3, dq1 = row % 2;
@@ -2617,6 +2632,7 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(LCtx& c, GD* g, const GD* lam) {
         }
       g[sp.var_off + v1] += c.sf * acc;
     }
+    EVT(c, 17);
   };
   // the per-sample fields are read ~10^5 times by the entry tasks: keep the first SC_LDS fields of the cache in LDS
   const int sstride = SC_LDS;
@@ -2629,6 +2645,7 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(LCtx& c, GD* g, const GD* lam) {
     CHD_SYNC();
     node_terms(lds_sample);
   } else node_terms(hbm_sample);
+  EVT_BEGIN();
   if (HC) {
     // toe x heel blocks of the heel-distance curvature: one thread per (pair, toe coefficient, heel coefficient); the entry is
     // - sum over the samples of lam sc w_toe w_heel, the same for the three dimensions
@@ -2668,6 +2685,7 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(LCtx& c, GD* g, const GD* lam) {
       kadd_batch<3>(c, pp, qv, vv);
     }
   }
+  EVT(c, 18);
   CHD_SYNC();
   TACC(c, 13, CHD_CLOCK() - tg_); tg_ = CHD_CLOCK();
   // ---- duration variables (stage 3 only)
@@ -2717,58 +2735,58 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(LCtx& c, GD* g, const GD* lam) {
   TACC(c, 14, CHD_CLOCK() - tg_); tg_ = CHD_CLOCK();
   if (S->opt_dur) {
     auto dur_terms = [&](auto sample) {
+    EVT_BEGIN();
     int tot = 0;
     for (int e = 0; e < 4; ++e) tot += (q->n_phase[e] - 1) * (q->n_phase[e] - 1);
-    PAR_FOR(idx0, tot) {       // (T_k, T_k2) entries
+    GROUP_FOR(idx0, tot) {     // (T_k, T_k2) entries: a lane group per entry, the samples and the table slots dealt out over its lanes (fixed-tree sums)
       int idx = idx0, e = 0;
       while (idx >= (q->n_phase[e] - 1) * (q->n_phase[e] - 1)) { idx -= (q->n_phase[e] - 1) * (q->n_phase[e] - 1); ++e; }
       const int s = 2 + e;
-      const auto& sp = q->sp[s];
       const int ntar = q->n_phase[e] - 1;
-      const int k = idx / ntar, tar = sp.n_var + idx % ntar;
+      const int k = idx / ntar, k2 = idx % ntar;
+      if (k2 > k) continue;            // (uniform over the group)
       const int Pk = c.pos_var[S->dur_off[e] + k];
       const double wdat = S->w_data[2], wvel = S->w_vel[2];
       const int nsm = n_smooth(q, s);
       const GD* dat = q->cd + q->o_data[s];
-      if (tar >= sp.n_var) {
-        // ---- (T_k, T_k2), k2 <= k : all residuals of this end-effector
-        const int k2 = tar - sp.n_var;
-        if (k2 > k) continue;
-        double hacc = 0, gacc = 0;
-        for (int i = 0; i < F; ++i) {
-          auto a = sample(s, i);
+      // ---- (T_k, T_k2), k2 <= k : all residuals of this end-effector
+      double hacc = 0, gacc = 0;
+      for (int i = lane_; i < F; i += CHD_GL) {
+        auto a = sample(s, i);
+        for (int dm = 0; dm < 3; ++dm) {
+          const double gk = -cache_djac(a, dm, k), gk2 = -cache_djac(a, dm, k2);
+          hacc += wdat * gk * gk2;
+          if (k2 == k) gacc += wdat * (dat[i * 3 + dm] - a[SC_P + dm]) * gk;
+        }
+        if (i < nsm && wvel >= 0) {
+          auto b = sample(s, i + 1);
           for (int dm = 0; dm < 3; ++dm) {
-            const double gk = -cache_djac(a, dm, k), gk2 = -cache_djac(a, dm, k2);
-            hacc += wdat * gk * gk2;
-            if (k2 == k) gacc += wdat * (dat[i * 3 + dm] - a[SC_P + dm]) * gk;
-          }
-          if (i < nsm && wvel >= 0) {
-            auto b = sample(s, i + 1);
-            for (int dm = 0; dm < 3; ++dm) {
-              const double gk = cache_djac(b, dm, k) - cache_djac(a, dm, k), gk2 = cache_djac(b, dm, k2) - cache_djac(a, dm, k2);
-              hacc += wvel * gk * gk2;
-              if (k2 == k) gacc += wvel * (b[SC_P + dm] - a[SC_P + dm]) * gk;
-            }
+            const double gk = cache_djac(b, dm, k) - cache_djac(a, dm, k), gk2 = cache_djac(b, dm, k2) - cache_djac(a, dm, k2);
+            hacc += wvel * gk * gk2;
+            if (k2 == k) gacc += wvel * (b[SC_P + dm] - a[SC_P + dm]) * gk;
           }
         }
-        if (lam && !c.second_model) {     // exact second-order terms collected by the row tasks and the cost pass above (first model of an iteration)
-          const GD* tb = q->wd + q->o_d2tab + (long long)e * q->d2_slots * D2_STRIDE;
-          double h2 = 0;
-          for (int sl = 0; sl < q->d2_slots; ++sl) h2 += d2_select(tb + sl * D2_STRIDE, k, k2);
-          hacc += h2 / c.sf;
-        }
-        if (k2 == k && S->w_dur >= 0) {     // DurationCost (duration_cost.cpp:25-50): 1/2 w (T0 - T)^2
-          hacc += S->w_dur;
-          gacc += S->w_dur * (q->wd[q->o_phase_dur + q->phase_off[e] + k] - q->cd[q->o_phase_dur0 + q->phase_off[e] + k]);
-        }
-        kadd(c, Pk, c.pos_var[S->dur_off[e] + k2], c.sf * hacc);
-        if (k2 == k) g[S->dur_off[e] + k] = c.sf * gacc;
       }
+      double h2 = 0;
+      if (lam && !c.second_model) {     // exact second-order terms collected by the row tasks and the cost pass above (first model of an iteration)
+        const GD* tb = q->wd + q->o_d2tab + (long long)e * q->d2_slots * D2_STRIDE;
+        for (int sl = lane_; sl < q->d2_slots; sl += CHD_GL) h2 += d2_select(tb + sl * D2_STRIDE, k, k2);
+      }
+      hacc = group_sum(hacc); gacc = group_sum(gacc); h2 = group_sum(h2);
+      if (lane_ != 0) continue;
+      hacc += h2 / c.sf;
+      if (k2 == k && S->w_dur >= 0) {     // DurationCost (duration_cost.cpp:25-50): 1/2 w (T0 - T)^2
+        hacc += S->w_dur;
+        gacc += S->w_dur * (q->wd[q->o_phase_dur + q->phase_off[e] + k] - q->cd[q->o_phase_dur0 + q->phase_off[e] + k]);
+      }
+      kadd(c, Pk, c.pos_var[S->dur_off[e] + k2], c.sf * hacc);
+      if (k2 == k) g[S->dur_off[e] + k] = c.sf * gacc;
     }
     // ---- (T_k, node variable) entries: one thread per node variable.  Gauss-Newton part (cost terms of the ee-motion splines): the thread gathers the
     // residuals that touch the variable's node(s) once and accumulates the entries of up to 8 durations at a time in registers.  Exact part (first model
     // of an iteration, multipliers given): + the residual curvature of the cost terms, sum_i df/dp_i . d2p_i/dx dT, and the records the row tasks left in
     // the node x duration table (chd_device.hpp, XR_* / XB_*) -- which also couple the durations with force, centre-of-mass and base-angle nodes.
+    EVT(c, 19);
     const bool DX = lam != nullptr && !c.second_model;
     const GI* varspl = q->ci + q->o_varspl; const GI* varnode = q->ci + q->o_varnode;
     PAR_FOR(var, q->n_nodesvars) {
@@ -2868,7 +2886,7 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(LCtx& c, GD* g, const GD* lam) {
         }
       }
     }
-  
+    EVT(c, 20);
     };
     if (in_lds) dur_terms(lds_sample); else dur_terms(hbm_sample);
   }
