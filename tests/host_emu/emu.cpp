@@ -216,3 +216,43 @@ extern "C" void emu_nnz_stats(void* h, int stage, double* out) {
   }
   out[0] = (double)env; out[1] = (double)nz; out[2] = (double)lines; out[3] = (double)benv; out[4] = (double)bnz; out[5] = (double)blines; out[6] = c.Nb; out[7] = c.bc;
 }
+
+// The occupancy list of the unfactored KKT matrix (chd_kernels.hpp "KKT storage") after TWO evaluations of `stage` (at its initial point with multipliers
+// lam0, then at x1 with lam1 -- the second one may move the pattern): out[0] = stored non-zeros that are not in the list (must be 0), out[1] = list entries,
+// out[2] = bits set in the masks (band + border rows + the transposed border; must equal out[1]), out[3] = max |list product - dense product| of K0 x for the
+// given x, out[4] = max |dense product|, out[5] = entries the second evaluation added to the list, out[6] = listed entries holding +0.0 or -0.0 (allowed)
+extern "C" int emu_list_check(void* h, int stage, const double* lam0, const double* x1, const double* lam1, const double* xv, double* out) {
+  Emu* e = (Emu*)h; e->bind();
+  double fo[2];
+  debug_eval(&e->M.d, e->ctx, stage, 0, e->lds.data(), (int)e->lds.size(), nullptr, (double*)lam0, fo);
+  Ctx& c = e->ctx;
+  const int nnz0 = c.csr_nnz;
+  // second evaluation in the same stage (no kreset): what solve_stage does iteration after iteration
+  double* x = VN(c, VN_X);
+  for (int j = 0; j < c.n; ++j) x[j] = x1[j];
+  for (int i = 0; i < c.m; ++i) VM(c, VM_LAM)[i] = lam1[i];
+  eval_nlp(c, x, EV_FULL, VM(c, VM_C), VN(c, VN_G), VM(c, VM_LAM));
+  const int N = c.N, Nb = c.Nb;
+  std::vector<char> listed((size_t)N * N, 0);
+  for (int i = 0; i < N; ++i)
+    for (int k = c.csr_rp[i]; k < c.csr_rp[i + 1]; ++k) { if (c.csr_row[k] != i) return -1; listed[(size_t)i * N + c.csr_col[k]] = 1; }
+  long long missing = 0, zeros = 0, bits = 0;
+  std::vector<double> yd(N, 0.0);
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) {
+      if (i < Nb && j < Nb && (j - i > c.w || i - j > c.w)) continue;
+      const double v = kget(c, i, j);
+      if (v != 0.0 && !listed[(size_t)i * N + j]) ++missing;
+      if (v == 0.0 && listed[(size_t)i * N + j]) ++zeros;
+      yd[i] += v * xv[j];
+    }
+  for (long long k = 0; k < (long long)Nb * c.MW; ++k) bits += __builtin_popcountll(c.pmb[k]);
+  for (long long k = 0; k < (long long)c.bc * c.LW; ++k) bits += __builtin_popcountll(c.pmx[k]);
+  for (long long k = 0; k < (long long)Nb * c.CW; ++k) bits += __builtin_popcountll(c.pmt[k]);
+  std::vector<double> xs(xv, xv + N), yl(N, 0.0);
+  kmatvec(c, xs.data(), yl.data(), nullptr, nullptr);
+  double err = 0, mag = 0;
+  for (int i = 0; i < N; ++i) { err = std::max(err, std::fabs(yl[i] - yd[i])); mag = std::max(mag, std::fabs(yd[i])); }
+  out[0] = (double)missing; out[1] = c.csr_nnz; out[2] = (double)bits; out[3] = err; out[4] = mag; out[5] = c.csr_nnz - nnz0; out[6] = (double)zeros;
+  return c.err;
+}

@@ -151,6 +151,38 @@ def test_kkt_structure_tables(emu):
     assert stats is None or all(int(s[0]) in (0, -1, -2) for s in stats)
 
 
+def test_occupancy_list_of_the_kkt_matrix(emu):
+    """The readers of the unfactored KKT matrix walk a list of the entries ever written in the stage, kept by the writers through a signed-zero marker
+    (chd_kernels.hpp "KKT storage").  After two evaluations per stage -- the second at moved durations in the duration stage, so that samples change
+    polynomial and the pattern grows -- every stored non-zero is in the list, the list is exactly the set of mask bits, and the product over the list equals
+    the dense product over the storage."""
+    import ctypes as C
+    L = emu.lib()
+    L.emu_list_check.argtypes = [C.c_void_p, C.c_int, emu.PD, emu.PD, emu.PD, emu.PD, emu.PD]
+    rng = np.random.default_rng(11)
+    grown = 0
+    for seed, F in ((3, 60), (7, 90)):
+        e = emu.EmuProblem(make_walk(seed=seed, F=F, randomize=True))
+        for st in range(5):
+            sz = e.sizes(st)
+            n, m = sz['n'], sz['m']
+            x0 = e.eval(st, jac=False, hess=False)['x']
+            x1 = x0 + 1e-3 * rng.normal(size=n)
+            if st == 4:                                   # durations: shorten / lengthen phases by up to 4 % (much more overflows the band, which the solver reports as an error) so that samples cross polynomial boundaries
+                nd = n - e.sizes(3)['n']
+                x1[n - nd:] = x0[n - nd:] * (1 + 0.04 * rng.uniform(-1, 1, size=nd))
+            lam0 = np.zeros(m); lam1 = rng.normal(size=m)
+            out = np.zeros(8)
+            err = L.emu_list_check(C.c_void_p(e.h), st, emu._p(lam0), emu._p(np.ascontiguousarray(x1)), emu._p(lam1), emu._p(rng.normal(size=n + m)), emu._p(out))
+            assert err == 0, (seed, st)
+            missing, listed, bits, perr, pmag, added = out[:6]
+            assert missing == 0 and listed == bits and listed > 0, (seed, st, out)
+            assert perr <= 1e-12 * max(pmag, 1.0), (seed, st, perr, pmag)
+            if st == 4:
+                grown += added
+    assert grown > 0        # the second evaluation of the duration stage did move the pattern
+
+
 def test_inertia_retry_switch_keeps_kernel_and_oracle_in_lockstep():
     """A sequence on which kernel source and oracle used to part ways in the duration stage (seed 31: at its second
     iteration the factorisation meets a pivot of unexpected sign, replaces it, and the oracle's line search accepted the
