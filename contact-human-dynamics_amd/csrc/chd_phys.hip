@@ -34,10 +34,26 @@ using namespace chd;
 static_assert(sizeof(SeqDesc) % 8 == 0, "SeqDesc is copied word by word");
 static_assert(sizeof(SeqDesc) + sizeof(Ctx) + 64 <= 4096, "static LDS of the solver kernel must fit the 4 KB left beside the dynamic part");
 
+// Workspace slots.  A resident workgroup needs a workspace (~35 MB at 90 frames) only while it is resident, and at most `n_slots` workgroups are (one per
+// compute unit: a workgroup needs the whole LDS) -- however many launches are in flight.  So the handle owns ONE set of n_slots workspaces, and a workgroup
+// claims a free one when it starts and gives it back when its launch's queue is drained.  Two launches that overlap in time hand a slot from a workgroup on
+// one XCD to a workgroup on another without a kernel boundary in between: the release (agent scope) writes the first owner's L2 back before the flag
+// clears, the acquire pairs with it.  (Until round 4 a launch indexed a pool of its own by blockIdx: four pools, four launches in flight, and a pool could not
+// be reused before the last straggler of its previous launch had finished.)
+__device__ inline int claim_slot(int* slot_busy, int n_slots) {
+  int s = (int)(blockIdx.x % (unsigned)n_slots);
+  for (int sweep = 0; sweep < 4096 * n_slots; ++sweep) {
+    int expected = 0;
+    if (__hip_atomic_compare_exchange_strong(&slot_busy[s], &expected, 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return s;
+    s = s + 1 == n_slots ? 0 : s + 1;
+    if ((sweep & 63) == 63) __builtin_amdgcn_s_sleep(32);
+  }
+  return -1;          // (cannot happen while n_slots >= the resident workgroups; a workgroup without a slot leaves the queue to the others instead of spinning on)
+}
 // (returns false when the queue is empty.  Not a pointer: the descriptor sits at LDS address 0, which is what a null
 // local-address-space pointer compares equal to.)
 __device__ inline bool take_sequence(SeqDesc* s_desc, int* s_item, const SeqDesc* descs, const int* order, int n_items, int* counter,
-                                   double* wd_pool, long long wd_stride, int* wi_pool, long long wi_stride) {
+                                   double* wd_pool, long long wd_stride, int* wi_pool, long long wi_stride, int slot) {
   __syncthreads();                                  // everybody is done with the previous descriptor
   if (threadIdx.x == 0) *s_item = atomicAdd(counter, 1);
   __syncthreads();
@@ -48,24 +64,31 @@ __device__ inline bool take_sequence(SeqDesc* s_desc, int* s_item, const SeqDesc
   for (int i = threadIdx.x; i < (int)(sizeof(SeqDesc) / 4); i += blockDim.x) dst[i] = src[i];
   __syncthreads();
   if (threadIdx.x == 0) {
-    s_desc->wd = (GD*)(wd_pool + (long long)blockIdx.x * wd_stride);
-    s_desc->wi = (GI*)(wi_pool + (long long)blockIdx.x * wi_stride);
+    s_desc->wd = (GD*)(wd_pool + (long long)slot * wd_stride);
+    s_desc->wi = (GI*)(wi_pool + (long long)slot * wi_stride);
   }
   __syncthreads();
   return true;
 }
 
 __global__ __launch_bounds__(CHD_MAX_THREADS) void chd_solve_kernel(const SeqDesc* descs, const int* order, int n_items, int* counter,
-                                                                    double* wd_pool, long long wd_stride, int* wi_pool, long long wi_stride,
+                                                                    double* wd_pool, long long wd_stride, int* wi_pool, long long wi_stride, int* slot_busy, int n_slots,
                                                                     int lds_doubles, double tol, int stall_window, int stage_first, int stage_last) {
   extern __shared__ double lds[];
   __shared__ SeqDesc s_desc;
   __shared__ Ctx s_ctx;
   __shared__ int s_item;
+  __shared__ int s_slot;
+  if (threadIdx.x == 0) s_slot = claim_slot(slot_busy, n_slots);
+  __syncthreads();
+  const int slot = s_slot;
+  if (slot < 0) return;
   for (;;) {
-    if (!take_sequence(&s_desc, &s_item, descs, order, n_items, counter, wd_pool, wd_stride, wi_pool, wi_stride)) break;
+    if (!take_sequence(&s_desc, &s_item, descs, order, n_items, counter, wd_pool, wd_stride, wi_pool, wi_stride, slot)) break;
     run_sequence((QP)&s_desc, *(LCtx*)&s_ctx, (LdsD*)lds, lds_doubles, tol, stall_window, stage_first, stage_last);
   }
+  __syncthreads();                                  // every wavefront's stores to the workspace are issued and complete (take_sequence ends on a barrier too)
+  if (threadIdx.x == 0) __hip_atomic_store(&slot_busy[slot], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ __launch_bounds__(CHD_MAX_THREADS) void chd_debug_eval_kernel(const SeqDesc* descs, const int* order, int* counter, double* wd_pool, int* wi_pool,
@@ -74,7 +97,7 @@ __global__ __launch_bounds__(CHD_MAX_THREADS) void chd_debug_eval_kernel(const S
   __shared__ SeqDesc s_desc;
   __shared__ Ctx s_ctx;
   __shared__ int s_item;
-  if (!take_sequence(&s_desc, &s_item, descs, order, 1, counter, wd_pool, 0, wi_pool, 0)) return;
+  if (!take_sequence(&s_desc, &s_item, descs, order, 1, counter, wd_pool, 0, wi_pool, 0, 0)) return;      // (alone on the device: slot 0, not claimed)
   debug_eval((QP)&s_desc, *(LCtx*)&s_ctx, stage, xin != nullptr, (LdsD*)lds, lds_doubles, (const GD*)xin, (const GD*)nullptr, f_out);
 }
 
@@ -85,17 +108,17 @@ __global__ __launch_bounds__(CHD_MAX_THREADS) void chd_debug_linsolve_kernel(con
   __shared__ SeqDesc s_desc;
   __shared__ Ctx s_ctx;
   __shared__ int s_item;
-  if (!take_sequence(&s_desc, &s_item, descs, order, 1, counter, wd_pool, 0, wi_pool, 0)) return;
+  if (!take_sequence(&s_desc, &s_item, descs, order, 1, counter, wd_pool, 0, wi_pool, 0, 0)) return;
   debug_linsolve((QP)&s_desc, *(LCtx*)&s_ctx, stage, (LdsD*)lds, lds_doubles, dw, dval, which, reps, (const GD*)rhs, (GD*)x, out);
 }
 
-// A handle owns CHD_N_POOLS workspace pools (one workspace per resident workgroup each) with a stream of their own: a launch uses one pool, so up to
-// CHD_N_POOLS persistent launches can be in flight -- chunk k + 1 of a pipelined call starts filling the compute units that chunk k's last
-// sequences leave idle, while the host builds the tables of chunk k + 2.  The split interface (chd_batch_solve) uses pool 0 only; the other
-// pools are allocated when a pipelined call first needs them.  Measured on the MI355X (profiles/r04_pipeline.md, 2 560 sequences, ~8 chunks): four pools
-// 0.90 of the solve-only rate, eight pools 0.79 (a launch's workgroups keep their compute units until ITS queue is drained: many launches in flight split
-// the units unevenly), caps on the grid of a launch 0.75-0.88.
-#define CHD_N_POOLS 4
+// A handle owns ONE set of workspaces -- one per workgroup that can be resident, claimed and released by the workgroups themselves (claim_slot above) --
+// and CHD_N_POOLS "lanes": a stream and a set of reusable device / page-locked buffers for one chunk of sequences each.  A launch uses one lane, so up to
+// CHD_N_POOLS persistent launches can be queued: in a pipelined call the host builds and launches chunk after chunk as fast as it can, and the
+// device works through them in order -- a workgroup of chunk k + 1 starts as soon as a compute unit has no sequence of chunk k left to take.  The split
+// interface (chd_batch_solve) uses lane 0.  (Rounds 3-4 had a workspace pool per lane: four launches in flight at 4 x the memory, and a lane could not be
+// reused before the last straggler of its previous launch had finished -- 0.84 of the solve-only rate; profiles/r04_pipeline.md.)
+#define CHD_N_POOLS 4          // = the hardware queues a process gets by default (GPU_MAX_HW_QUEUES): streams beyond that share a queue, and a persistent launch blocks the queue it is in until its last straggler ends (measured: eight lanes 0.60 of the solve-only rate)
 struct chd_handle {
   int device = 0;
   hipStream_t stream[CHD_N_POOLS] = {};
@@ -103,10 +126,10 @@ struct chd_handle {
   std::string err;
   int lds_bytes = 0;
   int threads = CHD_MAX_THREADS;
-  int n_wg = 0;                        // resident workgroups of a launch
-  // workgroup workspaces (grow-only)
-  double* d_wd[CHD_N_POOLS] = {}; int* d_wi[CHD_N_POOLS] = {};
-  long long wd_stride[CHD_N_POOLS] = {}, wi_stride[CHD_N_POOLS] = {};          // per pool: a pool that has to grow is reallocated alone, while it is idle
+  int n_wg = 0;                        // resident workgroups of a launch = workspace slots
+  // workgroup workspaces (grow-only; reallocated only while no launch is in flight) and their busy flags
+  double* d_wd = nullptr; int* d_wi = nullptr; int* d_slots = nullptr;
+  long long wd_stride = 0, wi_stride = 0;
   chd_call_stats call{};               // accounting of the last chd_phys_solve_batch / chd_phys_solve_dirs
   // device buffers of the pipelined path, one set per pool, grow-only and reused chunk after chunk: no hipMalloc / hipFree while launches are in flight
   // (measured, round 4: allocating per chunk serialised the chunks -- 214 ms of "upload" per chunk, the whole call at 0.72 of the solve-only rate)
@@ -171,35 +194,43 @@ static unsigned host_threads(int n) {
   return nt;
 }
 
-// workspaces of pool `pool` for `n_wg` resident workgroups of at least (wd_need, wi_need) elements each (+ `headroom` eighths when the pool has to be
-// (re)allocated: the pipelined path asks for 2/8, because a sequence that needs a few per cent more than its predecessors must not stall the pipeline --
-// measured in round 4: every new maximum drained all launches and reallocated every pool, 1.2 s each time).  The caller makes sure the pool is idle.
-static int ensure_workspace(chd_handle* h, int pool, long long wd_need, long long wi_need, int headroom = 0) {
+// workspaces for `n_wg` resident workgroups of at least (wd_need, wi_need) elements each (+ `headroom` eighths when they have to be (re)allocated: the
+// pipelined path asks for 2/8, because a sequence that needs a few per cent more than its predecessors must not stall the pipeline -- measured in round 4:
+// every new maximum drained all launches, 1.2 s each time).  The caller makes sure NO launch is in flight when the workspaces have to grow
+// (workspace_fits tells).
+static bool workspace_fits(const chd_handle* h, long long wd_need, long long wi_need) {
   auto al = [](long long v) { return (v + 63) & ~63LL; };
-  if (h->d_wd[pool] && al(wd_need) <= h->wd_stride[pool] && al(wi_need) <= h->wi_stride[pool]) return 0;
-  if (h->d_wd[pool]) {
-    HIP_TRY(h, hipStreamSynchronize(h->stream[pool]));
-    (void)hipFree(h->d_wd[pool]); (void)hipFree(h->d_wi[pool]);
-    h->d_wd[pool] = nullptr; h->d_wi[pool] = nullptr;
+  return h->d_wd && al(wd_need) <= h->wd_stride && al(wi_need) <= h->wi_stride;
+}
+static int ensure_workspace(chd_handle* h, long long wd_need, long long wi_need, int headroom = 0) {
+  auto al = [](long long v) { return (v + 63) & ~63LL; };
+  if (workspace_fits(h, wd_need, wi_need)) return 0;
+  if (h->d_wd) {
+    HIP_TRY(h, hipDeviceSynchronize());
+    (void)hipFree(h->d_wd); (void)hipFree(h->d_wi);
+    h->d_wd = nullptr; h->d_wi = nullptr;
   }
-  h->wd_stride[pool] = std::max(h->wd_stride[pool], al(wd_need + wd_need / 8 * headroom)); h->wi_stride[pool] = std::max(h->wi_stride[pool], al(wi_need + wi_need / 8 * headroom));
-  hipError_t e = hipMalloc((void**)&h->d_wd[pool], (size_t)h->wd_stride[pool] * 8 * h->n_wg);
-  if (e == hipSuccess) e = hipMalloc((void**)&h->d_wi[pool], (size_t)h->wi_stride[pool] * 4 * h->n_wg);
+  h->wd_stride = std::max(h->wd_stride, al(wd_need + wd_need / 8 * headroom)); h->wi_stride = std::max(h->wi_stride, al(wi_need + wi_need / 8 * headroom));
+  hipError_t e = hipMalloc((void**)&h->d_wd, (size_t)h->wd_stride * 8 * h->n_wg);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_wi, (size_t)h->wi_stride * 4 * h->n_wg);
   if (e != hipSuccess && headroom > 0) {          // not with head-room: exactly what is needed
-    (void)hipFree(h->d_wd[pool]); h->d_wd[pool] = nullptr; h->d_wi[pool] = nullptr;
-    h->wd_stride[pool] = al(wd_need); h->wi_stride[pool] = al(wi_need);
-    e = hipMalloc((void**)&h->d_wd[pool], (size_t)h->wd_stride[pool] * 8 * h->n_wg);
-    if (e == hipSuccess) e = hipMalloc((void**)&h->d_wi[pool], (size_t)h->wi_stride[pool] * 4 * h->n_wg);
+    (void)hipFree(h->d_wd); h->d_wd = nullptr; h->d_wi = nullptr;
+    h->wd_stride = al(wd_need); h->wi_stride = al(wi_need);
+    e = hipMalloc((void**)&h->d_wd, (size_t)h->wd_stride * 8 * h->n_wg);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_wi, (size_t)h->wi_stride * 4 * h->n_wg);
   }
+  if (e == hipSuccess && !h->d_slots) e = hipMalloc((void**)&h->d_slots, sizeof(int) * (size_t)h->n_wg);
   if (e != hipSuccess) {
-    (void)hipFree(h->d_wd[pool]); h->d_wd[pool] = nullptr; h->d_wi[pool] = nullptr;
-    const long long mib = (h->wd_stride[pool] * 8 + h->wi_stride[pool] * 4) * h->n_wg >> 20;
-    h->wd_stride[pool] = h->wi_stride[pool] = 0;
+    (void)hipFree(h->d_wd); h->d_wd = nullptr; h->d_wi = nullptr;
+    const long long mib = (h->wd_stride * 8 + h->wi_stride * 4) * h->n_wg >> 20;
+    h->wd_stride = h->wi_stride = 0;
     return fail(h, std::string("workspace allocation (") + std::to_string(mib) + " MiB): " + hipGetErrorString(e));
   }
-  // (no clearing needed for correctness: a workgroup zeroes / initialises what it reads, sequence by sequence and stage by stage)
-  HIP_TRY(h, hipMemsetAsync(h->d_wd[pool], 0, (size_t)h->wd_stride[pool] * 8 * h->n_wg, h->stream[pool]));
-  HIP_TRY(h, hipMemsetAsync(h->d_wi[pool], 0, (size_t)h->wi_stride[pool] * 4 * h->n_wg, h->stream[pool]));
+  // (no clearing needed for correctness: a workgroup zeroes / initialises what it reads, sequence by sequence and stage by stage; the slot flags must be clear)
+  HIP_TRY(h, hipMemsetAsync(h->d_wd, 0, (size_t)h->wd_stride * 8 * h->n_wg, h->stream[0]));
+  HIP_TRY(h, hipMemsetAsync(h->d_wi, 0, (size_t)h->wi_stride * 4 * h->n_wg, h->stream[0]));
+  HIP_TRY(h, hipMemsetAsync(h->d_slots, 0, sizeof(int) * (size_t)h->n_wg, h->stream[0]));
+  HIP_TRY(h, hipStreamSynchronize(h->stream[0]));          // (the launches of the other lanes do not wait for stream 0)
   return 0;
 }
 
@@ -385,7 +416,7 @@ static int launch_queue(chd_handle* h, chd_batch* b, const std::vector<int>& ite
   HIP_TRY(h, hipEventRecord(e0, st));
   (void)hipGetLastError();      // an error another library of the process left behind in this thread is not this launch's
   hipLaunchKernelGGL(chd_solve_kernel, dim3(grid), dim3(h->threads), h->lds_bytes, st, b->d_descs, (const int*)b->d_order, (int)items.size(),
-                     b->d_counter, h->d_wd[b->pool], h->wd_stride[b->pool], h->d_wi[b->pool], h->wi_stride[b->pool], h->lds_bytes / 8, h->cfg.tol, h->cfg.stall_window, stage_first, stage_last);
+                     b->d_counter, h->d_wd, h->wd_stride, h->d_wi, h->wi_stride, h->d_slots, h->n_wg, h->lds_bytes / 8, h->cfg.tol, h->cfg.stall_window, stage_first, stage_last);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipEventRecord(e1, st));
   return 0;          // (asynchronous: the kernel is waited for through e1; `items` must stay alive until then -- the callers pass vectors owned by the batch)
@@ -586,14 +617,18 @@ static int solve_pipelined(chd_handle* h, int B, const chd_seq_in* in, chd_seq_o
   HIP_TRY(h, hipSetDevice(h->device));
   const double t_begin = now_ms();
   h->call = chd_call_stats{};
-  // chunk plan: a small first chunk (the device starts after ~50 ms of host work instead of after the set-up of a full chunk), then chunks of `chunk`
+  // chunk plan: a small first chunk (one sequence per compute unit: the device starts after ~30 ms of host work instead of after the set-up of a full chunk), then the rest in
+  // CHD_N_POOLS - 1 equal chunks, so that every chunk has a lane (a hardware queue) of its own and all of them are in flight together: a lane is blocked until
+  // the LAST straggler of its launch has ended (~1.5 s for 90-frame walks), so reusing lanes with chunks of a few hundred sequences costs more than it hides
+  // (measured: ~8 chunks on four lanes 0.84 of the solve-only rate).  Chunks are capped at 4 096 sequences (device and page-locked buffers of a lane:
+  // ~0.6 MB per 90-frame sequence each); beyond 256 + 3 x 4 096 sequences lanes are reused, with launches long enough to make the straggler's share small.
   int chunk = h->cfg.pipeline_chunk;
-  if (chunk == 0) { chunk = (B + 6) / 7; if (chunk < 256) chunk = 256; if (chunk > 1024) chunk = 1024; }      // automatic: about eight chunks, four of them in flight
+  if (chunk == 0) { chunk = (B - 256 + CHD_N_POOLS - 2) / (CHD_N_POOLS - 1); if (chunk < 256) chunk = 256; if (chunk > 4096) chunk = 4096; }
   if (chunk < 0 || chunk > B) chunk = B;                                                                // < 0: one chunk, i.e. upload, solve, fetch in turn
   std::vector<std::unique_ptr<PipeChunk>> ch;
   {
     int c0 = 0;
-    const int first = (h->cfg.pipeline_chunk >= 0 && B > 2 * 128 && chunk > 128) ? 128 : chunk;
+    const int first = (h->cfg.pipeline_chunk >= 0 && B > 2 * 256 && chunk > 256) ? 256 : chunk;          // (one sequence for every compute unit)
     while (c0 < B) {
       int n = ch.empty() ? first : chunk;
       if (B - c0 - n < 64) n = B - c0;            // (no crumbs at the end)
@@ -640,7 +675,7 @@ static int solve_pipelined(chd_handle* h, int B, const chd_seq_in* in, chd_seq_o
     const long long scale_ = (chunk + n - 1) / n;          // (the first chunk is the small one: the pools are sized for a full chunk of sequences like its own)
     if (k == 0)          // before the first launch: workspaces and reusable buffers of every pool this call will use, sized by this chunk (+ head-room)
       for (int p = 0; p < n_pools && rc == 0; ++p) {
-        rc = ensure_workspace(h, p, c.b->wd_need, c.b->wi_need, 2);
+        if (p == 0) rc = ensure_workspace(h, c.b->wd_need, c.b->wi_need, 2);
         if (rc == 0) rc = ensure_pool_bufs(h, p, std::max<long long>(c.b->tot_cd, 1) * scale_, std::max<long long>(c.b->tot_ci, 1) * scale_, c.b->od_stride * chunk, c.b->oi_stride * chunk, chunk);
         if (rc == 0) {
           const size_t need[6] = {(size_t)c.b->tot_cd * 8 * scale_, (size_t)c.b->tot_ci * 4 * scale_, (sizeof(SeqDesc) + sizeof(int)) * (size_t)chunk, (size_t)c.b->od_stride * chunk * 8, (size_t)c.b->oi_stride * chunk * 4, (size_t)chunk * 1024};
@@ -649,7 +684,10 @@ static int solve_pipelined(chd_handle* h, int B, const chd_seq_in* in, chd_seq_o
         if (rc != 0 && p >= 1) { n_pools = p; rc = 0; h->err.clear(); break; }          // (long sequences: the memory holds fewer pools -- fewer launches in flight)
       }
     c.t_step[0] = now_ms() - t_begin;
-    if (rc == 0) rc = ensure_workspace(h, pool, c.b->wd_need, c.b->wi_need, 2);          // (this pool is idle; grows alone if this chunk holds a larger sequence than any before)
+    if (rc == 0 && !workspace_fits(h, c.b->wd_need, c.b->wi_need)) {          // this chunk holds a larger sequence than any before: every launch in flight has to end first
+      for (int j = 0; j < k; ++j) { PipeChunk& pj = *ch[j]; std::unique_lock<std::mutex> lk(pj.mu); pj.cv.wait(lk, [&] { return pj.device_done; }); }
+      rc = ensure_workspace(h, c.b->wd_need, c.b->wi_need, 2);
+    }
     c.t_step[1] = now_ms() - t_begin;
     if (rc == 0) rc = batch_to_device(h, c.b, pool, true);
     c.t_step[2] = now_ms() - t_begin;
@@ -770,7 +808,7 @@ void chd_phys_destroy(chd_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   for (int p = 0; p < CHD_N_POOLS; ++p) {
-    (void)hipFree(h->d_wd[p]); (void)hipFree(h->d_wi[p]);
+    if (p == 0) { (void)hipFree(h->d_wd); (void)hipFree(h->d_wi); (void)hipFree(h->d_slots); }
     chd_handle::PoolBufs& P = h->pb[p];
     (void)hipFree(P.d_cd); (void)hipFree(P.d_ci); (void)hipFree(P.d_od); (void)hipFree(P.d_oi); (void)hipFree(P.d_descs); (void)hipFree(P.d_order); (void)hipFree(P.d_counter); (void)hipFree(P.d_f);
     for (int q = 0; q < 6; ++q) if (P.pin[q]) (void)hipHostFree(P.pin[q]);
@@ -800,7 +838,7 @@ int chd_batch_upload(chd_handle* h, int B, const chd_seq_in* in, chd_batch** out
   chd_batch* b = batch_build(h->cfg, B, in, host_threads(B));
   if (b->order.empty()) { std::string m = "no solvable sequence in the batch (sequence 0: " + b->build_err[0] + ")"; chd_batch_free(h, b); return fail(h, m); }
   for (int i = 0; i < B; ++i) if (!b->ok[i]) h->err = "sequence " + std::to_string(i) + " rejected: " + b->build_err[i];
-  if (batch_to_device(h, b, 0) != 0 || ensure_workspace(h, 0, b->wd_need, b->wi_need) != 0) { std::string m = h->err; chd_batch_free(h, b); return fail(h, m); }
+  if (batch_to_device(h, b, 0) != 0 || ensure_workspace(h, b->wd_need, b->wi_need) != 0) { std::string m = h->err; chd_batch_free(h, b); return fail(h, m); }
   hipError_t e = hipStreamSynchronize(h->stream[0]);
   if (e != hipSuccess) { chd_batch_free(h, b); return fail(h, std::string("sync: ") + hipGetErrorString(e)); }
   *out = b;
@@ -810,7 +848,7 @@ int chd_batch_upload(chd_handle* h, int B, const chd_seq_in* in, chd_batch** out
 int chd_batch_solve(chd_handle* h, chd_batch* b) {
   if (!h || !b) return fail(h, "chd_batch_solve: bad arguments");
   HIP_TRY(h, hipSetDevice(h->device));
-  if (ensure_workspace(h, b->pool, b->wd_need, b->wi_need) != 0) return -1;
+  if (ensure_workspace(h, b->wd_need, b->wi_need) != 0) return -1;
   if (solve_launch_main(h, b) != 0) return -1;
   return solve_finish(h, b);
 }
@@ -901,7 +939,7 @@ int chd_debug_eval(chd_handle* h, chd_batch* b, int seq, int stage, const double
                    double* J, double* H) {
   if (!h || !b || seq < 0 || seq >= b->B || stage < 0 || stage >= N_STAGES || !b->ok[seq]) return fail(h, "chd_debug_eval: bad arguments");
   HIP_TRY(h, hipSetDevice(h->device));
-  if (ensure_workspace(h, 0, b->wd_need, b->wi_need) != 0) return -1;
+  if (ensure_workspace(h, b->wd_need, b->wi_need) != 0) return -1;
   const SeqModel& M = b->models[seq];
   const SeqDesc& dd = b->descs[seq];
   const StageDesc& S = M.d.st[stage];
@@ -913,14 +951,14 @@ int chd_debug_eval(chd_handle* h, chd_batch* b, int seq, int stage, const double
   HIP_TRY(h, hipMemcpyAsync(b->d_order, &seq, sizeof(int), hipMemcpyHostToDevice, h->stream[0]));
   HIP_TRY(h, hipMemsetAsync(b->d_counter, 0, sizeof(int), h->stream[0]));
   (void)hipGetLastError();
-  hipLaunchKernelGGL(chd_debug_eval_kernel, dim3(1), dim3(h->threads), h->lds_bytes, h->stream[0], b->d_descs, (const int*)b->d_order, b->d_counter, h->d_wd[0], h->d_wi[0],
+  hipLaunchKernelGGL(chd_debug_eval_kernel, dim3(1), dim3(h->threads), h->lds_bytes, h->stream[0], b->d_descs, (const int*)b->d_order, b->d_counter, h->d_wd, h->d_wi,
                      stage, x ? (const double*)b->d_x : (const double*)nullptr, h->lds_bytes / 8, b->d_f);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipStreamSynchronize(h->stream[0]));
   double fo[2];
   HIP_TRY(h, hipMemcpy(fo, b->d_f, 16, hipMemcpyDeviceToHost));
   if (f) *f = fo[0];
-  const double* wd = h->d_wd[0];          // workgroup 0's workspace
+  const double* wd = h->d_wd;          // workgroup 0's workspace
   if (x_out) HIP_TRY(h, hipMemcpy(x_out, wd + dd.o_vec_n + (long long)VN_X * dd.max_n, n * 8, hipMemcpyDeviceToHost));
   if (grad) HIP_TRY(h, hipMemcpy(grad, wd + dd.o_vec_n + (long long)VN_G * dd.max_n, n * 8, hipMemcpyDeviceToHost));
   if (cvals) HIP_TRY(h, hipMemcpy(cvals, wd + dd.o_vec_m + (long long)VM_C * dd.max_m, m * 8, hipMemcpyDeviceToHost));
@@ -947,7 +985,7 @@ int chd_debug_eval(chd_handle* h, chd_batch* b, int seq, int stage, const double
 int chd_debug_linsolve(chd_handle* h, chd_batch* b, int seq, int stage, double dw, double dval, int which, int reps, const double* rhs, double* x, double* info) {
   if (!h || !b || seq < 0 || seq >= b->B || stage < 0 || stage >= N_STAGES || !b->ok[seq] || !rhs || !x) return fail(h, "chd_debug_linsolve: bad arguments");
   HIP_TRY(h, hipSetDevice(h->device));
-  if (ensure_workspace(h, 0, b->wd_need, b->wi_need) != 0) return -1;
+  if (ensure_workspace(h, b->wd_need, b->wi_need) != 0) return -1;
   const StageDesc& S = b->models[seq].d.st[stage];
   const int N = S.n + S.m;
   double* d_buf = nullptr;
@@ -957,7 +995,7 @@ int chd_debug_linsolve(chd_handle* h, chd_batch* b, int seq, int stage, double d
   if (e == hipSuccess) e = hipMemsetAsync(b->d_counter, 0, sizeof(int), h->stream[0]);
   if (e == hipSuccess) {
     (void)hipGetLastError();
-    hipLaunchKernelGGL(chd_debug_linsolve_kernel, dim3(1), dim3(h->threads), h->lds_bytes, h->stream[0], b->d_descs, (const int*)b->d_order, b->d_counter, h->d_wd[0], h->d_wi[0],
+    hipLaunchKernelGGL(chd_debug_linsolve_kernel, dim3(1), dim3(h->threads), h->lds_bytes, h->stream[0], b->d_descs, (const int*)b->d_order, b->d_counter, h->d_wd, h->d_wi,
                        stage, h->lds_bytes / 8, dw, dval, which, reps < 1 ? 1 : reps, (const double*)d_buf, d_buf + N, d_buf + 2 * N);
     e = hipGetLastError();
   }

@@ -52,7 +52,7 @@ typedef struct chd_config {
                                  * accumulator registers (2); both were correct and measured slower on the MI355X, and were removed */
   int pipeline_chunk;           /* chd_phys_solve_batch / chd_phys_solve_dirs cut their B sequences into chunks of this many: the host builds the
                                  * tables of chunk k + 1 (and reads / writes the files of its neighbours) while the device solves chunk k, and up to
-                                 * four chunks' launches share the device.  0 = automatic (B / 7, between 256 and 1024, behind a first chunk of 128); < 0 = one chunk: set-up,
+                                 * four chunks' launches share the device.  0 = automatic (a first chunk of 256, the rest in three equal chunks of 256 .. 4 096); < 0 = one chunk: set-up,
                                  * solve and fetch in turn, as rounds 1-3 did */
   int reserved[2];
 } chd_config;
