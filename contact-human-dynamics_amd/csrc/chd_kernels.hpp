@@ -100,6 +100,7 @@ namespace chd {
 #define CHD_CONSTR_VIOL_TOL 1e-4
 #define CHD_MAX_BACKTRACK 3
 #define CHD_DUAL_RISE_K 6
+#define CHD_DW_GROW_SECOND 1.5
 #define CHD_MAX_ATTEMPTS 12
 #ifndef CHD_ABORT_BAD_FACTOR
 #define CHD_ABORT_BAD_FACTOR 1
@@ -3224,11 +3225,16 @@ CHD_NOINLINE CHD_DEV void solve_stage(LCtx& c, StageResult& res) {
       if (dw > CHD_DELTA_W_MAX) break;
     }
 #ifdef CHD_HOST_EMU
-    if (std::getenv("CHD_EMU_TRACE")) std::fprintf(stderr, "TRACE stage %d it %d E0 %.17g ed %.17g f %.17g mu %g dw %g att %d nls %d soc %d alpha %.17g nfact %d\n", S->stage, it, E0, e_d, f, mu, dw, attempt, nls, (int)used_soc, alpha, n_factor);
+    if (std::getenv("CHD_EMU_TRACE")) std::fprintf(stderr, "TRACE stage %d it %d E0 %.17g ed %.17g f %.17g mu %g dw %g att %d nls %d soc %d alpha %.17g nfact %d nu %g cn %g ep %g\n", S->stage, it, E0, e_d, f, mu, dw, attempt, nls, (int)used_soc, alpha, n_factor, nu, cn, e_p);
 #endif
     if (!ok) { status = -2; break; }
+    // the damping follows the exact model: halved after a clean step of the first model, raised by half when the iteration had to fall back to the second
+    // model -- so that it settles where the exact model just passes the pivot test, as IPOPT's inertia correction does, instead of staying at a level where
+    // every iteration pays a failed factorisation and takes a Gauss-Newton step (the two-cycles of the kinematic optimisation's clips: 1 700 iterations in
+    // stage 2.1 with the dual infeasibility alternating between 0.024 and 0.031; profiles/r04_curvature_study.md 6)
     if (attempt == 0 && nls == 0) dw = fmax(CHD_DELTA_W_MIN, dw / 2.0);
     else if (nls >= 1) dw *= 4.0;
+    else if (second_used) dw *= CHD_DW_GROW_SECOND;
     PAR_FOR(j, n) x[j] = used_soc ? xs[j] : x[j] + alpha * dx[j];
     PAR_FOR(i, m) {
       s[i] = used_soc ? ss2[i] : s[i] + alpha * ds[i];

@@ -39,6 +39,7 @@ struct IpmOptions {
   double mu_init_cold = 0.1;    // IPOPT default mu_init (first stage)
   double mu_init_warm = 1e-3;   // warm-started stages
   double delta_w0 = 1e-4, delta_w_min = 1e-9, delta_c = 1e-9, delta_w_max = 1e8;
+  double dw_grow_second = 1.5;      // growth of the damping after an iteration that needed the second model (CHD_DW_GROW_SECOND)
   double constr_viol_tol = 1e-4;   // IPOPT default (unscaled)
   int max_backtrack = 3;
   bool use_soc = true;
@@ -568,8 +569,11 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
       if (dw > opt.delta_w_max) break;
     }
     if (!ok) { status = -2; P.set_x(x.data()); break; }
+    // the damping follows the exact model: halved after a clean first-model step, raised by half when the iteration had to fall back to the second model
+    // (chd_kernels.hpp solve_stage has the same rule and the reason)
     if (attempt == 0 && nls == 0) dw = std::max(opt.delta_w_min, dw / 2.0);
     else if (nls >= 1) dw *= 4.0;
+    else if (second_used) dw *= opt.dw_grow_second;
     last_alpha = alpha; last_nls = nls; last_att = attempt; last_soc = used_soc;
     if (opt.lbfgs) lb_xold = x;
     if (used_soc) { for (int j = 0; j < n; ++j) x[j] = xs[j]; } else { for (int j = 0; j < n; ++j) x[j] += alpha * dx[j]; }
