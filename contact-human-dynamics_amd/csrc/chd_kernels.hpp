@@ -3101,6 +3101,9 @@ CHD_NOINLINE CHD_DEV void solve_stage(LCtx& c, StageResult& res) {
     cn = block_sum(c, cn);
 
     bool ok = false, used_soc = false;
+#ifdef CHD_HOST_EMU
+    double trace_dphi = 0.0;      // (CHD_EMU_TRACE: the directional derivative of the merit function the accepted step was judged with)
+#endif
     double alpha = 0, a_du = 1.0;
     int nls = 0, attempt = 0;
     // Second model of an iteration: when an attempt with the exact blocks (heel-distance curvature, duration-duration and node x duration blocks)
@@ -3173,6 +3176,9 @@ CHD_NOINLINE CHD_DEV void solve_stage(LCtx& c, StageResult& res) {
         nu = fmax(1.0, nut * 1.1 + 1e-8);
       }
       const double Dphi = dphi_bar - nu * cn;
+#ifdef CHD_HOST_EMU
+      trace_dphi = Dphi;
+#endif
       const double phi0 = f + barrier_val(c, s, mu) + nu * cn;
       alpha = a_pr; ok = false; nls = 0; used_soc = false;
       while (nls <= CHD_MAX_BACKTRACK) {
@@ -3225,7 +3231,7 @@ CHD_NOINLINE CHD_DEV void solve_stage(LCtx& c, StageResult& res) {
       if (dw > CHD_DELTA_W_MAX) break;
     }
 #ifdef CHD_HOST_EMU
-    if (std::getenv("CHD_EMU_TRACE")) std::fprintf(stderr, "TRACE stage %d it %d E0 %.17g ed %.17g f %.17g mu %g dw %g att %d nls %d soc %d alpha %.17g nfact %d nu %g cn %g ep %g\n", S->stage, it, E0, e_d, f, mu, dw, attempt, nls, (int)used_soc, alpha, n_factor, nu, cn, e_p);
+    if (std::getenv("CHD_EMU_TRACE")) std::fprintf(stderr, "TRACE stage %d it %d E0 %.17g ed %.17g f %.17g mu %g dw %g att %d nls %d soc %d alpha %.17g nfact %d nu %g cn %g ep %g Dphi %g\n", S->stage, it, E0, e_d, f, mu, dw, attempt, nls, (int)used_soc, alpha, n_factor, nu, cn, e_p, ok ? trace_dphi : 0.0);
 #endif
     if (!ok) { status = -2; break; }
     // the damping follows the exact model: halved after a clean step of the first model, raised by half when the iteration had to fall back to the second
