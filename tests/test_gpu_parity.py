@@ -183,7 +183,7 @@ def test_bench_workload_matches_oracle():
             assert r.stage_status[first_bad] == gs[first_bad] and list(r.stage_status[:first_bad]) == gs[:first_bad], (key, r.stage_status, gs)
             assert err < 1e-2, (key, err)
     print('bench workload parity: %d sequences, worst rel-L2 %.2e on the %d converging ones' % (len(cases), worst, len(cases) - n_failed))
-    assert n_failed <= 3          # (round 4: one of the 200 has a failing stage in the oracle -- a hard seed; flat, tilted and pipeline families: none)
+    assert n_failed <= 3          # (round 4: two of the 200 have a failing stage in the oracle and take the fallback -- bench seed 88 and a hard seed; tilted and pipeline families: none)
 
 
 def test_bad_sequence_loses_only_itself(tmp_path):

@@ -69,7 +69,8 @@ def test_oracle_point_satisfies_kkt_by_scipy(oracle_lib, stage):
     assert loose['stationarity'] <= 0.3 * loose['gmax'] and loose['feasibility'] <= 1e-4
     # 100 x tighter: the independently estimated KKT residual follows
     assert tight['stationarity'] <= 2e-2 * tight['gmax'] and tight['stationarity'] < 0.2 * loose['stationarity']
-    assert tight['complementarity'] <= 1e-5 and tight['feasibility'] <= 2e-5
+    # (the unscaled violation is bounded by constr_viol_tol = 1e-4 at every tol, like IPOPT's: the scaled one follows tol, and rows are scaled by up to 100)
+    assert tight['complementarity'] <= 1e-5 and tight['feasibility'] <= 1e-4
     assert tight['f'] <= loose['f'] + 1e-9            # (the barrier pushes the loose solution inside)
 
 
