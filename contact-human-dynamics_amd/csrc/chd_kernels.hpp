@@ -1438,14 +1438,15 @@ CHD_NOINLINE CHD_DEV void kfactor_rl(LCtx& c, const GD* diag, const GI* sign) {
   CHD_SYNC();
   TACC(c, 6, CHD_CLOCK() - tic_);
   // panel width from the LDS budget
+  // the widest panel whose buffers fit: two (pivots, nb x nb diagonal block) pairs, the panel, the two active-row lists.  (The blocks are sized by the
+  // panel width, not by its maximum of 32: with the 700-row border of a 600-frame sequence that is the difference between 16- and 8-column panels.)
+  int nb = 32;
+  while (nb > 8 && (long long)(nb + w + bc + 18) * nb > c.lds_cap - LDS_RED - 2 * (64 + nb * nb) - (w + bc + 66) - 8) nb >>= 1;
   LdsD* dv = c.lds + LDS_RED;            // pivots of the current panel (<= 32) and their reciprocals
   LdsD* DL = dv + 64;                    // dense copy of the panel's unit-lower diagonal block
-  LdsD* dv2 = DL + 32 * 32;              // the same pair for the next panel (look-ahead)
+  LdsD* dv2 = DL + nb * nb;              // the same pair for the next panel (look-ahead)
   LdsD* DL2 = dv2 + 64;
-  LdsD* PT = DL2 + 32 * 32;              // panel (the list of active window rows follows it)
-  const int avail = c.lds_cap - LDS_RED - 2 * (64 + 32 * 32) - (w + bc + 66) - 8;      // ints of the two active-row lists
-  int nb = 32;
-  while (nb > 8 && (long long)(nb + w + bc + 18) * nb > avail) nb >>= 1;
+  LdsD* PT = DL2 + nb * nb;              // panel (the list of active window rows follows it)
   const int ldp = (nb + w + bc + 17) | 1;  // odd leading dimension (conflict-free column walks), >= 16 rows of zero padding
   PAR_FOR(i, ldp * nb) PT[i] = 0.0;          // rows a panel does not load (inactive, padding) must read as zero
   CHD_SYNC();
