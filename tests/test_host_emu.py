@@ -151,6 +151,21 @@ def test_kkt_structure_tables(emu):
     assert stats is None or all(int(s[0]) in (0, -1, -2) for s in stats)
 
 
+def test_blocked_border_factorisation_for_borders_beyond_lds(emu, oracle_lib, monkeypatch):
+    """A border whose Schur complement does not fit LDS (600 frames: 700 rows) is factored by 16-column panels staged through LDS (dense_ldlt_blocked).  The
+    emulation's LDS holds any border, so the path is forced (CHD_EMU_BORDER_IN_HBM): linear solves stay accurate and a whole staged solve stays in lockstep
+    with the oracle."""
+    monkeypatch.setenv('CHD_EMU_BORDER_IN_HBM', '1')
+    seq = make_walk(seed=0, F=40, randomize=True)
+    e = emu.EmuProblem(seq, default_config())
+    for st in (1, 4):
+        sz = e.sizes(st)
+        b = np.random.default_rng(st).normal(size=sz['n'] + sz['m'])
+        x, bad = e.linsolve(st, b, dw=1e-2, dval=1e-3, refine=2)
+        assert bad == 0 and np.isfinite(x).all()
+    test_staged_solve_parity(emu, oracle_lib, 6, 60, 5.0)
+
+
 def test_occupancy_list_of_the_kkt_matrix(emu):
     """The readers of the unfactored KKT matrix walk a list of the entries ever written in the stage, kept by the writers through a signed-zero marker
     (chd_kernels.hpp "KKT storage").  After two evaluations per stage -- the second at moved durations in the duration stage, so that samples change

@@ -20,6 +20,7 @@ t0 = time.time(); b = s.upload([seq]); t1 = time.time(); st = b.solve(); t2 = ti
 print('F %d tilt %.0f: upload %.2fs solve %.2fs kernel %.0f + %.0f ms; sizes %s' % (F, tilt, t1 - t0, t2 - t1, st['kernel_ms'][0], st['kernel_ms'][1], r.sizes))
 print('stages', list(zip(r.stage_status, r.stage_iters)), 'viol', ['%.1e' % v for v in r.stage_constr_viol])
 print('phase share', {k: round(st['phase_ms'][i] / max(1e-9, st['phase_ms'][5]), 3) for k, i in (('eval', 0), ('eval_values', 1), ('factor', 2), ('solve', 3), ('matvec', 4))})
+print('factorisation ms', {k: round(st['phase_ms'][i], 1) for k, i in (('copy', 6), ('panel_load', 8), ('row_solve', 9), ('store_wait', 10), ('lookahead_wavefront', 11), ('border', 12))}, 'substitution ms', [round(st['phase_ms'][i], 1) for i in (16, 17, 18, 19, 20)], 'factorisations', st['total_factorizations'])
 g = np.load(os.path.join('tests', 'golden', 'bench_parity_golden.npz'))
 key = mk.case_key(0, F, tilt)
 if key + '_status' in g.files:
