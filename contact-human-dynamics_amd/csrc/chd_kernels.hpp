@@ -1390,41 +1390,40 @@ CHD_DEV void dense_ldlt(LCtx& c, P Sp, const int ld, const int n, const GI* sign
 // the LDS copy, one thread per entry.  Same result format as dense_ldlt: D on the diagonal, unit-lower L below.  (The column-at-a-time version above
 // spent 23 ms per factorisation in HBM round trips between 700 barriers: 29 % of a 600-frame solve.)
 CHD_DEV void dense_ldlt_blocked(LCtx& c, GD* Sg, const int ld, const int n, const GI* sign, LdsD* P, const int PB) {
+  const int LP = PB + 1;                           // padded leading dimension of the LDS panel (a lane per row walks a column: no bank conflicts)
   for (int j0 = 0; j0 < n; j0 += PB) {
     const int jb = n - j0 < PB ? n - j0 : PB, rows = n - j0;
-    PAR_FOR(idx, rows * PB) { const int r = idx / PB, k = idx % PB; P[idx] = (k < jb && k <= r) ? Sg[(long long)(j0 + r) * ld + j0 + k] : 0.0; }
+    PAR_FOR(idx, rows * PB) { const int r = idx / PB, k = idx % PB; P[r * LP + k] = (k < jb && k <= r) ? Sg[(long long)(j0 + r) * ld + j0 + k] : 0.0; }
     CHD_SYNC();
     for (int k = 0; k < jb; ++k) {
-      const double d = pivot_fix(c, P[k * PB + k], sign[j0 + k]);
+      const double d = pivot_fix(c, P[k * LP + k], sign[j0 + k]);
       const double id = 1.0 / d;
       CHD_SYNC();                                  // (everybody has read the pivot before thread 0 replaces it)
-      if (CHD_TID == 0) P[k * PB + k] = d;
+      if (CHD_TID == 0) P[k * LP + k] = d;
       // rows below the pivot: l = a / d, and the row's remaining panel columns lose l d l_kk'
       PAR_FOR(r0, rows - k - 1) {
         const int r = k + 1 + r0;
-        const double a = P[r * PB + k], l = a * id;
-        for (int kk = k + 1; kk < jb && kk <= r; ++kk) P[r * PB + kk] -= l * P[kk * PB + k];      // P[kk][k] still holds a_kk,k = l_kk,k d (rows are scaled after the loop)
+        const double l = P[r * LP + k] * id;
+        for (int kk = k + 1; kk < jb && kk <= r; ++kk) P[r * LP + kk] -= l * P[kk * LP + k];      // P[kk][k] still holds a_kk,k = l_kk,k d (the columns are scaled after the loop)
       }
       CHD_SYNC();
     }
     // scale the columns: L = A / d
-    PAR_FOR(idx, rows * PB) { const int r = idx / PB, k = idx % PB; if (k < jb && k < r) P[idx] /= P[k * PB + k]; }
+    PAR_FOR(idx, rows * PB) { const int r = idx / PB, k = idx % PB; if (k < jb && k < r) P[r * LP + k] /= P[k * LP + k]; }
     CHD_SYNC();
-    PAR_FOR(idx, rows * PB) { const int r = idx / PB, k = idx % PB; if (k < jb && k <= r) Sg[(long long)(j0 + r) * ld + j0 + k] = P[idx]; }
-    // trailing update of the lower triangle below / right of the panel
+    PAR_FOR(idx, rows * PB) { const int r = idx / PB, k = idx % PB; if (k < jb && k <= r) Sg[(long long)(j0 + r) * ld + j0 + k] = P[r * LP + k]; }
+    // trailing update of the lower triangle below / right of the panel: a wavefront per row, its lanes along the row (consecutive addresses); the row's
+    // own L d is the same for every lane (LDS broadcast), the other factor is a column walk through the padded panel.  Columns >= jb of a short last
+    // panel hold zeros.
     const int nt = rows - jb;
-    if (nt > 0) {
-      const long long ne = (long long)nt * (nt + 1) / 2;
-      for (long long e = CHD_TID; e < ne; e += CHD_NT) {
-        // entry e of the packed lower triangle -> (r, cc), cc <= r
-        int r = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
-        while ((long long)(r + 1) * (r + 2) / 2 <= e) ++r;
-        while ((long long)r * (r + 1) / 2 > e) --r;
-        const int cc = (int)(e - (long long)r * (r + 1) / 2);
-        const LdsD* lr = P + (long long)(jb + r) * PB; const LdsD* lc = P + (long long)(jb + cc) * PB;
+    for (int r = CHD_WAVE_ID; r < nt; r += CHD_NWAVES) {
+      const LdsD* lr = P + (long long)(jb + r) * LP;
+      GD* dst = Sg + (long long)(j0 + jb + r) * ld + j0 + jb;
+      for (int cc = CHD_LANE; cc <= r; cc += CHD_WAVE_SZ) {
+        const LdsD* lc = P + (long long)(jb + cc) * LP;
         double acc = 0;
-        for (int k = 0; k < jb; ++k) acc += lr[k] * P[k * PB + k] * lc[k];
-        Sg[(long long)(j0 + jb + r) * ld + j0 + jb + cc] -= acc;
+        for (int k = 0; k < jb; ++k) acc += lr[k] * P[k * LP + k] * lc[k];
+        dst[cc] -= acc;
       }
     }
     CHD_SYNC();
@@ -1516,8 +1515,8 @@ CHD_NOINLINE CHD_DEV void kfactor_rl(LCtx& c, const GD* diag, const GI* sign) {
       CHD_SYNC();
     } else {
       int pb = 16;
-      while (pb > 4 && (long long)bc * pb > c.lds_cap - LDS_RED) pb >>= 1;
-      if ((long long)bc * pb <= c.lds_cap - LDS_RED) dense_ldlt_blocked(c, c.Kfx + Nb, LD, bc, sign + Nb, SL, pb);
+      while (pb > 4 && (long long)bc * (pb + 1) > c.lds_cap - LDS_RED) pb >>= 1;
+      if ((long long)bc * (pb + 1) <= c.lds_cap - LDS_RED) dense_ldlt_blocked(c, c.Kfx + Nb, LD, bc, sign + Nb, SL, pb);
       else dense_ldlt(c, c.Kfx + Nb, LD, bc, sign + Nb);
     }
   }
