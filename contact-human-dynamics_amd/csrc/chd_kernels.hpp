@@ -1389,7 +1389,8 @@ CHD_DEV void dense_ldlt(LCtx& c, P Sp, const int ld, const int n, const GI* sign
 // factored in LDS (rows j0 .. n-1 of them: the only per-column barriers are LDS ones), written back, and the rest of the lower triangle is updated from
 // the LDS copy, one thread per entry.  Same result format as dense_ldlt: D on the diagonal, unit-lower L below.  (The column-at-a-time version above
 // spent 23 ms per factorisation in HBM round trips between 700 barriers: 29 % of a 600-frame solve.)
-CHD_DEV void dense_ldlt_blocked(LCtx& c, GD* Sg, const int ld, const int n, const GI* sign, LdsD* P, const int PB) {
+template <class SP>
+CHD_DEV void dense_ldlt_blocked(LCtx& c, SP Sg, const int ld, const int n, const GI* sign, LdsD* P, const int PB) {
   const int LP = PB + 1;                           // padded leading dimension of the LDS panel (a lane per row walks a column: no bank conflicts)
   for (int j0 = 0; j0 < n; j0 += PB) {
     const int jb = n - j0 < PB ? n - j0 : PB, rows = n - j0;
@@ -1418,7 +1419,7 @@ CHD_DEV void dense_ldlt_blocked(LCtx& c, GD* Sg, const int ld, const int n, cons
     const int nt = rows - jb;
     for (int r = CHD_WAVE_ID; r < nt; r += CHD_NWAVES) {
       const LdsD* lr = P + (long long)(jb + r) * LP;
-      GD* dst = Sg + (long long)(j0 + jb + r) * ld + j0 + jb;
+      SP dst = Sg + (long long)(j0 + jb + r) * ld + j0 + jb;
       for (int cc = CHD_LANE; cc <= r; cc += CHD_WAVE_SZ) {
         const LdsD* lc = P + (long long)(jb + cc) * LP;
         double acc = 0;
@@ -1510,7 +1511,8 @@ CHD_NOINLINE CHD_DEV void kfactor_rl(LCtx& c, const GD* diag, const GI* sign) {
     if (in_lds) {
       PAR_FOR(idx, bc * bc) { const int r = idx / bc, k = idx % bc; SL[idx] = k <= r ? c.Kfx[(long long)r * LD + Nb + k] : 0.0; }
       CHD_SYNC();
-      dense_ldlt(c, SL, bc, bc, sign + Nb);
+      if ((long long)bc * bc + (long long)bc * 17 <= c.lds_cap - LDS_RED) dense_ldlt_blocked(c, SL, bc, bc, sign + Nb, SL + bc * bc, 16);      // (a tenth of the LDS traffic and of the barriers' waiting of the column-at-a-time form)
+      else dense_ldlt(c, SL, bc, bc, sign + Nb);
       PAR_FOR(idx, bc * bc) { const int r = idx / bc, k = idx % bc; if (k <= r) c.Kfx[(long long)r * LD + Nb + k] = SL[idx]; }
       CHD_SYNC();
     } else {
