@@ -101,6 +101,7 @@ namespace chd {
 #define CHD_MAX_BACKTRACK 3
 #define CHD_DUAL_RISE_K 6
 #define CHD_DW_GROW_SECOND 1.5
+#define CHD_BLOCKED_BORDER_MIN 256
 #define CHD_MAX_ATTEMPTS 12
 #ifndef CHD_ABORT_BAD_FACTOR
 #define CHD_ABORT_BAD_FACTOR 1
@@ -1511,14 +1512,21 @@ CHD_NOINLINE CHD_DEV void kfactor_rl(LCtx& c, const GD* diag, const GI* sign) {
     if (in_lds) {
       PAR_FOR(idx, bc * bc) { const int r = idx / bc, k = idx % bc; SL[idx] = k <= r ? c.Kfx[(long long)r * LD + Nb + k] : 0.0; }
       CHD_SYNC();
-      if ((long long)bc * bc + (long long)bc * 17 <= c.lds_cap - LDS_RED) dense_ldlt_blocked(c, SL, bc, bc, sign + Nb, SL + bc * bc, 16);      // (a tenth of the LDS traffic and of the barriers' waiting of the column-at-a-time form)
-      else dense_ldlt(c, SL, bc, bc, sign + Nb);
+      dense_ldlt(c, SL, bc, bc, sign + Nb);
       PAR_FOR(idx, bc * bc) { const int r = idx / bc, k = idx % bc; if (k <= r) c.Kfx[(long long)r * LD + Nb + k] = SL[idx]; }
       CHD_SYNC();
     } else {
+      // The blocked form is for the long sequences' borders (600 frames: 700 rows, 23 -> 5.6 ms per factorisation).  Borders just beyond LDS (100-frame clips:
+      // ~160 rows) gain a few per cent at most, and the different summation order moves the chaotic clips of profiles/r04_curvature_study.md (section 7: one
+      // clip's duration stage 501 -> 1 681 iterations): they keep the column-at-a-time form, and with it the arithmetic the round's studies were run with.
       int pb = 16;
       while (pb > 4 && (long long)bc * (pb + 1) > c.lds_cap - LDS_RED) pb >>= 1;
-      if ((long long)bc * (pb + 1) <= c.lds_cap - LDS_RED) dense_ldlt_blocked(c, c.Kfx + Nb, LD, bc, sign + Nb, SL, pb);
+#ifdef CHD_HOST_EMU
+      const bool long_border = bc > CHD_BLOCKED_BORDER_MIN || std::getenv("CHD_EMU_BORDER_IN_HBM") != nullptr;      // (the test forces the blocked form on a short border)
+#else
+      const bool long_border = bc > CHD_BLOCKED_BORDER_MIN;
+#endif
+      if (long_border && (long long)bc * (pb + 1) <= c.lds_cap - LDS_RED) dense_ldlt_blocked(c, c.Kfx + Nb, LD, bc, sign + Nb, SL, pb);
       else dense_ldlt(c, c.Kfx + Nb, LD, bc, sign + Nb);
     }
   }
