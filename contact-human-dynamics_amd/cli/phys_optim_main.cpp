@@ -65,6 +65,10 @@ int main(int argc, char** argv) {
                 in_dir.c_str(), out_dir.c_str(), nframes, cfg.w_com_lin, cfg.w_com_ang, cfg.w_ee, cfg.w_smooth, cfg.w_dur, device, cfg.stall_window);
     return 0;
   }
+  if (chd_phys_version() != CHD_PHYS_ABI_VERSION) {
+    std::fprintf(stderr, "phys_optim: libchd_phys.so has ABI version %d, this executable was built against %d\n", chd_phys_version(), CHD_PHYS_ABI_VERSION);
+    return 2;
+  }
   chd_handle* h = nullptr;
   if (chd_phys_create(&cfg, device, &h) != 0) {
     std::fprintf(stderr, "phys_optim: no usable HIP device %d (this build has no CPU path)\n", device);

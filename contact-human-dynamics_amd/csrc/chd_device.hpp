@@ -134,7 +134,8 @@ struct SeqDesc {
 // per-stage statistics written to out_d (8 doubles per stage)
 enum { RS_STATUS = 0, RS_ITERS = 1, RS_KKT = 2, RS_VIOL = 3, RS_OBJ = 4, RS_MU = 5, RS_NFACT = 6, RS_AUX = 7 /* 1 = ended by the stall guard */, RS_STRIDE = 8 };
 // out_d layout: [N_STAGES x RS_STRIDE] then 3 snapshots x 10 blocks (base_lin, base_ang_deg, 4 ee_pos, 4 ee_force) x cap x 3, then
-// 24 phase timers, then the state stage 3 left (node values, phase durations: what the stage-4 fallback launch starts from)
+// 24 phase timers, then three state slots (node values, phase durations) as the stages behind the three snapshots left them (slot 2 after stage 3 is what
+// the stage-4 fallback launch starts from)
 // out_i layout: [3 x (n_samples, header)] then 3 x 4 x cap contact flags
 #if defined(__HIPCC__)
 #define CHD_HD __host__ __device__
@@ -142,7 +143,7 @@ enum { RS_STATUS = 0, RS_ITERS = 1, RS_KKT = 2, RS_VIOL = 3, RS_OBJ = 4, RS_MU =
 #define CHD_HD
 #endif
 CHD_HD inline long long out_d_state_off(int cap) { return (long long)N_STAGES * RS_STRIDE + 3LL * 10 * cap * 3 + 24; }
-CHD_HD inline long long out_d_size(int cap, int n_state) { return out_d_state_off(cap) + n_state; }
+CHD_HD inline long long out_d_size(int cap, int n_state) { return out_d_state_off(cap) + 3LL * n_state; }      // three state slots (one per snapshot): chd_kernels.hpp saved_state
 inline long long out_i_size(int cap) { return 8 + 3LL * 4 * cap; }
 
 }  // namespace chd

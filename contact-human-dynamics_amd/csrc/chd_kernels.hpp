@@ -3395,15 +3395,17 @@ CHD_DEV void init_state(QP q) {
 // The workspace belongs to the workgroup, not to the sequence: what a later launch needs of a sequence's state (the
 // stage-4 fallback starts from the node values and durations stage 3 left, phys_optim.cpp:714-749) is kept with the
 // sequence's results.
-CHD_DEV GD* saved_state(QP q) { return q->out_d + out_d_state_off(q->cap); }
-CHD_DEV void save_state(QP q) {
-  GD* st = saved_state(q);
+// Three slots, one per output snapshot (node values + phase durations as the stage that produced the snapshot left them): slot 2 is what the fallback
+// launch starts from; all three are what chd_debug_get_state hands to the tests' independent evaluator (the oracle's model functions at the returned point).
+CHD_DEV GD* saved_state(QP q, int slot) { return q->out_d + out_d_state_off(q->cap) + (long long)slot * (q->tot_entries + q->tot_phases); }
+CHD_DEV void save_state(QP q, int slot) {
+  GD* st = saved_state(q, slot);
   PAR_FOR(k, q->tot_entries) st[k] = q->wd[q->o_node + k];
   PAR_FOR(k, q->tot_phases) st[q->tot_entries + k] = q->wd[q->o_phase_dur + k];
   CHD_SYNC();
 }
 CHD_DEV void load_state(QP q) {
-  const GD* st = saved_state(q);
+  const GD* st = saved_state(q, 2);
   PAR_FOR(k, q->tot_entries) q->wd[q->o_node + k] = st[k];
   PAR_FOR(k, q->tot_phases) q->wd[q->o_phase_dur + k] = st[q->tot_entries + k];
   CHD_SYNC();
@@ -3438,10 +3440,9 @@ CHD_DEV void run_sequence(QP q, LCtx& c, LdsD* lds, int lds_cap, double tol, int
       rs[RS_STATUS] = r.status; rs[RS_ITERS] = r.iters; rs[RS_KKT] = r.kkt; rs[RS_VIOL] = r.viol; rs[RS_OBJ] = r.obj;
       rs[RS_MU] = r.mu; rs[RS_NFACT] = r.n_factor; rs[RS_AUX] = r.stalled;
     }
-    if (stage == 1) sample_solution(q, 0);       // sol_out_no_dynamics.txt  (phys_optim.cpp:603)
-    if (stage == 3) sample_solution(q, 1);       // sol_out_dynamics.txt     (:661)
-    if (stage == 4 || stage == 5) sample_solution(q, 2);   // sol_out_durations.txt (:757)
-    if (stage == 4) save_state(q);
+    if (stage == 1) { sample_solution(q, 0); save_state(q, 0); }       // sol_out_no_dynamics.txt  (phys_optim.cpp:603)
+    if (stage == 3) { sample_solution(q, 1); save_state(q, 1); }       // sol_out_dynamics.txt     (:661)
+    if (stage == 4 || stage == 5) { sample_solution(q, 2); save_state(q, 2); }   // sol_out_durations.txt (:757); stage 4's is also what the fallback launch starts from
     CHD_SYNC();
   }
   if (CHD_TID == 0) {      // phase timers (100 MHz wall clock ticks), accumulated over launches

@@ -41,14 +41,17 @@ static_assert(sizeof(SeqDesc) + sizeof(Ctx) + 64 <= 4096, "static LDS of the sol
 // clears, the acquire pairs with it.  (Until round 4 a launch indexed a pool of its own by blockIdx: four pools, four launches in flight, and a pool could not
 // be reused before the last straggler of its previous launch had finished.)
 __device__ inline int claim_slot(int* slot_busy, int n_slots) {
+  // Spins without a bound: a slot holder always makes progress (it never waits for anything a waiting workgroup owns), so a free slot turns up as soon as one
+  // launch's queue is drained.  (Until round 5 the loop gave up after 4096 sweeps and the workgroup left WITHOUT draining its queue: with more resident
+  // workgroups than slots -- max_workgroups below the compute-unit count, small lds_kilobytes, several launches in flight -- sequences were never solved and
+  // their zeroed result slots read as "converged".  The host now also checks every launch's queue counter: launch_drained.)
   int s = (int)(blockIdx.x % (unsigned)n_slots);
-  for (int sweep = 0; sweep < 4096 * n_slots; ++sweep) {
+  for (unsigned sweep = 0;; ++sweep) {
     int expected = 0;
     if (__hip_atomic_compare_exchange_strong(&slot_busy[s], &expected, 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return s;
     s = s + 1 == n_slots ? 0 : s + 1;
-    if ((sweep & 63) == 63) __builtin_amdgcn_s_sleep(32);
+    if ((sweep & 63u) == 63u) __builtin_amdgcn_s_sleep(64);
   }
-  return -1;          // (cannot happen while n_slots >= the resident workgroups; a workgroup without a slot leaves the queue to the others instead of spinning on)
 }
 // (returns false when the queue is empty.  Not a pointer: the descriptor sits at LDS address 0, which is what a null
 // local-address-space pointer compares equal to.)
@@ -82,7 +85,6 @@ __global__ __launch_bounds__(CHD_MAX_THREADS) void chd_solve_kernel(const SeqDes
   if (threadIdx.x == 0) s_slot = claim_slot(slot_busy, n_slots);
   __syncthreads();
   const int slot = s_slot;
-  if (slot < 0) return;
   for (;;) {
     if (!take_sequence(&s_desc, &s_item, descs, order, n_items, counter, wd_pool, wd_stride, wi_pool, wi_stride, slot)) break;
     run_sequence((QP)&s_desc, *(LCtx*)&s_ctx, (LdsD*)lds, lds_doubles, tol, stall_window, stage_first, stage_last);
@@ -167,7 +169,11 @@ struct chd_batch {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
-static int fail(chd_handle* h, const std::string& msg) { if (h) h->err = msg; return -1; }
+// Error text.  The finisher threads of a pipelined call work on the SHARED handle (its pools' buffers must be the real ones: a finisher that grew a page-locked
+// buffer in a private copy of the handle left the real handle with a dangling pointer -- round 4's use-after-free); what they must not share is the error
+// string, so a thread can redirect its error text to a string of its own (the chunk's).
+static thread_local std::string* tl_err_sink = nullptr;
+static int fail(chd_handle* h, const std::string& msg) { if (tl_err_sink) *tl_err_sink = msg; else if (h) h->err = msg; return -1; }
 #define HIP_TRY(h, call)                                                                                         \
   do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(h, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
 
@@ -377,6 +383,19 @@ static int batch_to_device(chd_handle* h, chd_batch* b, int pool, bool pooled = 
       hcd = (double*)pin_get(h, pool, 0, (size_t)std::max<long long>(b->tot_cd, 1) * 8); hci = (int*)pin_get(h, pool, 1, (size_t)std::max<long long>(b->tot_ci, 1) * 4);
       hdesc = (SeqDesc*)pin_get(h, pool, 2, sizeof(SeqDesc) * (size_t)B + sizeof(int) * (size_t)B);
       if (!hcd || !hci || !hdesc) return fail(h, "page-locked staging buffers: allocation failed");
+      // the staging the chunk's FINISHER thread will need (results, statistics, the stage-4 fallback's table regions) is sized here, on the calling thread and
+      // from this chunk's real strides, so that the finisher never reallocates page-locked memory while other lanes have launches in flight
+      size_t scratch = std::max<size_t>(sizeof(SeqDesc), (size_t)B * N_STAGES * RS_STRIDE * 8);
+      for (int i = 0; i < B; ++i) {
+        if (!b->ok[i]) continue;
+        const SeqModel& M = b->models[i];
+        const StageDesc& S5 = M.d.st[5];
+        scratch = std::max(scratch, (size_t)(S5.o_rcnt + (S5.n + M.stage_m_cap[5]) - S5.o_pos_var) * 4);
+        scratch = std::max(scratch, (size_t)(S5.o_task_t + M.stage_task_cap[5] - S5.o_cl) * 8);
+        scratch = std::max(scratch, (size_t)M.d.tot_phases * 8);
+      }
+      if (!pin_get(h, pool, 3, (size_t)b->od_stride * B * 8) || !pin_get(h, pool, 4, (size_t)b->oi_stride * B * 4) || !pin_get(h, pool, 5, scratch))
+        return fail(h, "page-locked result buffers: allocation failed");
     } else { hcd_v.assign(b->tot_cd, 0.0); hci_v.assign(b->tot_ci, 0); hcd = hcd_v.data(); hci = hci_v.data(); hdesc = nullptr; }
     for (int i = 0; i < B; ++i) {
       if (!b->ok[i]) continue;
@@ -422,6 +441,17 @@ static int launch_queue(chd_handle* h, chd_batch* b, const std::vector<int>& ite
   return 0;          // (asynchronous: the kernel is waited for through e1; `items` must stay alive until then -- the callers pass vectors owned by the batch)
 }
 
+// A finished launch must have drained its queue: every workgroup leaves after exactly one failed take, so the counter ends at n_items + grid.  Anything else
+// means sequences were never solved (their zeroed result slots would read as "converged"): fail loudly.
+static int launch_drained(chd_handle* h, chd_batch* b, size_t n_items) {
+  int cnt = -1;
+  HIP_TRY(h, copy_d2h(h, b, &cnt, b->d_counter, sizeof(int)));
+  const int grid = (int)std::min<size_t>(n_items, (size_t)h->n_wg);
+  if (cnt != (int)n_items + grid)
+    return fail(h, "solver launch left its queue undrained: counter " + std::to_string(cnt) + ", expected " + std::to_string((int)n_items + grid) + " (" + std::to_string(n_items) + " sequences, " + std::to_string(grid) + " workgroups)");
+  return 0;
+}
+
 // per-sequence statistics block (stages + phase timers are fetched with two strided copies)
 static int fetch_stats(chd_handle* h, chd_batch* b, std::vector<double>& st) {
   const size_t w = (size_t)N_STAGES * RS_STRIDE;
@@ -444,6 +474,7 @@ static int solve_finish(chd_handle* h, chd_batch* b) {
   float ms = 0;
   HIP_TRY(h, hipEventElapsedTime(&ms, b->ev[0], b->ev[1]));
   b->stats.kernel_ms[0] = ms;
+  if (launch_drained(h, b, b->order.size()) != 0) return -1;
   auto t0 = std::chrono::steady_clock::now();
   std::vector<double> st;
   if (fetch_stats(h, b, st) != 0) return -1;
@@ -459,7 +490,7 @@ static int solve_finish(chd_handle* h, chd_batch* b) {
     for (size_t k = 0; k < idx.size(); ++k) {
       const SeqModel& M = b->models[idx[k]];
       ph[k].resize(M.d.tot_phases);
-      HIP_TRY(h, copy_d2h(h, b, ph[k].data(), b->d_od + b->od_stride * idx[k] + out_d_state_off(M.d.cap) + M.d.tot_entries, ph[k].size() * 8));
+      HIP_TRY(h, copy_d2h(h, b, ph[k].data(), b->d_od + b->od_stride * idx[k] + out_d_state_off(M.d.cap) + 2LL * (M.d.tot_entries + M.d.tot_phases) + M.d.tot_entries, ph[k].size() * 8));      // (state slot 2: what stage 3 left)
     }
     const unsigned nt = host_threads((int)idx.size());
     std::vector<std::thread> pool;
@@ -492,6 +523,7 @@ static int solve_finish(chd_handle* h, chd_batch* b) {
     HIP_TRY(h, hipEventSynchronize(b->ev[3]));
     HIP_TRY(h, hipEventElapsedTime(&ms, b->ev[2], b->ev[3]));
     b->stats.kernel_ms[1] = ms;
+    if (launch_drained(h, b, idx.size()) != 0) return -1;
     if (fetch_stats(h, b, st) != 0) return -1;
   } else {
     b->stats.host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -702,14 +734,15 @@ static int solve_pipelined(chd_handle* h, int B, const chd_seq_in* in, chd_seq_o
     }
     c.fin = std::thread([h, &c, out, &fin, &agg_mu, &n_solved_chunks, t_begin]() {
       (void)hipSetDevice(h->device);
-      chd_handle local = *h;              // (error text of this thread's calls; the device resources are shared, read-only here)
-      int rc2 = solve_finish(&local, c.b);
+      tl_err_sink = &c.err;               // (error text of this thread's calls goes to the chunk; the handle itself is shared: this thread owns its lane's result / scratch staging until device_done)
+      int rc2 = solve_finish(h, c.b);
       c.t_solved = now_ms() - t_begin;
-      if (rc2 == 0) rc2 = batch_fetch(&local, c.b, out + c.c0);
+      if (rc2 == 0) rc2 = batch_fetch(h, c.b, out + c.c0);
       c.t_fetched = now_ms() - t_begin;
       { std::lock_guard<std::mutex> lk(c.mu); c.device_done = true; }          // (the pool's buffers are free again: the results are on the host)
       c.cv.notify_all();
-      if (rc2 != 0) { c.rc = -1; c.err = local.err; return; }
+      tl_err_sink = nullptr;
+      if (rc2 != 0) { c.rc = -1; return; }
       fin(c.c0, c.c1);
       c.t_finished = now_ms() - t_begin;
       std::lock_guard<std::mutex> lk(agg_mu);
@@ -977,6 +1010,32 @@ int chd_debug_eval(chd_handle* h, chd_batch* b, int seq, int stage, const double
     if (H) for (int a = 0; a < n; ++a) for (int c2 = 0; c2 < n; ++c2) H[(size_t)a * n + c2] = get(pv[a], pv[c2]);
   }
   return (int)fo[1];
+}
+
+// The point behind output snapshot `snapshot` (0 after stage 1.2, 1 after 2.2, 2 after 3 or its stage-4 fallback) of sequence `seq` of a solved batch, in the
+// NLP's own variables: the node variables (variable-set order, phys_optim.cpp:483-540 -- the first n_node_vars entries of every stage's x) and the phase
+// durations of the four end-effectors (NLP order, all phases).  For tests: an evaluator that shares nothing with the kernel recomputes objective and
+// constraint violation there.
+int chd_debug_get_state(chd_handle* h, chd_batch* b, int seq, int snapshot, double* node_vars, int* n_node_vars, double* phase_durations, int* n_phases /*4*/) {
+  if (!h || !b || seq < 0 || seq >= b->B || snapshot < 0 || snapshot >= CHD_N_SNAPSHOTS || !b->ok[seq] || !b->solved) return fail(h, "chd_debug_get_state: bad arguments");
+  HIP_TRY(h, hipSetDevice(h->device));
+  const SeqModel& M = b->models[seq];
+  const SeqDesc& d = M.d;
+  const long long ns = d.tot_entries + d.tot_phases;
+  std::vector<double> st((size_t)ns);
+  HIP_TRY(h, copy_d2h(h, b, st.data(), b->d_od + b->od_stride * seq + out_d_state_off(d.cap) + snapshot * ns, (size_t)ns * 8));
+  if (n_node_vars) *n_node_vars = d.n_nodesvars;
+  if (node_vars)
+    for (int sp = 0; sp < N_SPLINES; ++sp)
+      for (int k = 0; k < d.sp[sp].n_nodes * 6; ++k) {
+        const int v = M.ci[d.o_varof + d.sp[sp].node_off + k];
+        if (v >= 0) node_vars[d.sp[sp].var_off + v] = st[d.sp[sp].node_off + k];
+      }
+  for (int e = 0; e < N_EE; ++e) {
+    if (n_phases) n_phases[e] = d.n_phase[e];
+    if (phase_durations) for (int k = 0; k < d.n_phase[e]; ++k) phase_durations[d.phase_off[e] + k] = st[d.tot_entries + d.phase_off[e] + k];
+  }
+  return 0;
 }
 
 // Factor / solve self test of one sequence's KKT matrix (stage `stage` at the initial state, diagonal dw Dw / -dval):

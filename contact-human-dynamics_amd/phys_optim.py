@@ -20,11 +20,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.environ.get('CHD_PHYS_LIB') or os.path.join(_CSRC, 'libchd_phys.so')      # (override: kernel experiments with variant builds)
 SOURCES = ['chd_phys.hip', 'chd_kernels.hpp', 'chd_model.hpp', 'chd_device.hpp', 'chd_io.hpp']
+ABI_VERSION = 2      # CHD_PHYS_ABI_VERSION of include/chd_phys.h
 SNAPSHOT_FILES = ('sol_out_no_dynamics.txt', 'sol_out_dynamics.txt', 'sol_out_durations.txt')
 
 EXPORTS = ['chd_phys_version', 'chd_config_default', 'chd_phys_create', 'chd_phys_destroy', 'chd_phys_last_error',
            'chd_batch_upload', 'chd_batch_solve', 'chd_batch_fetch', 'chd_batch_free', 'chd_batch_get_stats',
-           'chd_phys_solve_batch', 'chd_phys_get_call_stats', 'chd_phys_solve_dirs', 'chd_debug_sizes', 'chd_debug_eval', 'chd_debug_linsolve']
+           'chd_phys_solve_batch', 'chd_phys_get_call_stats', 'chd_phys_solve_dirs', 'chd_debug_sizes', 'chd_debug_eval', 'chd_debug_linsolve', 'chd_debug_get_state']
 
 
 def build_library(force=False, verbose=False):
@@ -71,6 +72,9 @@ def load_library():
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.chd_phys_version.restype = C.c_int
+    if L.chd_phys_version() != ABI_VERSION:
+        raise RuntimeError('libchd_phys.so has ABI version %d, this host layer was written against %d (include/chd_phys.h): rebuild with __graft_entry__.build()'
+                           % (L.chd_phys_version(), ABI_VERSION))
     L.chd_config_default.argtypes = [C.POINTER(ChdConfig)]
     L.chd_phys_create.argtypes = [C.POINTER(ChdConfig), C.c_int, C.POINTER(vp)]
     L.chd_phys_destroy.argtypes = [vp]
@@ -85,6 +89,7 @@ def load_library():
     L.chd_phys_solve_dirs.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.chd_debug_sizes.argtypes = [vp, vp, C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 5
     L.chd_debug_eval.argtypes = [vp, vp, C.c_int, C.c_int, PD, PD, PD, PD, PD, PD, PD]
+    L.chd_debug_get_state.argtypes = [vp, vp, C.c_int, C.c_int, PD, C.POINTER(C.c_int), PD, C.POINTER(C.c_int)]
     L.chd_debug_linsolve.argtypes = [vp, vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, PD, PD, PD]
     _LIB = L
     return L
@@ -187,6 +192,17 @@ class Batch:
         if rc < 0:
             raise PhysError('chd_debug_eval: ' + self.solver.last_error())
         return dict(x=xo, f=f.value, g=g, c=c, J=J, H=H, err=rc)
+
+    def get_state(self, seq, snapshot):
+        """The point behind output snapshot `snapshot` of a solved batch in the NLP's variables: (node variables, [phase durations of the 4 end-effectors])."""
+        n = self.sizes(seq, 4)['n']
+        xv = np.zeros(n + 8); ph = np.zeros(4 * 64)
+        nn = C.c_int(0); nph = (C.c_int * 4)()
+        self.solver._check(self.solver.L.chd_debug_get_state(self.solver.h, self.h, seq, snapshot, xv.ctypes.data_as(PD), C.byref(nn), ph.ctypes.data_as(PD), nph), 'chd_debug_get_state')
+        durs, off = [], 0
+        for e in range(4):
+            durs.append(ph[off:off + nph[e]].copy()); off += nph[e]
+        return xv[:nn.value].copy(), durs
 
     def debug_linsolve(self, seq, stage, rhs, dw=1e-4, dval=1e-3, which=0, reps=1):
         """Factor / solve self test of the KKT matrix of (seq, stage) at the initial state (`which` is ignored since round 4: one factorisation is left).

@@ -24,7 +24,9 @@
 extern "C" {
 #endif
 
-#define CHD_PHYS_ABI_VERSION 1
+#define CHD_PHYS_ABI_VERSION 2   /* 2 (round 5): chd_config.reserved[0] became pipeline_chunk and `factorisation` is ignored (both since round 4, unversioned then),
+                                  * chd_phys_solve_batch is pipelined, chd_phys_get_call_stats and chd_debug_get_state were added.  Callers compare
+                                  * chd_phys_version() with the header they were built against (phys_optim.load_library, cli/phys_optim_main.cpp do). */
 #define CHD_N_EE 4          /* NLP end-effector order: 0 L-toe, 1 R-toe, 2 L-heel, 3 R-heel (phys_optim.cpp:505-513) */
 #define CHD_N_STAGES 6      /* 1.1, 1.2, 2.1, 2.2, 3, 4   (phys_optim.cpp:544-749) */
 #define CHD_N_SNAPSHOTS 3   /* sol_out_no_dynamics / sol_out_dynamics / sol_out_durations (run_phys_mocap.py:182) */
@@ -200,6 +202,11 @@ int chd_debug_linsolve(chd_handle* h, chd_batch* b, int seq, int stage, double d
                        const double* rhs, double* x, double* info);
 int chd_debug_eval(chd_handle* h, chd_batch* b, int seq, int stage, const double* x,
                    double* x_out, double* f, double* grad, double* c, double* J, double* H);
+/* chd_debug_get_state: the point behind output snapshot `snapshot` (0: after stage 1.2, 1: after 2.2, 2: after 3 or its stage-4 fallback) of sequence `seq`
+ * of a SOLVED batch, in the NLP's own variables -- node_vars: the node variables in variable-set order (the first *n_node_vars entries of every stage's x;
+ * room for chd_seq_out.n_vars doubles is enough), phase_durations: all phase durations of the four end-effectors, NLP order, concatenated (n_phases[e] each;
+ * room for 4 * 64).  tests/test_quality_gate.py recomputes objective and constraint violation at this point with the oracle's model functions. */
+int chd_debug_get_state(chd_handle* h, chd_batch* b, int seq, int snapshot, double* node_vars, int* n_node_vars, double* phase_durations, int* n_phases);
 
 #ifdef __cplusplus
 }

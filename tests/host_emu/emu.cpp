@@ -97,11 +97,25 @@ int emu_solve(void* h, int stage_first, int stage_last, int lds_doubles) {
 int emu_rebuild_fallback(void* h) {
   Emu* e = (Emu*)h; e->bind();
   std::vector<double> cur[4];
-  const double* ph = e->out_d.data() + out_d_state_off(e->M.d.cap) + e->M.d.tot_entries;      // the durations stage 3 left (save_state)
+  const double* ph = e->out_d.data() + out_d_state_off(e->M.d.cap) + 2LL * (e->M.d.tot_entries + e->M.d.tot_phases) + e->M.d.tot_entries;      // the durations stage 3 left (save_state, slot 2)
   for (int k = 0; k < 4; ++k) cur[k].assign(ph + e->M.d.phase_off[k], ph + e->M.d.phase_off[k] + e->M.d.n_phase[k]);
   e->M.build_stage(5, e->cfg, cur, false);
   e->bind();
   return e->M.d.st[5].valid;
+}
+// the point behind snapshot `snap` in the NLP's variables (what chd_debug_get_state returns on the device): node variables, then all phase durations
+int emu_get_state(void* h, int snap, double* node_vars, double* phase_durations) {
+  Emu* e = (Emu*)h;
+  const SeqDesc& d = e->M.d;
+  const long long ns = d.tot_entries + d.tot_phases;
+  const double* st = e->out_d.data() + out_d_state_off(d.cap) + snap * ns;
+  for (int sp = 0; sp < N_SPLINES; ++sp)
+    for (int k = 0; k < d.sp[sp].n_nodes * 6; ++k) {
+      const int v = e->M.ci[d.o_varof + d.sp[sp].node_off + k];
+      if (v >= 0) node_vars[d.sp[sp].var_off + v] = st[d.sp[sp].node_off + k];
+    }
+  for (int k = 0; k < d.tot_phases; ++k) phase_durations[k] = st[d.tot_entries + k];
+  return d.n_nodesvars;
 }
 void emu_get_out(void* h, double* od, int* oi) {
   Emu* e = (Emu*)h;

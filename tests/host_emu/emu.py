@@ -43,6 +43,7 @@ def lib():
         L.emu_linsolve.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, PD, PD, C.c_int]
         L.emu_solve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.emu_rebuild_fallback.argtypes = [C.c_void_p]
+        L.emu_get_state.argtypes = [C.c_void_p, C.c_int, PD, PD]
         L.emu_get_out.argtypes = [C.c_void_p, PD, C.POINTER(C.c_int)]
         _LIB = L
     return _LIB
@@ -91,6 +92,13 @@ class EmuProblem:
 
     def rebuild_fallback(self):
         return lib().emu_rebuild_fallback(self.h)
+
+    def state(self, snap):
+        """(node variables, phase durations [4 lists]) behind snapshot `snap`: what chd_debug_get_state returns on the device"""
+        n = self.sizes(0)['n']
+        xv = np.zeros(n + 8); ph = np.zeros(4 * 64)
+        nn = lib().emu_get_state(self.h, snap, _p(xv), _p(ph))
+        return xv[:nn].copy(), ph
 
     def results(self):
         cap = self.sizes(0)['cap']

@@ -35,7 +35,7 @@ def test_header_and_exports_agree(lib):
 
 
 def test_version_and_default_config(lib):
-    assert lib.chd_phys_version() == 1
+    assert lib.chd_phys_version() == phys_optim.ABI_VERSION == int(re.search(r'#define CHD_PHYS_ABI_VERSION (\d+)', open(os.path.join(ROOT, 'include', 'chd_phys.h')).read()).group(1))
     c = phys_capi.ChdConfig()
     lib.chd_config_default(C.byref(c))
     assert list(c.max_iter) == [7000, 7000, 7000, 2500, 2000, 7000] and c.tol == 1e-3      # phys_optim.cpp:571-743, :578

@@ -42,3 +42,45 @@ def test_pipelined_call_equals_the_split_interface(chunk):
     got2, _ = s.solve_batch(seqs[:300])
     assert all(_same(got2[i], ref[i]) for i in range(300))
     s.close()
+
+
+def test_lanes_are_reused_by_calls_of_growing_sequence_length():
+    """ADVICE r04 (use-after-free of the page-locked staging): three calls on ONE handle, each with longer sequences than the one before, chunks of 100 so that
+    every lane is used by every call -- result, statistics and scratch staging of a lane all have to grow between and within the calls (a later chunk with a
+    larger result stride; a stage-4 fallback in a small chunk, whose table regions are larger than the chunk's statistics) -- and a repeat of the first call
+    at the end, on the lanes the long call left behind.  Every call must equal the split interface on a fresh handle."""
+    from chd_amd.phys_optim import PhysOptim, default_config
+    cap = [300, 300, 300, 300, 6, 300]          # stage 3 capped at 6 iterations: most sequences take the stage-4 fallback launch
+    plans = [[30 + (i % 3) * 5 for i in range(250)], [40 + (i % 5) * 10 for i in range(230)], [60 if i % 7 else 100 for i in range(220)]]
+    s = PhysOptim(device=0, config=default_config(max_iter=cap, pipeline_chunk=100))
+    calls = []
+    for k, frames in enumerate(plans + [plans[0]]):
+        seqs = [make_walk(seed=9000 + 1000 * (k % 3) + i, F=f, randomize=True) for i, f in enumerate(frames)]
+        got, cs = s.solve_batch(seqs)
+        assert cs['n_chunks'] >= 2 and cs['n_fallback'] > 0
+        calls.append((seqs, got))
+    s.close()
+    for seqs, got in calls:
+        r = PhysOptim(device=0, config=default_config(max_iter=cap))
+        ref, _ = r.solve(seqs)
+        r.close()
+        bad = [i for i in range(len(seqs)) if not _same(got[i], ref[i])]
+        assert not bad, bad[:10]
+
+
+def test_more_resident_workgroups_than_workspace_slots():
+    """with max_workgroups below the compute-unit count the launches of a pipelined call bring more resident workgroups than the handle has
+    workspace slots (3 launches x 24 workgroups against 24 slots).  The late ones must WAIT for a slot and then drain their queue -- until round 5 they gave up
+    after a bounded spin and their sequences came back unsolved with status 0.  (The host now also checks every launch's queue counter.)"""
+    from chd_amd.phys_optim import PhysOptim, default_config
+    seqs = [make_walk(seed=12000 + i, F=30 + (i % 3) * 5, randomize=True) for i in range(300)]
+    r = PhysOptim(device=0, config=default_config(max_iter=CAP))
+    ref, _ = r.solve(seqs)
+    r.close()
+    s = PhysOptim(device=0, config=default_config(max_iter=CAP, pipeline_chunk=100, max_workgroups=24))
+    got, cs = s.solve_batch(seqs)
+    s.close()
+    assert cs['n_chunks'] == 3
+    assert all(g.total_iters > 0 for g in got)
+    bad = [i for i in range(300) if not _same(got[i], ref[i])]
+    assert not bad, bad[:10]

@@ -51,8 +51,12 @@ def _kkt_residuals(o, x):
     lb = np.where(eq[A], -np.inf, np.where(near_l, -np.inf, 0.0)); ub = np.where(eq[A], np.inf, np.where(near_l, 0.0, np.inf))
     lam = lsq_linear(J[A].T, -g, bounds=(lb, ub), tol=1e-13, max_iter=500).x
     slack = np.where(eq[A], 0.0, np.minimum(dl[A], du[A]))
+    viol = np.maximum(np.maximum(lo - c, 0), np.maximum(c - hi, 0))
+    # the solver's own row scaling (IPOPT's gradient-based scaling, nlp_scaling_max_gradient = 100), recomputed here from J: its stopping test bounds the
+    # SCALED violation by tol and the unscaled one by constr_viol_tol = 1e-4 -- both are checked (the unscaled bound alone let the check loosen)
+    rowscale = np.where(np.abs(J).max(axis=1) > 100.0, 100.0 / np.maximum(np.abs(J).max(axis=1), 1e-300), 1.0)
     return dict(f=f, stationarity=float(np.abs(J[A].T @ lam + g).max()), complementarity=float(np.abs(lam * slack).max()),
-                feasibility=float(max(np.maximum(lo - c, 0).max(), np.maximum(c - hi, 0).max())), gmax=float(np.abs(g).max()))
+                feasibility=float(viol.max()), feasibility_scaled=float((viol * rowscale).max()), gmax=float(np.abs(g).max()))
 
 
 @pytest.mark.parametrize('stage', [1, 3])       # 1.2 (kinematic rows) and 2.2 (dynamics, forces, height): phys_optim.cpp:591-599, :648-656
@@ -71,6 +75,8 @@ def test_oracle_point_satisfies_kkt_by_scipy(oracle_lib, stage):
     assert tight['stationarity'] <= 2e-2 * tight['gmax'] and tight['stationarity'] < 0.2 * loose['stationarity']
     # (the unscaled violation is bounded by constr_viol_tol = 1e-4 at every tol, like IPOPT's: the scaled one follows tol, and rows are scaled by up to 100)
     assert tight['complementarity'] <= 1e-5 and tight['feasibility'] <= 1e-4
+    # the scaled violation follows the tolerance (rows are scaled at the stage's starting point; here at the solution: a factor of head-room)
+    assert loose['feasibility_scaled'] <= 2e-3 and tight['feasibility_scaled'] <= 2e-5, (loose, tight)
     assert tight['f'] <= loose['f'] + 1e-9            # (the barrier pushes the loose solution inside)
 
 
