@@ -97,6 +97,40 @@ def cpu_baseline(max_workers=8):
             'note': 'the oracle is this repo\'s dense single-threaded restatement of the same algorithm, not IPOPT(MA57): the reference binary cannot be built here'}
 
 
+def _emu_worker(seed):
+    """One sequence through the host emulation of the KERNEL source (tests/host_emu: the same banded bordered L D L^T, the same iterations as the HIP path), one thread."""
+    import chd_amd  # noqa: F401
+    from chd_amd.synth import make_walk
+    from chd_amd.phys_capi import default_config
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'host_emu'))
+    import emu
+    seq = make_walk(seed=seed, F=FRAMES, randomize=True)
+    t0 = time.time()
+    e = emu.EmuProblem(seq, default_config(max_iter=CAPS))
+    e.solve(0, 4)
+    st, _ = e.results()
+    if int(st[4][0]) != 0 and e.rebuild_fallback():
+        e.solve(5, 5); st, _ = e.results()
+    return time.time() - t0, int(sum(st[k][1] for k in range(6)))
+
+
+def banded_emulation_baseline(n_seq=64):
+    """The honest "same algorithm on the host" number: the kernel source compiled for the CPU (g++ -O2, one thread per sequence) on ALL
+    host cores, bench seeds 0 .. n_seq - 1.  Test infrastructure used as a reported baseline, like the oracle."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'host_emu'))
+    import emu
+    emu.build()
+    cores = max(1, os.cpu_count() or 1)
+    n_seq = max(n_seq, cores)
+    t0 = time.time()
+    with mp.get_context('spawn').Pool(min(cores, n_seq)) as pool:
+        res = pool.map(_emu_worker, list(range(n_seq)), chunksize=1)
+    wall = time.time() - t0
+    return {'value': n_seq / wall, 'unit': 'sequences/s', 'cores': min(cores, n_seq), 'kind': 'port', 'value_one_core': len(res) / sum(r[0] for r in res),
+            'sample': 'bench seeds 0..%d, one emulation process per core, %d IPM iterations, %.1f s wall' % (n_seq - 1, sum(r[1] for r in res), wall),
+            'note': 'tests/host_emu: chd_kernels.hpp compiled with CHD_HOST_EMU for one CPU thread per sequence -- the banded bordered L D L^T and the iterations of the HIP path, not IPOPT(MA57)'}
+
+
 def parity_block(results, seqs_first_seed):
     """HIP results of the bench workload against the committed oracle results (tests/golden/bench_parity_golden.npz, made by
     tests/golden/make_bench_parity_golden.py with the same caps / tolerance): computed outside the timed region."""
@@ -236,6 +270,21 @@ def kinematic_optimisation_rate(device_index, n_clips=256, frames=100):
             'note': 'outside the timed region; the whole optimize() of %d clips x %d frames (IK initialisation, two least-squares solves, host floor fits)' % (n_clips, frames)}
 
 
+def _self_rank(rank, world, port, argv, solver_factory):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world))
+    main(argv, solver_factory)
+
+
+def _self_launch(world, argv, solver_factory):
+    """`python bench.py --gpus N` from a plain shell: start the N ranks here (one process per GPU, rendezvous on 127.0.0.1), exactly what
+    `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` would have started.  Rank 0's JSON line goes to this process's stdout."""
+    import socket
+    import torch.multiprocessing as tmp
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]
+    tmp.start_processes(_self_rank, args=(world, port, list(argv) if argv is not None else sys.argv[1:], solver_factory), nprocs=world, join=True, start_method='spawn')
+
+
 def main(argv=None, solver_factory=None):
     """`solver_factory` (tests only): a stand-in for PhysOptim on a box without a GPU -- the multi-rank plumbing (process group, barrier,
     the three all-reduces, rank 0's JSON line) then runs on the gloo backend with CPU tensors (tests/test_bench_multirank.py)."""
@@ -257,9 +306,14 @@ def main(argv=None, solver_factory=None):
     ap.add_argument('--no-side-metrics', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--worker', action='store_true', help=argparse.SUPPRESS)        # (accepted for old command lines; no effect)
     ap.add_argument('--frames', type=int, default=FRAMES, help=argparse.SUPPRESS)     # (tests: shorter sequences for the CPU stand-in)
+    ap.add_argument('--strong-total', type=int, default=4000, help='sequences of the strong-scaling leg (BASELINE configs[2]: ~2k motions x 2 cameras, LPT-sharded over the ranks); 0 = skip')
     args = ap.parse_args(argv)
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:          # no launcher around this process: be the launcher
+        return _self_launch(args.gpus, argv, solver_factory)
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d, but the launcher started %d rank(s) (WORLD_SIZE): one process per GPU' % (args.gpus, world))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     B = args.batch
@@ -285,6 +339,7 @@ def main(argv=None, solver_factory=None):
             dist.init_process_group('nccl', device_id=torch.device('cuda', local))
         else:
             dist.init_process_group('gloo')
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     def barrier():
         if world > 1:
@@ -314,6 +369,42 @@ def main(argv=None, solver_factory=None):
         tot_iters_all, alg_bytes_all = float(agg[0].item()), float(agg[1].item())
     else:
         tot_iters_all, alg_bytes_all = float(iters), float(alg_bytes)
+
+    # ---- strong-scaling leg (BASELINE configs[2]: the full synthetic set, ~2k motions x 2 cameras = 4 000 sequences, sharded over the ranks as
+    # run_phys_mocap.py shards its videos: sharding.lpt_assign by frame count -- an even split for equal lengths).  TOTAL work is fixed as N grows; every rank
+    # uploads its shard beforehand and solves it in one call; MAX over ranks.  Reported beside the weak-scaling `value`, never instead of it.
+    strong = None
+    if args.strong_total > 0:
+        from chd_amd.sharding import lpt_assign
+        mine = lpt_assign([args.frames] * args.strong_total, world)[rank]
+        runs = []                                                 # contiguous seed runs of this rank's shard
+        for i in mine:
+            if runs and runs[-1][0] + runs[-1][1] == i:
+                runs[-1][1] += 1
+            else:
+                runs.append([i, 1])
+        sseqs = []
+        for a, cnt in runs:
+            sseqs += make_sequences(1000000 + a, cnt, 1 if len(runs) > 8 else workers, args.frames)
+        sb = solver.upload(sseqs)
+        barrier()
+        t1 = time.perf_counter()
+        sst = sb.solve()
+        barrier()
+        dt_s = time.perf_counter() - t1
+        s_iters = float(sst['total_iters']); s_bytes = float(sst['alg_bytes'])
+        if world > 1:
+            t = torch.tensor([dt_s], dtype=torch.float64, device=tdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_s = float(t.item())
+            agg = torch.tensor([s_iters, s_bytes], dtype=torch.float64, device=tdev)
+            dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+            s_iters, s_bytes = float(agg[0].item()), float(agg[1].item())
+        sb.free()
+        strong = {'scaling': 'strong', 'total_sequences': args.strong_total, 'sequences_rank0': len(mine), 'n_gpus': world, 'seconds': dt_s,
+                  'value': args.strong_total / dt_s, 'unit': 'sequences/s', 'ipm_iterations_per_sequence': s_iters / args.strong_total,
+                  'roofline_frac': s_bytes / dt_s / 1e9 / (HBM_PEAK_GBS * world), 'kernel_busy_fraction_rank0': sst['phase_ms'][5] / max(1e-9, sst['n_workgroups'] * (sst['kernel_ms'][0] + sst['kernel_ms'][1])),
+                  'workload': 'BASELINE configs[2]: %d synthetic %d-frame walks (seeds 1000000 ..), LPT-sharded over the ranks (sharding.lpt_assign), inputs resident, one call per rank, MAX over ranks' % (args.strong_total, args.frames)}
 
     res = batch.fetch()
     n_ok = sum(1 for r in res if r.dynamics_succeed and r.durations_succeed)
@@ -375,6 +466,9 @@ def main(argv=None, solver_factory=None):
         try:
             v, st2 = timed_solve(seqs, stall_window=150)
             side['value_with_stall_guard_150'] = v; side['stall_guard_150_hits'] = st2['n_stalled']; side['stall_guard_150_fallbacks'] = st2['n_fallback']
+            v, st2 = timed_solve(seqs[:128])
+            side['value_128_sequences_in_one_call'] = v           # BASELINE configs[1] taken literally: ONE batch of 128 in a call of its own (half the compute units idle, the call lasts as long as its slowest sequence)
+            side['slowest_sequence_ms_128'] = st2['max_seq_ms']
             v, st2 = timed_solve(seqs[:500])
             side['value_500_sequences_in_one_call'] = v
             side['kernel_busy_fraction_500_sequences'] = st2['phase_ms'][5] / max(1e-9, st2['n_workgroups'] * (st2['kernel_ms'][0] + st2['kernel_ms'][1]))
@@ -396,21 +490,15 @@ def main(argv=None, solver_factory=None):
         total_seqs = world * B * steps
         # sum of algorithmic bytes (bytes_iter(seq) x iterations, all ranks) / wall time of the timed region
         ach = alg_bytes_all / elapsed / 1e9
-        # fp64 work of the factorisations / substitutions / products (band N_b, half-width w, border b; multiply-add = 2),
-        # from the mean problem size -- a secondary view: the trailing update of the factorisation runs on the fp64 matrix cores
-        Nb_ = sum(r.sizes['kkt_dim'] - r.sizes['border'] for r in res) / len(res)
-        w_ = sum(r.sizes['halfband'] for r in res) / len(res)
-        b_ = sum(r.sizes['border'] for r in res) / len(res)
-        fl_fact = Nb_ * w_ * w_ + 2 * Nb_ * w_ * b_ + Nb_ * b_ * b_ + b_ ** 3 / 3
-        fl_solve = 4 * (Nb_ * w_ + Nb_ * b_) + 2 * b_ * b_
-        fl_mv = 2 * (Nb_ * (2 * w_ + 1) + 2 * Nb_ * b_ + b_ * b_)
-        flops = nfact * (fl_fact + 2 * fl_solve + fl_mv) + iters * fl_mv
-        traffic = None; traffic_note = 'not measured for this build'
+        traffic = None; traffic_note = 'not measured for this build'; mfma = None; traffic_raw = None; wait_frac = None
         tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
-                traffic = tj.get('hbm_bytes_per_step')
+                traffic = tj.get('hbm_bytes_per_step'); traffic_raw = tj.get('hbm_bytes_per_step_raw'); wait_frac = tj.get('sq_wait_any_fraction')
+                if tj.get('mfma_tflops') is not None:          # COUNTED matrix-core instructions of the PMC pass (not a formula: the by-formula figure of rounds 1-4 counted the dense band, 12 x the envelope's flops)
+                    mfma = {'achieved': tj['mfma_tflops'], 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tj['mfma_tflops'] / FP64_PEAK_TFLOPS,
+                            'note': 'v_mfma_f64_16x16x4_f64 counted by SQ_INSTS_VALU_MFMA_MOPS_F64 in the PMC pass of profiles/traffic.json; only the trailing update of the factorisation runs there'}
                 traffic_note = tj.get('note', '')
                 if tj.get('sources_sha256') != kernel_sources_sha256():      # the PMC passes were made with other kernel sources than the ones that just ran
                     traffic_note = 'STALE (kernel sources changed since the PMC passes): ' + traffic_note
@@ -419,7 +507,7 @@ def main(argv=None, solver_factory=None):
         it_seq = np.array([r.total_iters for r in res], dtype=np.float64)
         out = {
             'metric': 'physics-optimized sequences/sec (90-frame)', 'value': total_seqs / elapsed, 'unit': 'sequences/s',
-            'n_gpus': world, 'steps': steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / steps,
+            'n_gpus': (dist.get_world_size() if world > 1 else 1), 'steps': steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': '%d batches (steps) of %d synthetic Mixamo-like %d-frame walks per GPU (BASELINE configs[1]; seeds rank*%d .. : a slice of configs[2]), '
                                    'staged NLP solve, reference iteration caps 7000/7000/7000/2500/2000/7000, tol 1e-3, stall guard %s'
@@ -441,12 +529,16 @@ def main(argv=None, solver_factory=None):
             'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS * world, 'unit': 'GB/s', 'frac': ach / (HBM_PEAK_GBS * world),
                          'definition': 'sum over sequences of SURVEY 8(d) bytes_iter x IPM iterations / wall time of the timed region / (8 TB/s x GPUs)',
                          'algorithmic_bytes_per_step': alg_bytes_all / steps / world, 'algorithmic_bytes_per_iteration': alg_bytes / max(1, iters),
-                         'traffic': traffic, 'traffic_note': traffic_note, 'kernel': 'chd_solve_kernel',
+                         'traffic': traffic, 'traffic_raw': traffic_raw, 'traffic_note': traffic_note, 'sq_wait_any_fraction': wait_frac, 'kernel': 'chd_solve_kernel',
                          'launches': 1 + (1 if st['kernel_ms'][1] > 0 else 0), 'kernel_ms_rank0': kernel_ms, 'fallback_launch_ms_rank0': st['kernel_ms'][1],
                          'kernel_busy_fraction': st['phase_ms'][5] / max(1e-9, st['n_workgroups'] * kernel_ms),
-                         'fp64': {'achieved': flops / elapsed / 1e12, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': flops / elapsed / 1e12 / FP64_PEAK_TFLOPS,
-                                  'note': 'rank 0, by formula: band LDL^T + substitutions + products at the mean problem size; MFMA counters: profiles/'}},
+                         'fp64_mfma': mfma},
         }
+        if strong is not None:
+            out['strong_scaling'] = strong
+        for k in ('value_including_setup', 'value_including_file_io', 'value_128_sequences_in_one_call', 'value_500_sequences_in_one_call'):      # what a caller sees, first-class (also under config)
+            if k in side:
+                out[k] = side[k]
         if world == 1 and not args.no_side_metrics:
             try:
                 out['parity'] = parity_block(res, seed0)
@@ -462,6 +554,10 @@ def main(argv=None, solver_factory=None):
                 out['reference_binary'] = {'status': 'not measured', 'reason': '%s: %s' % (type(exc).__name__, exc)}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
+            try:
+                out['cpu_baseline']['banded_emulation'] = banded_emulation_baseline()
+            except Exception as exc:
+                out['cpu_baseline']['banded_emulation'] = {'error': '%s: %s' % (type(exc).__name__, exc)}
             if ref_base is not None:          # the reference's own binary, timed on this box: that is the CPU baseline; the oracle's rate stays beside it
                 ref_base['oracle_port'] = out['cpu_baseline']; out['cpu_baseline'] = ref_base
         if world == 1 and not args.no_side_metrics:

@@ -29,6 +29,7 @@ if os.path.exists(ks):
     shutil.copy(ks, dst)
 out = ['# rocprofv3 PMC passes on the solver kernel (commit %s)' % commit, '', '| pass | counter | value summed over the device, main launch | fallback launch |', '|---|---|---|---|']
 tot = {}
+traffic_json = None
 for sub in ('pmc_fetch', 'pmc_write', 'pmc_mfma', 'pmc_sq', 'pmc_fetch_ll', 'pmc_write_ll'):
     for f in glob.glob(os.path.join(src, sub, '*counter_collection.csv')):
         agg = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -45,10 +46,10 @@ if 'FETCH_SIZE' in tot and 'WRITE_SIZE' in tot:
     raw = (tot['FETCH_SIZE'] + tot['WRITE_SIZE']) * 1024.0; corr = (2 * tot['FETCH_SIZE'] + tot['WRITE_SIZE']) * 1024.0
     out += ['', 'One step (128 sequences): FETCH_SIZE %.1f GB + WRITE_SIZE %.1f GB = %.1f GB raw = %.1f x the algorithmic bytes (%.2f GB); with the gfx950 FETCH x 2 correction %.1f GB = %.1f x.'
             % (tot['FETCH_SIZE'] * 1024 / 1e9, tot['WRITE_SIZE'] * 1024 / 1e9, raw / 1e9, raw / alg, alg / 1e9, corr / 1e9, corr / alg)]
-    json.dump({'hbm_bytes_per_step': corr, 'hbm_bytes_per_step_raw': raw, 'fetch_kb': tot['FETCH_SIZE'], 'write_kb': tot['WRITE_SIZE'], 'algorithmic_bytes_per_step': alg,
+    traffic_json = dict({'hbm_bytes_per_step': corr, 'hbm_bytes_per_step_raw': raw, 'fetch_kb': tot['FETCH_SIZE'], 'write_kb': tot['WRITE_SIZE'], 'algorithmic_bytes_per_step': alg,
                'tag': os.path.basename(dst.rstrip('/')), 'commit': commit, 'sources_sha256': __import__('bench').kernel_sources_sha256(),
                'note': 'rocprofv3 PMC passes of %s (one step = 128 sequences, seeds 0..127); FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section; measured on commit %s' % (dst, commit)},
-              open(os.path.join(root, 'profiles', 'traffic.json'), 'w'), indent=1)
+              )
 if 'FETCH_SIZE_LL' in tot and 'WRITE_SIZE_LL' in tot:
     b = json.loads(open(os.path.join(src, 'fetch_ll_bench.json')).read().strip().splitlines()[-1])
     alg = b['roofline']['algorithmic_bytes_per_step']
@@ -61,8 +62,14 @@ if 'SQ_INSTS_VALU_MFMA_MOPS_F64' in tot:
     fl = tot['SQ_INSTS_VALU_MFMA_MOPS_F64'] * 512
     out += ['', 'fp64 MFMA: %.3g v_mfma_f64_16x16x4_f64 (%.3g flop) in %.0f ms of kernel time = %.2f TFLOP/s = %.2f %% of the 78.6 TFLOP/s matrix peak.'
             % (tot['SQ_INSTS_VALU_MFMA_MOPS_F64'] / 4, fl, ms, fl / (ms * 1e-3) / 1e12, 100 * fl / (ms * 1e-3) / 78.6e12)]
+    if traffic_json is not None:
+        traffic_json['mfma_tflops'] = fl / (ms * 1e-3) / 1e12
 if 'SQ_WAVE_CYCLES' in tot and 'SQ_WAIT_ANY' in tot:
     out += ['', 'Wave states: %.0f %% SQ_WAIT_ANY, %.0f %% SQ_ACTIVE_INST_ANY, %.0f %% SQ_WAIT_INST_ANY of SQ_WAVE_CYCLES.'
             % (100 * tot['SQ_WAIT_ANY'] / tot['SQ_WAVE_CYCLES'], 100 * tot['SQ_ACTIVE_INST_ANY'] / tot['SQ_WAVE_CYCLES'], 100 * tot['SQ_WAIT_INST_ANY'] / tot['SQ_WAVE_CYCLES'])]
+    if traffic_json is not None:
+        traffic_json['sq_wait_any_fraction'] = tot['SQ_WAIT_ANY'] / tot['SQ_WAVE_CYCLES']
+if traffic_json is not None:
+    json.dump(traffic_json, open(os.path.join(root, 'profiles', 'traffic.json'), 'w'), indent=1)
 open(os.path.join(dst, 'pmc.md'), 'w').write('\n'.join(out) + '\n')
 print('\n'.join(out))
