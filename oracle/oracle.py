@@ -58,6 +58,8 @@ def lib():
         L.orc_sample_solution.restype = C.c_int
         L.orc_solve_stage.argtypes = [C.c_void_p, C.c_int, C.c_int, PD]
         L.orc_solve_stage.restype = C.c_int
+        L.orc_set_durations.argtypes = [C.c_void_p, PD]
+        L.orc_n_phases.argtypes = [C.c_void_p, C.c_int]
         L.orc_set_study_mask.argtypes = [C.c_int, C.c_double]
         if os.environ.get('ORC_STUDY_MASK'):          # study runs only (tests/tools): 0 = the shipped algorithm
             L.orc_set_study_mask(int(os.environ['ORC_STUDY_MASK']), float(os.environ.get('ORC_CLIP_CAP', '0')))
@@ -148,6 +150,31 @@ class OracleProblem:
         else:
             lib().orc_eval(self.h, _p(x), C.byref(f), _p(g), _p(c), _p(J) if jac else None, _p(H) if hess else None)
         return f.value, g, c, J, H
+
+    def eval_state(self, stage, node_vars, durations):
+        """The model of `stage` at a point given from outside (another solver's result): node variables in variable-set order and ALL phase durations of the
+        four end-effectors (NLP order; a list of four arrays).  Returns dict(objective, violation, dynamics_violation, c, cl, cu)."""
+        L = lib()
+        d = np.ascontiguousarray(np.concatenate([np.asarray(v, dtype=np.float64) for v in durations]))
+        assert [len(v) for v in durations] == [L.orc_n_phases(self.h, e) for e in range(4)]
+        L.orc_set_durations(self.h, _p(d))
+        self.set_stage(stage)
+        x = self.get_x()
+        nn = len(node_vars)
+        assert nn <= x.size
+        x[:nn] = node_vars
+        if x.size > nn:                       # the stage optimises durations: they follow the node variables, all but each end-effector's last phase
+            x[nn:] = np.concatenate([np.asarray(v, dtype=np.float64)[:-1] for v in durations])
+        f, _, c, _, _ = self.eval(x, jac=False)
+        cl, cu = self.bounds_at(x)
+        viol = np.maximum(np.maximum(cl - c, c - cu), 0.0)
+        dyn = viol[self.row_family() == 16]                      # FAM_DYNAMIC (nlp_model.hpp)
+        return dict(objective=f, violation=float(viol.max()) if viol.size else 0.0, dynamics_violation=float(dyn.max()) if dyn.size else 0.0, c=c, cl=cl, cu=cu, x=x)
+
+    def bounds_at(self, x):
+        """row bounds without moving the point (orc_bounds evaluates at the problem's current x)"""
+        self.set_x(x)
+        return self.bounds()
 
     def bounds(self):
         cl = np.zeros(self.m); cu = np.zeros(self.m)

@@ -79,6 +79,17 @@ int orc_m(void* h) { return ((Problem*)h)->m; }
 double orc_total_time(void* h) { return ((Problem*)h)->T; }
 void orc_get_x(void* h, double* x) { ((Problem*)h)->get_x(x); }
 void orc_set_x(void* h, const double* x) { ((Problem*)h)->set_x(x); }
+// all phase durations of the four end-effectors (NLP order, concatenated): for evaluating the model at a point another solver returned
+// (tests/test_quality_gate.py: the HIP path's snapshots, chd_debug_get_state).  Call set_stage afterwards: the rows of a stage depend on the durations.
+void orc_set_durations(void* h, const double* durs) {
+  Problem* p = (Problem*)h;
+  int k = 0;
+  for (int e = 0; e < 4; ++e) {
+    for (size_t i = 0; i < p->phase_dur[e].size(); ++i) p->phase_dur[e][i] = durs[k++];
+    p->update_phase_spline_durations(e);
+  }
+}
+int orc_n_phases(void* h, int e) { return (int)((Problem*)h)->phase_dur[e].size(); }
 void orc_eval(void* h, const double* x, double* f, double* grad, double* c, double* J, double* H) {
   ((Problem*)h)->eval(x, f, grad, c, J, H);
 }
