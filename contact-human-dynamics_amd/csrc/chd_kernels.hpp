@@ -234,8 +234,8 @@ CHD_DEV double pair_sum(double v) { return v + __shfl_xor(v, 32); }
 #define CHD_PEND_CAP 640
 #define CHD_PHEND_CAP 64
 #ifdef CHD_HOST_EMU
-static double chd_pend_l[CHD_PEND_CAP], chd_phend_l[CHD_PHEND_CAP];
-static int chd_tab_ok = 0;
+static thread_local double chd_pend_l[CHD_PEND_CAP], chd_phend_l[CHD_PHEND_CAP];      // (per emulated workgroup = per host thread: the sanitizer builds run several at once)
+static thread_local int chd_tab_ok = 0;
 #else
 __shared__ double chd_pend_l[CHD_PEND_CAP];
 __shared__ double chd_phend_l[CHD_PHEND_CAP];

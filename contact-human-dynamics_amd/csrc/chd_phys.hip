@@ -3,7 +3,11 @@
 // One workgroup per sequence; a batch is one launch (plus one more launch for the sequences
 // whose stage 3 did not converge: "STAGE 4: Durations failed ..." phys_optim.cpp:714-749).
 // There is no CPU solve path in this library: without a HIP device chd_phys_create fails.
+#ifdef CHD_HOST_EMU_HIP_STUB        // sanitizer builds of the HOST side (tests/host_emu/pipeline_stress.cpp): a stand-in runtime whose streams are threads and whose kernel
+#include CHD_HOST_EMU_HIP_STUB     // launches run the host emulation of the kernel source; test infrastructure -- libchd_phys.so is never built this way
+#else
 #include <hip/hip_runtime.h>
+#endif
 
 #include <algorithm>
 #include <atomic>
@@ -34,6 +38,7 @@ using namespace chd;
 static_assert(sizeof(SeqDesc) % 8 == 0, "SeqDesc is copied word by word");
 static_assert(sizeof(SeqDesc) + sizeof(Ctx) + 64 <= 4096, "static LDS of the solver kernel must fit the 4 KB left beside the dynamic part");
 
+#ifndef CHD_HOST_EMU
 // Workspace slots.  A resident workgroup needs a workspace (~35 MB at 90 frames) only while it is resident, and at most `n_slots` workgroups are (one per
 // compute unit: a workgroup needs the whole LDS) -- however many launches are in flight.  So the handle owns ONE set of n_slots workspaces, and a workgroup
 // claims a free one when it starts and gives it back when its launch's queue is drained.  Two launches that overlap in time hand a slot from a workgroup on
@@ -113,6 +118,53 @@ __global__ __launch_bounds__(CHD_MAX_THREADS) void chd_debug_linsolve_kernel(con
   if (!take_sequence(&s_desc, &s_item, descs, order, 1, counter, wd_pool, 0, wi_pool, 0, 0)) return;
   debug_linsolve((QP)&s_desc, *(LCtx*)&s_ctx, stage, (LdsD*)lds, lds_doubles, dw, dval, which, reps, (const GD*)rhs, (GD*)x, out);
 }
+
+#else
+// ---- host emulation of the three kernels (CHD_HOST_EMU: chd_kernels.hpp compiles as a single-"thread" host function).  One std::thread per resident
+// workgroup, the same protocol as the device code: claim a workspace slot (compare-and-swap, acquire), take sequences from the launch's queue until it is
+// drained, release the slot.  Used by the sanitizer builds of the host side only.
+static int claim_slot_emu(int* slot_busy, int n_slots, unsigned block) {
+  int s = (int)(block % (unsigned)n_slots);
+  for (;;) {
+    int expected = 0;
+    if (__atomic_compare_exchange_n(&slot_busy[s], &expected, 1, false, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED)) return s;
+    s = s + 1 == n_slots ? 0 : s + 1;
+    std::this_thread::yield();
+  }
+}
+static void chd_solve_kernel_emu(unsigned grid, const SeqDesc* descs, const int* order, int n_items, int* counter, double* wd_pool, long long wd_stride, int* wi_pool, long long wi_stride,
+                                 int* slot_busy, int n_slots, int lds_doubles, double tol, int stall_window, int stage_first, int stage_last) {
+  std::vector<std::thread> wg;
+  for (unsigned blk = 0; blk < grid; ++blk)
+    wg.emplace_back([=]() {
+      const int slot = claim_slot_emu(slot_busy, n_slots, blk);
+      std::vector<double> lds((size_t)lds_doubles, 0.0);
+      for (;;) {
+        const int item = __atomic_fetch_add(counter, 1, __ATOMIC_RELAXED);
+        if (item >= n_items) break;
+        SeqDesc d = descs[order[item]];
+        d.wd = wd_pool + (long long)slot * wd_stride; d.wi = wi_pool + (long long)slot * wi_stride;
+        Ctx ctx;
+        run_sequence(&d, ctx, lds.data(), lds_doubles, tol, stall_window, stage_first, stage_last);
+      }
+      __atomic_store_n(&slot_busy[slot], 0, __ATOMIC_RELEASE);
+    });
+  for (auto& t : wg) t.join();
+}
+static void chd_debug_eval_kernel_emu(unsigned, const SeqDesc* descs, const int* order, int*, double* wd_pool, int* wi_pool, int stage, const double* xin, int lds_doubles, double* f_out) {
+  SeqDesc d = descs[order[0]];
+  d.wd = wd_pool; d.wi = wi_pool;
+  Ctx ctx; std::vector<double> lds((size_t)lds_doubles, 0.0);
+  debug_eval(&d, ctx, stage, xin != nullptr, lds.data(), lds_doubles, xin, nullptr, f_out);
+}
+static void chd_debug_linsolve_kernel_emu(unsigned, const SeqDesc* descs, const int* order, int*, double* wd_pool, int* wi_pool, int stage, int lds_doubles, double dw, double dval, int which, int reps,
+                                          const double* rhs, double* x, double* out) {
+  SeqDesc d = descs[order[0]];
+  d.wd = wd_pool; d.wi = wi_pool;
+  Ctx ctx; std::vector<double> lds((size_t)lds_doubles, 0.0);
+  debug_linsolve(&d, ctx, stage, lds.data(), lds_doubles, dw, dval, which, reps, rhs, x, out);
+}
+#endif
 
 // A handle owns ONE set of workspaces -- one per workgroup that can be resident, claimed and released by the workgroups themselves (claim_slot above) --
 // and CHD_N_POOLS "lanes": a stream and a set of reusable device / page-locked buffers for one chunk of sequences each.  A launch uses one lane, so up to
@@ -663,7 +715,7 @@ static int solve_pipelined(chd_handle* h, int B, const chd_seq_in* in, chd_seq_o
     const int first = (h->cfg.pipeline_chunk >= 0 && B > 2 * 256 && chunk > 256) ? 256 : chunk;          // (one sequence for every compute unit)
     while (c0 < B) {
       int n = ch.empty() ? first : chunk;
-      if (B - c0 - n < 64) n = B - c0;            // (no crumbs at the end)
+      if (B - c0 - n < std::min(64, (chunk + 1) / 2)) n = B - c0;            // (no crumbs at the end: less than half a chunk -- at most 64 sequences -- joins the chunk before)
       ch.emplace_back(new PipeChunk()); ch.back()->c0 = c0; ch.back()->c1 = std::min(B, c0 + n); c0 = ch.back()->c1;
     }
   }
@@ -734,6 +786,9 @@ static int solve_pipelined(chd_handle* h, int B, const chd_seq_in* in, chd_seq_o
     }
     c.fin = std::thread([h, &c, out, &fin, &agg_mu, &n_solved_chunks, t_begin]() {
       (void)hipSetDevice(h->device);
+#ifdef CHD_STRESS_INJECT_RACE          // (tests/test_sanitizers.py: the harness must SEE a race when there is one -- an unsynchronised write to the shared handle from every finisher)
+      h->call.finish_ms += 1.0;
+#endif
       tl_err_sink = &c.err;               // (error text of this thread's calls goes to the chunk; the handle itself is shared: this thread owns its lane's result / scratch staging until device_done)
       int rc2 = solve_finish(h, c.b);
       c.t_solved = now_ms() - t_begin;
@@ -818,9 +873,11 @@ int chd_phys_create(const chd_config* cfg, int device_id, chd_handle** out) {
   if (lds < 64 * 1024) lds = 64 * 1024;
   h->lds_bytes = (int)lds - 12288;    // the 12 KB hold the kernel's static LDS: sequence descriptor + solver context (2.4 KB), cumulative-time tables (5.6 KB)
   if (h->cfg.lds_kilobytes > 0 && h->cfg.lds_kilobytes * 1024 < h->lds_bytes) h->lds_bytes = std::max(32, h->cfg.lds_kilobytes) * 1024;
+#ifndef CHD_HOST_EMU
   hipFuncSetAttribute((const void*)chd_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
   hipFuncSetAttribute((const void*)chd_debug_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
   hipFuncSetAttribute((const void*)chd_debug_linsolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes);
+#endif
   // the factorisation / substitution phases are written for eight wavefronts (wave-specialised look-ahead, register prefetch
   // by lane group): other workgroup sizes are refused rather than silently mis-solved
   // (experiment, profiles/r02k_final/two_workgroups.md: with CHD_EXPERIMENTAL_256 set, 256-thread workgroups -- two per compute unit with
