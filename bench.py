@@ -588,7 +588,8 @@ def main(argv=None, solver_factory=None):
                     out['parity']['acceptance'] = quality_block(batch, seqs, res, seed0)
                     vf = os.path.join(ROOT, 'tests', 'golden', 'ipopt_like_golden.json')
                     if os.path.exists(vf):          # committed study (tests/golden/make_ipopt_like_golden.py): the shipped algorithm against the oracle's IPOPT-like mode -- an explicit PROXY for the unmeasurable "vs IPOPT"
-                        out['parity']['vs_ipopt_like'] = json.load(open(vf))
+                        vj = json.load(open(vf))
+                        out['parity']['vs_ipopt_like'] = {k: vj[k] for k in ('what', 'proxy_for', 'snapshots', 'quantities', 'generator', 'summary') if k in vj}
             except Exception as exc:
                 out['parity'] = {'error': '%s: %s' % (type(exc).__name__, exc)}
         ref_base = None

@@ -100,12 +100,12 @@ class KinSolver:
 def update_skeleton(offsets, parents, targets):
     """:485-520.  Bone length = median over the frames of the target bone (the three spine bones: a third of root -> Spine2,
     'to avoid crunched spine from SMPL'); bone directions from the template; root offset zero."""
-    lengths = np.zeros(NJ)
-    for j in range(1, NJ):
-        if j in SPINE_JOINTS:
-            lengths[j] = np.median(np.linalg.norm(targets[:, SPINE_JOINTS[2]] - targets[:, 0], axis=1) / 3.0)
-        else:
-            lengths[j] = np.median(np.linalg.norm(targets[:, j] - targets[:, int(parents[j])], axis=1))
+    par = np.asarray(parents).astype(int).copy(); par[0] = 0
+    d = targets - targets[:, par]                                                  # every joint's bone at once (one median call instead of 27)
+    lengths = np.median(np.sqrt(np.sum(d * d, axis=2)), axis=0)
+    ds = targets[:, SPINE_JOINTS[2]] - targets[:, 0]
+    lengths[list(SPINE_JOINTS)] = np.median(np.sqrt(np.sum(ds * ds, axis=1)) / 3.0)
+    lengths[0] = 0.0
     out = np.array(offsets, dtype=np.float64)
     out[1:] = out[1:] / np.linalg.norm(out[1:], axis=1, keepdims=True) * lengths[1:, None]
     out[0] = 0.0
@@ -282,11 +282,11 @@ def _motions_batch(xs, offsets_list, parents):
         parents = parents[0]
     Fs = [x.shape[0] for x in xs]
     allx = np.concatenate(xs, axis=0)
-    rot = sio.quat_from_euler(allx[:, 3:].reshape(-1, NJ, 3), order='xyz', world=True)
+    rot = sio.quat_from_euler_xyz_world(allx[:, 3:].reshape(-1, NJ, 3))
     pos = np.concatenate([np.repeat(o[None], F, axis=0) for o, F in zip(offsets_list, Fs)], axis=0)
     pos[:, 0] = allx[:, :3]
     parents = np.asarray(parents)
-    gp = sio.positions_global(sio.Motion(rot, pos, np.tile([1.0, 0.0, 0.0, 0.0], (NJ, 1)), offsets_list[0].copy(), parents.copy()))
+    gp = sio.positions_global_fast(rot, pos, parents)
     out, a = [], 0
     for o, F in zip(offsets_list, Fs):
         out.append((sio.Motion(rot[a:a + F].copy(), pos[a:a + F].copy(), np.tile([1.0, 0.0, 0.0, 0.0], (NJ, 1)), o.copy(), parents.copy()), gp[a:a + F]))
@@ -314,6 +314,8 @@ class KinematicOptimizer:
         of its chunk -- bone lengths, floor fits, forward kinematics -- which are a third of the time of a chunk.  Every library call
         runs on a non-blocking stream of its own (chd_kinopt.hip, chd_ik.hip), so the kernels of the two threads can overlap; a clip's
         result does not depend on the chunk it is in."""
+        if workers >= 2 and 128 < len(clips) <= chunk:
+            chunk = (len(clips) + 1) // 2          # one GPU's worth of clips or less: two halves, so that one half's host steps run under the other half's kernels (each half still gets a workgroup per clip)
         if len(clips) <= chunk or workers < 2:
             return self._optimize(clips)
         from concurrent.futures import ThreadPoolExecutor

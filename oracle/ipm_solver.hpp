@@ -51,6 +51,13 @@ struct IpmOptions {
   // from the shipped Gauss-Newton algorithm at the same tolerance.
   bool lbfgs = false;
   int lbfgs_history = 6;
+  // ... with IPOPT's globalisation (round 5): the FILTER line search of Waechter & Biegler (2006, sec. 2.3; IPOPT's constants gamma_theta 1e-5, gamma_phi 1e-8,
+  // delta 1, s_theta 1.1, s_phi 2.3, eta_phi 1e-8, theta_max / theta_min = 1e4 / 1e-4 x max(1, theta(x0)), gamma_alpha 0.05), second-order correction on the
+  // first trial step, the filter reset at every barrier update -- in place of the l1 merit function.  What is still NOT IPOPT: there is no restoration phase
+  // (when the step length falls below alpha_min the damping delta_w grows tenfold and the step is recomputed: IPOPT would minimise the constraint violation
+  // instead), and MA57 is a banded L D L^T.  `acceptable_tol` = 1e-6 / 15 iterations is implemented and can never fire here: the
+  // reference's tol = 1e-3 is LOOSER than the acceptable level, so the regular test always stops first.
+  bool filter = false;
   int stall_window = 0;         // > 0: stall guard (chd_config.stall_window); 0 = off, as IPOPT has no such rule
   bool inertia_retry = true;    // a factorisation that had to replace a pivot counts as a failed attempt (see chd_kernels.hpp, CHD_INERTIA_RETRY)
 };
@@ -372,6 +379,10 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
   // least 4e-6 (x 4 above 1e-6).  Never fires on the 160 flat / tilted bench sequences of the fixture; -9 % iterations on the 40 hard ones.
   constexpr int dual_rise_k = 6;
   double ed_prev = -1.0; int ed_rise = 0;
+  // filter (IPOPT-like mode with opt.filter): pairs (theta, phi) a trial point must improve on; reset when mu changes
+  std::vector<std::pair<double, double>> filt;
+  double filt_mu = -1.0, theta_max = 0, theta_min = 0;
+  int acceptable_count = 0;
   for (it = 0; it < opt.max_iter; ++it) {
     double E0 = errors(0.0);
     if (ed_prev >= 0 && e_d > ed_prev) ++ed_rise; else ed_rise = 0;
@@ -381,6 +392,10 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
     if (opt.verbose) { int wi = 0; double wv = 0; for (int i = 0; i < m; ++i) { double v = std::fabs(eq[i] ? c[i] - l[i] : c[i] - s[i]); if (v > wv) { wv = v; wi = i; } } std::printf("[worst row %d fam %d eq %d c=%.4e s=%.4e l=%.3e u=%.3e lam=%.3e] ", wi, P.row_family[wi], (int)eq[wi], c[wi], s[wi], l[wi], u[wi], lam[wi]); }
     if (opt.verbose) std::printf("%4d f=%.6e E0=%.2e (d %.1e p %.1e pu %.1e c %.1e) mu=%.1e nu=%.1e dw=%.1e | last a=%.2e nls=%d att=%d soc=%d\n", it, f / sf, E0, e_d, e_p, e_p_unscaled, e_c, mu, nu, dw, last_alpha, last_nls, last_att, (int)last_soc);
     if (E0 <= tol && e_p_unscaled <= opt.constr_viol_tol) { status = 0; break; }
+    if (opt.filter) {      // IPOPT's acceptable-point exit: acceptable_tol 1e-6 for 15 consecutive iterations (never reached before the test above at tol 1e-3)
+      acceptable_count = (E0 <= 1e-6 && e_p_unscaled <= 1e-2) ? acceptable_count + 1 : 0;
+      if (acceptable_count >= 15) { status = 1; break; }
+    }
     // stall guard (optional, chd_config.stall_window): no factor-2 reduction of the optimality error over the last W iterations
     // -> give up (status -2) instead of running to the iteration cap; stage 3 then takes the reference's stage-4 fallback
     if (opt.stall_window > 0) {
@@ -524,6 +539,71 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
       double phi0 = f + barrier(s, mu) + nu * cn;
       alpha = a_pr; ok = false; nls = 0; used_soc = false;
       const double cn_floor = 1e-12;
+      if (opt.filter) {
+        // ---- filter line search: theta = |r|_1, phi = barrier objective, d phi = dphi_bar
+        const double g_th = 1e-5, g_ph = 1e-8, dl = 1.0, s_th = 1.1, s_ph = 2.3, eta = 1e-8, g_al = 0.05;
+        const double theta0 = cn, phib0 = f + barrier(s, mu);
+        if (filt_mu != mu) { filt.clear(); filt_mu = mu; if (theta_max == 0) { theta_max = 1e4 * std::max(1.0, theta0); theta_min = 1e-4 * std::max(1.0, theta0); } }
+        double alpha_min = g_th;
+        if (dphi_bar < 0) {
+          alpha_min = std::min(g_th, g_ph * theta0 / (-dphi_bar));
+          if (theta0 <= theta_min) alpha_min = std::min(alpha_min, dl * std::pow(theta0, s_th) / std::pow(-dphi_bar, s_ph));
+        }
+        alpha_min *= g_al;
+        auto acceptable = [&](double th, double ph) {
+          if (th > theta_max) return false;
+          for (auto& e : filt) if (!(th < (1 - g_th) * e.first || ph < e.second - g_ph * e.first)) return false;
+          return true;
+        };
+        bool first = true, htype = false;
+        while (alpha >= alpha_min && nls < 40) {
+          for (int j = 0; j < n; ++j) xt[j] = x[j] + alpha * dx[j];
+          for (int i = 0; i < m; ++i) st[i] = s[i] + alpha * ds[i];
+          double ft = 0;
+          P.eval(xt.data(), &ft, nullptr, ct.data(), nullptr, nullptr);
+          ft *= sf; for (int i = 0; i < m; ++i) ct[i] *= sc[i];
+          resid(ct, st, rt);
+          double tht = 0; for (int i = 0; i < m; ++i) tht += std::fabs(rt[i]);
+          const double pht = ft + barrier(st, mu);
+          auto test = [&](double th, double ph) {
+            if (!std::isfinite(th) || !std::isfinite(ph) || !acceptable(th, ph)) return 0;
+            const bool fty = dphi_bar < 0 && alpha * std::pow(-dphi_bar, s_ph) > dl * std::pow(theta0, s_th) && theta0 <= theta_min;
+            if (fty) return ph <= phib0 + eta * alpha * dphi_bar ? 1 : 0;
+            return (th <= (1 - g_th) * theta0 || ph <= phib0 - g_ph * theta0) ? 2 : 0;
+          };
+          int acc = test(tht, pht);
+          if (acc) { ok = true; htype = acc == 2; break; }
+          if (first && opt.use_soc && tht >= theta0 && tht > cn_floor) {      // second-order correction (one step; IPOPT allows four)
+            for (int j = 0; j < n; ++j) rhs2[pos_var[j]] = 0.0;
+            for (int i = 0; i < m; ++i) rhs2[pos_row[i]] = -rt[i];
+            kkt_solve(rhs2.data(), sol2.data());
+            bool inside = true;
+            for (int j = 0; j < n; ++j) xs[j] = xt[j] + sol2[pos_var[j]];
+            for (int i = 0; i < m; ++i) {
+              ss2[i] = st[i];
+              if (eq[i]) continue;
+              ss2[i] = st[i] + sol2[pos_row[i]] / Sigma[i];
+              if (hasL[i] && ss2[i] - l[i] < (1 - 1e-8) * (1 - tau) * (s[i] - l[i])) inside = false;
+              if (hasU[i] && u[i] - ss2[i] < (1 - 1e-8) * (1 - tau) * (u[i] - s[i])) inside = false;
+            }
+            if (inside) {
+              double fs = 0;
+              P.eval(xs.data(), &fs, nullptr, ct.data(), nullptr, nullptr);
+              fs *= sf; for (int i = 0; i < m; ++i) ct[i] *= sc[i];
+              resid(ct, ss2, rt);
+              double ths = 0; for (int i = 0; i < m; ++i) ths += std::fabs(rt[i]);
+              acc = test(ths, fs + barrier(ss2, mu));
+              if (acc) { ok = true; used_soc = true; htype = acc == 2; break; }
+            }
+          }
+          first = false; alpha *= 0.5; ++nls;
+        }
+        if (ok && htype) filt.emplace_back((1 - g_th) * theta0, phib0 - g_ph * theta0);
+        if (ok) break;
+        dw *= 10.0;          // (in place of the restoration phase)
+        if (dw > opt.delta_w_max) break;
+        continue;
+      }
       while (nls <= opt.max_backtrack) {
         for (int j = 0; j < n; ++j) xt[j] = x[j] + alpha * dx[j];
         for (int i = 0; i < m; ++i) st[i] = s[i] + alpha * ds[i];

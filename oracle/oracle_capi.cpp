@@ -13,7 +13,7 @@ void orc_set_inertia_retry(int v) { g_inertia_retry = v; }
 void orc_set_stall_window(int v) { g_stall_window = v; }
 static double g_clip_cap = 1e300;
 void orc_set_study_mask(int v, double clip_cap) { g_study_mask = v; g_clip_cap = clip_cap > 0 ? clip_cap : 1e300; }      // Problem::study_mask (0 = the shipped algorithm)
-void orc_set_ipopt_like(int v) { g_lbfgs = v; }      // L-BFGS(6) + mu_init 0.1 on every stage: see IpmOptions::lbfgs (oracle-only study mode)
+void orc_set_ipopt_like(int v) { g_lbfgs = v; }      // 1: L-BFGS(6) + mu_init 0.1 on every stage, l1 merit (round 2); 2: the same with IPOPT's filter line search (round 5): IpmOptions::lbfgs / filter (oracle-only study modes)
 
 struct orc_seq_in {
   int F;
@@ -143,6 +143,7 @@ int orc_solve_stage(void* h, int stage, int max_iter, double* stats /*8*/) {
   opt.inertia_retry = g_inertia_retry != 0;
   opt.stall_window = g_stall_window;
   opt.lbfgs = g_lbfgs != 0;
+  opt.filter = g_lbfgs >= 2;          // orc_set_ipopt_like(2): L-BFGS(6) + filter line search (round 5)
   IpmResult r = ipm_solve(*p, opt);
   if (stats) {
     stats[0] = r.iters; stats[1] = r.kkt_error; stats[2] = r.constr_viol; stats[3] = r.objective;

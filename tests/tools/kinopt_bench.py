@@ -47,7 +47,7 @@ if __name__ == '__main__':
         return r
 
     opt.kin.solve = timed
-    t0 = time.perf_counter(); res = opt.optimize(clips, chunk=int(os.environ.get('KIN_CHUNK', '256'))); t1 = time.perf_counter()
+    t0 = time.perf_counter(); res = opt.optimize(clips, chunk=int(os.environ.get('KIN_CHUNK', '256')), workers=int(os.environ.get('KIN_WORKERS', '2'))); t1 = time.perf_counter()
     ik_ms, ik_frames = opt.ik.last_kernel_ms()
     its = np.array([[s['lsmr_iterations'] for s in r['stages']] for r in res])
     nfev = np.array([[s['nfev'] for s in r['stages']] for r in res])
