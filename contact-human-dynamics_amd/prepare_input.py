@@ -8,8 +8,9 @@ columns left heel, left toe, right heel, right toe) and writes ``skel_info.txt``
 ``terrain_info.txt`` and ``contact_info.txt`` -- or, with `prepare_sequence`, hands the same data to the solver in
 memory (`io_formats.SeqInput`), skipping the files.  Per video this is small array work (NumPy on the host, as in the reference);
 for a run of thousands of videos (BASELINE configs[2]) `prepare_sequences_device` does the per-frame numerics -- two forward-kinematics
-passes, centre of mass, inertia, hip offsets, toe / heel trajectories -- for ALL clips at once as float64 tensor operations on the GPU
-(PyTorch-ROCm; padded over the frames), and leaves the sequential pieces (root-angle unwrapping, contact run lengths) on the host.
+passes, centre of mass, inertia, hip offsets, toe / heel trajectories -- for the frames of ALL clips in one launch of a hand-written HIP kernel
+(libchd_prepare.so, include/chd_prepare.h; the float64 tensor-operation form of rounds 2-4 stays as a cross-check), reads the BVH files with the
+library's native parser (`prepare_capi.load_bvh_batch`) and leaves the sequential pieces (root-angle unwrapping, contact run lengths) on the host.
 
 Coordinates: the animation is y-up in centimetres; the solver is z-up in metres with x, y negated
 (``p_solver = -0.01 * p[[x, z, y]]``, towr_utils.py:519-521, 568-571).
@@ -163,9 +164,18 @@ def _fk_device(rot, pos, parents):
 
 
 def prepare_sequences_device(motions, floors, foot_contacts, character: Character, starts=None, ends=None, dt=1.0 / 30.0, combined_contacts=False,
-                             device='cuda'):
+                             device='cuda', backend=None, frames_fn=None):
     """`prepare_sequence` for a list of clips of one character (same hierarchy) with the per-frame numerics batched on `device`.
-    Equal to the NumPy path to rounding (tests/test_prepare_input.py; tests/test_config4_gpu.py on the MI355X)."""
+    Equal to the NumPy path to rounding (tests/test_prepare_input.py; tests/test_config4_gpu.py on the MI355X).
+
+    backend 'hip' (the default on a cuda device): ONE launch of the hand-written kernel of libchd_prepare.so over the frames of all clips (include/chd_prepare.h,
+    csrc/chd_prepare_kernels.hpp); it raises when the library or a HIP device is missing -- no silent fallback.  backend 'torch': the same numerics as float64
+    tensor operations (rounds 2-4; kept as an independent cross-check and for the CPU device of torch in tests).  `frames_fn` (tests): a stand-in for
+    `prepare_capi.prep_frames` -- the host emulation of the kernel source."""
+    if backend is None:
+        backend = 'hip' if (frames_fn is not None or str(device).startswith('cuda')) else 'torch'
+    if backend == 'hip':
+        return _prepare_sequences_hip(motions, floors, foot_contacts, character, starts, ends, dt, combined_contacts, device, frames_fn)
     import torch
     for need in ('left_leg_chain', 'hip_inds', 'mass'):
         if getattr(character, need) is None:
@@ -234,6 +244,49 @@ def prepare_sequences_device(motions, floors, foot_contacts, character: Characte
                                 inertia=np.stack([I[:, 0, 0], I[:, 1, 1], I[:, 2, 2], I[:, 0, 1], I[:, 0, 2], I[:, 1, 2]], axis=1),
                                 com=com_traj[b, :F][sl], euler=root_rot[sl], ltoe=feet[b, :F][sl, 0], lheel=feet[b, :F][sl, 1], rtoe=feet[b, :F][sl, 2],
                                 rheel=feet[b, :F][sl, 3], normal=np.asarray(floors[b][0], dtype=np.float64), point=np.asarray(floors[b][1], dtype=np.float64),
+                                start_contact=start, durations=durations))
+    return out
+
+
+def _prepare_sequences_hip(motions, floors, foot_contacts, character, starts, ends, dt, combined_contacts, device, frames_fn):
+    from . import prepare_capi as pc
+    for need in ('left_leg_chain', 'hip_inds', 'mass'):
+        if getattr(character, need) is None:
+            raise ValueError('Character.%s is required by prepare_input' % need)
+    B = len(motions)
+    starts = [0 if s is None else s for s in (starts or [None] * B)]
+    ends = [m.n_frames if e is None else e for m, e in zip(motions, ends or [None] * B)]
+    anims = [m.copy() if character.heel_inds is not None else add_heels(m, character.toe_inds, character.ankle_inds) for m in motions]
+    J0 = motions[0].n_joints
+    parents0, parents1 = [int(a) for a in motions[0].parents], [int(a) for a in anims[0].parents]
+    if any(m.n_joints != J0 or [int(a) for a in m.parents] != parents0 for m in motions):
+        raise ValueError('prepare_sequences_device: the clips of a batch share one skeleton hierarchy')
+    skel = pc.skeleton_of(character, parents1, J0)
+    rot = np.concatenate([a.rotations for a in anims], axis=0); pos = np.concatenate([a.positions for a in anims], axis=0)      # the frames of all clips, one after the other
+    if frames_fn is not None:
+        fr = frames_fn(skel, rot, pos)
+    else:
+        dev = str(device)
+        fr = pc.prep_frames(skel, rot, pos, device=int(dev.split(':')[1]) if ':' in dev else 0)
+    lh = skel.heel_inds[0]
+    chain = list(character.left_leg_chain)
+    raw = []
+    for a in anims:
+        angle, axis = sk.quat_angle_axis(a.rotations[:, 0])
+        raw.append(sk.quat_to_euler_xyz(sk.quat_from_angle_axis(angle, -axis[:, _SWAP])))
+    root_rots = unwrap_batch(raw)
+    out, f0 = [], 0
+    for b, (m, a) in enumerate(zip(motions, anims)):
+        F = m.n_frames
+        o = fr[f0:f0 + F]; f0 += F
+        sl = slice(starts[b], ends[b])
+        start, durations = contact_schedule(foot_contacts[b], starts[b], ends[b], dt, combined_contacts)
+        out.append(iof.SeqInput(F=ends[b] - starts[b], dt=dt, hip_l=o[sl, 0:3], hip_r=o[sl, 3:6],
+                                leg_len=float(np.sum(np.linalg.norm(m.offsets[chain[1:]], axis=1)) * 0.01),
+                                heel_len=float((np.sum(np.linalg.norm(a.offsets[chain[1:-1]], axis=1)) + np.linalg.norm(a.offsets[lh])) * 0.01),
+                                heel_dist=float(np.mean(o[:, 27])), mass=float(character.mass), inertia=o[sl, 6:12],
+                                com=o[sl, 12:15], euler=root_rots[b][sl], ltoe=o[sl, 15:18], lheel=o[sl, 18:21], rtoe=o[sl, 21:24], rheel=o[sl, 24:27],
+                                normal=np.asarray(floors[b][0], dtype=np.float64), point=np.asarray(floors[b][1], dtype=np.float64),
                                 start_contact=start, durations=durations))
     return out
 

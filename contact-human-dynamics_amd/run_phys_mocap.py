@@ -45,8 +45,8 @@ def parse_args(argv):
                    'tracked_results.json and foot_contacts.npy gets kinematic_results/; all videos in one batched solve')
     p.add_argument('--skel-path', default='skeleton_fitting/combined_body_25.bvh', help='template of the combined skeleton for --kinematic (run_phys_mocap.py:106)')
     p.add_argument('--prepare', action='store_true', help='write phys_optim_in_<character>/ from kinematic_results/ first')
-    p.add_argument('--prepare-device', action='store_true', help='with --prepare: the per-frame numerics of all videos as one batch of tensor operations on the GPU '
-                   '(prepare_input.prepare_sequences_device) instead of NumPy video by video')
+    p.add_argument('--prepare-device', action='store_true', help='with --prepare: the BVH files of all videos read by the native parser and their per-frame numerics in ONE launch of the '
+                   'HIP kernel of libchd_prepare.so (prepare_input.prepare_sequences_device) instead of NumPy video by video')
     p.add_argument('--out-bvh', action='store_true', help='back-project the solutions onto the skeleton and write BVH files')
     p.add_argument('--character-json', default=None, help='joint / segment tables of the character (apply_results.Character)')
     p.add_argument('--fps', type=float, default=30.0, help='frame rate of the animation (the reference reads it from the video, :90-91)')
@@ -132,7 +132,8 @@ def main(argv=None):
         from . import prepare_input as pi
         from . import skeleton_io as sk
         kins = [os.path.join(vd, 'kinematic_results') for vd, _, _ in prep_batch]
-        motions = [sk.load_bvh(os.path.join(k, a.character + '_out.bvh'))[0] for k in kins]
+        from . import prepare_capi
+        motions = [m for m, _, _ in prepare_capi.load_bvh_batch([os.path.join(k, a.character + '_out.bvh') for k in kins])]      # native reader, all files on the host's cores
         seqs = pi.prepare_sequences_device(motions, [pi.read_floor(os.path.join(k, 'floor_out.txt')) for k in kins],
                                            [np.load(os.path.join(k, 'foot_contacts.npy')) for k in kins], character,
                                            starts=[0] * len(kins), ends=[n for _, _, n in prep_batch], dt=1.0 / a.fps, device='cuda:%d' % sharding.rank_world()[2])

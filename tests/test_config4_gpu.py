@@ -125,10 +125,26 @@ def test_kinematic_optimisation_to_bvh_on_one_gpu(tmp_path):
 
 
 def test_prepare_input_batched_on_gpu(tmp_path):
-    """prepare_input's per-frame numerics for a batch of clips of different lengths as tensor operations on the MI355X against the NumPy
-    mirror (which tests/test_prepare_input.py pins to the files the reference's own prepare_input wrote)."""
+    """prepare_input's per-frame numerics for a batch of clips of different lengths on the MI355X -- ONE launch of the HIP kernel of libchd_prepare.so over
+    the frames of all clips (the default of prepare_sequences_device on a cuda device) -- against the NumPy mirror (which tests/test_prepare_input.py pins to
+    the files the reference's own prepare_input wrote); then the tensor-operation form as a third opinion, and a batch of 4 000 frames for the kernel's rate."""
     sys.path.insert(0, HERE); sys.path.insert(0, os.path.join(HERE, 'golden'))
     from make_apply_golden import CHARACTER
     from chd_amd import apply_results as ar
-    from test_prepare_input import check_device_batch
-    check_device_batch(np.load(os.path.join(HERE, 'golden', 'apply_golden.npz')), tmp_path, ar.Character(**CHARACTER), 'cuda:0')
+    from chd_amd import prepare_capi as pc
+    from chd_amd import prepare_input as pi
+    from test_prepare_input import ARRAYS, _batch_inputs, check_device_batch
+    gold = np.load(os.path.join(HERE, 'golden', 'apply_golden.npz'))
+    character = ar.Character(**CHARACTER)
+    check_device_batch(gold, tmp_path, character, 'cuda:0')
+    assert pc.last_kernel_ms() > 0.0                                   # the library's kernel ran (not a fallback)
+    clips, floors, fcs, starts, ends = _batch_inputs(gold, tmp_path)
+    a = pi.prepare_sequences_device(clips, floors, fcs, character, starts, ends, device='cuda:0')
+    b = pi.prepare_sequences_device(clips, floors, fcs, character, starts, ends, device='cuda:0', backend='torch')
+    for x, y in zip(a, b):
+        for k in ARRAYS:
+            assert np.allclose(getattr(x, k), getattr(y, k), rtol=1e-11, atol=1e-13), k
+    many = [clips[0]] * 300                                            # 300 clips x 14 frames in one launch
+    got = pi.prepare_sequences_device(many, [floors[0]] * 300, [fcs[0]] * 300, character, device='cuda:0')
+    assert all(np.array_equal(g.com, got[0].com) for g in got)
+    print('prepare kernel: %d frames in %.3f ms' % (300 * clips[0].n_frames, pc.last_kernel_ms()))
