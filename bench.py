@@ -484,11 +484,11 @@ def main(argv=None, solver_factory=None):
                                        'host_cores_to_keep_one_gpu_busy': cs['setup_cpu_ms'] / max(1e-9, 1e3 * len(seqs) / (total_value_hint or 1.0)),
                                        'note': 'chd_phys_solve_batch on the SAME %d sequences: table build on the host threads, upload, persistent launches (up to 4 chunks in flight), '
                                                'stage-4 fallbacks, fetch -- one call, wall clock; host_cores_to_keep_one_gpu_busy = set-up thread-seconds per second of solve-only rate' % len(seqs)}
-            # (b) the same file to file ("I/O-inclusive figure reported separately"): chd_phys_solve_dirs on 1 024 directories of the workload
+            # (b) the same file to file ("I/O-inclusive figure reported separately"): chd_phys_solve_dirs on the workload's directories
             import tempfile
             import shutil
             from chd_amd import io_formats as iof
-            nd = min(1024, len(seqs))
+            nd = len(seqs)                                                # the SAME sequences as `value` (until round 5: the first 1 024 -- four per compute unit, whose tail was mistaken for an I/O cost)
             root = tempfile.mkdtemp(prefix='chd_bench_dirs_')
             try:
                 ins, outs_ = [], []

@@ -29,6 +29,31 @@
 
 using namespace chd;
 
+// ---- roctx ranges (SURVEY 5 "tracing"): the host phases of a call -- table build, upload + launch, wait / fallback, fetch, file output -- show up as named
+// ranges on rocprofv3's marker track (`rocprofv3 --marker-trace --kernel-trace`), next to the kernel launches they surround.  The marker library is looked
+// up at run time (no link dependency): without it the ranges are no-ops.
+#ifndef CHD_HOST_EMU
+#include <dlfcn.h>
+namespace {
+struct RoctxApi {
+  int (*push)(const char*) = nullptr; int (*pop)() = nullptr;
+  RoctxApi() {
+    void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_LAZY | RTLD_LOCAL);
+    if (!h) h = dlopen("libroctx64.so", RTLD_LAZY | RTLD_LOCAL);
+    if (h) { push = (int (*)(const char*))dlsym(h, "roctxRangePushA"); pop = (int (*)())dlsym(h, "roctxRangePop"); if (!push || !pop) push = nullptr; }
+  }
+};
+RoctxApi& roctx_api() { static RoctxApi a; return a; }
+}  // namespace
+struct TraceRange {
+  bool on;
+  explicit TraceRange(const std::string& name) : on(roctx_api().push != nullptr) { if (on) roctx_api().push(name.c_str()); }
+  ~TraceRange() { if (on) roctx_api().pop(); }
+};
+#else
+struct TraceRange { explicit TraceRange(const std::string&) {} };
+#endif
+
 #define CHD_MAX_THREADS 512
 
 // A launch is persistent: `grid` resident workgroups (one per compute unit: a workgroup needs the whole LDS) take sequence
@@ -732,7 +757,7 @@ static int solve_pipelined(chd_handle* h, int B, const chd_seq_in* in, chd_seq_o
     double t0 = now_ms();
     prep(c.c0, c.c1);
     prep_ms += now_ms() - t0; t0 = now_ms();
-    c.b = batch_build(h->cfg, n, in + c.c0, nt);
+    { TraceRange tr("chd set-up: tables of chunk " + std::to_string(k) + " (" + std::to_string(n) + " sequences)"); c.b = batch_build(h->cfg, n, in + c.c0, nt); }
     build_wall_ms += now_ms() - t0;
     c.t_built = now_ms() - t_begin;
     h->call.setup_cpu_ms += c.b->build_cpu_ms;
@@ -773,9 +798,10 @@ static int solve_pipelined(chd_handle* h, int B, const chd_seq_in* in, chd_seq_o
       rc = ensure_workspace(h, c.b->wd_need, c.b->wi_need, 2);
     }
     c.t_step[1] = now_ms() - t_begin;
+    { TraceRange tr("chd upload + launch: chunk " + std::to_string(k) + " on lane " + std::to_string(pool));
     if (rc == 0) rc = batch_to_device(h, c.b, pool, true);
     c.t_step[2] = now_ms() - t_begin;
-    if (rc == 0) rc = solve_launch_main(h, c.b);
+    if (rc == 0) rc = solve_launch_main(h, c.b); }
     upload_ms += now_ms() - t0;
     c.t_launched = now_ms() - t_begin;
     if (rc != 0) {
@@ -790,15 +816,16 @@ static int solve_pipelined(chd_handle* h, int B, const chd_seq_in* in, chd_seq_o
       h->call.finish_ms += 1.0;
 #endif
       tl_err_sink = &c.err;               // (error text of this thread's calls goes to the chunk; the handle itself is shared: this thread owns its lane's result / scratch staging until device_done)
-      int rc2 = solve_finish(h, c.b);
+      int rc2;
+      { TraceRange tr("chd finisher: wait for the launch, stage-4 fallback (" + std::to_string(c.c1 - c.c0) + " sequences)"); rc2 = solve_finish(h, c.b); }
       c.t_solved = now_ms() - t_begin;
-      if (rc2 == 0) rc2 = batch_fetch(h, c.b, out + c.c0);
+      if (rc2 == 0) { TraceRange tr("chd finisher: fetch results"); rc2 = batch_fetch(h, c.b, out + c.c0); }
       c.t_fetched = now_ms() - t_begin;
       { std::lock_guard<std::mutex> lk(c.mu); c.device_done = true; }          // (the pool's buffers are free again: the results are on the host)
       c.cv.notify_all();
       tl_err_sink = nullptr;
       if (rc2 != 0) { c.rc = -1; return; }
-      fin(c.c0, c.c1);
+      { TraceRange tr("chd finisher: output files"); fin(c.c0, c.c1); }
       c.t_finished = now_ms() - t_begin;
       std::lock_guard<std::mutex> lk(agg_mu);
       ++n_solved_chunks;
@@ -938,6 +965,7 @@ int chd_batch_upload(chd_handle* h, int B, const chd_seq_in* in, chd_batch** out
 int chd_batch_solve(chd_handle* h, chd_batch* b) {
   if (!h || !b) return fail(h, "chd_batch_solve: bad arguments");
   HIP_TRY(h, hipSetDevice(h->device));
+  TraceRange tr("chd_batch_solve (" + std::to_string(b->B) + " sequences)");
   if (ensure_workspace(h, b->wd_need, b->wi_need) != 0) return -1;
   if (solve_launch_main(h, b) != 0) return -1;
   return solve_finish(h, b);
@@ -977,7 +1005,8 @@ int chd_phys_solve_dirs(chd_handle* h, int B, const char* const* in_dirs, const 
   // (the token count of the four files is not known before they are parsed: every directory is read once, here, in parallel -- ~1 ms each -- and the
   //  pipeline below starts with the table builder.  Reading is `prep` for the accounting.)
   const double t_read0 = now_ms();
-  host_parallel_for(B, [&](int i) { readable[i] = io::read_inputs(in_dirs[i], nframes[i], files[i], errs[i]) ? 1 : 0; });
+  { TraceRange tr("chd read input files (" + std::to_string(B) + " directories)");
+  host_parallel_for(B, [&](int i) { readable[i] = io::read_inputs(in_dirs[i], nframes[i], files[i], errs[i]) ? 1 : 0; }); }
   const double read_ms = now_ms() - t_read0;
   std::vector<int> good;
   std::string first_err;
