@@ -282,16 +282,24 @@ def kinematic_optimisation_rate(device_index, n_clips=256, frames=100):
     worst = max(float(np.linalg.norm(r['pose3d'] - g['c%d_out_pose3d' % ci]) / np.linalg.norm(g['c%d_out_pose3d' % ci])) for ci, r in enumerate(res))
     contacts_equal = all(np.array_equal(r['velConstraints'], g['c%d_out_vel' % ci]) for ci, r in enumerate(res))
     clips = [make_kin_clip(s, frames, g['c0_skel_offsets'], g['c0_skel_parents']) for s in range(n_clips)]
-    ms = []
+    ms = []; spans = []
     solve = opt.kin.solve
 
     def timed(problems):
         r = solve(problems)
-        ms.append(opt.kin.last_kernel_ms())
+        k = opt.kin.last_kernel_ms()                     # (thread-local in the library: this thread's launch)
+        t1_ = time.perf_counter()
+        ms.append(k); spans.append((t1_ - k * 1e-3, t1_))
         return r
 
     opt.kin.solve = timed
     t0 = time.perf_counter(); out = opt.optimize(clips); dt = time.perf_counter() - t0
+    # up to 256 clips run as two halves on two host threads whose launches overlap on the device: the kernels' time is the UNION of their intervals
+    spans.sort(); busy = 0.0; end = -1e300
+    for a_, b_ in spans:
+        if b_ > end:
+            busy += b_ - max(a_, end); end = b_
+    kin_s = busy
     its = float(np.mean([sum(s['lsmr_iterations'] for s in r['stages']) for r in out]))
     n, m = 87 * frames, 507 * frames - 423
     alg = 8.0 * (2 * m + 8 * n + 2 * 420 * frames) * its * n_clips          # bytes per LSMR iteration x iterations
@@ -306,8 +314,10 @@ def kinematic_optimisation_rate(device_index, n_clips=256, frames=100):
         pass
     return {'clips': n_clips, 'frames': frames, 'clips_per_s': n_clips / dt, 'least_squares_kernel_ms': ms, 'ik_kernel_ms': opt.ik.last_kernel_ms()[0],
             'lsmr_iterations_per_clip': its, 'algorithmic_bytes_per_batch': alg,
-            'roofline': {'bound': 'hbm', 'kernel': 'chd_kin_solve_kernel', 'achieved': alg / (sum(ms) * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': alg / (sum(ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_note': tnote},
+            'least_squares_kernel_seconds_union': kin_s,
+            'roofline': {'bound': 'hbm', 'kernel': 'chd_kin_solve_kernel', 'achieved': alg / kin_s / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': alg / kin_s / 1e9 / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_note': tnote,
+                         'definition': 'algorithmic bytes of all LSMR iterations of all clips / time during which a least-squares launch was running (union over the overlapping launches of the two host threads)'},
             'fixture_worst_rel_l2_vs_reference': worst, 'fixture_contacts_equal_reference': bool(contacts_equal),
             'note': 'outside the timed region; the whole optimize() of %d clips x %d frames (IK initialisation, two least-squares solves, host floor fits)' % (n_clips, frames)}
 
