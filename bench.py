@@ -53,16 +53,23 @@ def _sources_sha256(files):
 def _gen(args):
     import chd_amd  # noqa: F401
     from chd_amd.synth import make_walk
-    seed0, n, frames = args
-    return [make_walk(seed=seed0 + i, F=frames, randomize=True) for i in range(n)]
+    seed0, n, frames = args[:3]
+    out = [make_walk(seed=seed0 + i, F=frames, randomize=True) for i in range(n)]
+    if len(args) > 3 and args[3]:                    # (the file-to-file side metric's input directories, written here: in parallel, before the timed regions)
+        from chd_amd import io_formats as iof
+        root, first = args[3], args[4]
+        for i, sq in enumerate(out):
+            iof.write_inputs(sq, os.path.join(root, 'v%05d' % (first + i), 'phys_optim_in_ybot'))
+            os.makedirs(os.path.join(root, 'v%05d' % (first + i), 'phys_optim_out_ybot'), exist_ok=True)
+    return out
 
 
-def make_sequences(seed0, n, workers, frames=FRAMES):
+def make_sequences(seed0, n, workers, frames=FRAMES, write_root=None):
     """Seeds seed0 .. seed0 + n - 1 (synth.make_walk is a Python loop over frames: spread over a few processes)."""
     if workers <= 1 or n < 64:
-        return _gen((seed0, n, frames))
+        return _gen((seed0, n, frames, write_root, 0))
     chunk = 32
-    parts = [(seed0 + a, min(chunk, n - a), frames) for a in range(0, n, chunk)]
+    parts = [(seed0 + a, min(chunk, n - a), frames, write_root, a) for a in range(0, n, chunk)]
     with mp.get_context('fork').Pool(workers) as pool:          # (forked before the HIP runtime is initialised)
         out = pool.map(_gen, parts)
     return [s for p in out for s in p]
@@ -372,7 +379,11 @@ def main(argv=None, solver_factory=None):
     steps = max(1, args.steps)
     workers = args.gen_workers if args.gen_workers > 0 else max(1, min(8, (os.cpu_count() or 1) // max(1, world)))
     seed0 = rank * steps * B
-    seqs = make_sequences(seed0, steps * B, workers, args.frames)         # before the HIP runtime exists in this process (fork)
+    dirs_root = None
+    if world == 1 and not args.no_side_metrics and solver_factory is None:
+        import tempfile
+        dirs_root = tempfile.mkdtemp(prefix='chd_bench_dirs_')          # inputs of the file-to-file side metric (removed at the end)
+    seqs = make_sequences(seed0, steps * B, workers, args.frames, dirs_root)         # before the HIP runtime exists in this process (fork)
 
     import torch
     import torch.distributed as dist
@@ -495,17 +506,12 @@ def main(argv=None, solver_factory=None):
                                        'note': 'chd_phys_solve_batch on the SAME %d sequences: table build on the host threads, upload, persistent launches (up to 4 chunks in flight), '
                                                'stage-4 fallbacks, fetch -- one call, wall clock; host_cores_to_keep_one_gpu_busy = set-up thread-seconds per second of solve-only rate' % len(seqs)}
             # (b) the same file to file ("I/O-inclusive figure reported separately"): chd_phys_solve_dirs on the workload's directories
-            import tempfile
             import shutil
-            from chd_amd import io_formats as iof
             nd = len(seqs)                                                # the SAME sequences as `value` (until round 5: the first 1 024 -- four per compute unit, whose tail was mistaken for an I/O cost)
-            root = tempfile.mkdtemp(prefix='chd_bench_dirs_')
+            root = dirs_root
             try:
-                ins, outs_ = [], []
-                for i in range(nd):
-                    d_in = os.path.join(root, 'v%05d' % i, 'phys_optim_in_ybot'); d_out = os.path.join(root, 'v%05d' % i, 'phys_optim_out_ybot')
-                    iof.write_inputs(seqs[i], d_in); os.makedirs(d_out)
-                    ins.append(d_in); outs_.append(d_out)
+                ins = [os.path.join(root, 'v%05d' % i, 'phys_optim_in_ybot') for i in range(nd)]
+                outs_ = [os.path.join(root, 'v%05d' % i, 'phys_optim_out_ybot') for i in range(nd)]
                 t1 = time.perf_counter(); stt = solver.solve_dirs(ins, outs_, [args.frames] * nd); dt_io = time.perf_counter() - t1
                 cs2 = solver.call_stats()
                 side['value_including_file_io'] = nd / dt_io
@@ -638,6 +644,9 @@ def main(argv=None, solver_factory=None):
         print(json.dumps(out), flush=True)
     batch.free()
     solver.close()
+    if dirs_root:
+        import shutil
+        shutil.rmtree(dirs_root, ignore_errors=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
