@@ -721,8 +721,9 @@ struct PipeChunk {
   std::mutex mu; std::condition_variable cv; bool device_done = false;
   double t_built = 0, t_launched = 0, t_solved = 0, t_fetched = 0, t_finished = 0, kernel_ms0 = 0, kernel_ms1 = 0, t_step[3] = {0, 0, 0};      // ms since the start of the call (CHD_PIPE_TRACE)
 };
+// (`caller_index`: position j of `in` is the caller's sequence caller_index[j] -- the call works through the batch in its own order, messages name the caller's)
 template <class Prep, class Fin>
-static int solve_pipelined(chd_handle* h, int B, const chd_seq_in* in, chd_seq_out* out, Prep prep, Fin fin) {
+static int solve_pipelined(chd_handle* h, int B, const chd_seq_in* in, chd_seq_out* out, Prep prep, Fin fin, const std::vector<int>* caller_index = nullptr) {
   HIP_TRY(h, hipSetDevice(h->device));
   const double t_begin = now_ms();
   h->call = chd_call_stats{};
@@ -761,7 +762,7 @@ static int solve_pipelined(chd_handle* h, int B, const chd_seq_in* in, chd_seq_o
     build_wall_ms += now_ms() - t0;
     c.t_built = now_ms() - t_begin;
     h->call.setup_cpu_ms += c.b->build_cpu_ms;
-    for (int i = 0; i < n; ++i) if (!c.b->ok[i]) { std::lock_guard<std::mutex> lk(agg_mu); first_err = "sequence " + std::to_string(c.c0 + i) + " rejected: " + c.b->build_err[i]; }
+    for (int i = 0; i < n; ++i) if (!c.b->ok[i]) { std::lock_guard<std::mutex> lk(agg_mu); first_err = "sequence " + std::to_string(caller_index ? (*caller_index)[c.c0 + i] : c.c0 + i) + " rejected: " + c.b->build_err[i]; }
     const int pool = k % n_pools;
     t0 = now_ms();
     if (k >= n_pools) {            // the pool's previous launch (and its fallback) must be over
@@ -984,9 +985,26 @@ int chd_batch_fetch(chd_handle* h, chd_batch* b, chd_seq_out* out) {
   return batch_fetch(h, b, out);
 }
 
+// The order a whole call works through its sequences: longest first, and among equal lengths the ones with the most contact phases first -- over the WHOLE batch, before it is cut into
+// chunks.  (Until round 5 only each chunk's own queue was ordered: the expensive sequences of the last chunk started last, and the call's tail was theirs.)  Both keys are in the
+// inputs; no table has to be built for them.
+static std::vector<int> call_order(int B, const chd_seq_in* in) {
+  std::vector<int> perm(B);
+  for (int i = 0; i < B; ++i) perm[i] = i;
+  if (std::getenv("CHD_CALL_ORDER_OFF")) return perm;          // (A/B switch of the study in profiles/r05_experiments.md)
+  auto phases = [&](int i) { return in[i].n_phases[0] + in[i].n_phases[1] + in[i].n_phases[2] + in[i].n_phases[3]; };
+  std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { if (in[a].F != in[b].F) return in[a].F > in[b].F; return phases(a) > phases(b); });
+  return perm;
+}
+
 int chd_phys_solve_batch(chd_handle* h, int B, const chd_seq_in* in, chd_seq_out* out) {
   if (!h || !in || !out || B <= 0) return fail(h, "chd_phys_solve_batch: bad arguments");
-  return solve_pipelined(h, B, in, out, [](int, int) {}, [](int, int) {});
+  const std::vector<int> perm = call_order(B, in);
+  std::vector<chd_seq_in> in_p(B); std::vector<chd_seq_out> out_p(B);
+  for (int j = 0; j < B; ++j) { in_p[j] = in[perm[j]]; out_p[j] = out[perm[j]]; }          // (the snapshot arrays are the caller's: results land there directly)
+  const int rc = solve_pipelined(h, B, in_p.data(), out_p.data(), [](int, int) {}, [](int, int) {}, &perm);
+  for (int j = 0; j < B; ++j) out[perm[j]] = out_p[j];
+  return rc;
 }
 
 int chd_phys_get_call_stats(chd_handle* h, chd_call_stats* out) {
@@ -1018,6 +1036,13 @@ int chd_phys_solve_dirs(chd_handle* h, int B, const char* const* in_dirs, const 
   std::vector<chd_seq_in> in(good.size());
   std::vector<chd_seq_out> out(good.size());
   std::vector<io::SnapStore> store(good.size());
+  for (size_t k = 0; k < good.size(); ++k) files[good[k]].fill(in[k]);
+  {          // the call's order over the whole batch (call_order): `good` is the only index everything below goes through
+    const std::vector<int> perm = call_order((int)good.size(), in.data());
+    std::vector<int> g2(good.size());
+    for (size_t j = 0; j < good.size(); ++j) g2[j] = good[perm[j]];
+    good.swap(g2);
+  }
   for (size_t k = 0; k < good.size(); ++k) {
     files[good[k]].fill(in[k]);
     store[k].bind(out[k], nframes[good[k]] + 4);
@@ -1035,7 +1060,7 @@ int chd_phys_solve_dirs(chd_handle* h, int B, const char* const* in_dirs, const 
     });
     write_us += (long long)((now_ms() - t0) * 1e3);
   };
-  int rc = solve_pipelined(h, (int)good.size(), in.data(), out.data(), [](int, int) {}, fin);
+  int rc = solve_pipelined(h, (int)good.size(), in.data(), out.data(), [](int, int) {}, fin, &good);
   h->call.prep_ms += read_ms; h->call.wall_ms += read_ms; h->call.finish_ms = write_us.load() * 1e-3;
   if (rc != 0) return rc;
   if (first_err.empty()) first_err = h->err;           // a sequence rejected at set-up (the rest was solved)
