@@ -588,6 +588,7 @@ def main(argv=None, solver_factory=None):
                          'definition': 'sum over sequences of SURVEY 8(d) bytes_iter x IPM iterations / wall time of the timed region / (8 TB/s x GPUs)',
                          'algorithmic_bytes_per_step': alg_bytes_all / steps / world, 'algorithmic_bytes_per_iteration': alg_bytes / max(1, iters),
                          'traffic': traffic, 'traffic_raw': traffic_raw, 'traffic_note': traffic_note, 'sq_wait_any_fraction': wait_frac, 'kernel': 'chd_solve_kernel',
+                         'achieved_over_kernel_events_rank0': alg_bytes / max(1e-9, kernel_ms * 1e-3) / 1e9,      # rank 0's algorithmic bytes / its launches' duration by the library's HIP events (main + fallback launch) -- agrees with `achieved` (wall clock, all ranks) to the launch overhead
                          'launches': 1 + (1 if st['kernel_ms'][1] > 0 else 0), 'kernel_ms_rank0': kernel_ms, 'fallback_launch_ms_rank0': st['kernel_ms'][1],
                          'kernel_busy_fraction': st['phase_ms'][5] / max(1e-9, st['n_workgroups'] * kernel_ms),
                          'fp64_mfma': mfma},
