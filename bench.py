@@ -64,6 +64,24 @@ def _gen(args):
     return out
 
 
+def _gen_seeds(args):
+    import chd_amd  # noqa: F401
+    from chd_amd.synth import make_walk
+    seeds, frames = args
+    return [make_walk(seed=sd, F=frames, randomize=True) for sd in seeds]
+
+
+def make_sequences_of(seeds, workers, frames=FRAMES):
+    """The sequences of an explicit seed list (a rank's shard of the strong-scaling leg), generated on `workers` processes, order preserved."""
+    seeds = list(seeds)
+    if workers <= 1 or len(seeds) < 64:
+        return _gen_seeds((seeds, frames))
+    parts = [(seeds[a:a + 32], frames) for a in range(0, len(seeds), 32)]
+    with mp.get_context('spawn').Pool(workers) as pool:          # (spawn: the HIP runtime exists in this process by now)
+        out = pool.map(_gen_seeds, parts)
+    return [s for p in out for s in p]
+
+
 def make_sequences(seed0, n, workers, frames=FRAMES, write_root=None):
     """Seeds seed0 .. seed0 + n - 1 (synth.make_walk is a Python loop over frames: spread over a few processes)."""
     if workers <= 1 or n < 64:
@@ -440,15 +458,7 @@ def main(argv=None, solver_factory=None):
     if args.strong_total > 0:
         from chd_amd.sharding import lpt_assign
         mine = lpt_assign([args.frames] * args.strong_total, world)[rank]
-        runs = []                                                 # contiguous seed runs of this rank's shard
-        for i in mine:
-            if runs and runs[-1][0] + runs[-1][1] == i:
-                runs[-1][1] += 1
-            else:
-                runs.append([i, 1])
-        sseqs = []
-        for a, cnt in runs:
-            sseqs += make_sequences(1000000 + a, cnt, 1 if len(runs) > 8 else workers, args.frames)
+        sseqs = make_sequences_of([1000000 + i for i in mine], workers if solver_factory is None else 1, args.frames)
         sb = solver.upload(sseqs)
         barrier()
         t1 = time.perf_counter()
