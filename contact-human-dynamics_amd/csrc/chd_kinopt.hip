@@ -1,8 +1,11 @@
 // chd_kinopt.hip -- C ABI of the kinematic optimisation's least-squares solves (include/chd_kinopt.h) on HIP / gfx950.
-// One workgroup of 512 threads per (video, stage) problem runs the whole trust-region solve (chd_kinopt_kernels.hpp);
-// the host packs the batch into three pools (constants, contacts, start points) and allocates one workspace per video.
+// A cluster of G = ceil(frames / 13) workgroups of 512 threads per (video, stage) problem runs the whole trust-region solve with LSMR's state in
+// the LDS of its G compute units (chd_kinopt_kernels.hpp); the host packs the batch into three pools (constants, contacts, start points), allocates
+// one workspace per video and launches one persistent grid per cluster size.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <mutex>
 #include <string>
 
 #include "chd_kinopt_host.hpp"
@@ -18,23 +21,43 @@ int fail(const std::string& what, hipError_t e = hipSuccess) {
 }
 }  // namespace
 
-// waves per SIMD the register budget is set for: 2 = one 512-thread workgroup per compute unit with up to 256 VGPRs,
-// 4 = two resident workgroups with up to 128 each
-#ifndef CHD_KIN_WAVES_PER_EU
-#define CHD_KIN_WAVES_PER_EU 2
-#endif
-__global__ void __launch_bounds__(512, CHD_KIN_WAVES_PER_EU) chd_kin_solve_kernel(const KinSeq* seqs, KinParams P, const double* dpool, const int* ipool, double* work,
-                                                            double* state, double* stats, int lds_doubles) {
-  extern __shared__ double tile[];              // the products' frame tiles
-  __shared__ double red[48];
+// One workgroup of 512 threads per compute unit (up to 256 VGPRs, the LDS block below), persistent: consecutive workgroups form clusters of G, each cluster
+// takes clips from the launch's queue until it is empty.  ALL workgroups of a launch must be resident at once -- the members of a cluster spin on each other's
+// flags (chd_kinopt_kernels.hpp, kc_sync) -- so the host sizes the grid by the device's occupancy for this kernel and never has two launches in flight.
+__global__ void __launch_bounds__(512, 2) chd_kin_solve_kernel(const KinSeq* seqs, const int* order, int n_clips, KinParams P, const double* dpool, const int* ipool, double* work,
+                                                               double* state, double* stats, KinSlot* slots, int* queue, int G, int lds_doubles) {
+  extern __shared__ double lds[];               // received halos + the slice's share of LSMR's state (kin_bind_wg)
+  __shared__ double red[16 * KC_PARTS], gath[KC_MAXG * KC_PARTS];
   __shared__ KinParams Ps;
+  __shared__ KinClip clip;
+  __shared__ KinWg wg;
+  __shared__ KinLsmr lsmr;
   if (threadIdx.x == 0) Ps = P;
   __syncthreads();
   KinCtx c;
-  const KinSeq* q = seqs + blockIdx.x;
-  kin_bind(c, q, &Ps, dpool, ipool, work, red, tile, lds_doubles);
-  kin_solve(c, state + q->o_x, stats + 8 * blockIdx.x);
+  const int cluster = blockIdx.x / G, g = blockIdx.x % G;
+  c.slots = slots + (size_t)cluster * G; c.epoch = 0; c.G = G;
+  c.red = (KO_LDSQ double*)red; c.gath = (KO_LDSQ double*)gath; c.P = (const KO_LDSQ KinParams*)&Ps; c.k = (KO_LDSQ KinClip*)&clip; c.wg = (KO_LDSQ KinWg*)&wg; c.S = (KO_LDSQ KinLsmr*)&lsmr;
+  if (threadIdx.x == 0) wg.g = g;
+  __syncthreads();
+  kin_lane_tables(c);
+  for (;;) {
+    KoAcc pick[1][KC_PARTS];                    // the cluster's first thread draws a clip; the number reaches the others as a "sum"
+    if (g == 0 && threadIdx.x == 0) pick[0][0].s = (double)atomicAdd(queue, 1);
+    kc_sync(c, pick, 1);
+    const int idx = (int)kc_sum(c, 0);
+    if (idx >= n_clips) break;
+    const int b = order[idx];
+    if (threadIdx.x == 0) {
+      kin_bind_clip(*c.k, seqs + b, dpool, ipool);
+      kin_bind_wg(c, *c.wg, g, work, lds, lds_doubles);
+    }
+    __syncthreads();
+    kin_solve(c, state + seqs[b].o_x, stats + (size_t)KIN_STATS * b);
+  }
 }
+
+static std::mutex g_launch_mutex;               // one spinning launch on the device at a time (per process)
 
 extern "C" {
 
@@ -50,19 +73,20 @@ int chd_kin_solve_batch(const chd_kin_config* cfg, int device, int B, chd_kin_se
   if (device < 0 || device >= ndev) return fail("device index out of range");
   hipError_t e;
   if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
-  {   // LDS doubles per workgroup (default 18 432 = 144 KB, or reserved[1]): the product passes address 3 * 84 * (TF + 2) doubles with TF >= 1 (kin_jv) and 336 (kin_jtu).
-      // The default is checked against the device like an explicit value: a device / partition mode with less LDS fails here with a message, not in the launch.
-    int lds_max = 0;
-    if ((e = hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device)) != hipSuccess) return fail("hipDeviceGetAttribute", e);
-    const long long want = cfg->reserved[1] > 0 ? cfg->reserved[1] : 18432;
-    if (want < 756 || want * 8 > lds_max) return fail(cfg->reserved[1] > 0 ? "reserved[1] (LDS doubles per workgroup) out of range: 756 .. device limit" : "the device offers less than the 144 KB of LDS per workgroup the default frame tiles need: set reserved[1] (LDS doubles per workgroup, >= 756)");
+  int lds_max = 0, n_cu = 0;
+  if ((e = hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device)) != hipSuccess) return fail("hipDeviceGetAttribute", e);
+  if ((e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return fail("hipDeviceGetAttribute", e);
+  {   // LDS doubles per workgroup (default 19 968 = 156 KB, or reserved[1]), checked against the device like an explicit value: a device / partition mode with
+      // less LDS fails here with a message, not in the launch
+    const long long want = cfg->reserved[1] > 0 ? cfg->reserved[1] : (long long)KIN_LDS_DOUBLES_DEFAULT;
+    if (want < HALO_V + KC_HALO || want * 8 + 4608 > lds_max) return fail(cfg->reserved[1] > 0 ? "reserved[1] (LDS doubles per workgroup) out of range: 598 .. device limit - 128" : "the device offers less than the 157 KB of LDS per workgroup the default slices need: set reserved[1] (LDS doubles per workgroup, >= 598)");
   }
   KinBatch bt;
   if (!bt.build(cfg, B, in)) return fail(bt.err);
   // Everything of a call is ordered on a stream of its own (stream-ordered allocations, asynchronous copies, one synchronisation at the
   // end): two host threads can keep the device busy back to back -- with the default stream and hipDeviceSynchronize each call would also
   // wait for the other thread's kernel, and the host steps of the two would fall into lockstep (kinematic_optimizer.KinematicOptimizer.optimize)
-  KinSeq* d_seqs = nullptr; double *d_dp = nullptr, *d_work = nullptr, *d_state = nullptr, *d_stats = nullptr; int* d_ip = nullptr;
+  KinSeq* d_seqs = nullptr; double *d_dp = nullptr, *d_work = nullptr, *d_state = nullptr, *d_stats = nullptr; int *d_ip = nullptr, *d_order = nullptr; KinSlot* d_slots = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t st = nullptr;
   if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
@@ -73,9 +97,9 @@ int chd_kin_solve_batch(const chd_kin_config* cfg, int device, int B, chd_kin_se
     return r;
   };
   auto release = [&]() {
-    for (void* p : {(void*)d_seqs, (void*)d_dp, (void*)d_work, (void*)d_state, (void*)d_stats, (void*)d_ip}) if (p && pool_ok) (void)hipFreeAsync(p, st);
+    for (void* p : {(void*)d_seqs, (void*)d_dp, (void*)d_work, (void*)d_state, (void*)d_stats, (void*)d_ip, (void*)d_order, (void*)d_slots}) if (p && pool_ok) (void)hipFreeAsync(p, st);
     (void)hipStreamSynchronize(st);
-    if (!pool_ok) for (void* p : {(void*)d_seqs, (void*)d_dp, (void*)d_work, (void*)d_state, (void*)d_stats, (void*)d_ip}) if (p) (void)hipFree(p);
+    if (!pool_ok) for (void* p : {(void*)d_seqs, (void*)d_dp, (void*)d_work, (void*)d_state, (void*)d_stats, (void*)d_ip, (void*)d_order, (void*)d_slots}) if (p) (void)hipFree(p);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     (void)hipStreamDestroy(st);
@@ -86,28 +110,54 @@ int chd_kin_solve_batch(const chd_kin_config* cfg, int device, int B, chd_kin_se
   KIN_TRY(dmalloc((void**)&d_ip, sizeof(int) * bt.ipool.size()), "hipMalloc contacts");
   KIN_TRY(dmalloc((void**)&d_work, sizeof(double) * (size_t)bt.work_total), "hipMalloc workspace");
   KIN_TRY(dmalloc((void**)&d_state, sizeof(double) * bt.state.size()), "hipMalloc state");
-  KIN_TRY(dmalloc((void**)&d_stats, sizeof(double) * 8 * (size_t)B), "hipMalloc statistics");
+  KIN_TRY(dmalloc((void**)&d_stats, sizeof(double) * KIN_STATS * (size_t)B), "hipMalloc statistics");
   KIN_TRY(hipMemcpyAsync(d_seqs, bt.seqs.data(), sizeof(KinSeq) * bt.seqs.size(), hipMemcpyHostToDevice, st), "copy descriptors");
   KIN_TRY(hipMemcpyAsync(d_dp, bt.dpool.data(), sizeof(double) * bt.dpool.size(), hipMemcpyHostToDevice, st), "copy constants");
   KIN_TRY(hipMemcpyAsync(d_ip, bt.ipool.data(), sizeof(int) * bt.ipool.size(), hipMemcpyHostToDevice, st), "copy contacts");
   KIN_TRY(hipMemcpyAsync(d_state, bt.state.data(), sizeof(double) * bt.state.size(), hipMemcpyHostToDevice, st), "copy start points");
-  KIN_TRY(hipMemsetAsync(d_stats, 0, sizeof(double) * 8 * (size_t)B, st), "clear statistics");
+  KIN_TRY(hipMemsetAsync(d_stats, 0, sizeof(double) * KIN_STATS * (size_t)B, st), "clear statistics");
+  // 512 threads per workgroup (one (frame, joint) item per thread for slices of up to 16 frames); results are bitwise reproducible for fixed
+  // reserved[] values (fixed reduction trees) and independent of the batch a clip is in
+  const int nthreads = 512;
+  const int lds_doubles = bt.lds_doubles;
+  KIN_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chd_kin_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * lds_doubles)), "hipFuncSetAttribute");
+  int per_cu = 0;
+  KIN_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chd_kin_solve_kernel, nthreads, sizeof(double) * (size_t)lds_doubles), "hipOccupancyMaxActiveBlocksPerMultiprocessor");
+  const long long resident = (long long)per_cu * n_cu;
+  if (resident < KC_MAXG) { release(); return fail("the device cannot hold a cluster of 16 workgroups of this kernel resident"); }
+  // the clips of a call by cluster size: one launch per size, in one order buffer; slots and queue counters of all launches cleared up front
+  std::vector<int> order; std::vector<long long> grid;
+  for (const KinGroup& g : bt.groups) {
+    long long clusters = resident / g.G;
+    if (clusters > (long long)g.clips.size()) clusters = (long long)g.clips.size();
+    grid.push_back(clusters * g.G);
+    order.insert(order.end(), g.clips.begin(), g.clips.end());
+  }
+  long long slots_total = 0;
+  for (long long g : grid) slots_total += g;
+  KIN_TRY(dmalloc((void**)&d_order, sizeof(int) * (order.size() + bt.groups.size())), "hipMalloc clip order");
+  KIN_TRY(dmalloc((void**)&d_slots, sizeof(KinSlot) * (size_t)slots_total), "hipMalloc cluster slots");
+  KIN_TRY(hipMemcpyAsync(d_order, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice, st), "copy clip order");
+  KIN_TRY(hipMemsetAsync(d_order + order.size(), 0, sizeof(int) * bt.groups.size(), st), "clear queues");
+  KIN_TRY(hipMemsetAsync(d_slots, 0, sizeof(KinSlot) * (size_t)slots_total, st), "clear cluster slots");
   KIN_TRY(hipEventCreate(&ev0), "hipEventCreate");
   KIN_TRY(hipEventCreate(&ev1), "hipEventCreate");
-  KIN_TRY(hipEventRecord(ev0, st), "hipEventRecord");
-  // 512 threads: measured against 256 and 1024 (profiles/r02h_kinopt/sweep.md); results are bitwise reproducible for a fixed
-  // workgroup size (fixed reduction trees) and move at the solve's own sensitivity level when it changes
-  const int nthreads = cfg->reserved[0] == 256 ? 256 : 512;
-  // 144 KB of LDS per workgroup: tiles of 71 frames for J v, 54 for J^T u.  (The kernel's 256 VGPRs allow one 512-thread workgroup
-  // per compute unit anyway; against 72 KB the larger tiles halve the number of phases and barriers per product: 2.54 -> 2.32 s of
-  // least-squares kernels for 256 clips x 100 frames.  A 128-VGPR build with two resident workgroups was measured too: 3.45 s.)
-  const int lds_doubles = cfg->reserved[1] > 0 ? cfg->reserved[1] : 18432;
-  KIN_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chd_kin_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * lds_doubles)), "hipFuncSetAttribute");
-  (void)hipGetLastError();      // an error another library of the process left behind in this thread is not this launch's
-  hipLaunchKernelGGL(chd_kin_solve_kernel, dim3((unsigned)B), dim3((unsigned)nthreads), sizeof(double) * (size_t)lds_doubles, st, d_seqs, bt.P, d_dp, d_ip, d_work, d_state, d_stats, lds_doubles);
-  KIN_TRY(hipGetLastError(), "launch");
-  KIN_TRY(hipEventRecord(ev1, st), "hipEventRecord");
-  std::vector<double> fin(bt.state.size()), stats(8 * (size_t)B);
+  {
+    std::lock_guard<std::mutex> only_one(g_launch_mutex);
+    KIN_TRY(hipEventRecord(ev0, st), "hipEventRecord");
+    (void)hipGetLastError();      // an error another library of the process left behind in this thread is not this launch's
+    size_t o_order = 0, o_slot = 0;
+    for (size_t k = 0; k < bt.groups.size(); ++k) {
+      const KinGroup& g = bt.groups[k];
+      hipLaunchKernelGGL(chd_kin_solve_kernel, dim3((unsigned)grid[k]), dim3((unsigned)nthreads), sizeof(double) * (size_t)lds_doubles, st, d_seqs, d_order + o_order, (int)g.clips.size(), bt.P,
+                         d_dp, d_ip, d_work, d_state, d_stats, d_slots + o_slot, d_order + order.size() + k, g.G, lds_doubles);
+      KIN_TRY(hipGetLastError(), "launch");
+      o_order += g.clips.size(); o_slot += (size_t)grid[k];
+    }
+    KIN_TRY(hipEventRecord(ev1, st), "hipEventRecord");
+    KIN_TRY(hipEventSynchronize(ev1), "synchronize");
+  }
+  std::vector<double> fin(bt.state.size()), stats((size_t)KIN_STATS * B);
   KIN_TRY(hipMemcpyAsync(fin.data(), d_state, sizeof(double) * fin.size(), hipMemcpyDeviceToHost, st), "copy solutions");
   KIN_TRY(hipMemcpyAsync(stats.data(), d_stats, sizeof(double) * stats.size(), hipMemcpyDeviceToHost, st), "copy statistics");
   KIN_TRY(hipStreamSynchronize(st), "synchronize");
@@ -115,6 +165,15 @@ int chd_kin_solve_batch(const chd_kin_config* cfg, int device, int B, chd_kin_se
   KIN_TRY(hipEventElapsedTime(&ms, ev0, ev1), "hipEventElapsedTime");
 #undef KIN_TRY
   bt.scatter(fin.data(), stats.data(), in);
+#ifdef KIN_PROFILE
+  {
+    double seg[16] = {0}, tot = 0, its = 0;
+    for (int b = 0; b < B; ++b) { for (int k = 0; k < 16; ++k) { seg[k] += stats[(size_t)KIN_STATS * b + 8 + k]; tot += stats[(size_t)KIN_STATS * b + 8 + k]; } its += stats[(size_t)KIN_STATS * b + 4]; }
+    fprintf(stderr, "KIN_PROFILE %d clips, %.0f LSMR iterations, ticks per iteration:", B, its);
+    for (int k = 0; k < 12; ++k) fprintf(stderr, " [%d] %.0f", k, seg[k] / its);
+    fprintf(stderr, " total %.0f\n", tot / its);
+  }
+#endif
   release();
   g_kernel_ms = ms;
   g_err.clear();

@@ -1,11 +1,30 @@
-// chd_kinopt_kernels.hpp -- one `least_squares` solve of the kinematic optimisation for one video, one workgroup.
+// chd_kinopt_kernels.hpp -- one `least_squares` solve of the kinematic optimisation for one video, on a CLUSTER of workgroups.
 //
 // Reference: optimize_trajectory.py:660-670 / :779-789 --
 //     least_squares(fun_anim_for_projection, x0, jac=jac_anim_for_projection_sparse, max_nfev=50, gtol=1e-12, tr_solver='lsmr')
 // i.e. SciPy's trust-region-reflective method without bounds in its 2-D subspace form (`trf_no_bounds`: Gauss-Newton direction
 // from LSMR with the Cauchy-step regularisation, trust-region problem in span{g, gn}) on the residual of :324-483 with the
-// Jacobian of :51-322.  The same source is compiled by hipcc for gfx950 (one workgroup of KO_NT threads per video) and by g++
-// with -DCHD_HOST_EMU (one emulated thread) for the CPU tests.
+// Jacobian of :51-322.  The same source is compiled by hipcc for gfx950 and by g++ with -DCHD_HOST_EMU (the workgroups of a cluster
+// emulated one after the other, phase by phase) for the CPU tests.
+//
+// Layout on the device (round 5).  Every row of the residual and every product touches the unknowns of at most three consecutive
+// frames, and LSMR's state for one frame -- u (507 rows), v, h, the linearisation (positions, axes, projection coefficients: 420 doubles)
+// and the products' per-joint intermediates -- is 1 353 doubles.  A 100-frame clip does not fit one compute unit's LDS; thirteen frames do.
+// So a clip is solved by G = ceil(F / 13) workgroups (one per compute unit) that each OWN a run of consecutive frames:
+//   * everything LSMR touches per iteration lives in the owner's LDS for the whole solve (flat pointers: the same code runs on a
+//     slice in device memory when a clip is too long for 16 workgroups); the vectors only the outer iteration needs (x, g, the
+//     residual, J g ...) are the owner's slices of device-memory arrays that no other workgroup ever touches;
+//   * a workgroup handles (frame, joint) items of its slice, one per thread: no tile loop, each phase is one LDS round trip;
+//   * what crosses a slice boundary is small and goes through one slot per workgroup in device memory: the two products need v of the
+//     two frames AFTER the slice (174 doubles, from the right neighbour) and the smoothness / contact / Euler rows of u of the two
+//     frames BEFORE it (423 doubles, from the left neighbour); every norm is a sum of G partial sums;
+//   * LSMR therefore synchronises the cluster twice per iteration -- after the rows of u are written (|u|, u halo) and after v is
+//     (|v|, v halo, and the three dot products that give |x| without a third round) -- by a flag all-gather: payload and flag are
+//     written and read with agent-scope relaxed atomics (`sc1`: write-through / read at the memory side) between workgroup-scope
+//     fences.  A release / acquire pair at agent scope costs 17 us on this part (L2 write-back + invalidate), this costs 2-3
+//     (tests/tools/cluster_sync_probe.hip, profiles/r05_experiments.md section 7);
+//   * a launch is persistent: as many clusters as the device holds resident (all workgroups of a cluster MUST be resident: they
+//     spin on each other), each taking clips from a queue.  Clips of 13 frames or fewer are a cluster of one: no device-memory traffic at all.
 //
 // What is different from the reference, all exact in real arithmetic:
 //  * the Jacobian is never formed (the reference allocates rows x (84 F) and rows x (87 F) dense arrays: 3.4 GB + 3.5 GB for
@@ -13,13 +32,14 @@
 //    cross(axis_{j,a}, p_t - p_j) for joint j an ancestor of t (InverseKinematics.py:192-230), so
 //        J v  : omega_j = sum_a v_{j,a} axis_{j,a};  dp_t = sum_{j anc t} omega_j x (p_t - p_j);  rows from dp
 //        J^T u: lambda_t from the rows;  (J^T u)_{j,a} = axis_{j,a} . sum_{t desc j} (p_t - p_j) x lambda_t
-//    with the linearisation (positions, axes, projection coefficients: 420 doubles per frame) cached per accepted point;
-//    both products run frame tile by frame tile through the workgroup's LDS block (kin_jv / kin_jtu), and LSMR's two half steps
-//    are fused into them (kin_lsmr): per iteration HBM sees U read + written, V / H / H-bar / x read + written and the
-//    linearisation read twice -- measured 0.8 .. 1.3 x that (profiles/r02k_final/kinopt_pmc.md);
-//  * every norm is a tree sum over the workgroup's 512 per-thread partial sums (KoAcc): with a single running sum per norm LSMR's
-//    iterate at its iteration limit drifts 5 % away from SciPy's and the solves end 1e-3 .. 3e-3 from the reference's
-//    instead of 1e-4 (tests/test_kinopt_emu.py);
+//    with the linearisation cached per accepted point;
+//  * rows are numbered frame by frame (507 per frame, the ones a clip's last frames do not have are kept at zero) instead of term by
+//    term: a permutation of the reference's residual vector, invisible in every quantity the solve uses;
+//  * every norm is a tree sum over the workgroup's 512 per-thread partial sums (KoAcc), then over the cluster in rank order: with a
+//    single running sum per norm LSMR's iterate at its iteration limit drifts 5 % away from SciPy's and the solves end
+//    1e-3 .. 3e-3 from the reference's instead of 1e-4 (tests/test_kinopt_emu.py);
+//  * |x| in LSMR's stopping test is sqrt(x.x + 2 k2 x.hbar + k2^2 hbar.hbar) from three dot products taken before the step length k2 is
+//    known (they ride on the synchronisation that yields it) instead of the norm of the updated x: equal up to rounding;
 //  * forward kinematics with rotation matrices instead of quaternions;
 //  * span{g, gn} is orthonormalised by Gram-Schmidt instead of Householder QR (same subspace, so the same step);
 //  * the boundary solution of the 2-D trust-region problem is found on the angle parametrisation (scan + bisection of the
@@ -43,6 +63,7 @@
 #define KO_NT 1
 #define KO_SYNC() ((void)0)
 #define KO_CONST static const
+#define KO_CLOCK() 0LL
 #else
 #include <hip/hip_runtime.h>
 #define KO_DEV __device__ inline
@@ -51,21 +72,46 @@
 #define KO_NT ((int)blockDim.x)
 #define KO_SYNC() __syncthreads()
 #define KO_CONST __constant__ const
-#endif
-#define KO_FOR(i, n) for (int i = KO_TID; i < (n); i += KO_NT)
-#ifdef CHD_HOST_EMU
-#define KO_CLOCK() 0LL
-#else
 #define KO_CLOCK() ((long long)wall_clock64())
 #endif
+#define KO_FOR(i, n) for (int i = KO_TID; i < (n); i += KO_NT)
+// between two steps in which the 32 lanes that share a frame exchange values through LDS: the frame's lanes are in one wavefront, whose LDS operations execute
+// in program order -- the compiler only has to keep them in that order
+#ifdef CHD_HOST_EMU
+#define KO_WSYNC() ((void)0)
+#else
+#define KO_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#endif
+// -DKIN_PROFILE: shader-clock ticks per segment of LSMR's iteration, summed per clip into stats[8 ..] (a study build; the shipped library does not read the clock here)
+#if defined(KIN_PROFILE) && !defined(CHD_HOST_EMU)
+#define KO_SEG(c, k) do { const long long t_ = (long long)clock64(); (c).seg[k] += t_ - (c).tlast; (c).tlast = t_; } while (0)
+#else
+#define KO_SEG(c, k) ((void)0)
+#endif
+enum { KIN_STATS = 24 };
+// Pointers the compiler knows to be LDS (ds_read / ds_write instead of flat accesses that wait on both memory pipes): Sp<true>.  The host emulation has one kind.
+#if defined(CHD_HOST_EMU) || defined(KIN_FLAT_LDS)
+#define KO_LDSQ
+template <bool L> struct Sp { typedef double* p; typedef const double* cp; typedef const int* ci; };
+#else
+#define KO_LDSQ __attribute__((address_space(3)))
+template <bool L> struct Sp { typedef double* p; typedef const double* cp; typedef const int* ci; };
+template <> struct Sp<true> { typedef KO_LDSQ double* p; typedef const KO_LDSQ double* cp; typedef const KO_LDSQ int* ci; };
+#endif                        // doubles of statistics per clip: 8 the ABI reports + 16 profile segments
 
 namespace chd_kin {
 
-enum { NJ = 28, NV = 87, ROOT = 8 };
-// SkeletonDefinitions.py:64-137 (combined skeleton = body-25 + three spine joints)
-KO_CONST int FWD[NJ] = {8, 12, 13, 14, 21, 19, 20, 9, 10, 11, 24, 22, 23, 25, 26, 27, 1, 0, 16, 18, 15, 17, 5, 6, 7, 2, 3, 4};      // skeleton joint -> data joint
-KO_CONST int BWD[NJ] = {17, 16, 25, 26, 27, 22, 23, 24, 0, 7, 8, 9, 1, 2, 3, 20, 18, 21, 19, 5, 6, 4, 11, 12, 10, 13, 14, 15};       // data joint -> skeleton joint
-KO_CONST double SMOOTH_W[NJ] = {2.5, 2.5, 2.5, 1.5, 1.0, 2.5, 1.5, 1.0, 1.0, 2.5, 1.5, 1.0, 2.5, 1.5, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.5, 1.5, 1.5};
+enum { NJ = 28, NV = 87, ROOT = 8, NR = 507 };
+// the 507 rows of one frame: projection (2 per joint), velocity smoothness, acceleration smoothness, 3-D data, contact velocity (3 per joint),
+// floor (1 per joint), Euler-angle smoothness (87).  Frames F-1 (velocity, contact velocity, Euler) and F-2, F-1 (acceleration) have no such rows.
+enum { R_PROJ = 0, R_VEL = 56, R_ACC = 140, R_DATA = 224, R_CVEL = 308, R_FLOOR = 392, R_EUL = 420 };
+enum { HALO_V = 2 * NV, HALO_U = 423, KC_PARTS = 4, KC_HALO = 424, KC_MAXG = 16 };
+enum { N_X, N_XN, N_G, N_GN, N_V, N_H, N_HB, N_S0, N_S1, N_COUNT };          // the slices of the n-vectors a workgroup owns (87 per frame)
+enum { M_FV, M_FN, M_U, M_T1, M_T2, M_COUNT };                                 // ... of the m-vectors (507 per frame)
+// SkeletonDefinitions.py:64-137 (combined skeleton = body-25 + three spine joints).  Host tables: the kernel reads them from its LDS copy of KinParams (fwd, bwd, smooth_w)
+static const int FWD[NJ] = {8, 12, 13, 14, 21, 19, 20, 9, 10, 11, 24, 22, 23, 25, 26, 27, 1, 0, 16, 18, 15, 17, 5, 6, 7, 2, 3, 4};      // skeleton joint -> data joint
+static const int BWD[NJ] = {17, 16, 25, 26, 27, 22, 23, 24, 0, 7, 8, 9, 1, 2, 3, 20, 18, 21, 19, 5, 6, 4, 11, 12, 10, 13, 14, 15};       // data joint -> skeleton joint
+static const double SMOOTH_W[NJ] = {2.5, 2.5, 2.5, 1.5, 1.0, 2.5, 1.5, 1.0, 1.0, 2.5, 1.5, 1.0, 2.5, 1.5, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.5, 1.5, 1.5};
 KO_CONST double SMOOTH_VEL[3] = {1.0, 1.0, 2.0};          // optimize_trajectory.py:43-45
 #define KO_SMOOTH_EULER 10.0                               // :46-48 (the same for the three angles)
 
@@ -76,92 +122,303 @@ struct KinParams {
   double ftol, xtol, gtol;       // 1e-8, 1e-8, 1e-12
   double atol, btol, conlim;     // LSMR: 1e-6, 1e-6, 1e8
   int lsmr_maxiter;              // 0: min(m, n) as SciPy
+  // the tree's walks as tables (built by the host from `parents`)
+  int desc_end[NJ];              // the last joint that can be a descendant of j: j + (number of descendants) when the joints are in depth-first order, else the last joint
+  int anc_n[NJ]; unsigned char anc[NJ][8]; // strict ancestors of joint t, nearest first (the first eight; a deeper walk continues through `parents`)
+  int fwd[NJ], bwd[NJ];          // FWD / BWD and SMOOTH_W below, for the kernel's copy of this struct in LDS (a per-lane index into constant memory is a device-memory load)
+  double smooth_w[NJ];
 };
 
 // one video inside the batch pools
 struct KinSeq {
-  int F, n, m;
+  int F, n, m;                   // frames, unknowns 87 F, rows of the reference's residual (507 F - 423)
   long long o_const;             // double pool: offsets[84] | pose3d[F*84] | root_trans[F*3] | pose2d[F*56] | proj_w[F*28] | data_w[F*28]
   long long o_contact;           // int pool: contact[F*28]
-  long long o_work;              // workspace pool (doubles), work_doubles(F)
+  long long o_work;              // workspace pool (doubles), work_doubles(F, G)
   long long o_x;                 // state pool: x[F*87] (start point in, solution out)
   double floor_n[3], floor_p[3];
   double w[6];                   // projWeight, smoothWeightVel, smoothWeightAcc, dataWeight, velWeight, floorWeight
 };
 
 KO_HD int rows_of(int F) { return 507 * F - 423; }      // 56F + 84(F-1) + 84(F-2) + 84F + 84(F-1) + 28F + 87(F-1)
-KO_HD long long work_doubles(int F) { return 9LL * NV * F + 5LL * rows_of(F) + 1008LL * F + 64; }
+// device-memory workspace of one clip solved by G workgroups: 9 n-vectors, 5 m-vectors (frame-major, 507 per frame), and the per-frame arrays --
+// P 84, E 252, RG 252, PN 84, LW 84, LD 84 with two halo frames per workgroup, C 84 and LL 84 without
+// and the per-item constants DW 28 (doubles), CT 28 (ints)
+KO_HD long long work_doubles(int F, int G) { return (long long)N_COUNT * NV * F + (long long)M_COUNT * NR * F + 840LL * (F + 2 * G) + 168LL * F + 42LL * F + 64; }
+// frames per workgroup the LDS block holds: 1 395 doubles per frame + two halo frames of P / E / LW / LD + the received halos
+enum { KIN_LDS_PER_FRAME = 1395, KIN_LDS_FIXED = 1008 + HALO_V + KC_HALO };
+KO_HD int lds_frames(int lds_doubles) { const int f = (lds_doubles - KIN_LDS_FIXED) / KIN_LDS_PER_FRAME; return f < 0 ? 0 : f; }
+// workgroups per clip: the fewest whose slices fit the LDS block (`cap` frames each), never more than 16, never slices of fewer than two frames
+KO_HD int cluster_size(int F, int cap) {
+  int G = cap > 0 ? (F + cap - 1) / cap : KC_MAXG;
+  if (G > KC_MAXG) G = KC_MAXG;
+  if (G > F / 2) G = F / 2;
+  return G < 1 ? 1 : G;
+}
 
-// views into a video's workspace
-struct KinWork {
-  double *X, *XN, *G, *GN, *V, *H, *HB, *S0, *S1;      // n
-  double *Fv, *FN, *U, *T1, *T2;                         // m
-  double *P, *E, *C, *RG, *PN, *RGN;                     // per frame: 84, 252, 84, 252, 84, 252
-  KO_HD void carve(double* b, int F) {
-    const long long n = (long long)NV * F, m = rows_of(F);
-    X = b; b += n; XN = b; b += n; G = b; b += n; GN = b; b += n; V = b; b += n; H = b; b += n; HB = b; b += n; S0 = b; b += n; S1 = b; b += n;
-    Fv = b; b += m; FN = b; b += m; U = b; b += m; T1 = b; b += m; T2 = b; b += m;
-    P = b; b += 84LL * F; E = b; b += 252LL * F; C = b; b += 84LL * F; RG = b; b += 252LL * F; PN = b; b += 84LL * F; RGN = b;
-  }
+// what a workgroup publishes at a synchronisation of its cluster (device memory; one per workgroup of the launch)
+struct KinSlot {
+  unsigned long long flag;       // number of the last synchronisation this workgroup has arrived at
+  double part[2][KC_PARTS];      // its partial sums (by parity of the synchronisation's number: a workgroup can be one synchronisation ahead of a neighbour that still reads)
+  double halo[2][KC_HALO];
+};
+
+// a workgroup's share of a clip: frames [a, a + nf), local frame index l = f - a; arrays marked (+2) carry the two frames after the slice
+struct KinWg {
+  int g, a, nf, nh;              // rank in the cluster; first frame; own frames; own + halo frames that exist (min(nf + 2, F - a))
+  double* nv[N_COUNT];           // nf x 87
+  double* mv[M_COUNT];           // nf x 507
+  double *P, *E, *RG, *PN;       // (+2) x 84 / 252 / 252 / 84: positions and axes of the linearisation, scratch of the forward kinematics, positions at a trial point
+  double *C, *LW, *LD, *LL;      // projection coefficients nf x 84; the products' per-joint intermediates (+2) x 84, (+2) x 84, nf x 84
+  double* DW; int* CT;           // per (frame, joint) item: dataWeight x data_w; bit 0 the joint is in contact in this frame, bit 1 it was in the frame before
+  double *vh, *uh;               // received halos (LDS): 2 x 87 values of an n-vector from the right neighbour, HALO_U rows of an m-vector from the left one
+  bool in_lds;                   // U, V, H, P, E, C, LW, LD, LL, DW, CT are in the LDS block (else: the slices in device memory)
+#ifdef CHD_HOST_EMU
+  double pub[KC_HALO];           // what this workgroup publishes at the next synchronisation
+#endif
+};
+
+// a clip's constants and LSMR's scalar state: small structs the kernel keeps in LDS, out of the register file (what is live across the product phases
+// otherwise ends up in scratch memory, and every phase then begins with a round trip to fetch its pointers)
+struct KinClip {
+  const KinSeq* q;
+  int F; double wt[6], fn[3], fp[3];      // frame count; term weights (projWeight, smoothWeightVel, smoothWeightAcc, dataWeight, velWeight, floorWeight); floor
+  const double *offs, *pose3d, *root_trans, *pose2d, *proj_w, *data_w;
+  const int* contact;
+};
+struct KinLsmr {
+  double normb, beta, alpha, su, sv, damp, ctol;
+  double zetabar, alphabar, rho, rhobar, cbar, sbar, betadd, betad, rhodold, tautildeold, thetatilde, zeta, d, normA2, maxrbar, minrbar;
+  double chat, shat, cc, s, rhoold, rhobarold, zetaold, thetabar, rhotemp;     // from the first half of an iteration for the second
+  double k1, k2, k3;
+  int itn, istop, maxiter;
 };
 
 struct KinCtx {
-  const KinSeq* q; const KinParams* P;
-  const double *offs, *pose3d, *root_trans, *pose2d, *proj_w, *data_w;
-  const int* contact;
-  KinWork w;
-  double* red;                   // workgroup reduction scratch (LDS on the device): 3 * 16 doubles
-  double* lds; int lds_doubles;  // the products' frame tiles (LDS on the device)
-  long long t_jv, t_jtu, t_all;  // wall-clock ticks spent in J v / J^T u / the whole solve (first thread's view; monitoring only)
-  int o2, o3, o4, o5, o6, o7;    // first row of each residual term after the projection rows
+  KO_LDSQ KinClip* k; const KO_LDSQ KinParams* P;
+  KO_LDSQ KinWg* wg;             // this workgroup's share (the emulation: all G of them)
+  KO_LDSQ KinLsmr* S;
+  KO_LDSQ double* gath;          // what the last synchronisation gathered: KC_PARTS values per workgroup of the cluster
+  int G;                         // workgroups of the cluster
+#ifndef CHD_HOST_EMU
+  KinSlot* slots;                // the cluster's G slots
+  unsigned long long epoch;      // synchronisations so far (the same in every workgroup of the cluster)
+  KO_LDSQ double* red;           // workgroup reduction scratch: KC_PARTS * 16 doubles
+#endif
+#ifndef CHD_HOST_EMU
+  // what the tables say about THIS lane's joint (lane & 31: the same in every item a thread handles), fetched once per launch
+  int lj_na, lj_f3, lj_b3, lj_dend;
+  unsigned lj_desc;
+  unsigned long long lj_anc;                  // ancestors, eight bits each
+#endif
+  long long seg[16], tlast;      // KIN_PROFILE
+  long long t_jv, t_jtu;         // wall-clock ticks in the two halves of LSMR's iterations (first thread's view; monitoring only)
 };
+// the tables' entries for joint j: the emulation looks them up, a device lane has its own joint's in registers
+#ifdef CHD_HOST_EMU
+KO_DEV int kj_na(const KinCtx& c, int j) { return c.P->anc_n[j]; }
+KO_DEV int kj_f3(const KinCtx& c, int j) { return 3 * c.P->fwd[j]; }
+KO_DEV int kj_b3(const KinCtx& c, int j) { return 3 * c.P->bwd[j]; }
+KO_DEV int kj_dend(const KinCtx& c, int j) { return c.P->desc_end[j]; }
+KO_DEV unsigned kj_desc(const KinCtx& c, int j) { return c.P->desc[j]; }
+KO_DEV unsigned long long kj_anc(const KinCtx& c, int j) { unsigned long long v = 0; for (int q = 0; q < 8; ++q) v |= (unsigned long long)c.P->anc[j][q] << (8 * q); return v; }
+#else
+KO_DEV int kj_na(const KinCtx& c, int) { return c.lj_na; }
+KO_DEV int kj_f3(const KinCtx& c, int) { return c.lj_f3; }
+KO_DEV int kj_b3(const KinCtx& c, int) { return c.lj_b3; }
+KO_DEV int kj_dend(const KinCtx& c, int) { return c.lj_dend; }
+KO_DEV unsigned kj_desc(const KinCtx& c, int) { return c.lj_desc; }
+KO_DEV unsigned long long kj_anc(const KinCtx& c, int) { return c.lj_anc; }
+KO_DEV void kin_lane_tables(KinCtx& c) {
+  const int j = threadIdx.x & 31, jj = j < NJ ? j : 0;
+  c.lj_na = j < NJ ? c.P->anc_n[jj] : 0; c.lj_f3 = 3 * c.P->fwd[jj]; c.lj_b3 = 3 * c.P->bwd[jj]; c.lj_dend = j < NJ ? c.P->desc_end[jj] : -1; c.lj_desc = j < NJ ? c.P->desc[jj] : 0u;
+  unsigned long long b = 0;
+  for (int q = 0; q < 8; ++q) b |= (unsigned long long)c.P->anc[jj][q] << (8 * q);
+  c.lj_anc = b;
+}
+#endif
 
-// ---- workgroup reductions (fixed tree: results do not depend on scheduling) -------------------------------------------------
-// A sum over a KO_FOR loop: every thread adds its own items in loop order, the per-thread sums are combined by a butterfly inside
-// each wavefront and then wavefront by wavefront.  The host emulation keeps 512 lane accumulators and combines them the same
-// way, so that its sums round like the 512-thread workgroup's (a single running sum over ~50 000 terms is 1000 times less
-// accurate, and LSMR's convergence over thousands of iterations feels that).
+// sum (or maximum) number i of the last synchronisation: the cluster's partial results in rank order -- the same bits in every workgroup
+KO_DEV double kc_sum(const KinCtx& c, int i, bool mx = false) {
+  double s = 0.0;
+  for (int g = 0; g < c.G; ++g) { const double t = c.gath[KC_PARTS * g + i]; s = mx ? (t > s ? t : s) : s + t; }
+  return s;
+}
+
+#ifdef CHD_HOST_EMU
+enum { KC_NW = KC_MAXG };
+#define KC_EACH(c, w) for (int wi = 0; wi < (c).G; ++wi) { KO_LDSQ KinWg& w = (c).wg[wi];
+#else
+enum { KC_NW = 1 };
+#define KC_EACH(c, w) { const int wi = 0; KO_LDSQ KinWg& w = (c).wg[0];
+#endif
+#define KC_DONE }
+
+// ---- sums over a workgroup's items and over the cluster (fixed trees: results do not depend on scheduling) -------------------------------
+// Every thread adds its own items in loop order, the per-thread sums are combined by a butterfly inside each wavefront, then wavefront by
+// wavefront, then workgroup by workgroup.  The host emulation keeps 512 lane accumulators per workgroup and combines them the same way, so that its
+// sums round like the device's (a single running sum over ~50 000 terms is 1000 times less accurate, and LSMR's convergence over thousands of
+// iterations feels that).
 #ifdef CHD_HOST_EMU
 enum { KO_LANES = 512 };
 struct KoAcc {
   double l[KO_LANES];
   KoAcc() { for (int i = 0; i < KO_LANES; ++i) l[i] = 0.0; }
   void add(long long i, double v) { l[i & (KO_LANES - 1)] += v; }
-  double total() const {
+  void hi(long long i, double v) { double& t = l[i & (KO_LANES - 1)]; t = v > t ? v : t; }
+  double total(bool mx = false) const {
     double s = 0.0;
     for (int w0 = 0; w0 < KO_LANES; w0 += 64) {
       double a[64], t[64];
       for (int k = 0; k < 64; ++k) a[k] = l[w0 + k];
-      for (int o = 32; o > 0; o >>= 1) { for (int k = 0; k < 64; ++k) t[k] = a[k] + a[k ^ o]; for (int k = 0; k < 64; ++k) a[k] = t[k]; }
-      s += a[0];
+      for (int o = 32; o > 0; o >>= 1) { for (int k = 0; k < 64; ++k) t[k] = mx ? (a[k ^ o] > a[k] ? a[k ^ o] : a[k]) : a[k] + a[k ^ o]; for (int k = 0; k < 64; ++k) a[k] = t[k]; }
+      s = mx ? (a[0] > s ? a[0] : s) : s + a[0];
     }
     return s;
   }
 };
-KO_DEV void ko_total3(KinCtx&, const KoAcc& A, const KoAcc& B, const KoAcc& C, double& a, double& b, double& c) { a = A.total(); b = B.total(); c = C.total(); }
+#define KC_PUB(c, w, i, val) ((w).pub[i] = (val))
 #else
 struct KoAcc {
   double s = 0.0;
   __device__ void add(long long, double v) { s += v; }
+  __device__ void hi(long long, double v) { s = v > s ? v : s; }
 };
-KO_DEV void ko_total3(KinCtx& c_, const KoAcc& A, const KoAcc& B, const KoAcc& C, double& a, double& b, double& c) {
-  a = A.s; b = B.s; c = C.s;
-  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
-  const int wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) { c_.red[wv] = a; c_.red[16 + wv] = b; c_.red[32 + wv] = c; }
-  __syncthreads();
-  double sa = 0, sb = 0, sc = 0;
-  for (int i = 0; i < nw; ++i) { sa += c_.red[i]; sb += c_.red[16 + i]; sc += c_.red[32 + i]; }
-  a = sa; b = sb; c = sc;
+KO_DEV double kc_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+KO_DEV void kc_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#define KC_PUB(c, w, i, val) kc_st(&(c).slots[(w).g].halo[((c).epoch + 1) & 1][i], (val))
+#endif
+
+// Sum over the joints of a frame of three values per joint, the joint `skip` left out: a butterfly over the frame's 32 lanes (the same bits in every lane).
+// Device: every lane of the frame passes its own values (`mine`; lanes that are not joints, and `skip`, contribute zero).  Emulation: from the frame's 84 stored values.
+#ifdef CHD_HOST_EMU
+KO_DEV void ko_frame_sum3(const double* frame, const double*, int, int skip, double* out) {
+  for (int k = 0; k < 3; ++k) {
+    double a[32], t[32];
+    for (int j = 0; j < 32; ++j) a[j] = (j < NJ && j != skip) ? frame[3 * j + k] : 0.0;
+    for (int o = 16; o > 0; o >>= 1) { for (int j = 0; j < 32; ++j) t[j] = a[j] + a[j ^ o]; for (int j = 0; j < 32; ++j) a[j] = t[j]; }
+    out[k] = a[0];
+  }
+}
+#else
+KO_DEV void ko_frame_sum3(const void*, const double* mine, int j, int skip, double* out) {
+  for (int k = 0; k < 3; ++k) {
+    double v = (j < NJ && j != skip) ? mine[k] : 0.0;
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    out[k] = v;
+  }
 }
 #endif
-KO_DEV double ko_total(KinCtx& c, const KoAcc& A) { KoAcc z1, z2; double a, b, d; ko_total3(c, A, z1, z2, a, b, d); return a; }
-KO_DEV double ko_dot(KinCtx& c, const double* a, const double* b, long long n) {
-  KoAcc s;
-  for (long long i = KO_TID; i < n; i += KO_NT) s.add(i, a[i] * b[i]);
-  return ko_total(c, s);
+
+// One synchronisation of the cluster.  In: `np` accumulators per workgroup (acc[wi][0 .. np)), and whatever the workgroups have published with KC_PUB.
+// Out: c.gath -- every workgroup's np partial sums (maxima with `mx`), read with kc_sum -- and, with dir = +1 / -1, the first `nrecv` values the right / left
+// neighbour published in w.vh / w.uh (a workgroup without that neighbour keeps what it had).  Ends with a workgroup barrier.
+KO_DEV void kc_sync(KinCtx& c, KoAcc (*acc)[KC_PARTS], int np, int dir = 0, int nrecv = 0, bool mx = false) {
+#ifdef CHD_HOST_EMU
+  for (int g = 0; g < c.G; ++g) for (int i = 0; i < np; ++i) c.gath[KC_PARTS * g + i] = acc[g][i].total(mx);
+  if (dir != 0)
+    for (int g = 0; g < c.G; ++g) {
+      const int nb = g + dir;
+      if (nb < 0 || nb >= c.G) continue;
+      double* dst = dir > 0 ? c.wg[g].vh : c.wg[g].uh;
+      for (int i = 0; i < nrecv; ++i) dst[i] = c.wg[nb].pub[i];
+    }
+#else
+  double v[KC_PARTS];
+#pragma unroll
+  for (int i = 0; i < KC_PARTS; ++i) {
+    v[i] = i < np ? acc[0][i].s : 0.0;
+    if (i < np) for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(v[i], o); v[i] = mx ? (t > v[i] ? t : v[i]) : v[i] + t; }
+  }
+  const int wv = threadIdx.x >> 6, nw = blockDim.x >> 6, ln = threadIdx.x & 63;
+  __syncthreads();                              // the previous use of c.red / c.gath is over
+  if (ln == 0)
+    for (int i = 0; i < np; ++i) c.red[16 * i + wv] = v[i];
+  __syncthreads();
+  const int me = c.wg[0].g;
+  if (c.G == 1) {                               // a cluster of one: nothing leaves the compute unit
+    if ((int)threadIdx.x < np) {
+      double s = 0.0;
+      for (int k = 0; k < nw; ++k) { const double t = c.red[16 * threadIdx.x + k]; s = mx ? (t > s ? t : s) : s + t; }
+      c.gath[threadIdx.x] = s;
+    }
+    __syncthreads();
+    return;
+  }
+  const unsigned long long e = ++c.epoch;
+  const int par = (int)(e & 1);
+  KinSlot* mine = c.slots + me;
+  if ((int)threadIdx.x < np) {
+    double s = 0.0;
+    for (int k = 0; k < nw; ++k) { const double t = c.red[16 * threadIdx.x + k]; s = mx ? (t > s ? t : s) : s + t; }
+    kc_st(&mine->part[par][threadIdx.x], s);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wavefront's write-through stores (partial sums, halo) have been acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(&mine->flag, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // first wavefront: lane g waits for workgroup g and fetches its partial sums; the other wavefronts wait for the neighbour only and fetch the halo meanwhile
+  const int nb = me + dir;
+  const bool want = dir != 0 && nb >= 0 && nb < c.G;
+  if (wv == 0) {
+    if (ln < c.G) {
+      const KinSlot* o = c.slots + ln;
+      while (__hip_atomic_load(&o->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < e) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      for (int i = 0; i < np; ++i) c.gath[KC_PARTS * ln + i] = kc_ld(&o->part[par][i]);
+    }
+  } else if (want) {
+    const KinSlot* o = c.slots + nb;
+    while (__hip_atomic_load(&o->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < e) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    KO_LDSQ double* dst = (KO_LDSQ double*)(dir > 0 ? c.wg[0].vh : c.wg[0].uh);
+    const double* src = o->halo[par];
+    for (int i = threadIdx.x - 64; i < nrecv; i += blockDim.x - 64) dst[i] = kc_ld(src + i);
+  }
+  __syncthreads();
+#endif
 }
+
+// entry k of local frame l of an n-vector slice: the slice itself, or for the two frames after it the received halo
+template <bool VL> KO_DEV double nvf(const KO_LDSQ KinWg& w, typename Sp<VL>::cp v, int l, int k) {
+  return l < w.nf ? v[NV * l + k] : ((typename Sp<true>::cp)w.vh)[NV * (l - w.nf) + k];
+}
+// row t of local frame l of an m-vector slice, l = -2, -1 being the last frames of the left neighbour (received halo: the acceleration rows of both, the
+// velocity, contact-velocity and Euler rows of the nearer one)
+KO_DEV int uh_index(int l, int t) { return l == -2 ? t - R_ACC : (t < R_ACC ? 84 + (t - R_VEL) : t < R_DATA ? 168 + (t - R_ACC) : t < R_FLOOR ? 252 + (t - R_CVEL) : 336 + (t - R_EUL)); }
+template <bool VL> KO_DEV double mv_row(const KO_LDSQ KinWg& w, typename Sp<VL>::cp u, int l, int t) { return l >= 0 ? u[NR * l + t] : ((typename Sp<true>::cp)w.uh)[uh_index(l, t)]; }
+
+// the same as a pointer, for the outer iteration's functions (generic addressing)
+KO_DEV const double* nv_frame(const KO_LDSQ KinWg& w, const double* v, int l) { return l < w.nf ? v + NV * l : w.vh + NV * (l - w.nf); }
+
+// publish the first two frames of n-vector `sel` (for the left neighbour) / the boundary rows of m-vector `sel` (for the right neighbour)
+template <bool VL> KO_DEV void kin_pub_v(KinCtx& c, int sel) {
+  KC_EACH(c, w)
+    (void)wi;
+    typename Sp<VL>::cp v = (typename Sp<VL>::cp)w.nv[sel];
+    if (w.g > 0) KO_FOR(i, HALO_V) KC_PUB(c, w, i, v[i]);
+  KC_DONE
+}
+template <bool VL> KO_DEV void kin_pub_u(KinCtx& c, int sel) {
+  KC_EACH(c, w)
+    (void)wi;
+    if (w.g < c.G - 1) {
+      typename Sp<VL>::cp u = (typename Sp<VL>::cp)w.mv[sel];
+      KO_FOR(i, HALO_U) {
+        const int l = i < 84 ? w.nf - 2 : w.nf - 1;
+        const int t = i < 84 ? R_ACC + i : i < 168 ? R_VEL + (i - 84) : i < 252 ? R_ACC + (i - 168) : i < 336 ? R_CVEL + (i - 252) : R_EUL + (i - 336);
+        KC_PUB(c, w, i, u[NR * l + t]);
+      }
+    }
+  KC_DONE
+}
+KO_DEV void kin_exchange_v(KinCtx& c, int sel) { kin_pub_v<false>(c, sel); KoAcc none[KC_NW][KC_PARTS]; kc_sync(c, none, 0, +1, HALO_V); }
+KO_DEV void kin_exchange_u(KinCtx& c, int sel) { kin_pub_u<false>(c, sel); KoAcc none[KC_NW][KC_PARTS]; kc_sync(c, none, 0, -1, HALO_U); }
+// a function template picked by where the slice lives (L) and whether the vector arguments are LSMR's own, LDS-resident ones (lsmr)
+#ifdef CHD_HOST_EMU
+#define KIN_DISPATCH(fn, lsmr, ...) fn<false, false>(__VA_ARGS__)
+#else
+#define KIN_DISPATCH(fn, lsmr, ...) do { if (c.wg[0].in_lds) { if (lsmr) fn<true, true>(__VA_ARGS__); else fn<true, false>(__VA_ARGS__); } else fn<false, false>(__VA_ARGS__); } while (0)
+#endif
 
 // ---- forward kinematics of one frame (Animation.py:294-323, 379-414; Quaternions.from_euler(order='xyz', world=True)) -------
 // R = Rz Ry Rx per joint; global rotation Rg_j = Rg_parent R_j; position p_j = p_parent + Rg_parent offset_j, root at 0
@@ -188,7 +445,7 @@ KO_DEV void fk_frame(const KinCtx& c, const double* xf, double* Pf, double* RGf,
       const double* Rp = RGf + 9 * p;
       for (int r = 0; r < 3; ++r)
         for (int k = 0; k < 3; ++k) Rg[3 * r + k] = Rp[3 * r] * R[k] + Rp[3 * r + 1] * R[3 + k] + Rp[3 * r + 2] * R[6 + k];
-      const double* o = c.offs + 3 * j;
+      const double* o = c.k->offs + 3 * j;
       for (int r = 0; r < 3; ++r) Pf[3 * j + r] = Pf[3 * p + r] + Rp[3 * r] * o[0] + Rp[3 * r + 1] * o[1] + Rp[3 * r + 2] * o[2];
       if (Ef) {
         const double l0[3] = {cz * cy, sz * cy, -sy}, l1[3] = {-sz, cz, 0.0};
@@ -203,290 +460,320 @@ KO_DEV void fk_frame(const KinCtx& c, const double* xf, double* Pf, double* RGf,
   }
 }
 
-// y of the reference (:356-359) for data joint jd of frame f: the root's entry is its translation, the others are root relative
-KO_DEV double y_of(const double* x, const double* P, int f, int jd, int cc) {
-  return jd == ROOT ? x[(long long)f * NV + cc] : P[(long long)f * 84 + 3 * BWD[jd] + cc];
-}
 
-// ---- residual (:324-483) at x into out; P/RG receive the forward kinematics of x -------------------------------------------
-KO_DEV void kin_residual(KinCtx& c, const double* x, double* P, double* RG, double* out) {
-  const int F = c.q->F;
-  KO_FOR(f, F) fk_frame(c, x + (long long)f * NV, P + (long long)f * 84, RG + (long long)f * 252, nullptr);
+// ---- residual (:324-483) at n-vector `xsel` into m-vector `osel` ---------------------------------------------------------------------------
+KO_DEV void kin_residual(KinCtx& c, int xsel, int osel) {
+  const int F = c.k->F;
+  kin_exchange_v(c, xsel);
+  KC_EACH(c, w)
+    KO_FOR(l, w.nh) fk_frame(c, nv_frame(w, w.nv[xsel], l), w.PN + 84 * l, w.RG + 252 * l, nullptr);
+  KC_DONE
   KO_SYNC();
-  const double pw = c.q->w[0], sv = c.q->w[1], sa = c.q->w[2], dw = c.q->w[3], vw = c.q->w[4], fw = c.q->w[5];
-  KO_FOR(idx, F * NJ) {
-    const int f = idx / NJ, jd = idx % NJ;
-    double y[3], yr[3];
-    for (int k = 0; k < 3; ++k) { y[k] = y_of(x, P, f, jd, k); yr[k] = x[(long long)f * NV + k]; }
-    // projection
-    {
-      const double w = c.proj_w[idx];
-      double r0 = 0, r1 = 0;
-      if (w > 0) {
-        const double ax = jd == ROOT ? yr[0] : y[0] + yr[0], ay = jd == ROOT ? yr[1] : y[1] + yr[1], az = jd == ROOT ? yr[2] : y[2] + yr[2];
-        r0 = pw * w * (ax / az - c.pose2d[2 * idx]);
-        r1 = pw * w * (ay / az - c.pose2d[2 * idx + 1]);
-      }
-      out[2 * idx] = r0; out[2 * idx + 1] = r1;
-    }
-    for (int k = 0; k < 3; ++k) {
-      if (f < F - 1) out[c.o2 + 3 * idx + k] = sv * SMOOTH_W[jd] * SMOOTH_VEL[k] * (y[k] - y_of(x, P, f + 1, jd, k));
-      if (f < F - 2) {
-        const double y1 = y_of(x, P, f + 1, jd, k), y2 = y_of(x, P, f + 2, jd, k);
-        out[c.o3 + 3 * idx + k] = sa * ((y2 - y1) - (y1 - y[k]));
-      }
-      const double tgt = jd == ROOT ? c.root_trans[3 * f + k] : c.pose3d[3 * idx + k];
-      out[c.o4 + 3 * idx + k] = dw * (y[k] - tgt) * c.data_w[idx];
-    }
-    const bool ct = c.contact[idx] == 1;
-    if (f < F - 1)
-      for (int k = 0; k < 3; ++k)
-        out[c.o5 + 3 * idx + k] = ct ? vw * ((yr[k] + y[k]) - (x[(long long)(f + 1) * NV + k] + y_of(x, P, f + 1, jd, k))) : 0.0;
-    double d = 0;
-    for (int k = 0; k < 3; ++k) d += c.q->floor_n[k] * (yr[k] + y[k] - c.q->floor_p[k]);
-    out[c.o6 + idx] = ct ? fw * d : 0.0;
-  }
-  KO_FOR(idx, (F - 1) * NV) out[c.o7 + idx] = sv * KO_SMOOTH_EULER * (x[idx] - x[idx + NV]);
-  KO_SYNC();
-}
-
-// ---- linearisation at x: positions, axes, projection coefficients ------------------------------------------------------------
-KO_DEV void kin_linearise(KinCtx& c, const double* x) {
-  const int F = c.q->F;
-  KO_FOR(f, F) fk_frame(c, x + (long long)f * NV, c.w.P + (long long)f * 84, c.w.RG + (long long)f * 252, c.w.E + (long long)f * 252);
-  KO_SYNC();
-  const double pw = c.q->w[0];
-  KO_FOR(idx, F * NJ) {
-    const int f = idx / NJ, jd = idx % NJ;
-    const double w = c.proj_w[idx];
-    double cx = 0, czx = 0, czy = 0;
-    if (w > 0) {
-      double a[3];
-      for (int k = 0; k < 3; ++k) a[k] = jd == ROOT ? x[(long long)f * NV + k] : y_of(x, c.w.P, f, jd, k) + x[(long long)f * NV + k];
-      const double ww = pw * w;
-      cx = ww / a[2]; czx = -ww * a[0] / (a[2] * a[2]); czy = -ww * a[1] / (a[2] * a[2]);
-    }
-    c.w.C[3 * idx] = cx; c.w.C[3 * idx + 1] = czx; c.w.C[3 * idx + 2] = czy;
-  }
-  KO_SYNC();
-}
-
-// ---- the two products, matrix free, frame tile by frame tile through LDS -------------------------------------------------------
-// A tile is as many consecutive frames as the workgroup's LDS block holds.  Everything a phase reads more than once -- joint
-// positions, the per-joint angular velocities / position increments (J v), the per-joint multipliers (J^T u) -- lives in LDS
-// for the tile, so the ancestor / descendant walks and the misplaced-root sums are LDS reads, and the intermediates never
-// touch HBM.  J v needs the position increments of frames f, f + 1, f + 2 for the rows of frame f: a tile carries two halo frames.
-
-// out = J v (:51-322 applied to a vector).
-// With `sumsq`: the fused form LSMR's bidiagonalisation needs, out <- scale * (J v) + keep * out in place and *sumsq = |out|^2
-// (every row has exactly one writer; saves writing J v, reading it back and a separate pass for the norm).
-KO_DEV void kin_jv(KinCtx& c, const double* v, double* out, const double scale = 1.0, const double keep = 0.0, double* sumsq = nullptr) {
-  const int F = c.q->F;
-  const double sv = c.q->w[1], sa = c.q->w[2], dw = c.q->w[3], vw = c.q->w[4], fw = c.q->w[5];
-  const bool fused = sumsq != nullptr;
-  KoAcc acc;
-  long long cur = 0;                          // the loop index the running sum belongs to
-  auto put = [&](long long r, double val) {
-    if (fused) { val = scale * val + keep * out[r]; acc.add(cur, val * val); }
-    out[r] = val;
-  };
-  int TF = c.lds_doubles / 252 - 2;
-  if (TF < 1) TF = 1;
-  double* LP = c.lds; double* LW = LP + 84 * (TF + 2); double* LD = LW + 84 * (TF + 2);
-  for (int f0 = 0; f0 < F; f0 += TF) {
-    const int nf = F - f0 < TF ? F - f0 : TF;
-    const int nh = F - f0 < nf + 2 ? F - f0 : nf + 2;                 // with the halo
-    KO_FOR(idx, nh * NJ) {                    // positions into LDS; omega_j = sum_a v_{j,a} axis_{j,a}
-      const int f = f0 + idx / NJ, j = idx % NJ;
-      const double* pp = c.w.P + (long long)f * 84 + 3 * j;
-      const double* e = c.w.E + (long long)f * 252 + 9 * j;
-      const double* vv = v + (long long)f * NV + 3 + 3 * j;
-      const double v0 = vv[0], v1 = vv[1], v2 = vv[2];
-      for (int k = 0; k < 3; ++k) { LP[3 * idx + k] = pp[k]; LW[3 * idx + k] = v0 * e[k] + v1 * e[3 + k] + v2 * e[6 + k]; }
-    }
-    KO_SYNC();
-    KO_FOR(idx, nh * NJ) {                    // dp_t = sum over the strict ancestors j of t of omega_j x (p_t - p_j); stored in data order
-      const int fl = idx / NJ, t = idx % NJ;
-      double d[3] = {0, 0, 0};
-      if (t == 0) { for (int k = 0; k < 3; ++k) d[k] = v[(long long)(f0 + fl) * NV + k]; }
-      else {
-        const double* Pf = LP + 84 * fl;
-        const double p0 = Pf[3 * t], p1 = Pf[3 * t + 1], p2 = Pf[3 * t + 2];
-        for (int j = c.P->parents[t]; j >= 0; j = c.P->parents[j]) {
-          const double* om = LW + 84 * fl + 3 * j;
-          const double r0 = p0 - Pf[3 * j], r1 = p1 - Pf[3 * j + 1], r2 = p2 - Pf[3 * j + 2];
-          d[0] += om[1] * r2 - om[2] * r1; d[1] += om[2] * r0 - om[0] * r2; d[2] += om[0] * r1 - om[1] * r0;
-        }
-      }
-      double* o = LD + 84 * fl + 3 * FWD[t];
-      o[0] = d[0]; o[1] = d[1]; o[2] = d[2];
-    }
-    KO_SYNC();
-    KO_FOR(idx, nf * NJ) {                    // the rows of frame f (the reference's order: term by term, frame, joint, coordinate)
-      cur = idx;
-      const int fl = idx / NJ, jd = idx % NJ, f = f0 + fl;
+  const double pw = c.k->wt[0], sv = c.k->wt[1], sa = c.k->wt[2], dw = c.k->wt[3], vw = c.k->wt[4], fw = c.k->wt[5];
+  KC_EACH(c, w)
+    const double* x = w.nv[xsel];
+    double* out = w.mv[osel];
+    // y of the reference (:356-359) for data joint jd of local frame l: the root's entry is its translation, the others are root relative
+    auto y_of = [&](int l, int jd, int k) { return jd == ROOT ? nv_frame(w, x, l)[k] : w.PN[84 * l + 3 * c.P->bwd[jd] + k]; };
+    KO_FOR(idx, w.nf * NJ) {
+      const int l = idx / NJ, jd = idx % NJ, f = w.a + l;
       const long long gi = (long long)f * NJ + jd;
-      const double* dy = LD + 84 * fl + 3 * jd;
-      const double* d0 = LD + 84 * fl;                               // data joint 0: where the reference puts the root's projection derivative
-      const double* dr = LD + 84 * fl + 3 * ROOT;
-      const double* C = c.w.C + 3 * gi;
-      const double C0 = C[0], C1 = C[1], C2 = C[2];
-      const bool ct = c.contact[gi] == 1;
-      const double dwj = dw * c.data_w[gi];
       const bool has1 = f < F - 1, has2 = f < F - 2;
-      // the fifteen rows of this (frame, joint): row index, whether it exists, its value.  In the fused form the old entries of all of them
-      // are requested before the first one is used (one after the other they were fifteen dependent HBM round trips per item)
-      long long rr[15]; bool on[15]; double val[15];
+      double* r = out + NR * l;
+      double y[3], yr[3];
+      for (int k = 0; k < 3; ++k) { y[k] = y_of(l, jd, k); yr[k] = x[NV * l + k]; }
+      {
+        const double pwt = c.k->proj_w[gi];
+        double r0 = 0, r1 = 0;
+        if (pwt > 0) {
+          const double ax = jd == ROOT ? yr[0] : y[0] + yr[0], ay = jd == ROOT ? yr[1] : y[1] + yr[1], az = jd == ROOT ? yr[2] : y[2] + yr[2];
+          r0 = pw * pwt * (ax / az - c.k->pose2d[2 * gi]);
+          r1 = pw * pwt * (ay / az - c.k->pose2d[2 * gi + 1]);
+        }
+        r[R_PROJ + 2 * jd] = r0; r[R_PROJ + 2 * jd + 1] = r1;
+      }
+      const bool ct = c.k->contact[gi] == 1;
+      for (int k = 0; k < 3; ++k) {
+        const double y1 = has1 ? y_of(l + 1, jd, k) : 0.0, y2 = has2 ? y_of(l + 2, jd, k) : 0.0;
+        r[R_VEL + 3 * jd + k] = has1 ? sv * c.P->smooth_w[jd] * SMOOTH_VEL[k] * (y[k] - y1) : 0.0;
+        r[R_ACC + 3 * jd + k] = has2 ? sa * ((y2 - y1) - (y1 - y[k])) : 0.0;
+        const double tgt = jd == ROOT ? c.k->root_trans[3 * f + k] : c.k->pose3d[3 * gi + k];
+        r[R_DATA + 3 * jd + k] = dw * (y[k] - tgt) * c.k->data_w[gi];
+        r[R_CVEL + 3 * jd + k] = (has1 && ct) ? vw * ((yr[k] + y[k]) - (nv_frame(w, x, l + 1)[k] + y1)) : 0.0;
+      }
+      double d = 0;
+      for (int k = 0; k < 3; ++k) d += c.k->fn[k] * (yr[k] + y[k] - c.k->fp[k]);
+      r[R_FLOOR + jd] = ct ? fw * d : 0.0;
+    }
+    KO_FOR(idx, w.nf * NV) {
+      const int l = idx / NV, i = idx % NV;
+      out[NR * l + R_EUL + i] = (w.a + l < F - 1) ? sv * KO_SMOOTH_EULER * (x[idx] - nv_frame(w, x, l + 1)[i]) : 0.0;
+    }
+  KC_DONE
+  KO_SYNC();
+}
+
+// ---- linearisation at n-vector `xsel`: positions and axes of the slice and its halo frames, projection coefficients of the slice ------------------
+KO_DEV void kin_linearise(KinCtx& c, int xsel) {
+  kin_exchange_v(c, xsel);
+  KC_EACH(c, w)
+    KO_FOR(l, w.nh) fk_frame(c, nv_frame(w, w.nv[xsel], l), w.P + 84 * l, w.RG + 252 * l, w.E + 252 * l);
+  KC_DONE
+  KO_SYNC();
+  const double pw = c.k->wt[0];
+  KC_EACH(c, w)
+    const double* x = w.nv[xsel];
+    KO_FOR(idx, w.nf * NJ) {
+      const int l = idx / NJ, jd = idx % NJ;
+      const double pwt = c.k->proj_w[(long long)(w.a + l) * NJ + jd];
+      double cx = 0, czx = 0, czy = 0;
+      if (pwt > 0) {
+        double a[3];
+        for (int k = 0; k < 3; ++k) a[k] = jd == ROOT ? x[NV * l + k] : w.P[84 * l + 3 * c.P->bwd[jd] + k] + x[NV * l + k];
+        const double ww = pw * pwt;
+        cx = ww / a[2]; czx = -ww * a[0] / (a[2] * a[2]); czy = -ww * a[1] / (a[2] * a[2]);
+      }
+      w.C[3 * idx] = cx; w.C[3 * idx + 1] = czx; w.C[3 * idx + 2] = czy;
+    }
+  KC_DONE
+  KO_SYNC();
+}
+
+// ---- the two products, matrix free, on the slice ----------------------------------------------------------------------------------------------
+// A (frame, joint) item per lane, 32 lanes per frame (28 joints + 4 idle): a frame never straddles a wavefront, so the steps in which the joints of a frame
+// exchange values (the walks up and down the tree, the two sums over a frame's joints) need no workgroup barrier, and what a lane needs to know about its
+// joint (ancestors, descendants, the data / skeleton permutation) sits in registers for the whole launch.
+// (Measured and dropped, profiles/r05_experiments.md section 8: recursions by tree level -- 28 cross products per frame instead of 101, but six dependent LDS
+// round trips per product where the walks have one or two.)
+//
+// out = J v (:51-322 applied to a vector) for the rows of the slice; w.vh must hold v of the two frames after it (kin_exchange_v, or LSMR's second
+// synchronisation).  With `fused`: the form LSMR's bidiagonalisation needs, out <- scale * (J v) + keep * out in place and acc[wi][0] += |out|^2 over the slice.
+// L: the slice's arrays are in LDS; VL: so are v and out.
+template <bool L, bool VL>
+KO_DEV void kin_jv(KinCtx& c, int vsel, int osel, const double scale, const double keep, const bool fused, KoAcc (*acc)[KC_PARTS]) {
+  typedef typename Sp<L>::p LP; typedef typename Sp<L>::cp LCP; typedef typename Sp<VL>::p VP; typedef typename Sp<VL>::cp VCP;
+  const int F = c.k->F;
+  const double sv = c.k->wt[1], sa = c.k->wt[2], vw = c.k->wt[4], fw = c.k->wt[5];
+  const double se = sv * KO_SMOOTH_EULER;
+  KC_EACH(c, w)
+    (void)wi;
+    VCP v = (VCP)w.nv[vsel]; LCP E = (LCP)w.E; LCP P = (LCP)w.P; LP LW = (LP)w.LW; LP LD = (LP)w.LD;
+    KO_FOR(idx, w.nh * 32) {                  // omega_j = sum_a v_{j,a} axis_{j,a}
+      const int l = idx >> 5, j = idx & 31;
+      if (j >= NJ) continue;
+      LCP e = E + 252 * l + 9 * j;
+      const double v0 = nvf<VL>(w, v, l, 3 + 3 * j), v1 = nvf<VL>(w, v, l, 4 + 3 * j), v2 = nvf<VL>(w, v, l, 5 + 3 * j);
+      for (int k = 0; k < 3; ++k) LW[84 * l + 3 * j + k] = v0 * e[k] + v1 * e[3 + k] + v2 * e[6 + k];
+    }
+    KO_WSYNC();
+    KO_SEG(c, 0);
+    KO_FOR(idx, w.nh * 32) {                  // dp_t = sum over the strict ancestors j of t of omega_j x (p_t - p_j), nearest first; stored in data order
+      const int l = idx >> 5, t = idx & 31;
+      if (t >= NJ) continue;
+      double d[3] = {0, 0, 0};
+      if (t == 0) { for (int k = 0; k < 3; ++k) d[k] = nvf<VL>(w, v, l, k); }
+      else {
+        LCP Pf = P + 84 * l; LCP Wf = LW + 84 * l;
+        const double p0 = Pf[3 * t], p1 = Pf[3 * t + 1], p2 = Pf[3 * t + 2];
+        const int na = kj_na(c, t);
+        const unsigned long long al = kj_anc(c, t);
+#pragma unroll 1
+        for (int q0 = 0; q0 < na && q0 < 8; q0 += 4) {          // four ancestors at a time, all operands requested before the first is used
+          double om[4][3], pj[4][3];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int j = (int)((al >> (8 * (q0 + q))) & 255);  // (beyond the walk: the table holds the joint itself)
+            for (int k = 0; k < 3; ++k) { om[q][k] = Wf[3 * j + k]; pj[q][k] = Pf[3 * j + k]; }
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (q0 + q < na) {
+              const double r0 = p0 - pj[q][0], r1 = p1 - pj[q][1], r2 = p2 - pj[q][2];
+              d[0] += om[q][1] * r2 - om[q][2] * r1; d[1] += om[q][2] * r0 - om[q][0] * r2; d[2] += om[q][0] * r1 - om[q][1] * r0;
+            }
+        }
+        if (na > 8)
+          for (int j = c.P->parents[(int)((al >> 56) & 255)]; j >= 0; j = c.P->parents[j]) {
+            const double r0 = p0 - Pf[3 * j], r1 = p1 - Pf[3 * j + 1], r2 = p2 - Pf[3 * j + 2];
+            d[0] += Wf[3 * j + 1] * r2 - Wf[3 * j + 2] * r1; d[1] += Wf[3 * j + 2] * r0 - Wf[3 * j] * r2; d[2] += Wf[3 * j] * r1 - Wf[3 * j + 1] * r0;
+          }
+      }
+      const int ft = kj_f3(c, t);
+      LD[84 * l + ft] = d[0]; LD[84 * l + ft + 1] = d[1]; LD[84 * l + ft + 2] = d[2];
+    }
+  KC_DONE
+  KO_SYNC();
+  KO_SEG(c, 1);
+  KC_EACH(c, w)
+    VCP v = (VCP)w.nv[vsel]; VP out = (VP)w.mv[osel]; LCP LD = (LCP)w.LD; LCP Cc = (LCP)w.C; LCP DW = (LCP)w.DW; typename Sp<L>::ci CT = (typename Sp<L>::ci)w.CT;
+    KO_FOR(idx, w.nf * 32) {                  // the fifteen rows of (frame, joint)
+      const int l = idx >> 5, jd = idx & 31, f = w.a + l;
+      if (jd >= NJ) continue;
+      const int it = NJ * l + jd;
+      LCP dy = LD + 84 * l + 3 * jd;
+      LCP d0 = LD + 84 * l;                                           // data joint 0: where the reference puts the root's projection derivative
+      LCP dr = LD + 84 * l + 3 * ROOT;
+      const double C0 = Cc[3 * it], C1 = Cc[3 * it + 1], C2 = Cc[3 * it + 2];
+      const bool ct = (CT[it] & 1) != 0;
+      const double dwj = DW[it], swj = sv * c.P->smooth_w[jd];
+      const bool has1 = f < F - 1, has2 = f < F - 2;
+      int rr[15]; double val[15];
       const double ex = jd == 0 ? dy[0] : d0[0] + dy[0], ey = jd == 0 ? dy[1] : d0[1] + dy[1], ez = jd == 0 ? dy[2] : d0[2] + dy[2];
-      rr[0] = 2 * gi; on[0] = true; val[0] = C0 * ex + C1 * ez;
-      rr[1] = 2 * gi + 1; on[1] = true; val[1] = C0 * ey + C2 * ez;
+      rr[0] = R_PROJ + 2 * jd; val[0] = C0 * ex + C1 * ez;
+      rr[1] = R_PROJ + 2 * jd + 1; val[1] = C0 * ey + C2 * ez;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int o = 2 + 4 * k;
-        rr[o] = c.o2 + 3 * gi + k; on[o] = has1; val[o] = sv * SMOOTH_W[jd] * SMOOTH_VEL[k] * (dy[k] - dy[84 + k]);
-        rr[o + 1] = c.o5 + 3 * gi + k; on[o + 1] = has1; val[o + 1] = ct ? vw * ((dr[k] + dy[k]) - (dr[84 + k] + dy[84 + k])) : 0.0;
-        rr[o + 2] = c.o3 + 3 * gi + k; on[o + 2] = has2; val[o + 2] = sa * (dy[k] - 2.0 * dy[84 + k] + dy[168 + k]);
-        rr[o + 3] = c.o4 + 3 * gi + k; on[o + 3] = true; val[o + 3] = dwj * dy[k];
+        const double n1 = has1 ? dy[84 + k] : 0.0, n2 = has2 ? dy[168 + k] : 0.0, nr1 = has1 ? dr[84 + k] : 0.0;
+        rr[o] = R_VEL + 3 * jd + k; val[o] = has1 ? swj * SMOOTH_VEL[k] * (dy[k] - n1) : 0.0;
+        rr[o + 1] = R_CVEL + 3 * jd + k; val[o + 1] = (has1 && ct) ? vw * ((dr[k] + dy[k]) - (nr1 + n1)) : 0.0;
+        rr[o + 2] = R_ACC + 3 * jd + k; val[o + 2] = has2 ? sa * (dy[k] - 2.0 * n1 + n2) : 0.0;
+        rr[o + 3] = R_DATA + 3 * jd + k; val[o + 3] = dwj * dy[k];
       }
       double d = 0;
-      for (int k = 0; k < 3; ++k) d += c.q->floor_n[k] * (dr[k] + dy[k]);
-      rr[14] = c.o6 + gi; on[14] = true; val[14] = ct ? fw * d : 0.0;
+      for (int k = 0; k < 3; ++k) d += c.k->fn[k] * (dr[k] + dy[k]);
+      rr[14] = R_FLOOR + jd; val[14] = ct ? fw * d : 0.0;
+      VP r = out + NR * l;
       if (fused) {
         double old[15];
 #pragma unroll
-        for (int q = 0; q < 15; ++q) old[q] = out[on[q] ? rr[q] : 0];
+        for (int q = 0; q < 15; ++q) old[q] = r[rr[q]];
 #pragma unroll
-        for (int q = 0; q < 15; ++q) { val[q] = scale * val[q] + keep * old[q]; acc.add(cur, on[q] ? val[q] * val[q] : 0.0); }
+        for (int q = 0; q < 15; ++q) { val[q] = scale * val[q] + keep * old[q]; acc[wi][0].add(idx, val[q] * val[q]); }
       }
 #pragma unroll
-      for (int q = 0; q < 15; ++q) if (on[q]) out[rr[q]] = val[q];
+      for (int q = 0; q < 15; ++q) r[rr[q]] = val[q];
     }
-    KO_FOR(idx, nf * NV) {                    // Euler-angle smoothness rows of the tile's frames
-      cur = idx;
-      const long long g0 = (long long)f0 * NV + idx;
-      if (f0 + idx / NV < F - 1) put(c.o7 + g0, sv * KO_SMOOTH_EULER * (v[g0] - v[g0 + NV]));
+    KO_FOR(idx, w.nf * NV) {                  // Euler-angle smoothness rows
+      const int l = idx / NV, i = idx % NV;
+      VP r = out + NR * l + R_EUL + i;
+      double val = (w.a + l < F - 1) ? se * (v[idx] - nvf<VL>(w, v, l + 1, i)) : 0.0;
+      if (fused) { val = scale * val + keep * *r; acc[wi][0].add(idx, val * val); }
+      *r = val;
     }
-    KO_SYNC();                                // the next tile overwrites the LDS block
-  }
-  if (fused) *sumsq = ko_total(c, acc);
+  KC_DONE
+  KO_SYNC();
+  KO_SEG(c, 2);
 }
 
-// out = J^T u.
-// With `sumsq`: out <- scale * (J^T u) + keep * out in place and *sumsq = |out|^2 (one writer per unknown).
-KO_DEV void kin_jtu(KinCtx& c, const double* u, double* out, const double scale = 1.0, const double keep = 0.0, double* sumsq = nullptr) {
-  const int F = c.q->F;
-  const double sv = c.q->w[1], sa = c.q->w[2], dw = c.q->w[3], vw = c.q->w[4], fw = c.q->w[5];
+// out = J^T u for the unknowns of the slice; w.uh must hold the boundary rows of u of the left neighbour (kin_exchange_u, or LSMR's first synchronisation).
+// With `fused`: out <- scale * (J^T u) + keep * out in place and acc[wi][0] += |out|^2 over the slice.  No workgroup barrier inside: every step is within a frame.
+template <bool L, bool VL>
+KO_DEV void kin_jtu(KinCtx& c, int usel, int osel, const double scale, const double keep, const bool fused, KoAcc (*acc)[KC_PARTS]) {
+  typedef typename Sp<L>::p LP; typedef typename Sp<L>::cp LCP; typedef typename Sp<VL>::p VP; typedef typename Sp<VL>::cp VCP;
+  const int F = c.k->F;
+  const double sv = c.k->wt[1], sa = c.k->wt[2], vw = c.k->wt[4], fw = c.k->wt[5];
   const double se = sv * KO_SMOOTH_EULER;
-  const bool fused = sumsq != nullptr;
-  KoAcc acc;
-  int TF = c.lds_doubles / 336;
-  if (TF < 1) TF = 1;
-  double* LP = c.lds; double* LQ = LP + 84 * TF; double* LR = LQ + 84 * TF; double* LL = LR + 84 * TF;
-  for (int f0 = 0; f0 < F; f0 += TF) {
-    const int nf = F - f0 < TF ? F - f0 : TF;
-    KO_FOR(idx, nf * NJ) {                    // positions; each joint's own projection rows and contact rows acting on a position they reference
-      const int f = f0 + idx / NJ, jd = idx % NJ;
-      const long long gi = (long long)f * NJ + jd;
+  KC_EACH(c, w)
+    VCP u = (VCP)w.mv[usel]; VP out = (VP)w.nv[osel]; LP LQ = (LP)w.LW; LP LR = (LP)w.LD; LP LL = (LP)w.LL; LCP Cc = (LCP)w.C; LCP DW = (LCP)w.DW; LCP P = (LCP)w.P; LCP E = (LCP)w.E;
+    typename Sp<L>::ci CT = (typename Sp<L>::ci)w.CT;
+    KO_FOR(idx, w.nf * 32) {                  // each joint's own projection rows and contact rows acting on a position they reference
+      const int l = idx >> 5, jd = idx & 31, f = w.a + l;
+      if (jd >= NJ) continue;
+      const int it = NJ * l + jd;
       const bool has1 = f < F - 1, hasm = f >= 1;
-      // every load is unconditional (a masked-off one reads entry 0 instead): the requests go out together, not one per branch
-      const double* pp = c.w.P + (long long)f * 84 + 3 * jd;       // (LP is in skeleton order: entry jd here is skeleton joint jd)
-      const double* C = c.w.C + 3 * gi;
-      const double p0 = pp[0], p1 = pp[1], p2 = pp[2], C0 = C[0], C1 = C[1], C2 = C[2];
-      const double ux = u[2 * gi], uy = u[2 * gi + 1];
-      const bool ct = c.contact[gi] == 1, ctm = c.contact[hasm ? gi - NJ : gi] == 1 && hasm;
-      const double u6 = u[c.o6 + gi];
-      double u5[3], u5m[3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) { u5[k] = u[has1 ? c.o5 + 3 * gi + k : 0]; u5m[k] = u[hasm ? c.o5 + 3 * (gi - NJ) + k : 0]; }
-      LP[3 * idx] = p0; LP[3 * idx + 1] = p1; LP[3 * idx + 2] = p2;
-      LQ[3 * idx] = C0 * ux; LQ[3 * idx + 1] = C0 * uy; LQ[3 * idx + 2] = C1 * ux + C2 * uy;
-      const double uf = fw * u6;
+      VCP r = u + NR * l;
+      const double C0 = Cc[3 * it], C1 = Cc[3 * it + 1], C2 = Cc[3 * it + 2];
+      const double ux = r[R_PROJ + 2 * jd], uy = r[R_PROJ + 2 * jd + 1];
+      const int cti = CT[it];
+      const bool ct = (cti & 1) != 0, ctm = (cti & 2) != 0;
+      const double uf = fw * r[R_FLOOR + jd];
+      LQ[84 * l + 3 * jd] = C0 * ux; LQ[84 * l + 3 * jd + 1] = C0 * uy; LQ[84 * l + 3 * jd + 2] = C1 * ux + C2 * uy;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        double r = 0.0;
-        r += (ct && has1) ? vw * u5[k] : 0.0;
-        r += ct ? c.q->floor_n[k] * uf : 0.0;
-        r -= ctm ? vw * u5m[k] : 0.0;
-        LR[3 * idx + k] = r;
+        const double u5 = r[R_CVEL + 3 * jd + k], u5m = hasm ? mv_row<VL>(w, u, l - 1, R_CVEL + 3 * jd + k) : 0.0;
+        double t = 0.0;
+        t += (ct && has1) ? vw * u5 : 0.0;
+        t += ct ? c.k->fn[k] * uf : 0.0;
+        t -= ctm ? vw * u5m : 0.0;
+        LR[84 * l + 3 * jd + k] = t;
       }
     }
-    KO_SYNC();
-    KO_FOR(idx, nf * NJ) {                    // lambda of data joint jd of frame f
-      const int fl = idx / NJ, jd = idx % NJ, f = f0 + fl;
-      const long long gi = (long long)f * NJ + jd;
+    KO_WSYNC();
+    KO_SEG(c, 5);
+    KO_FOR(idx, w.nf * 32) {                  // lambda of data joint jd of frame f
+      const int l = idx >> 5, jd = idx & 31, f = w.a + l;
+      const bool act = jd < NJ;
+      const int jq = act ? jd : 0;
+      double q[3], r3[3], sq[3] = {0, 0, 0}, sr[3] = {0, 0, 0};
+      for (int k = 0; k < 3; ++k) { q[k] = LQ[84 * l + 3 * jq + k]; r3[k] = LR[84 * l + 3 * jq + k]; }
+#ifdef CHD_HOST_EMU
+      if (jd == 0) ko_frame_sum3(LQ + 84 * l, q, jd, 0, sq);                // the misplaced root column: the other joints' projection terms
+      if (jd == ROOT) ko_frame_sum3(LR + 84 * l, r3, jd, ROOT, sr);         // root + joint in the contact rows
+#else
+      ko_frame_sum3(nullptr, q, jd, 0, sq);
+      ko_frame_sum3(nullptr, r3, jd, ROOT, sr);
+#endif
+      if (!act) continue;
+      const int it = NJ * l + jd;
       double lam[3];
-      for (int k = 0; k < 3; ++k) lam[k] = LQ[3 * idx + k] + LR[3 * idx + k];
-      if (jd == 0) for (int j = 1; j < NJ; ++j) for (int k = 0; k < 3; ++k) lam[k] += LQ[84 * fl + 3 * j + k];                      // the misplaced root column
-      if (jd == ROOT) for (int j = 0; j < NJ; ++j) if (j != ROOT) for (int k = 0; k < 3; ++k) lam[k] += LR[84 * fl + 3 * j + k];   // root + joint in the contact rows
-      const double dwj = dw * c.data_w[gi];
+      for (int k = 0; k < 3; ++k) lam[k] = q[k] + r3[k];
+      if (jd == 0) for (int k = 0; k < 3; ++k) lam[k] += sq[k];
+      if (jd == ROOT) for (int k = 0; k < 3; ++k) lam[k] += sr[k];
+      const double dwj = DW[it], swj = sv * c.P->smooth_w[jd];
       const bool b0 = f < F - 1, b1 = f >= 1, b2 = f < F - 2, b3 = f >= 1 && f - 1 < F - 2, b4 = f >= 2;
-      double t0[3], t1[3], t2[3], t3[3], t4[3], t5[3];      // all eighteen entries of u requested together (masked-off ones read entry 0)
+      VCP r = u + NR * l;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        t0[k] = u[b0 ? c.o2 + 3 * gi + k : 0]; t1[k] = u[b1 ? c.o2 + 3 * (gi - NJ) + k : 0];
-        t2[k] = u[b2 ? c.o3 + 3 * gi + k : 0]; t3[k] = u[b3 ? c.o3 + 3 * (gi - NJ) + k : 0]; t4[k] = u[b4 ? c.o3 + 3 * (gi - 2 * NJ) + k : 0];
-        t5[k] = u[c.o4 + 3 * gi + k];
+        const double s = swj * SMOOTH_VEL[k];
+        const double t0 = r[R_VEL + 3 * jd + k], t1 = b1 ? mv_row<VL>(w, u, l - 1, R_VEL + 3 * jd + k) : 0.0;
+        const double t2 = r[R_ACC + 3 * jd + k], t3 = b3 ? mv_row<VL>(w, u, l - 1, R_ACC + 3 * jd + k) : 0.0, t4 = b4 ? mv_row<VL>(w, u, l - 2, R_ACC + 3 * jd + k) : 0.0;
+        const double t5 = r[R_DATA + 3 * jd + k];
+        lam[k] += b0 ? s * t0 : 0.0;
+        lam[k] -= b1 ? s * t1 : 0.0;
+        lam[k] += b2 ? sa * t2 : 0.0;
+        lam[k] -= b3 ? 2.0 * sa * t3 : 0.0;
+        lam[k] += b4 ? sa * t4 : 0.0;
+        lam[k] += dwj * t5;
       }
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const double s = sv * SMOOTH_W[jd] * SMOOTH_VEL[k];
-        lam[k] += b0 ? s * t0[k] : 0.0;
-        lam[k] -= b1 ? s * t1[k] : 0.0;
-        lam[k] += b2 ? sa * t2[k] : 0.0;
-        lam[k] -= b3 ? 2.0 * sa * t3[k] : 0.0;
-        lam[k] += b4 ? sa * t4[k] : 0.0;
-        lam[k] += dwj * t5[k];
-      }
-      LL[3 * idx] = lam[0]; LL[3 * idx + 1] = lam[1]; LL[3 * idx + 2] = lam[2];
+      const int bj = kj_b3(c, jd);                // stored at the joint's skeleton index: the walk below then needs no table
+      LL[84 * l + bj] = lam[0]; LL[84 * l + bj + 1] = lam[1]; LL[84 * l + bj + 2] = lam[2];
     }
-    KO_SYNC();
-    KO_FOR(idx, nf * NJ) {                    // (J^T u)_{j,a} = axis_{j,a} . sum over the strict descendants t of j of (p_t - p_j) x lambda_t
-      const int fl = idx / NJ, j = idx % NJ, f = f0 + fl;
-      const double* Pf = LP + 84 * fl;
-      const double* L = LL + 84 * fl;
+    KO_WSYNC();
+    KO_SEG(c, 6);
+    KO_FOR(idx, w.nf * 32) {                  // (J^T u)_{j,a} = axis_{j,a} . sum over the strict descendants t of j of (p_t - p_j) x lambda_t, + the Euler-smoothness rows;
+      const int l = idx >> 5, j = idx & 31, f = w.a + l;   // the root's translation gets lambda of the root's data joint
+      if (j >= NJ) continue;
+      LCP Pf = P + 84 * l;
       const double q0 = Pf[3 * j], q1 = Pf[3 * j + 1], q2 = Pf[3 * j + 2];
-      double M[3] = {0, 0, 0};
-      const unsigned mask = c.P->desc[j];
-      for (int t = j + 1; t < NJ; ++t) {
-        if (!((mask >> t) & 1u)) continue;
-        const double* l = L + 3 * FWD[t];
-        const double r0 = Pf[3 * t] - q0, r1 = Pf[3 * t + 1] - q1, r2 = Pf[3 * t + 2] - q2;
-        M[0] += r1 * l[2] - r2 * l[1]; M[1] += r2 * l[0] - r0 * l[2]; M[2] += r0 * l[1] - r1 * l[0];
+      double M0 = 0, M1 = 0, M2 = 0;
+      const unsigned mask = kj_desc(c, j);
+      const int tend = kj_dend(c, j);
+#pragma unroll 1
+      for (int t0 = j + 1; t0 <= tend; t0 += 4) {   // four candidates at a time (descendants are the joints j+1 .. tend when the skeleton is in depth-first order), operands requested together
+        double pt[4][3], lm[4][3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int t = t0 + q <= tend ? t0 + q : j;
+          for (int k = 0; k < 3; ++k) { pt[q][k] = Pf[3 * t + k]; lm[q][k] = LL[84 * l + 3 * t + k]; }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (t0 + q <= tend && ((mask >> (t0 + q)) & 1u)) {
+            const double r0 = pt[q][0] - q0, r1 = pt[q][1] - q1, r2 = pt[q][2] - q2;
+            M0 += r1 * lm[q][2] - r2 * lm[q][1]; M1 += r2 * lm[q][0] - r0 * lm[q][2]; M2 += r0 * lm[q][1] - r1 * lm[q][0];
+          }
       }
-      const double* e = c.w.E + (long long)f * 252 + 9 * j;
-      double* o = out + (long long)f * NV;
+      LCP e = E + 252 * l + 9 * j;
+      LCP Lf = LL + 84 * l;
+      VP o = out + NV * l;
       const bool has1 = f < F - 1, hasm = f >= 1, isroot = j == 0;
-      // the six unknowns this item may write (three angles; the root translation for joint 0): Euler-smoothness entries of u and, in
-      // the fused form, the old values are requested up front (masked-off requests read entry 0)
-      int kk[6]; double ua[6], ub[6], oldv[6], val[6];
 #pragma unroll
-      for (int q = 0; q < 6; ++q) {
-        kk[q] = q < 3 ? 3 + 3 * j + q : q - 3;
+      for (int q = 0; q < 6; ++q) {             // three angles; the root translation for joint 0
         const bool live = q < 3 || isroot;
-        ua[q] = u[(live && has1) ? c.o7 + f * NV + kk[q] : 0];
-        ub[q] = u[(live && hasm) ? c.o7 + (f - 1) * NV + kk[q] : 0];
-        oldv[q] = (fused && live) ? o[kk[q]] : 0.0;
-      }
-      double ee[9];
-#pragma unroll
-      for (int q = 0; q < 9; ++q) ee[q] = e[q];
-#pragma unroll
-      for (int q = 0; q < 6; ++q) {
+        if (!live) continue;
+        const int kk = q < 3 ? 3 + 3 * j + q : q - 3;
         double eu = 0.0;
-        eu += has1 ? se * ua[q] : 0.0;
-        eu -= hasm ? se * ub[q] : 0.0;
-        val[q] = (q < 3 ? ee[3 * q] * M[0] + ee[3 * q + 1] * M[1] + ee[3 * q + 2] * M[2] : L[3 * ROOT + (q - 3)]) + eu;
-      }
-#pragma unroll
-      for (int q = 0; q < 6; ++q) {
-        const bool live = q < 3 || isroot;
-        if (fused) { val[q] = scale * val[q] + keep * oldv[q]; acc.add(idx, live ? val[q] * val[q] : 0.0); }
-        if (live) o[kk[q]] = val[q];
+        eu += has1 ? se * u[NR * l + R_EUL + kk] : 0.0;
+        eu -= hasm ? se * mv_row<VL>(w, u, l - 1, R_EUL + kk) : 0.0;
+        double val = (q < 3 ? e[3 * q] * M0 + e[3 * q + 1] * M1 + e[3 * q + 2] * M2 : Lf[3 * c.P->bwd[ROOT] + (q - 3)]) + eu;
+        if (fused) { val = scale * val + keep * o[kk]; acc[wi][0].add(idx, val * val); }
+        o[kk] = val;
       }
     }
-    KO_SYNC();
-  }
-  if (fused) *sumsq = ko_total(c, acc);
+  KC_DONE
+  KO_SYNC();
+  KO_SEG(c, 7);
 }
 
 // ---- LSMR (Fong & Saunders 2011, as scipy.sparse.linalg.lsmr with x0 = None) -----------------------------------------------------
@@ -498,122 +785,222 @@ KO_DEV void sym_ortho(double a, double b, double& cc, double& s, double& r) {
   else { const double tau = b / a; cc = sgn(a) / std::sqrt(1 + tau * tau); s = cc * tau; r = a / cc; }
 }
 
-// min |J x - b|^2 + damp^2 |x|^2 into c.w.GN; uses U (m), V, H, HB (n).  Returns the iteration count.
-// The Golub-Kahan vectors are kept UNNORMALISED (u = su * U, v = sv * V with the scalars in registers): each half step is one
-// fused product pass, beta u = A v - alpha u  ->  U <- sv * (J V) - (alpha su) * U,  beta = |U|,  su = 1 / beta, and the same for V.
-KO_DEV int kin_lsmr(KinCtx& c, const double* b, double damp, int* istop_out) {
-  const long long n = c.q->n, m = c.q->m;
-  const KinParams& P = *c.P;
-  const int maxiter = P.lsmr_maxiter > 0 ? P.lsmr_maxiter : (int)(m < n ? m : n);
-  double *u = c.w.U, *v = c.w.V, *h = c.w.H, *hbar = c.w.HB, *x = c.w.GN;
-  KoAcc s0;
-  for (long long i = KO_TID; i < m; i += KO_NT) { const double t = b[i]; u[i] = t; s0.add(i, t * t); }
-  const double normb = std::sqrt(ko_total(c, s0));
-  double beta = normb, alpha = 0, su = 0, sv = 0;
-  for (long long i = KO_TID; i < n; i += KO_NT) { x[i] = 0; hbar[i] = 0; v[i] = 0; }
+
+// min |J x - b|^2 + damp^2 |x|^2 into the GN slices, b = the FV slices; uses U (m), V, H, HB (n).  Returns the iteration count.
+// The Golub-Kahan vectors are kept UNNORMALISED (u = su * U, v = sv * V): each half step is one
+// fused product, beta u = A v - alpha u  ->  U <- sv * (J V) - (alpha su) * U,  beta = |U|,  su = 1 / beta, and the same for V.
+// Two synchronisations of the cluster per iteration:
+//   1. after the rows of U: |U|^2 and the boundary rows of U for the right neighbour.  beta fixes rho and with it k1: hbar <- k1 hbar + h can follow at once;
+//   2. after V: |V|^2, the first two frames of V for the left neighbour, and x.x, x.hbar, hbar.hbar -- alpha then fixes k2, k3: x <- x + k2 hbar, h <- k3 h + sv v,
+//      |x|^2 = x.x + 2 k2 x.hbar + k2^2 hbar.hbar.
+// The scalar recurrences (four plane rotations, the estimates of |r|, |A|, cond A, the stopping tests: ~30 divisions and square roots in a dependent chain) run
+// in the FIRST THREAD only, on a state kept in LDS (KinLsmr): seven wavefronts wait at the barrier instead of competing for the same SIMDs with the same arithmetic.
+template <bool L>
+KO_DEV int kin_lsmr_on(KinCtx& c, double damp, int* istop_out) {
+  typedef typename Sp<L>::p LP; typedef typename Sp<L>::cp LCP;
+  KO_LDSQ KinLsmr& S = *c.S;
+  // LSMR's x, h-bar and h: three entries per thread at most when the slice is in LDS (13 frames x 87 <= 3 x 512): in registers for the whole solve -- no
+  // device-memory traffic inside the loop; x goes to its slice once at the end.  (Slices in device memory, and the emulation: the arrays.)
+  double xr[3] = {0.0, 0.0, 0.0}, hbr[3] = {0.0, 0.0, 0.0}, hr[3] = {0.0, 0.0, 0.0};
+  KoAcc acc[KC_NW][KC_PARTS];
+  KC_EACH(c, w)
+    const double* b = w.mv[M_FV]; LP u = (LP)w.mv[M_U]; LP v = (LP)w.nv[N_V];
+    KO_FOR(i, w.nf * NR) { const double t = b[i]; u[i] = t; acc[wi][0].add(i, t * t); }
+    KO_FOR(i, w.nf * NV) { if (!L) { w.nv[N_GN][i] = 0; w.nv[N_HB][i] = 0; } v[i] = 0; }
+  KC_DONE
   KO_SYNC();
-  if (beta > 0) {
-    su = 1 / beta;
-    double a2 = 0;
-    { const long long t0_ = KO_CLOCK(); kin_jtu(c, u, v, su, 0.0, &a2); c.t_jtu += KO_CLOCK() - t0_; }
-    alpha = std::sqrt(a2);
+  kin_pub_u<L>(c, M_U);
+  kc_sync(c, acc, 1, -1, HALO_U);
+  if (KO_TID == 0) {
+    const long long n = c.k->q->n, m = c.k->q->m;
+    S.maxiter = c.P->lsmr_maxiter > 0 ? c.P->lsmr_maxiter : (int)(m < n ? m : n);
+    S.damp = damp; S.ctol = c.P->conlim > 0 ? 1 / c.P->conlim : 0;
+    S.normb = std::sqrt(kc_sum(c, 0));
+    S.beta = S.normb; S.alpha = 0; S.su = S.beta > 0 ? 1 / S.beta : 0.0; S.sv = 0;
   }
-  if (alpha > 0) sv = 1 / alpha;
-  for (long long i = KO_TID; i < n; i += KO_NT) h[i] = sv * v[i];
   KO_SYNC();
+  if (S.beta > 0) {
+    KoAcc a2[KC_NW][KC_PARTS];
+    const long long t0_ = KO_CLOCK();
+    kin_jtu<L, L>(c, M_U, N_V, S.su, 0.0, true, a2);
+    kin_pub_v<L>(c, N_V);
+    kc_sync(c, a2, 1, +1, HALO_V);
+    c.t_jtu += KO_CLOCK() - t0_;
+    if (KO_TID == 0) S.alpha = std::sqrt(kc_sum(c, 0));
+  }
+  if (KO_TID == 0) {
+    if (S.alpha > 0) S.sv = 1 / S.alpha;
+    S.itn = 0; S.istop = 0;
+    S.zetabar = S.alpha * S.beta; S.alphabar = S.alpha; S.rho = 1; S.rhobar = 1; S.cbar = 1; S.sbar = 0;
+    S.betadd = S.beta; S.betad = 0; S.rhodold = 1; S.tautildeold = 0; S.thetatilde = 0; S.zeta = 0; S.d = 0;
+    S.normA2 = S.alpha * S.alpha; S.maxrbar = 0; S.minrbar = 1e100;
+  }
+  KO_SYNC();
+  {
+    const double sv0 = S.sv;
+    KC_EACH(c, w)
+      (void)wi;
+      LP h = (LP)w.nv[N_H]; LCP v = (LCP)w.nv[N_V];
+      if (L) { for (int q = 0; q < 3; ++q) { const int i = KO_TID + q * KO_NT; if (i < w.nf * NV) hr[q] = sv0 * v[i]; } }
+      else KO_FOR(i, w.nf * NV) h[i] = sv0 * v[i];
+    KC_DONE
+  }
+  KO_SYNC();
+  if (S.alpha * S.beta == 0 || S.normb == 0) {
+    if (L) {
+      KC_EACH(c, w)
+        (void)wi;
+        for (int q = 0; q < 3; ++q) { const int i = KO_TID + q * KO_NT; if (i < w.nf * NV) w.nv[N_GN][i] = 0.0; }
+      KC_DONE
+      KO_SYNC();
+    }
+    *istop_out = 0; return 0;
+  }
+#if defined(KIN_PROFILE) && !defined(CHD_HOST_EMU)
+  c.tlast = (long long)clock64();
+#endif
+  const int maxiter = S.maxiter;
   int itn = 0, istop = 0;
-  double zetabar = alpha * beta, alphabar = alpha, rho = 1, rhobar = 1, cbar = 1, sbar = 0;
-  double betadd = beta, betad = 0, rhodold = 1, tautildeold = 0, thetatilde = 0, zeta = 0, d = 0;
-  double normA2 = alpha * alpha, maxrbar = 0, minrbar = 1e100;
-  const double ctol = P.conlim > 0 ? 1 / P.conlim : 0;
-  if (alpha * beta == 0 || normb == 0) { *istop_out = 0; return 0; }
   while (itn < maxiter) {
     ++itn;
-    double b2 = 0;
-    { const long long t0_ = KO_CLOCK(); kin_jv(c, v, u, sv, -alpha * su, &b2); c.t_jv += KO_CLOCK() - t0_; }
-    beta = std::sqrt(b2);
-    if (beta > 0) {
-      su = 1 / beta;
-      double a2 = 0;
-      { const long long t0_ = KO_CLOCK(); kin_jtu(c, u, v, su, -beta * sv, &a2); c.t_jtu += KO_CLOCK() - t0_; }
-      alpha = std::sqrt(a2);
-      if (alpha > 0) sv = 1 / alpha;
+    KO_SEG(c, 15);
+    {
+      KoAcc b2[KC_NW][KC_PARTS];
+      const long long t0_ = KO_CLOCK();
+      kin_jv<L, L>(c, N_V, M_U, S.sv, -S.alpha * S.su, true, b2);
+      kin_pub_u<L>(c, M_U);
+      kc_sync(c, b2, 1, -1, HALO_U);
+      KO_SEG(c, 3);
+      c.t_jv += KO_CLOCK() - t0_;
     }
-    double chat, shat, alphahat, cc, s, ctildeold, stildeold, rhotildeold;
-    sym_ortho(alphabar, damp, chat, shat, alphahat);
-    const double rhoold = rho;
-    sym_ortho(alphahat, beta, cc, s, rho);
-    const double thetanew = s * alpha;
-    alphabar = cc * alpha;
-    const double rhobarold = rhobar, zetaold = zeta, thetabar = sbar * rho, rhotemp = cbar * rho;
-    sym_ortho(cbar * rho, thetanew, cbar, sbar, rhobar);
-    zeta = cbar * zetabar;
-    zetabar = -sbar * zetabar;
-    const double k1 = -(thetabar * rho / (rhoold * rhobarold)), k2 = zeta / (rho * rhobar), k3 = -(thetanew / rho);
-    KoAcc sx;
-    {   // four elements per thread per pass, all sixteen loads issued before the first use (one element at a time leaves four loads in
-        // flight per wavefront: the pass is latency bound)
-      const double* __restrict__ vr = v; double* __restrict__ hr = h; double* __restrict__ hbr = hbar; double* __restrict__ xr = x;
-      long long i = KO_TID;
-      for (; i + 3LL * KO_NT < n; i += 4LL * KO_NT) {
-        double a[4], b[4], cx[4], dv[4];
+    if (KO_TID == 0) {
+      const double beta = std::sqrt(kc_sum(c, 0));
+      double chat, shat, alphahat, cc, s, rho;
+      sym_ortho(S.alphabar, S.damp, chat, shat, alphahat);
+      const double rhoold = S.rho;
+      sym_ortho(alphahat, beta, cc, s, rho);
+      S.beta = beta; S.chat = chat; S.shat = shat; S.cc = cc; S.s = s; S.rhoold = rhoold; S.rho = rho;
+      S.rhobarold = S.rhobar; S.zetaold = S.zeta; S.thetabar = S.sbar * rho; S.rhotemp = S.cbar * rho;
+      S.k1 = -(S.thetabar * rho / (rhoold * S.rhobarold));
+      if (beta > 0) S.su = 1 / beta;
+    }
+    KO_SYNC();
+    KO_SEG(c, 4);
+    {
+      KoAcc a2[KC_NW][KC_PARTS];
+      const long long t0_ = KO_CLOCK();
+      const double beta = S.beta, k1 = S.k1;
+      if (beta > 0) {
+        kin_jtu<L, L>(c, M_U, N_V, S.su, -beta * S.sv, true, a2);
+        kin_pub_v<L>(c, N_V);
+      }
+      KC_EACH(c, w)
+        double* __restrict__ hb = w.nv[N_HB]; LCP h = (LCP)w.nv[N_H]; const double* __restrict__ x = w.nv[N_GN];
+        if (L) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const long long k = i + (long long)q * KO_NT; a[q] = hbr[k]; b[q] = hr[k]; cx[q] = xr[k]; dv[q] = vr[k]; }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const long long k = i + (long long)q * KO_NT;
-          const double hb = a[q] * k1 + b[q];
-          hbr[k] = hb;
-          const double xi = cx[q] + k2 * hb;
-          xr[k] = xi; sx.add(k, xi * xi);
-          hr[k] = b[q] * k3 + sv * dv[q];
+          for (int q = 0; q < 3; ++q) {
+            const int i = KO_TID + q * KO_NT;
+            if (i < w.nf * NV) { const double t = hbr[q] * k1 + hr[q], xi = xr[q]; hbr[q] = t; a2[wi][1].add(i, xi * xi); a2[wi][2].add(i, xi * t); a2[wi][3].add(i, t * t); }
+          }
+        } else
+        KO_FOR(i, w.nf * NV) {
+          const double t = hb[i] * k1 + h[i], xi = x[i];
+          hb[i] = t;
+          a2[wi][1].add(i, xi * xi); a2[wi][2].add(i, xi * t); a2[wi][3].add(i, t * t);
         }
-      }
-      for (; i < n; i += KO_NT) {
-        const double hb = hbr[i] * k1 + hr[i];
-        hbr[i] = hb;
-        const double xi = xr[i] + k2 * hb;
-        xr[i] = xi; sx.add(i, xi * xi);
-        hr[i] = hr[i] * k3 + sv * vr[i];
-      }
+      KC_DONE
+      KO_SEG(c, 8);
+      kc_sync(c, a2, 4, +1, HALO_V);
+      KO_SEG(c, 9);
+      c.t_jtu += KO_CLOCK() - t0_;
     }
-    const double normx = std::sqrt(ko_total(c, sx));
-    const double betaacute = chat * betadd, betacheck = -shat * betadd;
-    const double betahat = cc * betaacute;
-    betadd = -s * betaacute;
-    const double thetatildeold = thetatilde;
-    sym_ortho(rhodold, thetabar, ctildeold, stildeold, rhotildeold);
-    thetatilde = stildeold * rhobar;
-    rhodold = ctildeold * rhobar;
-    betad = -stildeold * betad + ctildeold * betahat;
-    tautildeold = (zetaold - thetatildeold * tautildeold) / rhotildeold;
-    const double taud = (zeta - thetatilde * tautildeold) / rhodold;
-    d += betacheck * betacheck;
-    const double normr = std::sqrt(d + (betad - taud) * (betad - taud) + betadd * betadd);
-    normA2 += beta * beta;
-    const double normA = std::sqrt(normA2);
-    normA2 += alpha * alpha;
-    maxrbar = maxrbar > rhobarold ? maxrbar : rhobarold;
-    if (itn > 1) minrbar = minrbar < rhobarold ? minrbar : rhobarold;
-    const double condA = (maxrbar > rhotemp ? maxrbar : rhotemp) / (minrbar < rhotemp ? minrbar : rhotemp);
-    const double normar = std::fabs(zetabar);
-    const double test1 = normr / normb;
-    const double test2 = normA * normr != 0 ? normar / (normA * normr) : INFINITY;
-    const double test3 = 1 / condA;
-    const double t1 = test1 / (1 + normA * normx / normb);
-    const double rtol = P.btol + P.atol * normA * normx / normb;
-    if (itn >= maxiter) istop = 7;
-    if (1 + test3 <= 1) istop = 6;
-    if (1 + test2 <= 1) istop = 5;
-    if (1 + t1 <= 1) istop = 4;
-    if (test3 <= ctol) istop = 3;
-    if (test2 <= P.atol) istop = 2;
-    if (test1 <= rtol) istop = 1;
+    if (KO_TID == 0) {
+      const double beta = S.beta, cc = S.cc, s = S.s, rho = S.rho, chat = S.chat, shat = S.shat, thetabar = S.thetabar, rhobarold = S.rhobarold, zetaold = S.zetaold, rhotemp = S.rhotemp;
+      double alpha = S.alpha;
+      if (beta > 0) {
+        alpha = std::sqrt(kc_sum(c, 0));
+        if (alpha > 0) S.sv = 1 / alpha;
+      }
+      S.alpha = alpha;
+      double ctildeold, stildeold, rhotildeold, cbar, sbar, rhobar;
+      const double thetanew = s * alpha;
+      S.alphabar = cc * alpha;
+      sym_ortho(S.cbar * rho, thetanew, cbar, sbar, rhobar);
+      S.cbar = cbar; S.sbar = sbar; S.rhobar = rhobar;
+      const double zeta = cbar * S.zetabar;
+      S.zeta = zeta;
+      S.zetabar = -sbar * S.zetabar;
+      const double k2 = zeta / (rho * rhobar);
+      S.k2 = k2; S.k3 = -(thetanew / rho);
+      const double nx2 = kc_sum(c, 1) + 2.0 * k2 * kc_sum(c, 2) + k2 * k2 * kc_sum(c, 3);
+      const double normx = nx2 > 0 ? std::sqrt(nx2) : 0.0;
+      const double betaacute = chat * S.betadd, betacheck = -shat * S.betadd;
+      const double betahat = cc * betaacute;
+      S.betadd = -s * betaacute;
+      const double thetatildeold = S.thetatilde;
+      sym_ortho(S.rhodold, thetabar, ctildeold, stildeold, rhotildeold);
+      S.thetatilde = stildeold * rhobar;
+      S.rhodold = ctildeold * rhobar;
+      S.betad = -stildeold * S.betad + ctildeold * betahat;
+      S.tautildeold = (zetaold - thetatildeold * S.tautildeold) / rhotildeold;
+      const double taud = (zeta - S.thetatilde * S.tautildeold) / S.rhodold;
+      S.d += betacheck * betacheck;
+      const double normr = std::sqrt(S.d + (S.betad - taud) * (S.betad - taud) + S.betadd * S.betadd);
+      S.normA2 += beta * beta;
+      const double normA = std::sqrt(S.normA2);
+      S.normA2 += alpha * alpha;
+      S.maxrbar = S.maxrbar > rhobarold ? S.maxrbar : rhobarold;
+      if (itn > 1) S.minrbar = S.minrbar < rhobarold ? S.minrbar : rhobarold;
+      const double condA = (S.maxrbar > rhotemp ? S.maxrbar : rhotemp) / (S.minrbar < rhotemp ? S.minrbar : rhotemp);
+      const double normar = std::fabs(S.zetabar);
+      const double normb = S.normb;
+      const double test1 = normr / normb;
+      const double test2 = normA * normr != 0 ? normar / (normA * normr) : INFINITY;
+      const double test3 = 1 / condA;
+      const double t1 = test1 / (1 + normA * normx / normb);
+      const double rtol = c.P->btol + c.P->atol * normA * normx / normb;
+      int st = 0;
+      if (itn >= maxiter) st = 7;
+      if (1 + test3 <= 1) st = 6;
+      if (1 + test2 <= 1) st = 5;
+      if (1 + t1 <= 1) st = 4;
+      if (test3 <= S.ctol) st = 3;
+      if (test2 <= c.P->atol) st = 2;
+      if (test1 <= rtol) st = 1;
+      S.istop = st;
+    }
+    KO_SYNC();
+    {
+      const double k2 = S.k2, k3 = S.k3, sv = S.sv;
+      KC_EACH(c, w)
+        (void)wi;
+        double* __restrict__ x = w.nv[N_GN]; LP h = (LP)w.nv[N_H]; const double* __restrict__ hb = w.nv[N_HB]; LCP v = (LCP)w.nv[N_V];
+        if (L) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) { const int i = KO_TID + q * KO_NT; if (i < w.nf * NV) { xr[q] = xr[q] + k2 * hbr[q]; hr[q] = hr[q] * k3 + sv * v[i]; } }
+        } else
+        KO_FOR(i, w.nf * NV) { x[i] = x[i] + k2 * hb[i]; h[i] = h[i] * k3 + sv * v[i]; }
+      KC_DONE
+    }
+    istop = S.istop;
+    KO_SEG(c, 10);
     if (istop > 0) break;
+  }
+  if (L) {
+    KC_EACH(c, w)
+      (void)wi;
+      for (int q = 0; q < 3; ++q) { const int i = KO_TID + q * KO_NT; if (i < w.nf * NV) w.nv[N_GN][i] = xr[q]; }
+    KC_DONE
   }
   KO_SYNC();
   *istop_out = istop;
   return itn;
+}
+KO_DEV int kin_lsmr(KinCtx& c, double damp, int* istop_out) {
+#ifndef CHD_HOST_EMU
+  if (c.wg[0].in_lds) return kin_lsmr_on<true>(c, damp, istop_out);
+#endif
+  return kin_lsmr_on<false>(c, damp, istop_out);
 }
 
 // ---- 2-D trust-region problem (scipy solve_trust_region_2d) -------------------------------------------------------------------------
@@ -649,95 +1036,133 @@ KO_DEV void tr2d(double B00, double B01, double B11, double g0, double g1, doubl
   p0 = Delta * std::sin(best); p1 = Delta * std::cos(best);
 }
 
+
+// sums over the slices: up to three dot products of vectors picked by (kind 'n' / 'm', index) in one synchronisation
+struct KinDot { char kind; int a, b; };
+KO_DEV void kin_dots(KinCtx& c, const KinDot* d, int nd, double* out) {
+  KoAcc acc[KC_NW][KC_PARTS];
+  KC_EACH(c, w)
+    for (int k = 0; k < nd; ++k) {
+      const bool isn = d[k].kind == 'n';
+      const double* a = isn ? w.nv[d[k].a] : w.mv[d[k].a];
+      const double* b = isn ? w.nv[d[k].b] : w.mv[d[k].b];
+      KO_FOR(i, w.nf * (isn ? (int)NV : (int)NR)) acc[wi][k].add(i, a[i] * b[i]);
+    }
+  KC_DONE
+  kc_sync(c, acc, nd);
+  for (int k = 0; k < nd; ++k) out[k] = kc_sum(c, k);
+}
+KO_DEV double kin_dot(KinCtx& c, char kind, int a, int b) { const KinDot d = {kind, a, b}; double r; kin_dots(c, &d, 1, &r); return r; }
+
 // ---- the solve: scipy trf_no_bounds (x_scale = 1, linear loss, tr_solver = 'lsmr', regularize = True) ---------------------------------
-// stats: cost, nfev, njev, status, total LSMR iterations, last gradient infinity norm
+// stats: cost, nfev, njev, status, total LSMR iterations, last gradient infinity norm, shares of the time in LSMR's two halves
 KO_DEV void kin_solve(KinCtx& c, double* xio, double* stats) {
-  const long long n = c.q->n, m = c.q->m;
-  const KinParams& P = *c.P;
-  KinWork& w = c.w;
+  const KO_LDSQ KinParams& P = *c.P;
   c.t_jv = c.t_jtu = 0;
+  for (int k = 0; k < 16; ++k) c.seg[k] = 0;
   const long long t_begin = KO_CLOCK();
-  for (long long i = KO_TID; i < n; i += KO_NT) w.X[i] = xio[i];
+  KC_EACH(c, w)
+    KO_FOR(i, w.nf * NV) w.nv[N_X][i] = xio[(long long)NV * w.a + i];
+    KO_FOR(i, HALO_V) w.vh[i] = 0.0;
+    KO_FOR(i, HALO_U) w.uh[i] = 0.0;
+    KO_FOR(idx, w.nf * NJ) {                  // the items' constants
+      const long long gi = (long long)w.a * NJ + idx;
+      w.DW[idx] = c.k->wt[3] * c.k->data_w[gi];
+      w.CT[idx] = (c.k->contact[gi] == 1 ? 1 : 0) | ((gi >= NJ && c.k->contact[gi - NJ] == 1) ? 2 : 0);
+    }
+  KC_DONE
   KO_SYNC();
-  kin_residual(c, w.X, w.PN, w.RGN, w.Fv);
+  kin_residual(c, N_X, M_FV);
   int nfev = 1, njev = 1, status = -1;
   long long lsmr_total = 0;
-  kin_linearise(c, w.X);
-  double cost = 0.5 * ko_dot(c, w.Fv, w.Fv, m);
-  kin_jtu(c, w.Fv, w.G);
-  double Delta = std::sqrt(ko_dot(c, w.X, w.X, n));
+  kin_linearise(c, N_X);
+  double cost = 0.5 * kin_dot(c, 'm', M_FV, M_FV);
+  { kin_exchange_u(c, M_FV); KoAcc none[KC_NW][KC_PARTS]; KIN_DISPATCH(kin_jtu, false, c, M_FV, N_G, 1.0, 0.0, false, none); }
+  double Delta = std::sqrt(kin_dot(c, 'n', N_X, N_X));
   if (Delta == 0) Delta = 1.0;
   double g_norm = 0;
   while (true) {
-    double gi = 0;
-    for (long long i = KO_TID; i < n; i += KO_NT) { const double a = std::fabs(w.G[i]); gi = a > gi ? a : gi; }
-#ifndef CHD_HOST_EMU
-    {                                          // max over the workgroup
-      for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(gi, o); gi = t > gi ? t : gi; }
-      __syncthreads();
-      if ((threadIdx.x & 63) == 0) c.red[threadIdx.x >> 6] = gi;
-      __syncthreads();
-      gi = 0;
-      for (int i = 0; i < (int)(blockDim.x >> 6); ++i) gi = c.red[i] > gi ? c.red[i] : gi;
+    {
+      KoAcc gm[KC_NW][KC_PARTS];
+      KC_EACH(c, w)
+        KO_FOR(i, w.nf * NV) gm[wi][0].hi(i, std::fabs(w.nv[N_G][i]));
+      KC_DONE
+      kc_sync(c, gm, 1, 0, 0, true);
+      g_norm = kc_sum(c, 0, true);
     }
-#endif
-    g_norm = gi;
     if (g_norm < P.gtol) status = 1;
     if (status != -1 || nfev == P.max_nfev) break;
     // regularisation from the Cauchy step (build_quadratic_1d / minimize_quadratic_1d)
-    for (long long i = KO_TID; i < n; i += KO_NT) w.S0[i] = -w.G[i];
+    KC_EACH(c, w)
+      KO_FOR(i, w.nf * NV) w.nv[N_S0][i] = -w.nv[N_G][i];
+    KC_DONE
     KO_SYNC();
-    kin_jv(c, w.S0, w.T1);
-    double a = 0.5 * ko_dot(c, w.T1, w.T1, m);
-    const double gg = ko_dot(c, w.G, w.G, n);
+    KoAcc none[KC_NW][KC_PARTS];
+    kin_exchange_v(c, N_S0);
+    KIN_DISPATCH(kin_jv, false, c, N_S0, M_T1, 1.0, 0.0, false, none);
+    double gg, a;
+    { const KinDot dd[2] = {{'m', M_T1, M_T1}, {'n', N_G, N_G}}; double r[2]; kin_dots(c, dd, 2, r); a = 0.5 * r[0]; gg = r[1]; }
     const double b = -gg, to_tr = Delta / std::sqrt(gg);
     double ag = 0.0;                            // t = 0
     { const double y1 = to_tr * (a * to_tr + b); if (y1 < ag) ag = y1; }
     if (a != 0) { const double ext = -0.5 * b / a; if (0 < ext && ext < to_tr) { const double y2 = ext * (a * ext + b); if (y2 < ag) ag = y2; } }
     const double reg_term = -ag / (Delta * Delta);
     int istop = 0;
-    { const int it_ = kin_lsmr(c, w.Fv, std::sqrt(reg_term), &istop); lsmr_total += it_; KO_TRACE("iter cost %.10g Delta %.10g gnorm %.6g damp %.10g lsmr %d istop %d\n", cost, Delta, g_norm, std::sqrt(reg_term), it_, istop); }
+    { const int it_ = kin_lsmr(c, std::sqrt(reg_term), &istop); lsmr_total += it_; KO_TRACE("iter cost %.10g Delta %.10g gnorm %.6g damp %.10g lsmr %d istop %d\n", cost, Delta, g_norm, std::sqrt(reg_term), it_, istop); }
     // orthonormal basis of span{g, gn}
     const double ng = std::sqrt(gg);
-    for (long long i = KO_TID; i < n; i += KO_NT) w.S0[i] = w.G[i] / ng;
+    KC_EACH(c, w)
+      KO_FOR(i, w.nf * NV) w.nv[N_S0][i] = w.nv[N_G][i] / ng;
+    KC_DONE
     KO_SYNC();
-    double pr = ko_dot(c, w.S0, w.GN, n);
-    for (long long i = KO_TID; i < n; i += KO_NT) w.S1[i] = w.GN[i] - pr * w.S0[i];
+    double pr = kin_dot(c, 'n', N_S0, N_GN);
+    KC_EACH(c, w)
+      KO_FOR(i, w.nf * NV) w.nv[N_S1][i] = w.nv[N_GN][i] - pr * w.nv[N_S0][i];
+    KC_DONE
     KO_SYNC();
-    pr = ko_dot(c, w.S0, w.S1, n);            // second pass
-    KoAcc s1a;
-    for (long long i = KO_TID; i < n; i += KO_NT) { const double t = w.S1[i] - pr * w.S0[i]; w.S1[i] = t; s1a.add(i, t * t); }
-    const double s1 = std::sqrt(ko_total(c, s1a));
-    const double is1 = s1 > 0 ? 1 / s1 : 0.0;
-    for (long long i = KO_TID; i < n; i += KO_NT) w.S1[i] *= is1;
-    KO_SYNC();
-    kin_jv(c, w.S0, w.T1);
-    kin_jv(c, w.S1, w.T2);
-    double B00, B01, B11, gS0, gS1, dummy;
+    pr = kin_dot(c, 'n', N_S0, N_S1);           // second pass
+    double s1;
     {
-      KoAcc a00, a01, a11;
-      for (long long i = KO_TID; i < m; i += KO_NT) { a00.add(i, w.T1[i] * w.T1[i]); a01.add(i, w.T1[i] * w.T2[i]); a11.add(i, w.T2[i] * w.T2[i]); }
-      ko_total3(c, a00, a01, a11, B00, B01, B11);
-      KoAcc g0, g1, z;
-      for (long long i = KO_TID; i < n; i += KO_NT) { g0.add(i, w.S0[i] * w.G[i]); g1.add(i, w.S1[i] * w.G[i]); }
-      ko_total3(c, g0, g1, z, gS0, gS1, dummy);
+      KoAcc sa[KC_NW][KC_PARTS];
+      KC_EACH(c, w)
+        KO_FOR(i, w.nf * NV) { const double t = w.nv[N_S1][i] - pr * w.nv[N_S0][i]; w.nv[N_S1][i] = t; sa[wi][0].add(i, t * t); }
+      KC_DONE
+      kc_sync(c, sa, 1);
+      s1 = std::sqrt(kc_sum(c, 0));
     }
+    const double is1 = s1 > 0 ? 1 / s1 : 0.0;
+    KC_EACH(c, w)
+      KO_FOR(i, w.nf * NV) w.nv[N_S1][i] *= is1;
+    KC_DONE
+    KO_SYNC();
+    kin_exchange_v(c, N_S0);
+    KIN_DISPATCH(kin_jv, false, c, N_S0, M_T1, 1.0, 0.0, false, none);
+    kin_exchange_v(c, N_S1);
+    KIN_DISPATCH(kin_jv, false, c, N_S1, M_T2, 1.0, 0.0, false, none);
+    double B00, B01, B11, gS0, gS1;
+    { const KinDot dd[3] = {{'m', M_T1, M_T1}, {'m', M_T1, M_T2}, {'m', M_T2, M_T2}}; double r[3]; kin_dots(c, dd, 3, r); B00 = r[0]; B01 = r[1]; B11 = r[2]; }
+    { const KinDot dd[2] = {{'n', N_S0, N_G}, {'n', N_S1, N_G}}; double r[2]; kin_dots(c, dd, 2, r); gS0 = r[0]; gS1 = r[1]; }
     double actual = -1, cost_new = cost;
     while (actual <= 0 && nfev < P.max_nfev) {
       double p0, p1;
       tr2d(B00, B01, B11, gS0, gS1, Delta, p0, p1);
       const double predicted = -(0.5 * (B00 * p0 * p0 + 2 * B01 * p0 * p1 + B11 * p1 * p1) + gS0 * p0 + gS1 * p1);
       const double step_norm = std::sqrt(p0 * p0 + p1 * p1);          // |S p| with orthonormal S
-      for (long long i = KO_TID; i < n; i += KO_NT) w.XN[i] = w.X[i] + (p0 * w.S0[i] + p1 * w.S1[i]);
+      KC_EACH(c, w)
+        KO_FOR(i, w.nf * NV) w.nv[N_XN][i] = w.nv[N_X][i] + (p0 * w.nv[N_S0][i] + p1 * w.nv[N_S1][i]);
+      KC_DONE
       KO_SYNC();
-      kin_residual(c, w.XN, w.PN, w.RGN, w.FN);
+      kin_residual(c, N_XN, M_FN);
       ++nfev;
       double cn, bad, xx;
       {
-        KoAcc acn, abad, axx;
-        for (long long i = KO_TID; i < m; i += KO_NT) { const double t = w.FN[i]; acn.add(i, t * t); if (!(std::fabs(t) <= 1.79e308)) abad.add(i, 1.0); }
-        for (long long i = KO_TID; i < n; i += KO_NT) axx.add(i, w.X[i] * w.X[i]);
-        ko_total3(c, acn, abad, axx, cn, bad, xx);
+        KoAcc sa[KC_NW][KC_PARTS];
+        KC_EACH(c, w)
+          KO_FOR(i, w.nf * NR) { const double t = w.mv[M_FN][i]; sa[wi][0].add(i, t * t); if (!(std::fabs(t) <= 1.79e308)) sa[wi][1].add(i, 1.0); }
+          KO_FOR(i, w.nf * NV) sa[wi][2].add(i, w.nv[N_X][i] * w.nv[N_X][i]);
+        KC_DONE
+        kc_sync(c, sa, 3);
+        cn = kc_sum(c, 0); bad = kc_sum(c, 1); xx = kc_sum(c, 2);
       }
       if (bad > 0) { Delta = 0.25 * step_norm; continue; }
       cost_new = 0.5 * cn;
@@ -757,33 +1182,66 @@ KO_DEV void kin_solve(KinCtx& c, double* xio, double* stats) {
       Delta = Delta_new;
     }
     if (actual > 0) {
-      for (long long i = KO_TID; i < n; i += KO_NT) w.X[i] = w.XN[i];
-      for (long long i = KO_TID; i < m; i += KO_NT) w.Fv[i] = w.FN[i];
+      KC_EACH(c, w)
+        KO_FOR(i, w.nf * NV) w.nv[N_X][i] = w.nv[N_XN][i];
+        KO_FOR(i, w.nf * NR) w.mv[M_FV][i] = w.mv[M_FN][i];
+      KC_DONE
       cost = cost_new;
       KO_SYNC();
-      kin_linearise(c, w.X);
+      kin_linearise(c, N_X);
       ++njev;
-      kin_jtu(c, w.Fv, w.G);
+      kin_exchange_u(c, M_FV);
+      KIN_DISPATCH(kin_jtu, false, c, M_FV, N_G, 1.0, 0.0, false, none);
     }
   }
-  for (long long i = KO_TID; i < n; i += KO_NT) xio[i] = w.X[i];
-  if (KO_TID == 0) {
-    stats[0] = cost; stats[1] = nfev; stats[2] = njev; stats[3] = status == -1 ? 0 : status; stats[4] = (double)lsmr_total; stats[5] = g_norm;
-    const double tall = (double)(KO_CLOCK() - t_begin);
-    stats[6] = tall > 0 ? (double)c.t_jv / tall : 0.0; stats[7] = tall > 0 ? (double)c.t_jtu / tall : 0.0;
-  }
+  KC_EACH(c, w)
+    KO_FOR(i, w.nf * NV) xio[(long long)NV * w.a + i] = w.nv[N_X][i];
+    if (w.g == 0 && KO_TID == 0) {
+      stats[0] = cost; stats[1] = nfev; stats[2] = njev; stats[3] = status == -1 ? 0 : status; stats[4] = (double)lsmr_total; stats[5] = g_norm;
+      const double tall = (double)(KO_CLOCK() - t_begin);
+      stats[6] = tall > 0 ? (double)c.t_jv / tall : 0.0; stats[7] = tall > 0 ? (double)c.t_jtu / tall : 0.0;
+      for (int k = 0; k < 16; ++k) stats[8 + k] = (double)c.seg[k];
+    }
+  KC_DONE
   KO_SYNC();
 }
 
-KO_DEV void kin_bind(KinCtx& c, const KinSeq* q, const KinParams* P, const double* dpool, const int* ipool, double* work, double* red, double* lds, int lds_doubles) {
-  c.q = q; c.P = P;
+// ---- binding a clip to the cluster ---------------------------------------------------------------------------------------------------------------------
+// (the LDS structs are filled by ONE thread; the caller puts a barrier behind kin_bind_clip + kin_bind_wg)
+KO_DEV void kin_bind_clip(KO_LDSQ KinClip& k, const KinSeq* q, const double* dpool, const int* ipool) {
+  k.q = q;
   const int F = q->F;
+  k.F = F;
+  for (int i = 0; i < 6; ++i) k.wt[i] = q->w[i];
+  for (int i = 0; i < 3; ++i) { k.fn[i] = q->floor_n[i]; k.fp[i] = q->floor_p[i]; }
   const double* d = dpool + q->o_const;
-  c.offs = d; d += 84; c.pose3d = d; d += 84LL * F; c.root_trans = d; d += 3LL * F; c.pose2d = d; d += 56LL * F; c.proj_w = d; d += 28LL * F; c.data_w = d;
-  c.contact = ipool + q->o_contact;
-  c.w.carve(work + q->o_work, F);
-  c.red = red; c.lds = lds; c.lds_doubles = lds_doubles;
-  c.o2 = 56 * F; c.o3 = c.o2 + 84 * (F - 1); c.o4 = c.o3 + 84 * (F - 2); c.o5 = c.o4 + 84 * F; c.o6 = c.o5 + 84 * (F - 1); c.o7 = c.o6 + 28 * F;
+  k.offs = d; d += 84; k.pose3d = d; d += 84LL * F; k.root_trans = d; d += 3LL * F; k.pose2d = d; d += 56LL * F; k.proj_w = d; d += 28LL * F; k.data_w = d;
+  k.contact = ipool + q->o_contact;
+}
+// workgroup g of G: its frames, its slices of the clip's device-memory workspace, and -- when the slice fits -- the LDS block for everything LSMR's products touch
+KO_DEV void kin_bind_wg(const KinCtx& c, KO_LDSQ KinWg& w, int g, double* work, double* lds, int lds_doubles) {
+  const int F = c.k->F, G = c.G;
+  w.g = g; w.a = (int)((long long)g * F / G); w.nf = (int)((long long)(g + 1) * F / G) - w.a;
+  w.nh = F - w.a < w.nf + 2 ? F - w.a : w.nf + 2;
+  double* b = work + c.k->q->o_work;
+  for (int i = 0; i < N_COUNT; ++i) { w.nv[i] = b + (long long)NV * w.a; b += (long long)NV * F; }
+  for (int i = 0; i < M_COUNT; ++i) { w.mv[i] = b + (long long)NR * w.a; b += (long long)NR * F; }
+  const long long FH = F + 2LL * G, ah = w.a + 2LL * g;
+  w.P = b + 84 * ah; b += 84 * FH; w.E = b + 252 * ah; b += 252 * FH; w.RG = b + 252 * ah; b += 252 * FH; w.PN = b + 84 * ah; b += 84 * FH;
+  w.LW = b + 84 * ah; b += 84 * FH; w.LD = b + 84 * ah; b += 84 * FH;
+  w.C = b + 84LL * w.a; b += 84LL * F; w.LL = b + 84LL * w.a; b += 84LL * F;
+  w.DW = b + 28LL * w.a; b += 28LL * F; w.CT = (int*)b + 28LL * w.a;
+  // LDS: the received halos always; the slice when it fits (h-bar and LSMR's x stay in device memory: one streaming pass per iteration)
+  double* l = lds;
+  w.vh = l; l += HALO_V; w.uh = l; l += KC_HALO;
+  const int nf = w.nf;
+  w.in_lds = (long long)KIN_LDS_FIXED + (long long)KIN_LDS_PER_FRAME * nf <= lds_doubles;
+  if (w.in_lds) {
+    w.mv[M_U] = l; l += NR * nf; w.nv[N_V] = l; l += NV * nf; w.nv[N_H] = l; l += NV * nf;
+    w.P = l; l += 84 * (nf + 2); w.E = l; l += 252 * (nf + 2); w.C = l; l += 84 * nf;
+    w.LW = l; l += 84 * (nf + 2); w.LD = l; l += 84 * (nf + 2); w.LL = l; l += 84 * nf;
+    w.DW = l; l += 28 * nf; w.CT = (int*)l;
+  }
 }
 
 }  // namespace chd_kin

@@ -27,9 +27,10 @@ typedef struct chd_kin_config {
   double lsmr_atol, lsmr_btol, lsmr_conlim;   /* 1e-6, 1e-6, 1e8 (SciPy's lsmr defaults; least_squares passes no tr_options) */
   int lsmr_maxiter;        /* 0 = min(rows, unknowns), SciPy's default */
   int parents[CHD_KIN_JOINTS];   /* skeleton.parents (BVH order); parents[0] = -1, parents[j] < j */
-  int reserved[4];         /* tuning knobs, 0 = default: [0] threads per workgroup (256 or 512; default 512), [1] doubles of LDS per workgroup for
-                              the products' frame tiles (default 18 432 = 144 KB: one workgroup per compute unit, two tiles per 100 frames).  Results are bitwise
-                              reproducible for fixed values and independent of the batch a clip is in. */
+  int reserved[4];         /* tuning knobs, 0 = default: [1] doubles of LDS per workgroup (default 19 760 = 154 KB: slices of up to 13 frames stay in LDS),
+                              [2] frames per workgroup (default: what the LDS block holds; smaller = more workgroups per clip, larger = slices that live in
+                              device memory), [0] and [3] unused.  A clip of F frames is solved by a cluster of ceil(F / frames-per-workgroup) workgroups (at most
+                              16, never slices of fewer than two frames).  Results are bitwise reproducible for fixed values and independent of the batch a clip is in. */
 } chd_kin_config;
 
 /* One video, one solve: the `args` tuple of :667-670 after `optimize_trajectory`'s own preparation (:544-572). */
@@ -55,8 +56,10 @@ typedef struct chd_kin_seq {
 const char* chd_kin_version(void);
 void chd_kin_config_default(chd_kin_config* cfg);      /* the reference's values; parents of combined_body_25.bvh */
 
-/* Solves B (video, stage) problems on HIP device `device`, one workgroup each.  Returns 0 on success; non-zero with a
- * message in chd_kin_last_error() (no device, bad sizes, allocation failure).  There is no CPU path. */
+/* Solves B (video, stage) problems on HIP device `device`, each on a cluster of workgroups whose members own runs of consecutive frames (LSMR's state
+ * in their compute units' LDS; two small exchanges between neighbours per LSMR iteration).  The launch is persistent -- as many clusters as the device
+ * holds resident, taking clips from a queue -- and its workgroups wait on each other, so calls from several host threads take turns on the device.
+ * Returns 0 on success; non-zero with a message in chd_kin_last_error() (no device, bad sizes, allocation failure).  There is no CPU path. */
 int chd_kin_solve_batch(const chd_kin_config* cfg, int device, int B, chd_kin_seq* seqs);
 const char* chd_kin_last_error(void);
 

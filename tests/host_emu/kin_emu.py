@@ -38,6 +38,11 @@ def default_config(**kw):
     return cfg
 
 
+def cluster_size(cfg, n_frames):
+    """workgroups the library would give a clip of `n_frames` frames under `cfg`"""
+    return int(lib().kin_emu_cluster_size(C.byref(cfg), int(n_frames)))
+
+
 def solve(problems, cfg=None):
     cfg = cfg or default_config()
     arr, keep, xs = problems_to_c(problems)

@@ -167,20 +167,27 @@ def test_whole_optimisation_and_its_files(gold, tmp_path):
     assert int(np.abs(res[0]['velConstraints'] - g['c0_vel']).sum()) == 1 and int(np.abs(res[1]['velConstraints'] - g['c1_vel']).sum()) == 1
 
 
-@pytest.mark.parametrize('lds_doubles', [1100, 2600])
-def test_products_across_tile_boundaries(gold, lds_doubles):
-    """The products walk the clip in frame tiles (with two halo frames for J v); the fixture's clips fit one default tile, so the tile
-    loops are forced here: 1 100 doubles of LDS = tiles of 2 (J v) and 3 (J^T u) frames, 2 600 = 8 and 7 -- neither divides 16 or 12."""
+@pytest.mark.parametrize('frames_cap,lds_doubles', [(2, 0), (3, 0), (5, 0), (7, 0), (5, 700), (0, 9000)])
+def test_a_clip_split_over_a_cluster_of_workgroups(gold, frames_cap, lds_doubles):
+    """A clip is solved by G workgroups that each own a run of frames, its LSMR state in the owner's LDS (round 5).  The fixture's clips (12 and 16
+    frames) are one and two workgroups by default; `reserved[2]` (frames per workgroup) forces 2 .. 8, with slices that do not divide the clip evenly, and
+    `reserved[1]` (LDS doubles) decides what stays in LDS: 700 = the received halos only, every slice in device memory; 9 000 = slices of 5 frames, all of
+    LSMR's vectors in LDS.  The building blocks against the reference's vectors whatever the split; bounded solves against the one-workgroup solve (the
+    partial sums of a norm are added in a different order: rounding level)."""
     import kin_emu
     for ci, li in [(1, 1), (2, 0)]:
         p, q = problem(gold, ci, li)
         cfg = kin_emu.default_config()
-        cfg.reserved[1] = lds_doubles
+        cfg.reserved[1] = lds_doubles; cfg.reserved[2] = frames_cap
+        F = p['pose3d'].shape[0]
+        G = kin_emu.cluster_size(cfg, F)
+        assert G == (min(8, F // 2, -(-F // frames_cap)) if frames_cap else -(-F // 5)) and G >= 2
         assert rel(kin_emu.probe(p, 0, cfg=cfg)[0], gold[q + 'f0']) < 5e-9
         assert rel(kin_emu.probe(p, 1, gold[q + 'v'], cfg=cfg)[0], gold[q + 'Jv']) < 5e-9
         assert rel(kin_emu.probe(p, 2, gold[q + 'u'], cfg=cfg)[0], gold[q + 'JTu']) < 5e-9
-        one = kin_emu.default_config(lsmr_maxiter=3)
-        many = kin_emu.default_config(lsmr_maxiter=3); many.reserved[1] = lds_doubles
+        one = kin_emu.default_config(lsmr_maxiter=3); one.reserved[2] = 1000
+        many = kin_emu.default_config(lsmr_maxiter=3); many.reserved[1] = lds_doubles; many.reserved[2] = frames_cap
+        assert kin_emu.cluster_size(one, F) == 1
         a = kin_emu.solve([p], one)[0]; b = kin_emu.solve([p], many)[0]
         assert (a['nfev'], a['status']) == (b['nfev'], b['status']) and rel(b['x'], a['x']) < 1e-9
 
