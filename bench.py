@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 BATCH = 128
 FRAMES = 90
+LDS_PEAK_GBS = 256.0 * 256 * 2.4            # MI355X_MICROARCH.md (LDS): 256 B/clk/CU for ds_read_b64, 256 CUs, 2.4 GHz
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector = matrix peak (AMD spec)
 CAPS = [7000, 7000, 7000, 2500, 2000, 7000]
@@ -319,7 +320,7 @@ def kinematic_optimisation_rate(device_index, n_clips=256, frames=100):
 
     opt.kin.solve = timed
     t0 = time.perf_counter(); out = opt.optimize(clips); dt = time.perf_counter() - t0
-    # up to 256 clips run as two halves on two host threads whose launches overlap on the device: the kernels' time is the UNION of their intervals
+    # up to 256 clips run as two halves on two host threads (their launches take turns on the device since round 5; before, they overlapped): the kernels' time is the UNION of their intervals
     spans.sort(); busy = 0.0; end = -1e300
     for a_, b_ in spans:
         if b_ > end:
@@ -333,16 +334,18 @@ def kinematic_optimisation_rate(device_index, n_clips=256, frames=100):
         tj = json.load(open(os.path.join(ROOT, 'profiles', 'kinopt_traffic.json')))
         if (tj['clips'], tj['frames']) == (n_clips, frames):
             traffic = tj['hbm_bytes_per_batch']; tnote = tj.get('note', '')
-            if tj.get('sources_sha256') != _sources_sha256(('chd_kinopt.hip', 'chd_kinopt_kernels.hpp')) or tj.get('lds_doubles') != 18432:      # kernel AND launch (tile size, launch bounds)
+            if tj.get('sources_sha256') != _sources_sha256(('chd_kinopt.hip', 'chd_kinopt_kernels.hpp', 'chd_kinopt_host.hpp')):      # kernel, launch and the default LDS block
                 tnote = 'STALE (kernel source changed since the PMC passes): ' + tnote
     except Exception:
         pass
     return {'clips': n_clips, 'frames': frames, 'clips_per_s': n_clips / dt, 'least_squares_kernel_ms': ms, 'ik_kernel_ms': opt.ik.last_kernel_ms()[0],
             'lsmr_iterations_per_clip': its, 'algorithmic_bytes_per_batch': alg,
             'least_squares_kernel_seconds_union': kin_s,
-            'roofline': {'bound': 'hbm', 'kernel': 'chd_kin_solve_kernel', 'achieved': alg / kin_s / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': alg / kin_s / 1e9 / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_note': tnote,
-                         'definition': 'algorithmic bytes of all LSMR iterations of all clips / time during which a least-squares launch was running (union over the overlapping launches of the two host threads)'},
+            'roofline': {'bound': 'lds', 'kernel': 'chd_kin_solve_kernel', 'achieved': alg / kin_s / 1e9, 'peak': LDS_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': alg / kin_s / 1e9 / LDS_PEAK_GBS, 'traffic': traffic, 'traffic_note': tnote,
+                         'hbm_equivalent_frac': alg / kin_s / 1e9 / HBM_PEAK_GBS,
+                         'definition': 'algorithmic bytes of all LSMR iterations of all clips (u, v, h, the linearisation: they live in the LDS of the cluster that solves a clip) / time during which a least-squares launch was running; '
+                                       'peak = 256 B/clk/CU x 256 CUs x 2.4 GHz (MI355X_MICROARCH.md, LDS); `traffic` = HBM bytes of the same batch from the PMC passes; `hbm_equivalent_frac` = the same bytes against the HBM peak, for comparison with rounds 2-4 where they did come from HBM'},
             'fixture_worst_rel_l2_vs_reference': worst, 'fixture_contacts_equal_reference': bool(contacts_equal),
             'note': 'outside the timed region; the whole optimize() of %d clips x %d frames (IK initialisation, two least-squares solves, host floor fits)' % (n_clips, frames)}
 

@@ -25,18 +25,21 @@ int fail(const std::string& what, hipError_t e = hipSuccess) {
 // takes clips from the launch's queue until it is empty.  ALL workgroups of a launch must be resident at once -- the members of a cluster spin on each other's
 // flags (chd_kinopt_kernels.hpp, kc_sync) -- so the host sizes the grid by the device's occupancy for this kernel and never has two launches in flight.
 __global__ void __launch_bounds__(512, 2) chd_kin_solve_kernel(const KinSeq* seqs, const int* order, int n_clips, KinParams P, const double* dpool, const int* ipool, double* work,
-                                                               double* state, double* stats, KinSlot* slots, int* queue, int G, int lds_doubles) {
+                                                               double* state, double* stats, KinSlot* slots, int* queue, int* abort_flag, int G, int lds_doubles, int test_absent) {
   extern __shared__ double lds[];               // received halos + the slice's share of LSMR's state (kin_bind_wg)
   __shared__ double red[16 * KC_PARTS], gath[KC_MAXG * KC_PARTS];
   __shared__ KinParams Ps;
   __shared__ KinClip clip;
   __shared__ KinWg wg;
   __shared__ KinLsmr lsmr;
-  if (threadIdx.x == 0) Ps = P;
+  __shared__ int dead;
+  if (threadIdx.x == 0) { Ps = P; dead = 0; }
   __syncthreads();
   KinCtx c;
   const int cluster = blockIdx.x / G, g = blockIdx.x % G;
-  c.slots = slots + (size_t)cluster * G; c.epoch = 0; c.G = G;
+  if (test_absent && G > 1 && cluster == 0 && g == G - 1) return;      // (test hook: a member that never shows up)
+  c.patience = test_absent ? KC_PATIENCE / 20 : KC_PATIENCE;
+  c.slots = slots + (size_t)cluster * G; c.epoch = 0; c.G = G; c.abort_flag = abort_flag; c.dead = (KO_LDSQ int*)&dead;
   c.red = (KO_LDSQ double*)red; c.gath = (KO_LDSQ double*)gath; c.P = (const KO_LDSQ KinParams*)&Ps; c.k = (KO_LDSQ KinClip*)&clip; c.wg = (KO_LDSQ KinWg*)&wg; c.S = (KO_LDSQ KinLsmr*)&lsmr;
   if (threadIdx.x == 0) wg.g = g;
   __syncthreads();
@@ -46,7 +49,7 @@ __global__ void __launch_bounds__(512, 2) chd_kin_solve_kernel(const KinSeq* seq
     if (g == 0 && threadIdx.x == 0) pick[0][0].s = (double)atomicAdd(queue, 1);
     kc_sync(c, pick, 1);
     const int idx = (int)kc_sum(c, 0);
-    if (idx >= n_clips) break;
+    if (kc_dead(c) || idx >= n_clips) break;
     const int b = order[idx];
     if (threadIdx.x == 0) {
       kin_bind_clip(*c.k, seqs + b, dpool, ipool);
@@ -135,10 +138,10 @@ int chd_kin_solve_batch(const chd_kin_config* cfg, int device, int B, chd_kin_se
   }
   long long slots_total = 0;
   for (long long g : grid) slots_total += g;
-  KIN_TRY(dmalloc((void**)&d_order, sizeof(int) * (order.size() + bt.groups.size())), "hipMalloc clip order");
+  KIN_TRY(dmalloc((void**)&d_order, sizeof(int) * (order.size() + bt.groups.size() + 1)), "hipMalloc clip order");      // + the queues' counters + the abort flag
   KIN_TRY(dmalloc((void**)&d_slots, sizeof(KinSlot) * (size_t)slots_total), "hipMalloc cluster slots");
   KIN_TRY(hipMemcpyAsync(d_order, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice, st), "copy clip order");
-  KIN_TRY(hipMemsetAsync(d_order + order.size(), 0, sizeof(int) * bt.groups.size(), st), "clear queues");
+  KIN_TRY(hipMemsetAsync(d_order + order.size(), 0, sizeof(int) * (bt.groups.size() + 1), st), "clear queues");
   KIN_TRY(hipMemsetAsync(d_slots, 0, sizeof(KinSlot) * (size_t)slots_total, st), "clear cluster slots");
   KIN_TRY(hipEventCreate(&ev0), "hipEventCreate");
   KIN_TRY(hipEventCreate(&ev1), "hipEventCreate");
@@ -150,7 +153,7 @@ int chd_kin_solve_batch(const chd_kin_config* cfg, int device, int B, chd_kin_se
     for (size_t k = 0; k < bt.groups.size(); ++k) {
       const KinGroup& g = bt.groups[k];
       hipLaunchKernelGGL(chd_kin_solve_kernel, dim3((unsigned)grid[k]), dim3((unsigned)nthreads), sizeof(double) * (size_t)lds_doubles, st, d_seqs, d_order + o_order, (int)g.clips.size(), bt.P,
-                         d_dp, d_ip, d_work, d_state, d_stats, d_slots + o_slot, d_order + order.size() + k, g.G, lds_doubles);
+                         d_dp, d_ip, d_work, d_state, d_stats, d_slots + o_slot, d_order + order.size() + k, d_order + order.size() + bt.groups.size(), g.G, lds_doubles, cfg->reserved[3] == 0x7e57 ? 1 : 0);
       KIN_TRY(hipGetLastError(), "launch");
       o_order += g.clips.size(); o_slot += (size_t)grid[k];
     }
@@ -158,12 +161,15 @@ int chd_kin_solve_batch(const chd_kin_config* cfg, int device, int B, chd_kin_se
     KIN_TRY(hipEventSynchronize(ev1), "synchronize");
   }
   std::vector<double> fin(bt.state.size()), stats((size_t)KIN_STATS * B);
+  int gave_up = 0;
+  KIN_TRY(hipMemcpyAsync(&gave_up, d_order + order.size() + bt.groups.size(), sizeof(int), hipMemcpyDeviceToHost, st), "copy abort flag");
   KIN_TRY(hipMemcpyAsync(fin.data(), d_state, sizeof(double) * fin.size(), hipMemcpyDeviceToHost, st), "copy solutions");
   KIN_TRY(hipMemcpyAsync(stats.data(), d_stats, sizeof(double) * stats.size(), hipMemcpyDeviceToHost, st), "copy statistics");
   KIN_TRY(hipStreamSynchronize(st), "synchronize");
   float ms = 0.0f;
   KIN_TRY(hipEventElapsedTime(&ms, ev0, ev1), "hipEventElapsedTime");
 #undef KIN_TRY
+  if (gave_up) { release(); return fail("a cluster of workgroups waited too long (5 s) for a member: the launch was not fully resident (another process on the device, or a partition with fewer compute units than reported?)"); }
   bt.scatter(fin.data(), stats.data(), in);
 #ifdef KIN_PROFILE
   {

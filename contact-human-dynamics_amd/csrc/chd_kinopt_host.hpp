@@ -43,17 +43,31 @@ struct KinBatch {
     for (int t = 1; t < NJ; ++t) for (int a = P.parents[t]; a >= 0; a = P.parents[a]) P.desc[a] |= 1u << t;
     for (int j = 0; j < NJ; ++j) { P.fwd[j] = FWD[j]; P.bwd[j] = BWD[j]; P.smooth_w[j] = SMOOTH_W[j]; }
     bool dfs = true;                            // depth-first order: the descendants of j are j + 1 .. j + (their number)
+    int nd[NJ];
     for (int j = 0; j < NJ; ++j) {
-      int nd = 0;
-      for (int t = j + 1; t < NJ; ++t) nd += (P.desc[j] >> t) & 1u;
-      for (int t = j + 1; t <= j + nd; ++t) if (!((P.desc[j] >> t) & 1u)) dfs = false;
-      P.desc_end[j] = j + nd;
+      nd[j] = 0;
+      for (int t = j + 1; t < NJ; ++t) nd[j] += (P.desc[j] >> t) & 1u;
+      for (int t = j + 1; t <= j + nd[j]; ++t) if (!((P.desc[j] >> t) & 1u)) dfs = false;
       int na = 0;
       for (int a = P.parents[j]; a >= 0; a = P.parents[a]) { if (na < 8) P.anc[j][na] = (unsigned char)a; ++na; }
       P.anc_n[j] = na;
       for (int q = na; q < 8; ++q) P.anc[j][q] = (unsigned char)j;
     }
-    if (!dfs) for (int j = 0; j < NJ; ++j) P.desc_end[j] = NJ - 1;
+    // the walks over the descendants: the shortest piece length T with which the four idle lanes of a frame can take every piece beyond a joint's first
+    for (int j = 0; j < 32; ++j) { P.walk_of[j] = j < NJ ? j : 0; P.walk_t0[j] = j < NJ ? j + 1 : 1; P.walk_t1[j] = j < NJ ? (dfs ? j + nd[j] : NJ - 1) : 0; P.walk_help[j] = 0; }
+    if (dfs) {
+      int T = 1;
+      for (;; ++T) { int extra = 0; for (int j = 0; j < NJ; ++j) extra += nd[j] > T ? (nd[j] + T - 1) / T - 1 : 0; if (extra <= 4) break; }
+      int h = 0;
+      for (int j = 0; j < NJ; ++j)
+        if (nd[j] > T) {
+          P.walk_t1[j] = j + T;
+          for (int t0 = j + 1 + T; t0 <= j + nd[j]; t0 += T, ++h) {
+            P.walk_of[NJ + h] = j; P.walk_t0[NJ + h] = t0; P.walk_t1[NJ + h] = t0 + T - 1 < j + nd[j] ? t0 + T - 1 : j + nd[j];
+            P.walk_help[j] |= 1 << h;
+          }
+        }
+    }
     if (cfg->max_nfev < 1) { err = "max_nfev must be positive"; return false; }
     P.max_nfev = cfg->max_nfev; P.ftol = cfg->ftol; P.xtol = cfg->xtol; P.gtol = cfg->gtol;
     P.atol = cfg->lsmr_atol; P.btol = cfg->lsmr_btol; P.conlim = cfg->lsmr_conlim; P.lsmr_maxiter = cfg->lsmr_maxiter;

@@ -123,7 +123,10 @@ struct KinParams {
   double atol, btol, conlim;     // LSMR: 1e-6, 1e-6, 1e8
   int lsmr_maxiter;              // 0: min(m, n) as SciPy
   // the tree's walks as tables (built by the host from `parents`)
-  int desc_end[NJ];              // the last joint that can be a descendant of j: j + (number of descendants) when the joints are in depth-first order, else the last joint
+  // the walk over a joint's descendants, by lane of the frame (0 .. 27 the joints themselves, 28 .. 31 helpers that take over part of the longest walks): the joint
+  // the walk belongs to, the candidates walk_t0 .. walk_t1 (descendants are contiguous when the joints are in depth-first order; else every later joint is a
+  // candidate and the helpers stay idle), and for a joint's own lane the helpers whose partial sums it adds (bit h: lane 28 + h)
+  int walk_of[32], walk_t0[32], walk_t1[32], walk_help[32];
   int anc_n[NJ]; unsigned char anc[NJ][8]; // strict ancestors of joint t, nearest first (the first eight; a deeper walk continues through `parents`)
   int fwd[NJ], bwd[NJ];          // FWD / BWD and SMOOTH_W below, for the kernel's copy of this struct in LDS (a per-lane index into constant memory is a device-memory load)
   double smooth_w[NJ];
@@ -203,11 +206,14 @@ struct KinCtx {
 #ifndef CHD_HOST_EMU
   KinSlot* slots;                // the cluster's G slots
   unsigned long long epoch;      // synchronisations so far (the same in every workgroup of the cluster)
+  long long patience;            // KC_PATIENCE (a test shortens it)
+  int* abort_flag;               // device memory, one per launch: a workgroup that has waited KC_PATIENCE for a neighbour sets it, every workgroup that sees it gives up
+  KO_LDSQ int* dead;             // this workgroup has given up (LDS; changes only inside kc_sync, before its last barrier)
   KO_LDSQ double* red;           // workgroup reduction scratch: KC_PARTS * 16 doubles
 #endif
 #ifndef CHD_HOST_EMU
   // what the tables say about THIS lane's joint (lane & 31: the same in every item a thread handles), fetched once per launch
-  int lj_na, lj_f3, lj_b3, lj_dend;
+  int lj_na, lj_f3, lj_b3, lj_wof, lj_wt0, lj_wt1, lj_whelp;
   unsigned lj_desc;
   unsigned long long lj_anc;                  // ancestors, eight bits each
 #endif
@@ -219,22 +225,52 @@ struct KinCtx {
 KO_DEV int kj_na(const KinCtx& c, int j) { return c.P->anc_n[j]; }
 KO_DEV int kj_f3(const KinCtx& c, int j) { return 3 * c.P->fwd[j]; }
 KO_DEV int kj_b3(const KinCtx& c, int j) { return 3 * c.P->bwd[j]; }
-KO_DEV int kj_dend(const KinCtx& c, int j) { return c.P->desc_end[j]; }
-KO_DEV unsigned kj_desc(const KinCtx& c, int j) { return c.P->desc[j]; }
+KO_DEV int kj_wof(const KinCtx& c, int j) { return c.P->walk_of[j]; }
+KO_DEV int kj_wt0(const KinCtx& c, int j) { return c.P->walk_t0[j]; }
+KO_DEV int kj_wt1(const KinCtx& c, int j) { return c.P->walk_t1[j]; }
+KO_DEV int kj_whelp(const KinCtx& c, int j) { return c.P->walk_help[j]; }
+KO_DEV unsigned kj_desc(const KinCtx& c, int j) { return c.P->desc[c.P->walk_of[j]]; }
 KO_DEV unsigned long long kj_anc(const KinCtx& c, int j) { unsigned long long v = 0; for (int q = 0; q < 8; ++q) v |= (unsigned long long)c.P->anc[j][q] << (8 * q); return v; }
 #else
 KO_DEV int kj_na(const KinCtx& c, int) { return c.lj_na; }
 KO_DEV int kj_f3(const KinCtx& c, int) { return c.lj_f3; }
 KO_DEV int kj_b3(const KinCtx& c, int) { return c.lj_b3; }
-KO_DEV int kj_dend(const KinCtx& c, int) { return c.lj_dend; }
+KO_DEV int kj_wof(const KinCtx& c, int) { return c.lj_wof; }
+KO_DEV int kj_wt0(const KinCtx& c, int) { return c.lj_wt0; }
+KO_DEV int kj_wt1(const KinCtx& c, int) { return c.lj_wt1; }
+KO_DEV int kj_whelp(const KinCtx& c, int) { return c.lj_whelp; }
 KO_DEV unsigned kj_desc(const KinCtx& c, int) { return c.lj_desc; }
 KO_DEV unsigned long long kj_anc(const KinCtx& c, int) { return c.lj_anc; }
 KO_DEV void kin_lane_tables(KinCtx& c) {
   const int j = threadIdx.x & 31, jj = j < NJ ? j : 0;
-  c.lj_na = j < NJ ? c.P->anc_n[jj] : 0; c.lj_f3 = 3 * c.P->fwd[jj]; c.lj_b3 = 3 * c.P->bwd[jj]; c.lj_dend = j < NJ ? c.P->desc_end[jj] : -1; c.lj_desc = j < NJ ? c.P->desc[jj] : 0u;
+  c.lj_na = j < NJ ? c.P->anc_n[jj] : 0; c.lj_f3 = 3 * c.P->fwd[jj]; c.lj_b3 = 3 * c.P->bwd[jj];
+  c.lj_wof = c.P->walk_of[j]; c.lj_wt0 = c.P->walk_t0[j]; c.lj_wt1 = c.P->walk_t1[j]; c.lj_whelp = c.P->walk_help[j]; c.lj_desc = c.P->desc[c.lj_wof];
   unsigned long long b = 0;
   for (int q = 0; q < 8; ++q) b |= (unsigned long long)c.P->anc[jj][q] << (8 * q);
   c.lj_anc = b;
+}
+#endif
+
+// A launch whose workgroups are not all resident would wait for ever (its members spin on each other).  The host sizes the grid so that they are; should that
+// fail all the same -- a partitioned device, another process holding compute units -- the wait is bounded: after KC_PATIENCE the launch winds down (every loop of
+// the solve checks kc_dead) and the call returns an error instead of hanging the device.
+#ifdef CHD_HOST_EMU
+KO_DEV bool kc_dead(const KinCtx&) { return false; }
+#else
+#define KC_PATIENCE 500000000LL                 // wall_clock64 ticks (100 MHz): 5 s
+KO_DEV bool kc_dead(const KinCtx& c) { return *c.dead != 0; }
+KO_DEV bool kc_wait(KinCtx& c, const KinSlot* o, unsigned long long e) {      // false: gave up
+  const long long t0 = (long long)wall_clock64();
+  unsigned spins = 0;
+  while (__hip_atomic_load(&o->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < e) {
+    __builtin_amdgcn_s_sleep(1);
+    if ((++spins & 1023u) == 0 && (__hip_atomic_load(c.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || (long long)wall_clock64() - t0 > c.patience)) {
+      __hip_atomic_store(c.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *c.dead = 1;
+      return false;
+    }
+  }
+  return true;
 }
 #endif
 
@@ -324,6 +360,7 @@ KO_DEV void kc_sync(KinCtx& c, KoAcc (*acc)[KC_PARTS], int np, int dir = 0, int 
       for (int i = 0; i < nrecv; ++i) dst[i] = c.wg[nb].pub[i];
     }
 #else
+  if (kc_dead(c)) return;
   double v[KC_PARTS];
 #pragma unroll
   for (int i = 0; i < KC_PARTS; ++i) {
@@ -362,17 +399,17 @@ KO_DEV void kc_sync(KinCtx& c, KoAcc (*acc)[KC_PARTS], int np, int dir = 0, int 
   if (wv == 0) {
     if (ln < c.G) {
       const KinSlot* o = c.slots + ln;
-      while (__hip_atomic_load(&o->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < e) __builtin_amdgcn_s_sleep(1);
+      const bool ok = kc_wait(c, o, e);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      for (int i = 0; i < np; ++i) c.gath[KC_PARTS * ln + i] = kc_ld(&o->part[par][i]);
+      for (int i = 0; i < np; ++i) c.gath[KC_PARTS * ln + i] = ok ? kc_ld(&o->part[par][i]) : 0.0;
     }
   } else if (want) {
     const KinSlot* o = c.slots + nb;
-    while (__hip_atomic_load(&o->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < e) __builtin_amdgcn_s_sleep(1);
+    const bool ok = kc_wait(c, o, e);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     KO_LDSQ double* dst = (KO_LDSQ double*)(dir > 0 ? c.wg[0].vh : c.wg[0].uh);
     const double* src = o->halo[par];
-    for (int i = threadIdx.x - 64; i < nrecv; i += blockDim.x - 64) dst[i] = kc_ld(src + i);
+    if (ok) for (int i = threadIdx.x - 64; i < nrecv; i += blockDim.x - 64) dst[i] = kc_ld(src + i);
   }
   __syncthreads();
 #endif
@@ -731,20 +768,20 @@ KO_DEV void kin_jtu(KinCtx& c, int usel, int osel, const double scale, const dou
     }
     KO_WSYNC();
     KO_SEG(c, 6);
-    KO_FOR(idx, w.nf * 32) {                  // (J^T u)_{j,a} = axis_{j,a} . sum over the strict descendants t of j of (p_t - p_j) x lambda_t, + the Euler-smoothness rows;
-      const int l = idx >> 5, j = idx & 31, f = w.a + l;   // the root's translation gets lambda of the root's data joint
-      if (j >= NJ) continue;
+    LP MP = LR;                                 // (the contact terms are used up: the helpers' partial sums go here)
+    KO_FOR(idx, w.nf * 32) {                  // M_j = sum over the strict descendants t of j of (p_t - p_j) x lambda_t: each lane its part of a walk
+      const int l = idx >> 5, j = idx & 31;
       LCP Pf = P + 84 * l;
-      const double q0 = Pf[3 * j], q1 = Pf[3 * j + 1], q2 = Pf[3 * j + 2];
+      const int jo = kj_wof(c, j), tbeg = kj_wt0(c, j), tend = kj_wt1(c, j);
+      const double q0 = Pf[3 * jo], q1 = Pf[3 * jo + 1], q2 = Pf[3 * jo + 2];
       double M0 = 0, M1 = 0, M2 = 0;
       const unsigned mask = kj_desc(c, j);
-      const int tend = kj_dend(c, j);
 #pragma unroll 1
-      for (int t0 = j + 1; t0 <= tend; t0 += 4) {   // four candidates at a time (descendants are the joints j+1 .. tend when the skeleton is in depth-first order), operands requested together
+      for (int t0 = tbeg; t0 <= tend; t0 += 4) {   // four candidates at a time, operands requested together
         double pt[4][3], lm[4][3];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int t = t0 + q <= tend ? t0 + q : j;
+          const int t = t0 + q <= tend ? t0 + q : jo;
           for (int k = 0; k < 3; ++k) { pt[q][k] = Pf[3 * t + k]; lm[q][k] = LL[84 * l + 3 * t + k]; }
         }
 #pragma unroll
@@ -754,6 +791,18 @@ KO_DEV void kin_jtu(KinCtx& c, int usel, int osel, const double scale, const dou
             M0 += r1 * lm[q][2] - r2 * lm[q][1]; M1 += r2 * lm[q][0] - r0 * lm[q][2]; M2 += r0 * lm[q][1] - r1 * lm[q][0];
           }
       }
+      LP o = j < NJ ? LQ + 84 * l + 3 * j : MP + 84 * l + 3 * (j - NJ);      // (the projection terms are used up too: a joint's own part waits here)
+      o[0] = M0; o[1] = M1; o[2] = M2;
+    }
+    KO_WSYNC();
+    KO_FOR(idx, w.nf * 32) {                  // (J^T u)_{j,a} = axis_{j,a} . M_j, + the Euler-smoothness rows; the root's translation gets lambda of the root's data joint
+      const int l = idx >> 5, j = idx & 31, f = w.a + l;
+      if (j >= NJ) continue;
+      double M0 = LQ[84 * l + 3 * j], M1 = LQ[84 * l + 3 * j + 1], M2 = LQ[84 * l + 3 * j + 2];
+      const int hm = kj_whelp(c, j);
+#pragma unroll
+      for (int h = 0; h < 4; ++h)
+        if ((hm >> h) & 1) { M0 += MP[84 * l + 3 * h]; M1 += MP[84 * l + 3 * h + 1]; M2 += MP[84 * l + 3 * h + 2]; }
       LCP e = E + 252 * l + 9 * j;
       LCP Lf = LL + 84 * l;
       VP o = out + NV * l;
@@ -862,6 +911,7 @@ KO_DEV int kin_lsmr_on(KinCtx& c, double damp, int* istop_out) {
   const int maxiter = S.maxiter;
   int itn = 0, istop = 0;
   while (itn < maxiter) {
+    if (kc_dead(c)) break;
     ++itn;
     KO_SEG(c, 15);
     {
@@ -1082,6 +1132,7 @@ KO_DEV void kin_solve(KinCtx& c, double* xio, double* stats) {
   if (Delta == 0) Delta = 1.0;
   double g_norm = 0;
   while (true) {
+    if (kc_dead(c)) break;
     {
       KoAcc gm[KC_NW][KC_PARTS];
       KC_EACH(c, w)
@@ -1143,7 +1194,7 @@ KO_DEV void kin_solve(KinCtx& c, double* xio, double* stats) {
     { const KinDot dd[3] = {{'m', M_T1, M_T1}, {'m', M_T1, M_T2}, {'m', M_T2, M_T2}}; double r[3]; kin_dots(c, dd, 3, r); B00 = r[0]; B01 = r[1]; B11 = r[2]; }
     { const KinDot dd[2] = {{'n', N_S0, N_G}, {'n', N_S1, N_G}}; double r[2]; kin_dots(c, dd, 2, r); gS0 = r[0]; gS1 = r[1]; }
     double actual = -1, cost_new = cost;
-    while (actual <= 0 && nfev < P.max_nfev) {
+    while (actual <= 0 && nfev < P.max_nfev && !kc_dead(c)) {
       double p0, p1;
       tr2d(B00, B01, B11, gS0, gS1, Delta, p0, p1);
       const double predicted = -(0.5 * (B00 * p0 * p0 + 2 * B01 * p0 * p1 + B11 * p1 * p1) + gS0 * p0 + gS1 * p1);

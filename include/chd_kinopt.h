@@ -29,7 +29,8 @@ typedef struct chd_kin_config {
   int parents[CHD_KIN_JOINTS];   /* skeleton.parents (BVH order); parents[0] = -1, parents[j] < j */
   int reserved[4];         /* tuning knobs, 0 = default: [1] doubles of LDS per workgroup (default 19 760 = 154 KB: slices of up to 13 frames stay in LDS),
                               [2] frames per workgroup (default: what the LDS block holds; smaller = more workgroups per clip, larger = slices that live in
-                              device memory), [0] and [3] unused.  A clip of F frames is solved by a cluster of ceil(F / frames-per-workgroup) workgroups (at most
+                              device memory), [3] = 0x7e57: test hook (one workgroup of the first cluster never shows up: the call must come back
+                              with an error after the waiting limit, not hang), [0] unused.  A clip of F frames is solved by a cluster of ceil(F / frames-per-workgroup) workgroups (at most
                               16, never slices of fewer than two frames).  Results are bitwise reproducible for fixed values and independent of the batch a clip is in. */
 } chd_kin_config;
 

@@ -41,8 +41,9 @@ def test_bounded_solve_in_lockstep_with_oracle_and_emulation(gold):
         assert rel(r['x'], x) < 1e-7 and rel(r['x'], e['x']) < 1e-7 and abs(r['cost'] - cost) < 1e-6 * cost
 
 
-def test_small_frame_tiles_on_gpu(gold):
-    """The frame-tile loops of the products with tiles of 2 / 3 frames (1 100 doubles of LDS) against the one-tile default and the emulation."""
+def test_slices_in_device_memory_on_gpu(gold):
+    """1 100 doubles of LDS hold no frame: the clip is cut into two-frame slices (8 workgroups for 16 frames) whose arrays stay in device memory -- the
+    same code through generic pointers -- against the default (one workgroup, everything in LDS) and the emulation."""
     import kin_emu
     p, q = problem(gold, 1, 1)
     small = kopt.KinSolver(device=0, lsmr_maxiter=3); small.cfg.reserved[1] = 1100
@@ -52,6 +53,38 @@ def test_small_frame_tiles_on_gpu(gold):
     e = kin_emu.solve([p], ecfg)[0]
     assert (a['nfev'], a['status']) == (b['nfev'], b['status']) == (e['nfev'], e['status'])
     assert rel(b['x'], a['x']) < 1e-8 and rel(b['x'], e['x']) < 1e-8
+
+
+@pytest.mark.parametrize('frames_cap', [2, 3, 5])
+def test_clusters_of_workgroups_on_gpu(gold, frames_cap):
+    """A clip split over G workgroups that exchange halos and partial sums through device memory (round 5), forced on the fixture's 12- and 16-frame clips by
+    `reserved[2]` (frames per workgroup): G = 6 / 8, 4 / 6, 3 / 4.  Sixty clips of mixed length in one call: two launches (one per cluster size), more clips
+    than resident clusters for the larger size (the queue), every copy of a clip bit for bit the same, and each equal to the emulation of the same split
+    to rounding (bounded solves: the comparison is of the arithmetic, not of where a sensitive solve ends)."""
+    import kin_emu
+    ps = [problem(gold, ci, li)[0] for ci, li in [(1, 1), (2, 0), (0, 0)]]
+    solver = kopt.KinSolver(device=0, lsmr_maxiter=4); solver.cfg.reserved[2] = frames_cap
+    res = solver.solve(ps * 20)
+    ecfg = kin_emu.default_config(lsmr_maxiter=4); ecfg.reserved[2] = frames_cap
+    emu = kin_emu.solve(ps, ecfg)
+    for k, r in enumerate(res):
+        e, first = emu[k % 3], res[k % 3]
+        assert np.array_equal(r['x'], first['x']) and r['cost'] == first['cost']
+        assert (r['nfev'], r['njev'], r['status']) == (e['nfev'], e['njev'], e['status'])
+        assert rel(r['x'], e['x']) < 1e-8 and abs(r['cost'] - e['cost']) < 1e-7 * e['cost']      # (device and host sin / cos differ in the last bit)
+
+
+def test_a_missing_workgroup_is_an_error_not_a_hang(gold):
+    """The members of a cluster wait on each other: a launch that is not fully resident would spin for ever.  The wait is bounded (5 s; 0.25 s under the
+    test hook `reserved[3] = 0x7e57`, which makes the last workgroup of the first cluster return at once): the launch winds down, the call reports it, and
+    the next call on the same device works."""
+    p = problem(gold, 1, 1)[0]
+    bad = kopt.KinSolver(device=0, lsmr_maxiter=3); bad.cfg.reserved[2] = 4; bad.cfg.reserved[3] = 0x7e57
+    with pytest.raises(RuntimeError, match='waited too long'):
+        bad.solve([p, p, p])
+    good = kopt.KinSolver(device=0, lsmr_maxiter=3); good.cfg.reserved[2] = 4
+    r = good.solve([p])[0]
+    assert r['nfev'] >= 1 and np.isfinite(r['cost'])
 
 
 def test_every_solve_of_the_fixture_matches_the_reference(gold):

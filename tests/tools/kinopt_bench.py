@@ -33,10 +33,10 @@ if __name__ == '__main__':
     FO = int(sys.argv[3]) if len(sys.argv) > 3 else 12
     clips = [make_clip(s, F) for s in range(B)]
     opt = kopt.KinematicOptimizer(device=0)
-    if os.environ.get('KIN_THREADS'):
-        opt.kin.cfg.reserved[0] = int(os.environ['KIN_THREADS'])
     if os.environ.get('KIN_LDS_DOUBLES'):
         opt.kin.cfg.reserved[1] = int(os.environ['KIN_LDS_DOUBLES'])
+    if os.environ.get('KIN_FRAMES_PER_WORKGROUP'):
+        opt.kin.cfg.reserved[2] = int(os.environ['KIN_FRAMES_PER_WORKGROUP'])
     opt.optimize([make_clip(10_000, 8)])                      # warm-up (module load)
     kin_ms = []
     real_solve = opt.kin.solve
@@ -53,12 +53,12 @@ if __name__ == '__main__':
     nfev = np.array([[s['nfev'] for s in r['stages']] for r in res])
     n, m = 87 * F, 507 * F - 423
     # algorithmic bytes per LSMR iteration ("kinematic optimisation"): u (m) read + written, v / h / hbar / x (n each) read + written, the
-    # linearisation (420 F doubles) read twice (J v, J^T u); per clip
+    # linearisation (420 F doubles) read twice (J v, J^T u); per clip.  Since round 5 they move through LDS, not HBM.
     alg_bytes = 8.0 * (2 * m + 8 * n + 2 * 420 * F) * its.sum()
     out = dict(clips=B, frames=F, unknowns=n, rows=m, wall_s=t1 - t0, clips_per_s=B / (t1 - t0), ik_kernel_ms=ik_ms, lsq_kernel_ms=kin_ms,
                lsmr_iterations_per_clip=float(its.sum(axis=1).mean()), nfev_per_stage=nfev.mean(axis=0).tolist(),
                status_counts={str(k): int(v) for k, v in zip(*np.unique([s['status'] for r in res for s in r['stages']], return_counts=True))},
-               algorithmic_GBps=alg_bytes / (sum(kin_ms) * 1e-3) / 1e9, us_per_lsmr_iteration_per_workgroup=1e3 * sum(kin_ms) / max(1.0, its.sum() / min(B, 256 * 2)),
+               algorithmic_GBps=alg_bytes / (sum(kin_ms) * 1e-3) / 1e9,
                lsq_time_share={'jv': float(np.mean([s['jv_fraction'] for r in res for s in r['stages']])), 'jtu': float(np.mean([s['jtu_fraction'] for r in res for s in r['stages']]))},
                relabelled_contacts_per_clip=float(np.mean([np.abs(r['velConstraints'] - c['velConstraints']).sum() for r, c in zip(res, clips)])))
     # CPU: the oracle (dense restatement of the reference, with SciPy's sparse products) on a short clip, scaled per frame
