@@ -308,24 +308,19 @@ def kinematic_optimisation_rate(device_index, n_clips=256, frames=100):
     worst = max(float(np.linalg.norm(r['pose3d'] - g['c%d_out_pose3d' % ci]) / np.linalg.norm(g['c%d_out_pose3d' % ci])) for ci, r in enumerate(res))
     contacts_equal = all(np.array_equal(r['velConstraints'], g['c%d_out_vel' % ci]) for ci, r in enumerate(res))
     clips = [make_kin_clip(s, frames, g['c0_skel_offsets'], g['c0_skel_parents']) for s in range(n_clips)]
-    ms = []; spans = []
+    ms = []
     solve = opt.kin.solve
 
     def timed(problems):
         r = solve(problems)
-        k = opt.kin.last_kernel_ms()                     # (thread-local in the library: this thread's launch)
-        t1_ = time.perf_counter()
-        ms.append(k); spans.append((t1_ - k * 1e-3, t1_))
+        ms.append(opt.kin.last_kernel_ms())              # (thread-local in the library: this thread's launch)
         return r
 
     opt.kin.solve = timed
     t0 = time.perf_counter(); out = opt.optimize(clips); dt = time.perf_counter() - t0
-    # up to 256 clips run as two halves on two host threads (their launches take turns on the device since round 5; before, they overlapped): the kernels' time is the UNION of their intervals
-    spans.sort(); busy = 0.0; end = -1e300
-    for a_, b_ in spans:
-        if b_ > end:
-            busy += b_ - max(a_, end); end = b_
-    kin_s = busy
+    # up to 256 clips run as two halves on two host threads whose launches take turns on the device (round 5: the workgroups of a launch wait on each other, the library lets one
+    # run at a time): the kernels' time is the SUM of the launches' device times (until round 4 the launches overlapped and it was the union of their intervals)
+    kin_s = sum(ms) * 1e-3
     its = float(np.mean([sum(s['lsmr_iterations'] for s in r['stages']) for r in out]))
     n, m = 87 * frames, 507 * frames - 423
     alg = 8.0 * (2 * m + 8 * n + 2 * 420 * frames) * its * n_clips          # bytes per LSMR iteration x iterations
@@ -340,11 +335,11 @@ def kinematic_optimisation_rate(device_index, n_clips=256, frames=100):
         pass
     return {'clips': n_clips, 'frames': frames, 'clips_per_s': n_clips / dt, 'least_squares_kernel_ms': ms, 'ik_kernel_ms': opt.ik.last_kernel_ms()[0],
             'lsmr_iterations_per_clip': its, 'algorithmic_bytes_per_batch': alg,
-            'least_squares_kernel_seconds_union': kin_s,
+            'least_squares_kernel_seconds': kin_s,
             'roofline': {'bound': 'lds', 'kernel': 'chd_kin_solve_kernel', 'achieved': alg / kin_s / 1e9, 'peak': LDS_PEAK_GBS, 'unit': 'GB/s',
                          'frac': alg / kin_s / 1e9 / LDS_PEAK_GBS, 'traffic': traffic, 'traffic_note': tnote,
                          'hbm_equivalent_frac': alg / kin_s / 1e9 / HBM_PEAK_GBS,
-                         'definition': 'algorithmic bytes of all LSMR iterations of all clips (u, v, h, the linearisation: they live in the LDS of the cluster that solves a clip) / time during which a least-squares launch was running; '
+                         'definition': 'algorithmic bytes of all LSMR iterations of all clips (u, v, h, the linearisation: they live in the LDS of the cluster that solves a clip) / summed device time of the least-squares launches (they take turns on the device); '
                                        'peak = 256 B/clk/CU x 256 CUs x 2.4 GHz (MI355X_MICROARCH.md, LDS); `traffic` = HBM bytes of the same batch from the PMC passes; `hbm_equivalent_frac` = the same bytes against the HBM peak, for comparison with rounds 2-4 where they did come from HBM'},
             'fixture_worst_rel_l2_vs_reference': worst, 'fixture_contacts_equal_reference': bool(contacts_equal),
             'note': 'outside the timed region; the whole optimize() of %d clips x %d frames (IK initialisation, two least-squares solves, host floor fits)' % (n_clips, frames)}

@@ -3,8 +3,8 @@
 
 * the IK initialisation (:605-617, ``JacobianInverseKinematicsCK(translate=False, iterations=200, smoothness=0, damping=7)``)
   through ``libchd_ik.so`` (include/chd_ik.h) -- all clips in one call;
-* the two ``least_squares`` solves (:660-670, :779-789) through ``libchd_kinopt.so`` (include/chd_kinopt.h) -- one workgroup
-  per clip, all clips of a stage in one launch.  The reference assembles a dense Jacobian in Python loops (3.5 GB and minutes
+* the two ``least_squares`` solves (:660-670, :779-789) through ``libchd_kinopt.so`` (include/chd_kinopt.h) -- a cluster of
+  workgroups per clip (each owns a run of frames, LSMR's state in LDS), all clips of a stage in one persistent launch.  The reference assembles a dense Jacobian in Python loops (3.5 GB and minutes
   per evaluation for 100 frames); the kernel never forms it.
 
 Host code (NumPy, negligible cost): bone lengths (``update_skeleton``, :485-520), weights and normalised 2D targets (:556-572),
@@ -309,13 +309,13 @@ class KinematicOptimizer:
         offsets (28,3), parents (28,), ppx, ppy, camFocal (2,), velConstraints (F,28) and optionally plane_normal / plane_point --
         the arguments of optimize_trajectory (:522-526).  Returns one dict per clip (see the end of `_optimize`).
 
-        More than `chunk` clips are processed chunk by chunk on `workers` threads: a chunk of 256 fills the GPU (one workgroup per
-        clip), and while one thread waits in a library call (ctypes releases the interpreter lock) the other does the host steps
-        of its chunk -- bone lengths, floor fits, forward kinematics -- which are a third of the time of a chunk.  Every library call
-        runs on a non-blocking stream of its own (chd_kinopt.hip, chd_ik.hip), so the kernels of the two threads can overlap; a clip's
-        result does not depend on the chunk it is in."""
+        More than `chunk` clips are processed chunk by chunk on `workers` threads: while one thread waits in a library call (ctypes releases the
+        interpreter lock) the other does the host steps of its chunk -- bone lengths, floor fits, forward kinematics -- which are a third of the time of a
+        chunk.  The least-squares launches of the threads take turns on the device (a launch's workgroups wait on each other: chd_kinopt.hip lets one run at
+        a time), each of them fills it: a 100-frame clip is a cluster of 8 workgroups, 32 clusters are resident and draw clips from the launch's queue.  More
+        than two threads do not help (measured: every launch has a tail).  A clip's result does not depend on the chunk it is in."""
         if workers >= 2 and 128 < len(clips) <= chunk:
-            chunk = (len(clips) + 1) // 2          # one GPU's worth of clips or less: two halves, so that one half's host steps run under the other half's kernels (each half still gets a workgroup per clip)
+            chunk = (len(clips) + 1) // 2          # two halves, so that one half's host steps run under the other half's kernels
         if len(clips) <= chunk or workers < 2:
             return self._optimize(clips)
         from concurrent.futures import ThreadPoolExecutor
