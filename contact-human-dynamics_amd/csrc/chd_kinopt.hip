@@ -178,6 +178,9 @@ int chd_kin_solve_batch(const chd_kin_config* cfg, int device, int B, chd_kin_se
     fprintf(stderr, "KIN_PROFILE %d clips, %.0f LSMR iterations, ticks per iteration:", B, its);
     for (int k = 0; k < 12; ++k) fprintf(stderr, " [%d] %.0f", k, seg[k] / its);
     fprintf(stderr, " total %.0f\n", tot / its);
+    fprintf(stderr, "KIN_PROFILE waits per iteration by rank (sync 1 / sync 2):");
+    for (int g = 0; g < 16; ++g) { double a = 0, b2 = 0; for (int b = 0; b < B; ++b) { a += stats[(size_t)KIN_STATS * b + 24 + 2 * g]; b2 += stats[(size_t)KIN_STATS * b + 25 + 2 * g]; } if (a > 0) fprintf(stderr, " [%d] %.0f / %.0f", g, a / its, b2 / its); }
+    fprintf(stderr, "\n");
   }
 #endif
   release();

@@ -88,7 +88,11 @@
 #else
 #define KO_SEG(c, k) ((void)0)
 #endif
-enum { KIN_STATS = 24 };
+#ifdef KIN_PROFILE
+enum { KIN_STATS = 24 + 2 * 16 };               // + per rank of the cluster: ticks spent waiting in the two synchronisations of LSMR's iterations
+#else
+enum { KIN_STATS = 24 };                        // doubles of statistics per clip: 8 the ABI reports + 16 profile segments
+#endif
 // Pointers the compiler knows to be LDS (ds_read / ds_write instead of flat accesses that wait on both memory pipes): Sp<true>.  The host emulation has one kind.
 #if defined(CHD_HOST_EMU) || defined(KIN_FLAT_LDS)
 #define KO_LDSQ
@@ -193,8 +197,8 @@ struct KinLsmr {
   double normb, beta, alpha, su, sv, damp, ctol;
   double zetabar, alphabar, rho, rhobar, cbar, sbar, betadd, betad, rhodold, tautildeold, thetatilde, zeta, d, normA2, maxrbar, minrbar;
   double chat, shat, cc, s, rhoold, rhobarold, zetaold, thetabar, rhotemp;     // from the first half of an iteration for the second
-  double k1, k2, k3;
-  int itn, istop, maxiter;
+  double k1, k2, k3, nx2;
+  int itn, istop, maxiter, tested;        // `tested`: the last iteration whose stopping tests have run
 };
 
 struct KinCtx {
@@ -220,6 +224,14 @@ struct KinCtx {
   long long seg[16], tlast;      // KIN_PROFILE
   long long t_jv, t_jtu;         // wall-clock ticks in the two halves of LSMR's iterations (first thread's view; monitoring only)
 };
+// The thread that runs LSMR's scalar recurrences: the first lane of the LAST half wavefront, which has no (frame, joint) item while a slice of up to 14 frames is
+// multiplied by J^T or its rows are written -- the recurrences then run beside those phases instead of between them.
+#ifdef CHD_HOST_EMU
+#define KO_IS_SCALAR() true
+#else
+#define KO_IS_SCALAR() ((int)threadIdx.x == (int)blockDim.x - 32)
+#endif
+
 // the tables' entries for joint j: the emulation looks them up, a device lane has its own joint's in registers
 #ifdef CHD_HOST_EMU
 KO_DEV int kj_na(const KinCtx& c, int j) { return c.P->anc_n[j]; }
@@ -390,7 +402,12 @@ KO_DEV void kc_sync(KinCtx& c, KoAcc (*acc)[KC_PARTS], int np, int dir = 0, int 
     for (int k = 0; k < nw; ++k) { const double t = c.red[16 * threadIdx.x + k]; s = mx ? (t > s ? t : s) : s + t; }
     kc_st(&mine->part[par][threadIdx.x], s);
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wavefront's write-through stores (partial sums, halo) have been acknowledged
+  // The flag must not overtake the payload: every wavefront waits until its write-through stores (partial sums, halo) have been ACKNOWLEDGED before the barrier
+  // behind which the first thread raises the flag.  A workgroup-scope release fence does not do that (it orders the compiler, but on this target emits no
+  // s_waitcnt for device memory: the stores of other wavefronts were still in flight when the flag went out -- readers saw the flag and stale halo values, the
+  // ranks of a cluster took different decisions and waited for each other: one call in three with two host threads uploading beside the launch).
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(&mine->flag, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // first wavefront: lane g waits for workgroup g and fetches its partial sums; the other wavefronts wait for the neighbour only and fetch the halo meanwhile
@@ -399,7 +416,13 @@ KO_DEV void kc_sync(KinCtx& c, KoAcc (*acc)[KC_PARTS], int np, int dir = 0, int 
   if (wv == 0) {
     if (ln < c.G) {
       const KinSlot* o = c.slots + ln;
+#if defined(KIN_PROFILE)
+      const long long tw_ = (long long)clock64();
+#endif
       const bool ok = kc_wait(c, o, e);
+#if defined(KIN_PROFILE)
+      if (ln == 0) { const long long dw_ = (long long)clock64() - tw_; if (dir < 0) c.seg[12] += dw_; else c.seg[13] += dw_; }      // (lane 0 leaves the loop with the wavefront's last lane)
+#endif
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       for (int i = 0; i < np; ++i) c.gath[KC_PARTS * ln + i] = ok ? kc_ld(&o->part[par][i]) : 0.0;
     }
@@ -576,6 +599,8 @@ KO_DEV void kin_linearise(KinCtx& c, int xsel) {
   KO_SYNC();
 }
 
+KO_DEV void kin_lsmr_tests(KinCtx& c);
+
 // ---- the two products, matrix free, on the slice ----------------------------------------------------------------------------------------------
 // A (frame, joint) item per lane, 32 lanes per frame (28 joints + 4 idle): a frame never straddles a wavefront, so the steps in which the joints of a frame
 // exchange values (the walks up and down the tree, the two sums over a frame's joints) need no workgroup barrier, and what a lane needs to know about its
@@ -696,7 +721,7 @@ KO_DEV void kin_jv(KinCtx& c, int vsel, int osel, const double scale, const doub
 // out = J^T u for the unknowns of the slice; w.uh must hold the boundary rows of u of the left neighbour (kin_exchange_u, or LSMR's first synchronisation).
 // With `fused`: out <- scale * (J^T u) + keep * out in place and acc[wi][0] += |out|^2 over the slice.  No workgroup barrier inside: every step is within a frame.
 template <bool L, bool VL>
-KO_DEV void kin_jtu(KinCtx& c, int usel, int osel, const double scale, const double keep, const bool fused, KoAcc (*acc)[KC_PARTS]) {
+KO_DEV void kin_jtu(KinCtx& c, int usel, int osel, const double scale_, const double keep_, const bool fused, KoAcc (*acc)[KC_PARTS], const bool late = false) {
   typedef typename Sp<L>::p LP; typedef typename Sp<L>::cp LCP; typedef typename Sp<VL>::p VP; typedef typename Sp<VL>::cp VCP;
   const int F = c.k->F;
   const double sv = c.k->wt[1], sa = c.k->wt[2], vw = c.k->wt[4], fw = c.k->wt[5];
@@ -795,6 +820,14 @@ KO_DEV void kin_jtu(KinCtx& c, int usel, int osel, const double scale, const dou
       o[0] = M0; o[1] = M1; o[2] = M2;
     }
     KO_WSYNC();
+    double scale = scale_, keep = keep_;
+    bool apply = true;
+    if (late) {                                 // LSMR: su, beta, sv come from the scalar thread, which worked beside the steps above
+      KO_SYNC();
+      const double beta = c.S->beta;
+      scale = c.S->su; keep = -beta * c.S->sv; apply = beta > 0;
+    }
+    if (apply)
     KO_FOR(idx, w.nf * 32) {                  // (J^T u)_{j,a} = axis_{j,a} . M_j, + the Euler-smoothness rows; the root's translation gets lambda of the root's data joint
       const int l = idx >> 5, j = idx & 31, f = w.a + l;
       if (j >= NJ) continue;
@@ -835,6 +868,53 @@ KO_DEV void sym_ortho(double a, double b, double& cc, double& s, double& r) {
 }
 
 
+// The second half's estimates and stopping tests of iteration S.itn (scipy lsmr, after the update of x), run by the scalar thread beside the next iteration's J^T U.
+// Must come BEFORE that iteration's first rotations (they overwrite beta, the rotation and thetabar ...).
+KO_DEV void kin_lsmr_tests(KinCtx& c) {
+  KO_LDSQ KinLsmr& S = *c.S;
+  const int itn = S.itn;
+  if (itn <= S.tested) return;
+  S.tested = itn;
+  const double beta = S.beta, alpha = S.alpha, cc = S.cc, s = S.s, chat = S.chat, shat = S.shat, thetabar = S.thetabar, rhobarold = S.rhobarold, zetaold = S.zetaold, rhotemp = S.rhotemp;
+  const double rhobar = S.rhobar, zeta = S.zeta;
+  double ctildeold, stildeold, rhotildeold;
+  const double normx = S.nx2 > 0 ? std::sqrt(S.nx2) : 0.0;
+  const double betaacute = chat * S.betadd, betacheck = -shat * S.betadd;
+  const double betahat = cc * betaacute;
+  S.betadd = -s * betaacute;
+  const double thetatildeold = S.thetatilde;
+  sym_ortho(S.rhodold, thetabar, ctildeold, stildeold, rhotildeold);
+  S.thetatilde = stildeold * rhobar;
+  S.rhodold = ctildeold * rhobar;
+  S.betad = -stildeold * S.betad + ctildeold * betahat;
+  S.tautildeold = (zetaold - thetatildeold * S.tautildeold) / rhotildeold;
+  const double taud = (zeta - S.thetatilde * S.tautildeold) / S.rhodold;
+  S.d += betacheck * betacheck;
+  const double normr = std::sqrt(S.d + (S.betad - taud) * (S.betad - taud) + S.betadd * S.betadd);
+  S.normA2 += beta * beta;
+  const double normA = std::sqrt(S.normA2);
+  S.normA2 += alpha * alpha;
+  S.maxrbar = S.maxrbar > rhobarold ? S.maxrbar : rhobarold;
+  if (itn > 1) S.minrbar = S.minrbar < rhobarold ? S.minrbar : rhobarold;
+  const double condA = (S.maxrbar > rhotemp ? S.maxrbar : rhotemp) / (S.minrbar < rhotemp ? S.minrbar : rhotemp);
+  const double normar = std::fabs(S.zetabar);
+  const double normb = S.normb;
+  const double test1 = normr / normb;
+  const double test2 = normA * normr != 0 ? normar / (normA * normr) : INFINITY;
+  const double test3 = 1 / condA;
+  const double t1 = test1 / (1 + normA * normx / normb);
+  const double rtol = c.P->btol + c.P->atol * normA * normx / normb;
+  int st = 0;
+  if (itn >= S.maxiter) st = 7;
+  if (1 + test3 <= 1) st = 6;
+  if (1 + test2 <= 1) st = 5;
+  if (1 + t1 <= 1) st = 4;
+  if (test3 <= S.ctol) st = 3;
+  if (test2 <= c.P->atol) st = 2;
+  if (test1 <= rtol) st = 1;
+  S.istop = st;
+}
+
 // min |J x - b|^2 + damp^2 |x|^2 into the GN slices, b = the FV slices; uses U (m), V, H, HB (n).  Returns the iteration count.
 // The Golub-Kahan vectors are kept UNNORMALISED (u = su * U, v = sv * V): each half step is one
 // fused product, beta u = A v - alpha u  ->  U <- sv * (J V) - (alpha su) * U,  beta = |U|,  su = 1 / beta, and the same for V.
@@ -843,7 +923,11 @@ KO_DEV void sym_ortho(double a, double b, double& cc, double& s, double& r) {
 //   2. after V: |V|^2, the first two frames of V for the left neighbour, and x.x, x.hbar, hbar.hbar -- alpha then fixes k2, k3: x <- x + k2 hbar, h <- k3 h + sv v,
 //      |x|^2 = x.x + 2 k2 x.hbar + k2^2 hbar.hbar.
 // The scalar recurrences (four plane rotations, the estimates of |r|, |A|, cond A, the stopping tests: ~30 divisions and square roots in a dependent chain) run
-// in the FIRST THREAD only, on a state kept in LDS (KinLsmr): seven wavefronts wait at the barrier instead of competing for the same SIMDs with the same arithmetic.
+// in ONE thread (KO_IS_SCALAR), on a state kept in LDS (KinLsmr), and as far as the data allows BESIDE the products instead of between them:
+//   * the first half's rotations (beta -> rho, k1) while the other wavefronts compute J^T U -- only its last step (V <- su J^T U - beta sv V) needs them;
+//   * of the second half only alpha, the rotation and k2, k3 (what the vector updates need) stay between the synchronisation and the updates; the estimates and
+//     the stopping tests of iteration k run in the same window of iteration k + 1, and are looked at after that iteration's second synchronisation, BEFORE its
+//     update of x: a stop costs one wasted iteration (which touched U, V and h-bar: nothing reads them after the solve), about one in four hundred.
 template <bool L>
 KO_DEV int kin_lsmr_on(KinCtx& c, double damp, int* istop_out) {
   typedef typename Sp<L>::p LP; typedef typename Sp<L>::cp LCP;
@@ -860,7 +944,7 @@ KO_DEV int kin_lsmr_on(KinCtx& c, double damp, int* istop_out) {
   KO_SYNC();
   kin_pub_u<L>(c, M_U);
   kc_sync(c, acc, 1, -1, HALO_U);
-  if (KO_TID == 0) {
+  if (KO_IS_SCALAR()) {
     const long long n = c.k->q->n, m = c.k->q->m;
     S.maxiter = c.P->lsmr_maxiter > 0 ? c.P->lsmr_maxiter : (int)(m < n ? m : n);
     S.damp = damp; S.ctol = c.P->conlim > 0 ? 1 / c.P->conlim : 0;
@@ -875,11 +959,11 @@ KO_DEV int kin_lsmr_on(KinCtx& c, double damp, int* istop_out) {
     kin_pub_v<L>(c, N_V);
     kc_sync(c, a2, 1, +1, HALO_V);
     c.t_jtu += KO_CLOCK() - t0_;
-    if (KO_TID == 0) S.alpha = std::sqrt(kc_sum(c, 0));
+    if (KO_IS_SCALAR()) S.alpha = std::sqrt(kc_sum(c, 0));
   }
-  if (KO_TID == 0) {
+  if (KO_IS_SCALAR()) {
     if (S.alpha > 0) S.sv = 1 / S.alpha;
-    S.itn = 0; S.istop = 0;
+    S.itn = 0; S.istop = 0; S.tested = 0;
     S.zetabar = S.alpha * S.beta; S.alphabar = S.alpha; S.rho = 1; S.rhobar = 1; S.cbar = 1; S.sbar = 0;
     S.betadd = S.beta; S.betad = 0; S.rhodold = 1; S.tautildeold = 0; S.thetatilde = 0; S.zeta = 0; S.d = 0;
     S.normA2 = S.alpha * S.alpha; S.maxrbar = 0; S.minrbar = 1e100;
@@ -910,9 +994,8 @@ KO_DEV int kin_lsmr_on(KinCtx& c, double damp, int* istop_out) {
 #endif
   const int maxiter = S.maxiter;
   int itn = 0, istop = 0;
-  while (itn < maxiter) {
+  while (true) {
     if (kc_dead(c)) break;
-    ++itn;
     KO_SEG(c, 15);
     {
       KoAcc b2[KC_NW][KC_PARTS];
@@ -923,8 +1006,10 @@ KO_DEV int kin_lsmr_on(KinCtx& c, double damp, int* istop_out) {
       KO_SEG(c, 3);
       c.t_jv += KO_CLOCK() - t0_;
     }
-    if (KO_TID == 0) {
+    ++itn;
+    if (KO_IS_SCALAR()) {                       // beside J^T U: the stopping tests of the iteration before, then this iteration's first rotations
       const double beta = std::sqrt(kc_sum(c, 0));
+      kin_lsmr_tests(c);
       double chat, shat, alphahat, cc, s, rho;
       sym_ortho(S.alphabar, S.damp, chat, shat, alphahat);
       const double rhoold = S.rho;
@@ -934,16 +1019,13 @@ KO_DEV int kin_lsmr_on(KinCtx& c, double damp, int* istop_out) {
       S.k1 = -(S.thetabar * rho / (rhoold * S.rhobarold));
       if (beta > 0) S.su = 1 / beta;
     }
-    KO_SYNC();
     KO_SEG(c, 4);
     {
       KoAcc a2[KC_NW][KC_PARTS];
       const long long t0_ = KO_CLOCK();
-      const double beta = S.beta, k1 = S.k1;
-      if (beta > 0) {
-        kin_jtu<L, L>(c, M_U, N_V, S.su, -beta * S.sv, true, a2);
-        kin_pub_v<L>(c, N_V);
-      }
+      kin_jtu<L, L>(c, M_U, N_V, 0.0, 0.0, true, a2, true);                 // (its last step waits for the scalars above and takes su, beta, sv from the state)
+      kin_pub_v<L>(c, N_V);
+      const double k1 = S.k1;
       KC_EACH(c, w)
         double* __restrict__ hb = w.nv[N_HB]; LCP h = (LCP)w.nv[N_H]; const double* __restrict__ x = w.nv[N_GN];
         if (L) {
@@ -964,15 +1046,17 @@ KO_DEV int kin_lsmr_on(KinCtx& c, double damp, int* istop_out) {
       KO_SEG(c, 9);
       c.t_jtu += KO_CLOCK() - t0_;
     }
-    if (KO_TID == 0) {
-      const double beta = S.beta, cc = S.cc, s = S.s, rho = S.rho, chat = S.chat, shat = S.shat, thetabar = S.thetabar, rhobarold = S.rhobarold, zetaold = S.zetaold, rhotemp = S.rhotemp;
+    istop = S.istop;                            // (of the iteration before: x has not moved since)
+    if (istop > 0) { --itn; break; }
+    if (KO_IS_SCALAR()) {                       // what the vector updates need
+      const double beta = S.beta, cc = S.cc, s = S.s, rho = S.rho;
       double alpha = S.alpha;
       if (beta > 0) {
         alpha = std::sqrt(kc_sum(c, 0));
         if (alpha > 0) S.sv = 1 / alpha;
       }
       S.alpha = alpha;
-      double ctildeold, stildeold, rhotildeold, cbar, sbar, rhobar;
+      double cbar, sbar, rhobar;
       const double thetanew = s * alpha;
       S.alphabar = cc * alpha;
       sym_ortho(S.cbar * rho, thetanew, cbar, sbar, rhobar);
@@ -982,42 +1066,8 @@ KO_DEV int kin_lsmr_on(KinCtx& c, double damp, int* istop_out) {
       S.zetabar = -sbar * S.zetabar;
       const double k2 = zeta / (rho * rhobar);
       S.k2 = k2; S.k3 = -(thetanew / rho);
-      const double nx2 = kc_sum(c, 1) + 2.0 * k2 * kc_sum(c, 2) + k2 * k2 * kc_sum(c, 3);
-      const double normx = nx2 > 0 ? std::sqrt(nx2) : 0.0;
-      const double betaacute = chat * S.betadd, betacheck = -shat * S.betadd;
-      const double betahat = cc * betaacute;
-      S.betadd = -s * betaacute;
-      const double thetatildeold = S.thetatilde;
-      sym_ortho(S.rhodold, thetabar, ctildeold, stildeold, rhotildeold);
-      S.thetatilde = stildeold * rhobar;
-      S.rhodold = ctildeold * rhobar;
-      S.betad = -stildeold * S.betad + ctildeold * betahat;
-      S.tautildeold = (zetaold - thetatildeold * S.tautildeold) / rhotildeold;
-      const double taud = (zeta - S.thetatilde * S.tautildeold) / S.rhodold;
-      S.d += betacheck * betacheck;
-      const double normr = std::sqrt(S.d + (S.betad - taud) * (S.betad - taud) + S.betadd * S.betadd);
-      S.normA2 += beta * beta;
-      const double normA = std::sqrt(S.normA2);
-      S.normA2 += alpha * alpha;
-      S.maxrbar = S.maxrbar > rhobarold ? S.maxrbar : rhobarold;
-      if (itn > 1) S.minrbar = S.minrbar < rhobarold ? S.minrbar : rhobarold;
-      const double condA = (S.maxrbar > rhotemp ? S.maxrbar : rhotemp) / (S.minrbar < rhotemp ? S.minrbar : rhotemp);
-      const double normar = std::fabs(S.zetabar);
-      const double normb = S.normb;
-      const double test1 = normr / normb;
-      const double test2 = normA * normr != 0 ? normar / (normA * normr) : INFINITY;
-      const double test3 = 1 / condA;
-      const double t1 = test1 / (1 + normA * normx / normb);
-      const double rtol = c.P->btol + c.P->atol * normA * normx / normb;
-      int st = 0;
-      if (itn >= maxiter) st = 7;
-      if (1 + test3 <= 1) st = 6;
-      if (1 + test2 <= 1) st = 5;
-      if (1 + t1 <= 1) st = 4;
-      if (test3 <= S.ctol) st = 3;
-      if (test2 <= c.P->atol) st = 2;
-      if (test1 <= rtol) st = 1;
-      S.istop = st;
+      S.nx2 = kc_sum(c, 1) + 2.0 * k2 * kc_sum(c, 2) + k2 * k2 * kc_sum(c, 3);
+      S.itn = itn;
     }
     KO_SYNC();
     {
@@ -1032,10 +1082,9 @@ KO_DEV int kin_lsmr_on(KinCtx& c, double damp, int* istop_out) {
         KO_FOR(i, w.nf * NV) { x[i] = x[i] + k2 * hb[i]; h[i] = h[i] * k3 + sv * v[i]; }
       KC_DONE
     }
-    istop = S.istop;
     KO_SEG(c, 10);
-    if (istop > 0) break;
   }
+  KO_SYNC();
   if (L) {
     KC_EACH(c, w)
       (void)wi;
@@ -1253,6 +1302,9 @@ KO_DEV void kin_solve(KinCtx& c, double* xio, double* stats) {
       stats[6] = tall > 0 ? (double)c.t_jv / tall : 0.0; stats[7] = tall > 0 ? (double)c.t_jtu / tall : 0.0;
       for (int k = 0; k < 16; ++k) stats[8 + k] = (double)c.seg[k];
     }
+#if defined(KIN_PROFILE) && !defined(CHD_HOST_EMU)
+    if (KO_TID == 0 && w.g < 16) { stats[24 + 2 * w.g] = (double)c.seg[12]; stats[25 + 2 * w.g] = (double)c.seg[13]; }
+#endif
   KC_DONE
   KO_SYNC();
 }

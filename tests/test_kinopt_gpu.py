@@ -74,6 +74,25 @@ def test_clusters_of_workgroups_on_gpu(gold, frames_cap):
         assert rel(r['x'], e['x']) < 1e-8 and abs(r['cost'] - e['cost']) < 1e-7 * e['cost']      # (device and host sin / cos differ in the last bit)
 
 
+def test_clusters_under_concurrent_calls_and_uploads(gold):
+    """Two host threads call the library at once, as `KinematicOptimizer.optimize` does: their launches take turns, but one thread's uploads run beside the other's
+    launch.  That is how round 5 found a flag overtaking its payload (a workgroup-scope release fence emits no `s_waitcnt` for device memory here: the halo
+    stores of other wavefronts were still in flight when the flag went out; the ranks of a cluster then disagreed and waited for each other).  Every result of
+    eight interleaved calls must be bit for bit the single-threaded one."""
+    from concurrent.futures import ThreadPoolExecutor
+    ps = [problem(gold, ci, li)[0] for ci, li in [(1, 1), (2, 0), (0, 0)]] * 12
+    def make():
+        k = kopt.KinSolver(device=0, lsmr_maxiter=40); k.cfg.reserved[2] = 3
+        return k
+    ref = make().solve(ps)
+    solvers = [make(), make()]
+    with ThreadPoolExecutor(max_workers=2) as ex:
+        outs = list(ex.map(lambda i: solvers[i % 2].solve(ps), range(8)))
+    for out in outs:
+        for r, a in zip(out, ref):
+            assert np.array_equal(r['x'], a['x']) and r['cost'] == a['cost'] and r['lsmr_iterations'] == a['lsmr_iterations']
+
+
 def test_a_missing_workgroup_is_an_error_not_a_hang(gold):
     """The members of a cluster wait on each other: a launch that is not fully resident would spin for ever.  The wait is bounded (5 s; 0.25 s under the
     test hook `reserved[3] = 0x7e57`, which makes the last workgroup of the first cluster return at once): the launch winds down, the call reports it, and
