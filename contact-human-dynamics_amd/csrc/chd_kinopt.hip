@@ -22,8 +22,8 @@ int fail(const std::string& what, hipError_t e = hipSuccess) {
 }  // namespace
 
 // One workgroup of 512 threads per compute unit (up to 256 VGPRs, the LDS block below), persistent: consecutive workgroups form clusters of G, each cluster
-// takes clips from the launch's queue until it is empty.  ALL workgroups of a launch must be resident at once -- the members of a cluster spin on each other's
-// flags (chd_kinopt_kernels.hpp, kc_sync) -- so the host sizes the grid by the device's occupancy for this kernel and never has two launches in flight.
+// takes clips from the launch's queue until it is empty.  ALL workgroups of a launch must be resident at once -- the members of a cluster poll each other's
+// published values (chd_kinopt_kernels.hpp, kc_sync) -- so the host sizes the grid by the device's occupancy for this kernel and never has two launches in flight.
 __global__ void __launch_bounds__(512, 2) chd_kin_solve_kernel(const KinSeq* seqs, const int* order, int n_clips, KinParams P, const double* dpool, const int* ipool, double* work,
                                                                double* state, double* stats, KinSlot* slots, int* queue, int* abort_flag, int G, int lds_doubles, int test_absent) {
   extern __shared__ double lds[];               // received halos + the slice's share of LSMR's state (kin_bind_wg)

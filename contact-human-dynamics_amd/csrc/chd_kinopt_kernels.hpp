@@ -19,10 +19,11 @@
 //     two frames AFTER the slice (174 doubles, from the right neighbour) and the smoothness / contact / Euler rows of u of the two
 //     frames BEFORE it (423 doubles, from the left neighbour); every norm is a sum of G partial sums;
 //   * LSMR therefore synchronises the cluster twice per iteration -- after the rows of u are written (|u|, u halo) and after v is
-//     (|v|, v halo, and the three dot products that give |x| without a third round) -- by a flag all-gather: payload and flag are
-//     written and read with agent-scope relaxed atomics (`sc1`: write-through / read at the memory side) between workgroup-scope
-//     fences.  A release / acquire pair at agent scope costs 17 us on this part (L2 write-back + invalidate), this costs 2-3
-//     (tests/tools/cluster_sync_probe.hip, profiles/r05_experiments.md section 7);
+//     (|v|, v halo, and the three dot products that give |x| without a third round) -- by an all-gather of TAGGED values: every
+//     8-byte granule a workgroup publishes carries 32 data bits and the number of the synchronisation it belongs to, written and
+//     polled with agent-scope relaxed atomics (`sc1`: write-through / read at the memory side).  No flag, no fence: a release /
+//     acquire pair at agent scope costs 17 us on this part (L2 write-back + invalidate), a flag behind acknowledged stores 2.5-3,
+//     this 1.6-2.4 (tests/tools/cluster_sync_probe.hip, profiles/r05_experiments.md sections 7, 8b);
 //   * a launch is persistent: as many clusters as the device holds resident (all workgroups of a cluster MUST be resident: they
 //     spin on each other), each taking clips from a queue.  Clips of 13 frames or fewer are a cluster of one: no device-memory traffic at all.
 //
@@ -165,9 +166,10 @@ KO_HD int cluster_size(int F, int cap) {
 
 // what a workgroup publishes at a synchronisation of its cluster (device memory; one per workgroup of the launch)
 struct KinSlot {
-  unsigned long long flag;       // number of the last synchronisation this workgroup has arrived at
-  double part[2][KC_PARTS];      // its partial sums (by parity of the synchronisation's number: a workgroup can be one synchronisation ahead of a neighbour that still reads)
-  double halo[2][KC_HALO];
+  // 8-byte granules {32 data bits | 32-bit tag}, a double as two of them; the tag is the number of the synchronisation the value belongs to, so a reader needs no flag:
+  // it polls the granule itself (an aligned 8-byte atomic is never torn).  By parity of the synchronisation's number: a workgroup can be one synchronisation
+  // ahead of a neighbour that still reads.  First the KC_PARTS partial sums, then the halo.
+  unsigned long long gran[2][2 * (KC_PARTS + KC_HALO)];
 };
 
 // a workgroup's share of a clip: frames [a, a + nf), local frame index l = f - a; arrays marked (+2) carry the two frames after the slice
@@ -271,18 +273,26 @@ KO_DEV bool kc_dead(const KinCtx&) { return false; }
 #else
 #define KC_PATIENCE 500000000LL                 // wall_clock64 ticks (100 MHz): 5 s
 KO_DEV bool kc_dead(const KinCtx& c) { return *c.dead != 0; }
-KO_DEV bool kc_wait(KinCtx& c, const KinSlot* o, unsigned long long e) {      // false: gave up
+KO_DEV unsigned long long kc_poll(KinCtx& c, const unsigned long long* g, unsigned tag, bool& ok) {      // the granule once it carries `tag`; ok = false: gave up
+  unsigned long long v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if ((unsigned)v == tag) return v;
   const long long t0 = (long long)wall_clock64();
   unsigned spins = 0;
-  while (__hip_atomic_load(&o->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < e) {
+  for (;;) {
     __builtin_amdgcn_s_sleep(1);
+    v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)v == tag) return v;
     if ((++spins & 1023u) == 0 && (__hip_atomic_load(c.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || (long long)wall_clock64() - t0 > c.patience)) {
       __hip_atomic_store(c.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       *c.dead = 1;
-      return false;
+      ok = false;
+      return 0;
     }
   }
-  return true;
+}
+KO_DEV double kc_get(KinCtx& c, const unsigned long long* g2, unsigned tag, bool& ok) {
+  const unsigned long long hi = kc_poll(c, g2, tag, ok), lo = ok ? kc_poll(c, g2 + 1, tag, ok) : 0ull;
+  return __longlong_as_double((long long)((hi & 0xffffffff00000000ull) | (lo >> 32)));
 }
 #endif
 
@@ -332,9 +342,12 @@ struct KoAcc {
   __device__ void add(long long, double v) { s += v; }
   __device__ void hi(long long, double v) { s = v > s ? v : s; }
 };
-KO_DEV double kc_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-KO_DEV void kc_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-#define KC_PUB(c, w, i, val) kc_st(&(c).slots[(w).g].halo[((c).epoch + 1) & 1][i], (val))
+KO_DEV void kc_put(unsigned long long* g2, double x, unsigned tag) {      // agent-scope relaxed atomics: write-through, visible to the other XCDs' sc1 loads
+  const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  __hip_atomic_store(g2, (b & 0xffffffff00000000ull) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(g2 + 1, (b << 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#define KC_PUB(c, w, i, val) kc_put(&(c).slots[(w).g].gran[((c).epoch + 1) & 1][2 * (KC_PARTS + (i))], (val), (unsigned)((c).epoch + 1))
 #endif
 
 // Sum over the joints of a frame of three values per joint, the joint `skip` left out: a butterfly over the frame's 32 lanes (the same bits in every lane).
@@ -394,45 +407,37 @@ KO_DEV void kc_sync(KinCtx& c, KoAcc (*acc)[KC_PARTS], int np, int dir = 0, int 
     __syncthreads();
     return;
   }
+  // Every synchronisation gathers at least one value from EVERY rank (a zero when the caller has none): a workgroup thus never gets more than one synchronisation ahead
+  // of any other, which is what the two-deep slots rely on.
   const unsigned long long e = ++c.epoch;
   const int par = (int)(e & 1);
+  const unsigned tag = (unsigned)e;
+  const int npp = np > 0 ? np : 1;
   KinSlot* mine = c.slots + me;
-  if ((int)threadIdx.x < np) {
+  if ((int)threadIdx.x < npp) {
     double s = 0.0;
-    for (int k = 0; k < nw; ++k) { const double t = c.red[16 * threadIdx.x + k]; s = mx ? (t > s ? t : s) : s + t; }
-    kc_st(&mine->part[par][threadIdx.x], s);
+    if ((int)threadIdx.x < np) for (int k = 0; k < nw; ++k) { const double t = c.red[16 * threadIdx.x + k]; s = mx ? (t > s ? t : s) : s + t; }
+    kc_put(&mine->gran[par][2 * threadIdx.x], s, tag);
   }
-  // The flag must not overtake the payload: every wavefront waits until its write-through stores (partial sums, halo) have been ACKNOWLEDGED before the barrier
-  // behind which the first thread raises the flag.  A workgroup-scope release fence does not do that (it orders the compiler, but on this target emits no
-  // s_waitcnt for device memory: the stores of other wavefronts were still in flight when the flag went out -- readers saw the flag and stale halo values, the
-  // ranks of a cluster took different decisions and waited for each other: one call in three with two host threads uploading beside the launch).
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(&mine->flag, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // first wavefront: lane g waits for workgroup g and fetches its partial sums; the other wavefronts wait for the neighbour only and fetch the halo meanwhile
+  // first wavefront: lane g fetches workgroup g's partial sums; the other wavefronts fetch the neighbour's halo meanwhile.  No flag, no fence: a value is there when its tag is
   const int nb = me + dir;
   const bool want = dir != 0 && nb >= 0 && nb < c.G;
+  bool ok = true;
   if (wv == 0) {
     if (ln < c.G) {
-      const KinSlot* o = c.slots + ln;
+      const unsigned long long* o = c.slots[ln].gran[par];
 #if defined(KIN_PROFILE)
       const long long tw_ = (long long)clock64();
 #endif
-      const bool ok = kc_wait(c, o, e);
+      for (int i = 0; i < npp; ++i) { const double t = kc_get(c, o + 2 * i, tag, ok); if (i < np) c.gath[KC_PARTS * ln + i] = ok ? t : 0.0; }
 #if defined(KIN_PROFILE)
       if (ln == 0) { const long long dw_ = (long long)clock64() - tw_; if (dir < 0) c.seg[12] += dw_; else c.seg[13] += dw_; }      // (lane 0 leaves the loop with the wavefront's last lane)
 #endif
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      for (int i = 0; i < np; ++i) c.gath[KC_PARTS * ln + i] = ok ? kc_ld(&o->part[par][i]) : 0.0;
     }
   } else if (want) {
-    const KinSlot* o = c.slots + nb;
-    const bool ok = kc_wait(c, o, e);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const unsigned long long* o = c.slots[nb].gran[par] + 2 * KC_PARTS;
     KO_LDSQ double* dst = (KO_LDSQ double*)(dir > 0 ? c.wg[0].vh : c.wg[0].uh);
-    const double* src = o->halo[par];
-    if (ok) for (int i = threadIdx.x - 64; i < nrecv; i += blockDim.x - 64) dst[i] = kc_ld(src + i);
+    for (int i = threadIdx.x - 64; i < nrecv && ok; i += blockDim.x - 64) { const double t = kc_get(c, o + 2 * i, tag, ok); if (ok) dst[i] = t; }
   }
   __syncthreads();
 #endif

@@ -53,6 +53,8 @@ def run(n_videos=32, frames=60, keep=None):
     torch.save(cn.randomize_batchnorm_stats(cn.OpenPoseModel(), seed=0).state_dict(), weights)
     t_make = time.perf_counter() - t0
     stages = {}
+    if torch.cuda.is_available():                  # (context creation and the first library GEMM are the process's, not the stage's: 1.3 s of the 1.4 s this stage showed for 64 x 100)
+        a = torch.randn(64, 64, device='cuda'); (a @ a).sum().item()
     t = time.perf_counter()
     rc0 = run_detect_contacts.main(['--data', root, '--weights', weights, '--device-ops'])
     torch.cuda.synchronize()
