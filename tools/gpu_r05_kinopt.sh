@@ -19,3 +19,4 @@ except Exception as e:
 P
 done
 if [ "${2:-}" != "nopmc" ]; then bash tools/gpu_kinopt_pmc.sh $tag > $out/pmc.log 2>&1; tail -6 $out/pmc.log; fi
+timeout 400 python tests/tools/pipeline_bench.py --videos 64 --frames 100 > $out/pipe100.json 2> $out/pipe100.err; tail -c 700 $out/pipe100.json
