@@ -145,6 +145,8 @@ int chd_kin_solve_batch(const chd_kin_config* cfg, int device, int B, chd_kin_se
   KIN_TRY(hipMemsetAsync(d_slots, 0, sizeof(KinSlot) * (size_t)slots_total, st), "clear cluster slots");
   KIN_TRY(hipEventCreate(&ev0), "hipEventCreate");
   KIN_TRY(hipEventCreate(&ev1), "hipEventCreate");
+  std::vector<double> fin(bt.state.size()), stats((size_t)KIN_STATS * B);
+  int gave_up = 0;
   {
     std::lock_guard<std::mutex> only_one(g_launch_mutex);
     KIN_TRY(hipEventRecord(ev0, st), "hipEventRecord");
@@ -158,14 +160,14 @@ int chd_kin_solve_batch(const chd_kin_config* cfg, int device, int B, chd_kin_se
       o_order += g.clips.size(); o_slot += (size_t)grid[k];
     }
     KIN_TRY(hipEventRecord(ev1, st), "hipEventRecord");
-    KIN_TRY(hipEventSynchronize(ev1), "synchronize");
+    // the results come back INSIDE the lock: a copy from pageable memory is a small kernel of the runtime, and once the next caller's launch holds every compute unit
+    // (its workgroups fill LDS and the register file) that kernel waits for the whole launch -- this caller's host steps then no longer overlap it (measured: both
+    // halves of a 256-clip batch returned from their first solve only when the SECOND half's kernel had ended)
+    KIN_TRY(hipMemcpyAsync(&gave_up, d_order + order.size() + bt.groups.size(), sizeof(int), hipMemcpyDeviceToHost, st), "copy abort flag");
+    KIN_TRY(hipMemcpyAsync(fin.data(), d_state, sizeof(double) * fin.size(), hipMemcpyDeviceToHost, st), "copy solutions");
+    KIN_TRY(hipMemcpyAsync(stats.data(), d_stats, sizeof(double) * stats.size(), hipMemcpyDeviceToHost, st), "copy statistics");
+    KIN_TRY(hipStreamSynchronize(st), "synchronize");
   }
-  std::vector<double> fin(bt.state.size()), stats((size_t)KIN_STATS * B);
-  int gave_up = 0;
-  KIN_TRY(hipMemcpyAsync(&gave_up, d_order + order.size() + bt.groups.size(), sizeof(int), hipMemcpyDeviceToHost, st), "copy abort flag");
-  KIN_TRY(hipMemcpyAsync(fin.data(), d_state, sizeof(double) * fin.size(), hipMemcpyDeviceToHost, st), "copy solutions");
-  KIN_TRY(hipMemcpyAsync(stats.data(), d_stats, sizeof(double) * stats.size(), hipMemcpyDeviceToHost, st), "copy statistics");
-  KIN_TRY(hipStreamSynchronize(st), "synchronize");
   float ms = 0.0f;
   KIN_TRY(hipEventElapsedTime(&ms, ev0, ev1), "hipEventElapsedTime");
 #undef KIN_TRY

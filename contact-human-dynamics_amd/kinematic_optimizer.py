@@ -324,6 +324,8 @@ class KinematicOptimizer:
             return [r for part in ex.map(self._optimize, parts) for r in part]
 
     def _optimize(self, clips):
+        import time as _time
+        marks = [('start', _time.perf_counter())]               # wall-clock marks of this chunk's steps (self.timings: one list per chunk; monitoring only)
         prep = []
         for cl in clips:
             F = cl['poses2D'].shape[0]
@@ -344,7 +346,9 @@ class KinematicOptimizer:
                              floor_n=np.asarray(cl['plane_normal'], dtype=np.float64) if given else np.zeros(3),
                              floor_p=np.asarray(cl['plane_point'], dtype=np.float64) if given else np.zeros(3),
                              ik=dict(parents=parents, target_joints=tj, targets=np.swapaxes(targets[:, tj], 0, 1), rot=rot0, pos=pos)))
+        marks.append(('prepared', _time.perf_counter()))
         iks = self.ik.solve([p['ik'] for p in prep])                                                             # :611-617
+        marks.append(('ik', _time.perf_counter()))
         for p, (rot, pos) in zip(prep, iks):
             p['ik_rot'] = rot
             p['x'] = np.concatenate([pos[:, 0], sio.quat_to_euler_xyz(rot).reshape(p['F'], -1)], axis=1).reshape(-1)      # :638-640
@@ -354,6 +358,7 @@ class KinematicOptimizer:
                          contact=p['vel'], floor_n=p['floor_n'], floor_p=p['floor_p'], weights=STAGE_WEIGHTS[stage], x0=p['x']) for p, cl in zip(prep, clips)]
 
         r1 = self.kin.solve(problems(0))                                                                         # :660-670
+        marks.append(('solve_1', _time.perf_counter()))
         feet_contact = FORWARD_MAPPING[FEET_IDX]
         to_fit = []
         mg = _motions_batch([r['x'].reshape(p['F'], NV) for p, r in zip(prep, r1)], [p['offs'] for p in prep], [p['parents'] for p in prep]) if prep else []
@@ -373,7 +378,9 @@ class KinematicOptimizer:
                 fv = p['vel'][:, feet_contact].copy()
                 fv[fv == 1] = np.where(outl, 0, 1)                                                               # :755-767 (row-major walk = the reference's loops)
                 p['vel'][:, feet_contact] = fv
+        marks.append(('floor_fit', _time.perf_counter()))
         r2 = self.kin.solve(problems(1))                                                                         # :779-789
+        marks.append(('solve_2', _time.perf_counter()))
         out = []
         mg = _motions_batch([b['x'].reshape(p['F'], NV) for p, b in zip(prep, r2)], [p['offs'] for p in prep], [p['parents'] for p in prep]) if prep else []
         for p, cl, a, b, (motion, gp) in zip(prep, clips, r1, r2, mg):
@@ -382,6 +389,8 @@ class KinematicOptimizer:
                              cl['camFocal'][1] * new3d[..., 1] / new3d[..., 2] + cl['ppy']], axis=-1)            # :816-830
             out.append(dict(motion=motion, pose3d=new3d, proj2d=proj, plane_normal=p['floor_n'], plane_point=p['floor_p'], velConstraints=p['vel'],
                             ik_rot=p['ik_rot'], stages=[{k: v for k, v in s.items()} for s in (a, b)], error=p['error']))
+        marks.append(('outputs', _time.perf_counter()))
+        self.timings.setdefault('chunks', []).append(marks)
         return out
 
 

@@ -48,6 +48,7 @@ if __name__ == '__main__':
 
     opt.kin.solve = timed
     t0 = time.perf_counter(); res = opt.optimize(clips, chunk=int(os.environ.get('KIN_CHUNK', '256')), workers=int(os.environ.get('KIN_WORKERS', '2'))); t1 = time.perf_counter()
+    chunk_marks = opt.timings.get('chunks', [])[-max(1, (B + 255) // 256 * 2):] if B > 128 else opt.timings.get('chunks', [])[-1:]
     ik_ms, ik_frames = opt.ik.last_kernel_ms()
     its = np.array([[s['lsmr_iterations'] for s in r['stages']] for r in res])
     nfev = np.array([[s['nfev'] for s in r['stages']] for r in res])
@@ -60,6 +61,7 @@ if __name__ == '__main__':
                status_counts={str(k): int(v) for k, v in zip(*np.unique([s['status'] for r in res for s in r['stages']], return_counts=True))},
                algorithmic_GBps=alg_bytes / (sum(kin_ms) * 1e-3) / 1e9,
                lsq_time_share={'jv': float(np.mean([s['jv_fraction'] for r in res for s in r['stages']])), 'jtu': float(np.mean([s['jtu_fraction'] for r in res for s in r['stages']]))},
+               chunk_timelines=[[(n, round(t - t0, 3)) for n, t in m] for m in chunk_marks],
                relabelled_contacts_per_clip=float(np.mean([np.abs(r['velConstraints'] - c['velConstraints']).sum() for r, c in zip(res, clips)])))
     # CPU: the oracle (dense restatement of the reference, with SciPy's sparse products) on a short clip, scaled per frame
     if FO > 0:
