@@ -192,6 +192,27 @@ def test_a_clip_split_over_a_cluster_of_workgroups(gold, frames_cap, lds_doubles
         assert (a['nfev'], a['status']) == (b['nfev'], b['status']) and rel(b['x'], a['x']) < 1e-9
 
 
+def test_a_skeleton_that_is_not_in_depth_first_order(gold):
+    """The walk over a joint's descendants takes the contiguous range j + 1 .. j + n when the joints are in depth-first order (the reference's skeleton is), with the four
+    idle lanes of a frame helping on the longest walks; any other numbering (parents[j] < j is all the ABI asks for) falls back to every later joint as a candidate under the
+    descendant mask.  Products and residual against the oracle's Jacobian for such a tree, one workgroup and clusters of four."""
+    from oracle import kinopt_oracle as ko
+    import kin_emu
+    p, q = problem(gold, 1, 1)
+    par = np.array([-1, 0, 0, 1, 2, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23])      # siblings interleaved with each other's children
+    P = ko.Problem(p['offsets'], par, p['pose3d'], p['root_trans'], p['pose2d_n'], p['proj_w'], p['data_w'], p['contact'], p['floor_n'], p['floor_p'], kopt.STAGE_WEIGHTS[1])
+    J = P.jac(p['x0']); J = J.toarray() if hasattr(J, 'toarray') else np.asarray(J)
+    rng = np.random.default_rng(1)
+    v, u = rng.normal(size=J.shape[1]), rng.normal(size=J.shape[0])
+    for cap in (0, 3):
+        cfg = kin_emu.default_config()
+        for j in range(28):
+            cfg.parents[j] = int(par[j])
+        cfg.reserved[2] = cap
+        assert rel(kin_emu.probe(p, 0, cfg=cfg)[0], P.fun(p['x0'])) < 5e-9
+        assert rel(kin_emu.probe(p, 1, v, cfg=cfg)[0], J @ v) < 5e-9 and rel(kin_emu.probe(p, 2, u, cfg=cfg)[0], J.T @ u) < 5e-9
+
+
 def test_batched_huber_fits_find_the_regressors_minimum():
     """The floor fits of a batch (`huber_fit_batch`: block descent on all clips' problems at once) against the per-clip solve that mirrors
     HuberRegressor (`huber_fit`: SciPy's L-BFGS-B, gtol 1e-5) and against scikit-learn itself: never a higher objective, the same outlier
