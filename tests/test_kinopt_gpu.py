@@ -74,6 +74,28 @@ def test_clusters_of_workgroups_on_gpu(gold, frames_cap):
         assert rel(r['x'], e['x']) < 1e-8 and abs(r['cost'] - e['cost']) < 1e-7 * e['cost']      # (device and host sin / cos differ in the last bit)
 
 
+def test_a_clip_too_long_for_sixteen_slices_in_lds(gold):
+    """250 frames: sixteen workgroups with slices of 15-16 frames, more than the LDS block holds (13) -- the slices' arrays stay in device memory and the same templates run
+    through generic pointers (items in two rounds per phase: 16 x 32 lanes against 512 threads).  A bounded solve against the emulation of the same split."""
+    import kin_emu
+    from chd_amd.synth import make_kin_clip
+    F = 250
+    cl = make_kin_clip(11, F, gold['c0_skel_offsets'], gold['c0_skel_parents'])
+    p2n, pw, dw = kopt.prepare_weights(cl['poses2D'], cl['joint_conf_2d'], (cl['ppx'], cl['ppy']), cl['camFocal'])
+    rng = np.random.default_rng(5)
+    p = dict(offsets=cl['offsets'], pose3d=cl['poses3D'], root_trans=cl['root_pos'], pose2d_n=p2n, proj_w=pw, data_w=dw, contact=np.array(cl['velConstraints']),
+             floor_n=np.array([0.0, 1.0, 0.0]), floor_p=np.zeros(3), weights=kopt.STAGE_WEIGHTS[1],
+             x0=np.concatenate([cl['root_pos'], rng.normal(size=(F, 84)) * 0.2], axis=1).reshape(-1))
+    cfg = kin_emu.default_config(lsmr_maxiter=3, max_nfev=4)
+    assert kin_emu.cluster_size(cfg, F) == 16
+    e = kin_emu.solve([p], cfg)[0]
+    solver = kopt.KinSolver(device=0, lsmr_maxiter=3); solver.cfg.max_nfev = 4
+    r = solver.solve([p, p])
+    assert np.array_equal(r[0]['x'], r[1]['x'])
+    assert (r[0]['nfev'], r[0]['njev'], r[0]['status'], r[0]['lsmr_iterations']) == (e['nfev'], e['njev'], e['status'], e['lsmr_iterations'])
+    assert rel(r[0]['x'], e['x']) < 1e-8 and abs(r[0]['cost'] - e['cost']) < 1e-7 * e['cost']
+
+
 def test_clusters_under_concurrent_calls_and_uploads(gold):
     """Two host threads call the library at once, as `KinematicOptimizer.optimize` does: their launches take turns, but one thread's uploads run beside the other's
     launch.  That is how round 5 found a flag overtaking its payload (a workgroup-scope release fence emits no `s_waitcnt` for device memory here: the halo
