@@ -4,6 +4,7 @@
 // iterate.  See chd_ik_kernels.hpp for the per-frame step and its reference citations.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <string>
 
 #include "chd_ik_host.hpp"
@@ -109,6 +110,18 @@ int chd_ik_solve_batch(const chd_ik_config* cfg, int device, int B, const chd_ik
   IK_TRY(hipEventElapsedTime(&ms, ev0, ev1), "hipEventElapsedTime");
 #undef IK_TRY
   bt.scatter(fin.data(), in);
+#ifdef IK_PROFILE
+  {
+    unsigned long long pr[16];
+    if (hipMemcpyFromSymbol(pr, HIP_SYMBOL(ik_prof), sizeof(pr)) == hipSuccess) {
+      double tot = 0; for (int k = 0; k < 12; ++k) tot += (double)pr[k];
+      fprintf(stderr, "IK_PROFILE %lld frames x %d iterations, ticks per frame-step:", (long long)nwg, P.iterations);
+      for (int k = 0; k < 12; ++k) fprintf(stderr, " [%d] %.0f", k, (double)pr[k] / ((double)((nwg + 63) / 64) * P.iterations));
+      fprintf(stderr, " total %.0f\n", tot / ((double)((nwg + 63) / 64) * P.iterations));
+      unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(ik_prof), z, sizeof(z));
+    }
+  }
+#endif
   release();
   g_kernel_ms = ms; g_frames = (long long)nwg;
   g_err.clear();

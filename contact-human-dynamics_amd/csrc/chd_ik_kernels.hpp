@@ -43,6 +43,15 @@
 #define IK_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 #endif
 #define IK_FOR(i, n) for (int i = IK_TID; i < (n); i += IK_NT)
+// -DIK_PROFILE: shader-clock ticks per phase of a step, summed over all workgroups of a call (first thread's view; a study build)
+#if defined(IK_PROFILE) && !defined(CHD_HOST_EMU)
+__device__ unsigned long long ik_prof[16];
+#define IK_SEG(k) do { if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) { const long long t_ = (long long)clock64(); atomicAdd(&ik_prof[k], (unsigned long long)(t_ - ik_t0)); ik_t0 = t_; } } while (0)      /* (one workgroup in 64: every workgroup adding to the same twelve words serialises them) */
+#define IK_SEG_BEGIN() long long ik_t0 = (long long)clock64()
+#else
+#define IK_SEG(k) ((void)0)
+#define IK_SEG_BEGIN() ((void)0)
+#endif
 
 namespace chd_ik {
 
@@ -75,10 +84,11 @@ struct IkLds {
   static IK_HD int stride(int T) { return (3 * T) | 1; }
   unsigned short* pair;             // (row, column) offsets of the idx-th entry of a lower triangle, (i << 8) | j: decoded once per step
                                     // instead of a square root per entry per eliminated column (the same table serves every column)
-  static IK_HD int doubles(int J, int T) { return 51 * J + 6 * T + (3 * T + 1) * stride(T) + (3 * J + 5 * T + 1) / 2 + (3 * T * (3 * T + 1) / 2 + 3) / 4; }
+  double* col;                      // 4 x (3T + 2): the two columns being eliminated together, as they stood before the pass (two generations: one barrier per pass)
+  static IK_HD int doubles(int J, int T) { return 51 * J + 6 * T + (3 * T + 1) * stride(T) + 4 * (3 * T + 2) + (3 * J + 5 * T + 1) / 2 + (3 * T * (3 * T + 1) / 2 + 3) / 4; }
   IK_HD void carve(double* b, int J, int T) {
     x = b; b += 6 * J; Rl = b; b += 9 * J; Rg = b; b += 9 * J; pg = b; b += 3 * J; es = b; b += 18 * J; dx = b; b += 6 * J;
-    e = b; b += 3 * T; y = b; b += 3 * T; G = b; gs = stride(T); b += (3 * T + 1) * gs;
+    e = b; b += 3 * T; y = b; b += 3 * T; G = b; gs = stride(T); b += (3 * T + 1) * gs; col = b; b += 4 * (3 * T + 2);
     itab = reinterpret_cast<int*>(b);
     pair = reinterpret_cast<unsigned short*>(b + (3 * J + 5 * T + 1) / 2);
   }
@@ -132,6 +142,7 @@ IK_DEV void ik_step_frame(const IkSeq& s, const int f, const IkParams& P, const 
                           const double* Xin, double* Xout, const IkLds& L) {
   const int J = s.J, T = s.T, F = s.F;
   const int nvar = P.translate ? 6 * J : 3 * J, R = 3 * T, gs = L.gs;
+  IK_SEG_BEGIN();
   const double* xin = Xin + s.o_state + (long long)f * 7 * J;
   IK_FOR(k, 3 * J + 5 * T) L.itab[k] = ipool[s.o_parents + k];      // parents | tj | masks are contiguous in the pool (IkBatch::build)
   const int* parents = L.itab; const int* tj = parents + J;
@@ -143,6 +154,7 @@ IK_DEV void ik_step_frame(const IkSeq& s, const int f, const IkParams& P, const 
     quat_to_mat(xin + 4 * j, L.Rl + 9 * j);
   }
   IK_SYNC();
+  IK_SEG(0);
   // ---- B: global transforms (Animation.transforms_global): every joint walks up its ancestor chain
   IK_FOR(j, J) {
     double Rm[9], p[3];
@@ -158,6 +170,7 @@ IK_DEV void ik_step_frame(const IkSeq& s, const int f, const IkParams& P, const 
     for (int k = 0; k < 3; ++k) L.pg[3 * j + k] = p[k];
   }
   IK_SYNC();
+  IK_SEG(1);
   // ---- C: axes of the unknowns (jacobian(), InverseKinematics.py:414-426, 438-443): parent rotation x partial Euler rotations
   IK_FOR(j, J) {
     const double I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -172,6 +185,7 @@ IK_DEV void ik_step_frame(const IkSeq& s, const int f, const IkParams& P, const 
   // ---- D: residual, stored as row R of G (see F)
   IK_FOR(r, R) { const int t = r / 3, a = r % 3; L.G[R * gs + r] = P.gamma * (dpool[s.o_targets + ((long long)t * F + f) * 3 + a] - L.pg[3 * tj[t] + a]); }
   IK_SYNC();
+  IK_SEG(2);
   // ---- E: G = J J^T + lambda^2 I  (dual form of jf.T.dot(jf) + d, InverseKinematics.py:497-502; w = 1 => l = damping / 1.001).
   //         Jacobian entries (InverseKinematics.py:428-447): rows of target t, column of rotation unknown (j, a):
   //         es[3j+a] x (p_target - p_j) if j is a strict ancestor of the target; column of translation unknown (j, a): es[3J+3j+a]
@@ -212,6 +226,7 @@ IK_DEV void ik_step_frame(const IkSeq& s, const int f, const IkParams& P, const 
       L.G[(3 * t1 + i) * gs + 3 * t2 + k] = g[3 * i + k] + ((t1 == t2 && i == k) ? lam * lam : 0.0);      // only c <= r is read below
   }
   IK_SYNC();
+  IK_SEG(3);
   // ---- F: (G + lambda^2 I) y = e.  G = L D L^T without pivoting or square roots (G is SPD), right-looking with unscaled
   //         columns U[r][k] = L[r][k] d_k so that a column needs ONE workgroup barrier; the residual rides along as row R
   //         (its eliminated entries are U[R][k] = (D^-1 L^-1 e)_k d_k, i.e. the forward substitution comes for free).
@@ -222,18 +237,52 @@ IK_DEV void ik_step_frame(const IkSeq& s, const int f, const IkParams& P, const 
     L.pair[idx] = (unsigned short)((i << 8) | (idx - i * (i + 1) / 2));
   }
   IK_SYNC();
-  for (int k = 0; k < R; ++k) {
-    const double inv = 1.0 / L.G[k * gs + k];
+  IK_SEG(4);
+  // Two columns per pass (round 5): the chain of R dependent column steps (barrier, pivot reciprocal, column reads, update) is what bounds the elimination
+  // (profiles/r05_experiments.md section 9), so a pass eliminates columns k and k + 1 together.  Every thread recomputes, for its entry's row and column, what column
+  // k + 1 looks like after step k (a' = G[r][k+1] - G[r][k] G[k+1][k] / d_k ...) and applies both updates -- the same products subtracted in the same order as column
+  // by column, bit for bit the same factor, with half the barriers.  The two columns are read from a copy taken before the pass; the threads that finish the NEXT two
+  // columns' entries leave their copy for the next pass.
+  const int cw = R + 2;
+  IK_FOR(r, R + 1) { L.col[r] = L.G[r * gs + 0]; if (R > 1) L.col[cw + r] = r >= 1 ? L.G[r * gs + 1] : 0.0; }
+  IK_SYNC();
+  IK_SEG(5);
+  int k = 0;
+  for (; k + 1 < R; k += 2) {
+    const double* c0 = L.col + ((k >> 1) & 1) * 2 * cw; const double* c1 = c0 + cw;      // columns k and k + 1 before this pass
+    double* n0 = L.col + (((k >> 1) + 1) & 1) * 2 * cw; double* n1 = n0 + cw;              // columns k + 2 and k + 3 after it
+    const double inv0 = 1.0 / c0[k];
+    const double m = c0[k + 1];                                    // G[k+1][k]
+    const double inv1 = 1.0 / (c1[k + 1] - m * m * inv0);          // 1 / d_{k+1}
     const int n = R - k;                                          // rows k+1 .. R, columns k+1 .. R-1, lower triangle
     for (int idx = IK_TID; idx < n * (n + 1) / 2 - 1; idx += IK_NT) {      // the last entry would be (R, R): not needed
+      const unsigned pr = L.pair[idx];
+      const int r = k + 1 + (int)(pr >> 8), cc = k + 1 + (int)(pr & 255u);
+      double g = L.G[r * gs + cc] - c0[r] * c0[cc] * inv0;        // step k
+      if (cc > k + 1) {                                           // step k + 1, with column k + 1 as step k left it
+        const double a = c1[r] - c0[r] * m * inv0, b = c1[cc] - c0[cc] * m * inv0;
+        g -= a * b * inv1;
+      }
+      L.G[r * gs + cc] = g;
+      if (cc == k + 2) n0[r] = g; else if (cc == k + 3) n1[r] = g;
+    }
+    IK_SYNC();
+    IK_SEG(6);
+  }
+  for (; k < R; ++k) {                                            // an odd column at the end
+    const double inv = 1.0 / L.G[k * gs + k];
+    const int n = R - k;
+    for (int idx = IK_TID; idx < n * (n + 1) / 2 - 1; idx += IK_NT) {
       const unsigned pr = L.pair[idx];
       const int r = k + 1 + (int)(pr >> 8), cc = k + 1 + (int)(pr & 255u);
       L.G[r * gs + cc] -= L.G[r * gs + k] * L.G[cc * gs + k] * inv;
     }
     IK_SYNC();
+    IK_SEG(7);
   }
   IK_FOR(k, R) { L.e[k] = L.G[R * gs + k]; L.G[k * gs + k] = 1.0 / L.G[k * gs + k]; }      // right-hand side of L^T y = D^-1 (.), and 1 / d_k
   IK_SYNC();
+  IK_SEG(8);
   // back substitution y_k = (U[R][k] - sum_{r > k} U[r][k] y_r) / d_k by one wavefront, scatter form: once y_k is known
   // every lane r < k takes U[k][r] y_k off its own accumulator e[r] (row k of G is contiguous).  Two unknowns per wavefront
   // synchronisation: y_{k-1} only needs y_k on top of what the lanes hold (same operations in the same order as one at a time).
@@ -249,6 +298,7 @@ IK_DEV void ik_step_frame(const IkSeq& s, const int f, const IkParams& P, const 
     }
   }
   IK_SYNC();
+  IK_SEG(9);
   // ---- G: dx = J^T y, one unknown per thread: dx[v] = sum over the targets below joint j of (es[v] x d_t) . y_t = es[v] . (d_t x y_t)
   IK_FOR(v, nvar) {
     const bool rot = v < 3 * J;
@@ -269,6 +319,7 @@ IK_DEV void ik_step_frame(const IkSeq& s, const int f, const IkParams& P, const 
     L.dx[v] = u[0] * acc[0] + u[1] * acc[1] + u[2] * acc[2];
   }
   IK_SYNC();
+  IK_SEG(10);
   // ---- H: smoothness term on the previous iterate of the neighbouring frames (InverseKinematics.py:506-517);
   //         new rotations from the new Euler angles (:540-544)
   double* xout = Xout + s.o_state + (long long)f * 7 * J;
@@ -289,6 +340,7 @@ IK_DEV void ik_step_frame(const IkSeq& s, const int f, const IkParams& P, const 
       xout[4 * J + 3 * j + a] = xn;
     }
   }
+  IK_SEG(11);
 }
 
 }  // namespace chd_ik
