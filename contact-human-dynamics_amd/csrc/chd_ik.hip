@@ -1,10 +1,11 @@
 // chd_ik.hip -- C ABI of the IK back-projection step (include/chd_ik.h) on HIP / gfx950.
-// One launch per solver iteration; one workgroup of 128 (<= 16 targets) or 512 threads per (video, frame); the state (local rotations and
+// One launch per solver iteration; one workgroup of 128 (<= 16 targets) or 256 threads per (video, frame), four to seven of them per compute unit; the state (local rotations and
 // translations of every joint of every frame) is double-buffered in HBM because a frame reads its neighbours' previous
 // iterate.  See chd_ik_kernels.hpp for the per-frame step and its reference citations.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 
 #include "chd_ik_host.hpp"
@@ -23,10 +24,11 @@ int fail(const std::string& what, hipError_t e = hipSuccess) {
 
 __global__ void __launch_bounds__(512) chd_ik_step_kernel(const IkSeq* seqs, const int* frame_seq, const int* frame_idx, IkParams P,
                                                           const int* ipool, const double* dpool, const double* Xin, double* Xout,
-                                                          int max_J, int max_T) {
+                                                          int max_J, int max_T, const unsigned short* pair_tab) {
   extern __shared__ double scratch[];          // IkLds::doubles(max_J, max_T) doubles
   IkLds L;
   L.carve(scratch, max_J, max_T);
+  L.pair = pair_tab;
   const int wg = blockIdx.x;
   ik_step_frame(seqs[frame_seq[wg]], frame_idx[wg], P, ipool, dpool, Xin, Xout, L);
 }
@@ -53,7 +55,7 @@ int chd_ik_solve_batch(const chd_ik_config* cfg, int device, int B, const chd_ik
   const IkParams P = params_of(cfg);
   // a stream of its own per call (stream-ordered allocations, asynchronous copies, one synchronisation at the end): calls from two host
   // threads queue back to back on the device instead of waiting for each other's kernels (see chd_kinopt.hip)
-  IkSeq* d_seqs = nullptr; int *d_fs = nullptr, *d_fi = nullptr, *d_ip = nullptr; double *d_dp = nullptr, *d_x0 = nullptr, *d_x1 = nullptr;
+  IkSeq* d_seqs = nullptr; int *d_fs = nullptr, *d_fi = nullptr, *d_ip = nullptr; double *d_dp = nullptr, *d_x0 = nullptr, *d_x1 = nullptr; unsigned short* d_pair = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t st = nullptr;
   if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
@@ -64,9 +66,9 @@ int chd_ik_solve_batch(const chd_ik_config* cfg, int device, int B, const chd_ik
     return r;
   };
   auto release = [&]() {
-    for (void* p : {(void*)d_seqs, (void*)d_fs, (void*)d_fi, (void*)d_ip, (void*)d_dp, (void*)d_x0, (void*)d_x1}) if (p && pool_ok) (void)hipFreeAsync(p, st);
+    for (void* p : {(void*)d_seqs, (void*)d_fs, (void*)d_fi, (void*)d_ip, (void*)d_dp, (void*)d_x0, (void*)d_x1, (void*)d_pair}) if (p && pool_ok) (void)hipFreeAsync(p, st);
     (void)hipStreamSynchronize(st);
-    if (!pool_ok) for (void* p : {(void*)d_seqs, (void*)d_fs, (void*)d_fi, (void*)d_ip, (void*)d_dp, (void*)d_x0, (void*)d_x1}) if (p) (void)hipFree(p);
+    if (!pool_ok) for (void* p : {(void*)d_seqs, (void*)d_fs, (void*)d_fi, (void*)d_ip, (void*)d_dp, (void*)d_x0, (void*)d_x1, (void*)d_pair}) if (p) (void)hipFree(p);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     (void)hipStreamDestroy(st);
@@ -86,19 +88,24 @@ int chd_ik_solve_batch(const chd_ik_config* cfg, int device, int B, const chd_ik
   IK_TRY(hipMemcpyAsync(d_ip, bt.ipool.data(), sizeof(int) * bt.ipool.size(), hipMemcpyHostToDevice, st), "copy ints");
   IK_TRY(hipMemcpyAsync(d_dp, bt.dpool.data(), sizeof(double) * bt.dpool.size(), hipMemcpyHostToDevice, st), "copy targets");
   IK_TRY(hipMemcpyAsync(d_x0, bt.state.data(), sizeof(double) * nst, hipMemcpyHostToDevice, st), "copy state");
-  const size_t lds = sizeof(double) * (size_t)IkLds::doubles(bt.max_J, bt.max_T);      // 28 KB for J = 33, T = 13; 66 KB for the kinematic optimisation (J = 28, T = 25); 85 KB at the size limits
+  std::vector<unsigned short> pairs((size_t)IkLds::pair_entries());      // the elimination's (row, column) table: one for every size
+  IkLds::fill_pairs(pairs.data());
+  IK_TRY(dmalloc((void**)&d_pair, sizeof(unsigned short) * pairs.size()), "hipMalloc pair table");
+  IK_TRY(hipMemcpyAsync(d_pair, pairs.data(), sizeof(unsigned short) * pairs.size(), hipMemcpyHostToDevice, st), "copy pair table");
+  const size_t lds = sizeof(double) * (size_t)IkLds::doubles(bt.max_J, bt.max_T);      // 21 KB for J = 33, T = 13; 39 KB for the kinematic optimisation (J = 28, T = 25): four frames per compute unit
   if (lds > 48 * 1024) IK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(chd_ik_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
   IK_TRY(hipEventCreate(&ev0), "hipEventCreate");
   IK_TRY(hipEventCreate(&ev1), "hipEventCreate");
-  // the 3T x 3T elimination dominates a step: 128 threads for the back-projection's 13 targets (39 x 39), 512 for the 25 targets
-  // (75 x 75) of the kinematic optimisation's initialisation -- measured 1 819 / 1 154 / 934 ms for 256 clips x 100 frames x 200
-  // iterations at 128 / 256 / 512 threads, no difference at 13 targets (profiles/r02k_final/ik_threads.md)
-  const unsigned nthreads = bt.max_T > 16 ? 512u : 128u;
+  // A step is a sequence of short dependent chains (the 3T x 3T elimination 57 % of it: profiles/r05_experiments.md section 9): frames in flight per compute unit are what
+  // counts.  128 threads for the back-projection's 13 targets (39 x 39); for the 25 targets (75 x 75) of the kinematic optimisation's initialisation CHD_IK_THREADS (default 256:
+  // with the packed matrix four workgroups of 256 fit a compute unit's LDS and registers, of 512 only two)
+  unsigned nthreads = bt.max_T > 16 ? 256u : 128u;
+  if (const char* e_ = getenv("CHD_IK_THREADS")) { const int v = atoi(e_); if (v == 128 || v == 256 || v == 512) nthreads = (unsigned)v; }
   double* cur = d_x0; double* nxt = d_x1;
   IK_TRY(hipEventRecord(ev0, st), "hipEventRecord");
   (void)hipGetLastError();      // an error another library of the process left behind in this thread (hipBLASLt's kernel look-ups do) is not this launch's
   for (int it = 0; it < P.iterations; ++it) {
-    hipLaunchKernelGGL(chd_ik_step_kernel, dim3((unsigned)nwg), dim3(nthreads), lds, st, d_seqs, d_fs, d_fi, P, d_ip, d_dp, cur, nxt, bt.max_J, bt.max_T);
+    hipLaunchKernelGGL(chd_ik_step_kernel, dim3((unsigned)nwg), dim3(nthreads), lds, st, d_seqs, d_fs, d_fi, P, d_ip, d_dp, cur, nxt, bt.max_J, bt.max_T, (const unsigned short*)d_pair);
     IK_TRY(hipGetLastError(), "launch");
     double* t = cur; cur = nxt; nxt = t;
   }

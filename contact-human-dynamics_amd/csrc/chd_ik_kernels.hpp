@@ -12,7 +12,7 @@
 //    in LDS, so J J^T is accumulated per pair of targets over their common ancestors and J^T y per unknown.
 // A frame only needs its neighbours' previous iterate (smoothness term), so every iteration is one launch over all frames
 // of all videos with the state double-buffered in HBM.  Per frame the kernel touches 3 x 7J doubles of state in, 7J out
-// and 3T target coordinates; everything else lives in LDS (51 J + 6 T + 9 T^2 doubles + index tables: 27 KB for J = 33, T = 13).
+// and 3T target coordinates; everything else lives in LDS (51 J + 6 T + (3T + 1)(3T + 2) / 2 doubles + index tables: 21 KB for J = 33, T = 13; 39 KB for J = 28, T = 25).
 #pragma once
 #include <cmath>
 
@@ -77,20 +77,25 @@ struct IkLds {
   double* es;                       // 18J: axes of the 3J rotation unknowns, then of the 3J translation unknowns
   double* dx;                       // 6J: J^T y
   double *e, *y;                    // 3T each
-  double* G;                        // 3T + 1 rows of stride gs (odd number of doubles: conflict-free column access); row 3T: residual
-  int gs;
+  double* G;                        // the lower triangle of the (3T + 1) x (3T + 1) matrix, row by row (entry (r, c), c <= r, at r (r + 1) / 2 + c); row 3T: residual.
+                                    // Packed since round 5: half the LDS of the square it was, so that four frames instead of two fit a compute unit -- every phase of a
+                                    // step is a short dependent chain (profiles/r05_experiments.md section 9), more frames in flight is what raises the throughput
   int* itab;                        // the sequence's index tables (3J + 5T ints: parents | target joints | masks, as in the pool),
                                     // staged once per step: the chain walks and mask tests would otherwise be dependent L2 round trips
-  static IK_HD int stride(int T) { return (3 * T) | 1; }
-  unsigned short* pair;             // (row, column) offsets of the idx-th entry of a lower triangle, (i << 8) | j: decoded once per step
-                                    // instead of a square root per entry per eliminated column (the same table serves every column)
+  const unsigned short* pair;       // (row, column) offsets of the idx-th entry of a lower triangle, (i << 8) | j: one table for every size and column, built by the host
+                                    // (device memory, 6 KB: it stays in the compute unit's cache; it used to be rebuilt in LDS every step)
   double* col;                      // 4 x (3T + 2): the two columns being eliminated together, as they stood before the pass (two generations: one barrier per pass)
-  static IK_HD int doubles(int J, int T) { return 51 * J + 6 * T + (3 * T + 1) * stride(T) + 4 * (3 * T + 2) + (3 * J + 5 * T + 1) / 2 + (3 * T * (3 * T + 1) / 2 + 3) / 4; }
+  static IK_HD int tri(int r) { return r * (r + 1) / 2; }
+  static IK_HD int doubles(int J, int T) { return 51 * J + 6 * T + tri(3 * T + 1) + 4 * (3 * T + 2) + (3 * J + 5 * T + 1) / 2; }
+  static IK_HD int pair_entries() { return MAXR * (MAXR + 1) / 2; }
+  static inline void fill_pairs(unsigned short* t) {      // host: idx -> (i, j) of the triangle enumerated row by row
+    int idx = 0;
+    for (int i = 0; i < MAXR; ++i) for (int j = 0; j <= i; ++j) t[idx++] = (unsigned short)((i << 8) | j);
+  }
   IK_HD void carve(double* b, int J, int T) {
     x = b; b += 6 * J; Rl = b; b += 9 * J; Rg = b; b += 9 * J; pg = b; b += 3 * J; es = b; b += 18 * J; dx = b; b += 6 * J;
-    e = b; b += 3 * T; y = b; b += 3 * T; G = b; gs = stride(T); b += (3 * T + 1) * gs; col = b; b += 4 * (3 * T + 2);
+    e = b; b += 3 * T; y = b; b += 3 * T; G = b; b += tri(3 * T + 1); col = b; b += 4 * (3 * T + 2);
     itab = reinterpret_cast<int*>(b);
-    pair = reinterpret_cast<unsigned short*>(b + (3 * J + 5 * T + 1) / 2);
   }
 };
 
@@ -141,7 +146,7 @@ IK_DEV void cross3(const double* u, const double* v, double* o) {
 IK_DEV void ik_step_frame(const IkSeq& s, const int f, const IkParams& P, const int* ipool, const double* dpool,
                           const double* Xin, double* Xout, const IkLds& L) {
   const int J = s.J, T = s.T, F = s.F;
-  const int nvar = P.translate ? 6 * J : 3 * J, R = 3 * T, gs = L.gs;
+  const int nvar = P.translate ? 6 * J : 3 * J, R = 3 * T;
   IK_SEG_BEGIN();
   const double* xin = Xin + s.o_state + (long long)f * 7 * J;
   IK_FOR(k, 3 * J + 5 * T) L.itab[k] = ipool[s.o_parents + k];      // parents | tj | masks are contiguous in the pool (IkBatch::build)
@@ -183,7 +188,7 @@ IK_DEV void ik_step_frame(const IkSeq& s, const int f, const IkParams& P, const 
     for (int a = 0; a < 3; ++a) for (int k = 0; k < 3; ++k) L.es[9 * J + 9 * j + 3 * a + k] = Pr[3 * k + a];      // Pr e_a
   }
   // ---- D: residual, stored as row R of G (see F)
-  IK_FOR(r, R) { const int t = r / 3, a = r % 3; L.G[R * gs + r] = P.gamma * (dpool[s.o_targets + ((long long)t * F + f) * 3 + a] - L.pg[3 * tj[t] + a]); }
+  IK_FOR(r, R) { const int t = r / 3, a = r % 3; L.G[IkLds::tri(R) + r] = P.gamma * (dpool[s.o_targets + ((long long)t * F + f) * 3 + a] - L.pg[3 * tj[t] + a]); }
   IK_SYNC();
   IK_SEG(2);
   // ---- E: G = J J^T + lambda^2 I  (dual form of jf.T.dot(jf) + d, InverseKinematics.py:497-502; w = 1 => l = damping / 1.001).
@@ -223,28 +228,20 @@ IK_DEV void ik_step_frame(const IkSeq& s, const int f, const IkParams& P, const 
         }
     }
     for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k)
-      L.G[(3 * t1 + i) * gs + 3 * t2 + k] = g[3 * i + k] + ((t1 == t2 && i == k) ? lam * lam : 0.0);      // only c <= r is read below
+      if (3 * t2 + k <= 3 * t1 + i) L.G[IkLds::tri(3 * t1 + i) + 3 * t2 + k] = g[3 * i + k] + ((t1 == t2 && i == k) ? lam * lam : 0.0);      // (lower triangle only)
   }
   IK_SYNC();
   IK_SEG(3);
   // ---- F: (G + lambda^2 I) y = e.  G = L D L^T without pivoting or square roots (G is SPD), right-looking with unscaled
   //         columns U[r][k] = L[r][k] d_k so that a column needs ONE workgroup barrier; the residual rides along as row R
   //         (its eliminated entries are U[R][k] = (D^-1 L^-1 e)_k d_k, i.e. the forward substitution comes for free).
-  IK_FOR(idx, R * (R + 1) / 2) {
-    int i = (int)((std::sqrt(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
-    while (i * (i + 1) / 2 > idx) --i;
-    while ((i + 1) * (i + 2) / 2 <= idx) ++i;
-    L.pair[idx] = (unsigned short)((i << 8) | (idx - i * (i + 1) / 2));
-  }
-  IK_SYNC();
-  IK_SEG(4);
   // Two columns per pass (round 5): the chain of R dependent column steps (barrier, pivot reciprocal, column reads, update) is what bounds the elimination
   // (profiles/r05_experiments.md section 9), so a pass eliminates columns k and k + 1 together.  Every thread recomputes, for its entry's row and column, what column
   // k + 1 looks like after step k (a' = G[r][k+1] - G[r][k] G[k+1][k] / d_k ...) and applies both updates -- the same products subtracted in the same order as column
   // by column, bit for bit the same factor, with half the barriers.  The two columns are read from a copy taken before the pass; the threads that finish the NEXT two
   // columns' entries leave their copy for the next pass.
   const int cw = R + 2;
-  IK_FOR(r, R + 1) { L.col[r] = L.G[r * gs + 0]; if (R > 1) L.col[cw + r] = r >= 1 ? L.G[r * gs + 1] : 0.0; }
+  IK_FOR(r, R + 1) { L.col[r] = L.G[IkLds::tri(r)]; if (R > 1) L.col[cw + r] = r >= 1 ? L.G[IkLds::tri(r) + 1] : 0.0; }
   IK_SYNC();
   IK_SEG(5);
   int k = 0;
@@ -258,29 +255,29 @@ IK_DEV void ik_step_frame(const IkSeq& s, const int f, const IkParams& P, const 
     for (int idx = IK_TID; idx < n * (n + 1) / 2 - 1; idx += IK_NT) {      // the last entry would be (R, R): not needed
       const unsigned pr = L.pair[idx];
       const int r = k + 1 + (int)(pr >> 8), cc = k + 1 + (int)(pr & 255u);
-      double g = L.G[r * gs + cc] - c0[r] * c0[cc] * inv0;        // step k
+      double g = L.G[IkLds::tri(r) + cc] - c0[r] * c0[cc] * inv0;        // step k
       if (cc > k + 1) {                                           // step k + 1, with column k + 1 as step k left it
         const double a = c1[r] - c0[r] * m * inv0, b = c1[cc] - c0[cc] * m * inv0;
         g -= a * b * inv1;
       }
-      L.G[r * gs + cc] = g;
+      L.G[IkLds::tri(r) + cc] = g;
       if (cc == k + 2) n0[r] = g; else if (cc == k + 3) n1[r] = g;
     }
     IK_SYNC();
     IK_SEG(6);
   }
   for (; k < R; ++k) {                                            // an odd column at the end
-    const double inv = 1.0 / L.G[k * gs + k];
+    const double inv = 1.0 / L.G[IkLds::tri(k) + k];
     const int n = R - k;
     for (int idx = IK_TID; idx < n * (n + 1) / 2 - 1; idx += IK_NT) {
       const unsigned pr = L.pair[idx];
       const int r = k + 1 + (int)(pr >> 8), cc = k + 1 + (int)(pr & 255u);
-      L.G[r * gs + cc] -= L.G[r * gs + k] * L.G[cc * gs + k] * inv;
+      L.G[IkLds::tri(r) + cc] -= L.G[IkLds::tri(r) + k] * L.G[IkLds::tri(cc) + k] * inv;
     }
     IK_SYNC();
     IK_SEG(7);
   }
-  IK_FOR(k, R) { L.e[k] = L.G[R * gs + k]; L.G[k * gs + k] = 1.0 / L.G[k * gs + k]; }      // right-hand side of L^T y = D^-1 (.), and 1 / d_k
+  IK_FOR(k, R) { L.e[k] = L.G[IkLds::tri(R) + k]; L.G[IkLds::tri(k) + k] = 1.0 / L.G[IkLds::tri(k) + k]; }      // right-hand side of L^T y = D^-1 (.), and 1 / d_k
   IK_SYNC();
   IK_SEG(8);
   // back substitution y_k = (U[R][k] - sum_{r > k} U[r][k] y_r) / d_k by one wavefront, scatter form: once y_k is known
@@ -288,11 +285,11 @@ IK_DEV void ik_step_frame(const IkSeq& s, const int f, const IkParams& P, const 
   // synchronisation: y_{k-1} only needs y_k on top of what the lanes hold (same operations in the same order as one at a time).
   if (IK_WAVE0) {
     for (int k = R - 1; k >= 0; k -= 2) {
-      const double yk = L.e[k] * L.G[k * gs + k];
+      const double yk = L.e[k] * L.G[IkLds::tri(k) + k];
       const bool two = k >= 1;
-      const double yk1 = two ? (L.e[k - 1] - L.G[k * gs + k - 1] * yk) * L.G[(k - 1) * gs + k - 1] : 0.0;
+      const double yk1 = two ? (L.e[k - 1] - L.G[IkLds::tri(k) + k - 1] * yk) * L.G[IkLds::tri(k - 1) + k - 1] : 0.0;
       const int lim = two ? k - 1 : 0;
-      for (int r = IK_WLANE; r < lim; r += IK_WSTEP) L.e[r] = (L.e[r] - L.G[k * gs + r] * yk) - L.G[(k - 1) * gs + r] * yk1;
+      for (int r = IK_WLANE; r < lim; r += IK_WSTEP) L.e[r] = (L.e[r] - L.G[IkLds::tri(k) + r] * yk) - L.G[IkLds::tri(k - 1) + r] * yk1;
       if (IK_WLANE == 0) { L.y[k] = yk; if (two) L.y[k - 1] = yk1; }
       IK_WSYNC();
     }

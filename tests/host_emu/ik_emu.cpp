@@ -17,8 +17,11 @@ int ik_emu_solve_batch(const chd_ik_config* cfg, int B, const chd_ik_seq* in) {
   if (!bt.build(B, in)) { g_err = bt.err; return 1; }
   const IkParams P = params_of(cfg);
   std::vector<double> x0 = bt.state, x1 = bt.state, scratch((size_t)IkLds::doubles(bt.max_J, bt.max_T));
+  std::vector<unsigned short> pairs((size_t)IkLds::pair_entries());
+  IkLds::fill_pairs(pairs.data());
   IkLds L;
   L.carve(scratch.data(), bt.max_J, bt.max_T);
+  L.pair = pairs.data();
   double* cur = x0.data(); double* nxt = x1.data();
   for (int it = 0; it < P.iterations; ++it) {
     for (size_t wg = 0; wg < bt.frame_seq.size(); ++wg)
