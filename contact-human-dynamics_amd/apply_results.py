@@ -171,15 +171,24 @@ def finish(task: BackProjectionTask, out_bvh: str) -> None:
     sk.save_bvh(out_bvh, remove_heels(task.motion) if task.heels_added else task.motion, task.names)
 
 
-def apply_results_batch(solution_files, anim_bvhs, out_bvhs, characters, solver, starts=None, ends=None):
-    """`--viz --out-bvh` of towr_utils.py (:951-975) for a list of videos: parse, prepare, ONE batched solver call, write."""
+def apply_results_batch(solution_files, anim_bvhs, out_bvhs, characters, solver, starts=None, ends=None, animations=None):
+    """`--viz --out-bvh` of towr_utils.py (:951-975) for a list of videos: parse, prepare, ONE batched solver call, write.
+    `animations`: a dict path -> (Motion, names, frame time) that is filled with the parsed input animations and consulted first -- the driver back-projects three
+    solution kinds onto the SAME animations; the files that are missing from it are read in one call of the native reader (prepare_capi.load_bvh_batch: all files on
+    the host's cores) instead of one Python parse per video and kind (0.3 of the 0.5 s this stage took for 32 videos)."""
     n = len(solution_files)
     starts = starts or [None] * n
     ends = ends or [None] * n
     chars = characters if isinstance(characters, (list, tuple)) else [characters] * n
+    cache = animations if animations is not None else {}
+    missing = sorted({p for p in anim_bvhs if p not in cache})
+    if missing:
+        from . import prepare_capi
+        for p, parsed in zip(missing, prepare_capi.load_bvh_batch(missing)):
+            cache[p] = parsed
     tasks = []
     for k in range(n):
-        motion, names, _ = sk.load_bvh(anim_bvhs[k])
+        motion, names, _ = cache[anim_bvhs[k]]
         tasks.append(prepare(load_towr_results(solution_files[k], flip_coords=True), motion, names, starts[k], ends[k], chars[k]))
     back_project(tasks, solver)
     for k in range(n):

@@ -158,6 +158,7 @@ def main(argv=None):
         from . import apply_results as ar
         from .ik_backproject import IkBackProject
         ik = IkBackProject(device=local)
+        parsed = {}                                                          # the input animations, read once for the three kinds
         for kind in ('no_dynamics', 'dynamics', 'durations'):               # run_phys_mocap.py:183-186
             part = [jobs[i] for i in mine if os.path.exists(os.path.join(jobs[i][1], 'sol_out_%s.txt' % kind))]
             if not part:
@@ -166,7 +167,7 @@ def main(argv=None):
             ar.apply_results_batch([os.path.join(p[1], 'sol_out_%s.txt' % kind) for p in part],
                                    [os.path.join(vd, 'kinematic_results', a.character + '_out.bvh') for vd in vdirs],
                                    [os.path.join(p[1], '%s_%s_%s.bvh' % (os.path.basename(vd), a.character, kind)) for p, vd in zip(part, vdirs)],
-                                   character, ik, starts=[0] * len(part), ends=[p[2] for p in part])
+                                   character, ik, starts=[0] * len(part), ends=[p[2] for p in part], animations=parsed)
     LAST_TIMINGS['back_projection'] = _time.perf_counter() - _t
     print('[run_phys_mocap] rank %d/%d: %d sequences, %d failed (unreadable inputs, rejected at set-up or unwritable outputs: each loses only itself)' % (rank, world, len(mine), bad))
     return 0 if bad == 0 else 1
