@@ -45,8 +45,9 @@ def run_clips(clips: Sequence[Clip], character: ar.Character, phys, ik, dt=1.0 /
     loaded = []
     seqs = []
     pending = []
-    for c in clips:
-        motion, names, _ = sk.load_bvh(c.bvh)
+    from . import prepare_capi
+    parsed = prepare_capi.load_bvh_batch([c.bvh for c in clips])      # native reader: all files of the batch on the host's cores
+    for c, (motion, names, _) in zip(clips, parsed):
         floor = pi.read_floor(c.floor) if isinstance(c.floor, str) else c.floor
         contacts = np.load(c.contacts) if isinstance(c.contacts, str) else np.asarray(c.contacts)
         start = 0 if c.start is None else c.start
