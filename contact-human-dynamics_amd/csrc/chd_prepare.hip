@@ -4,6 +4,7 @@
 //                       centre of mass, hip offsets, inertia, toe / heel trajectories).  A frame reads (7 J) doubles and writes 28: HBM bound, 1.8 KB per frame at
 //                       31 joints; the chain products run out of the thread's private arrays.  No CPU path: without a HIP device the call fails.
 //   chd_bvh_load_batch  native BVH reader on the host's cores (chd_bvh.hpp).
+//   chd_openpose_load_dirs / chd_totalcap_load_batch  the JSON inputs in front of the kinematic optimisation and the contact network (chd_json.hpp), all videos of a run on the host's cores.
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -15,7 +16,12 @@
 #include <thread>
 #include <vector>
 
+#include <dirent.h>
+
+#include <algorithm>
+
 #include "chd_bvh.hpp"
+#include "chd_json.hpp"
 #include "chd_prepare_kernels.hpp"
 
 static thread_local std::string g_err;
@@ -142,6 +148,139 @@ void chd_bvh_free(int n, chd_bvh_clip* clips) {
   for (int i = 0; i < n; ++i) {
     free(clips[i].names); free(clips[i].parents); free(clips[i].offsets); free(clips[i].positions); free(clips[i].rotations); free(clips[i].error);
     memset(&clips[i], 0, sizeof(chd_bvh_clip));
+  }
+}
+
+}  // extern "C"
+
+// ---- JSON ingest (host) ------------------------------------------------------------------------------------------------------------------------------------------
+namespace {
+bool read_file(const std::string& path, std::string& text) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  char buf[1 << 16];
+  size_t n;
+  text.clear();
+  while ((n = fread(buf, 1, sizeof(buf), f)) > 0) text.append(buf, n);
+  const bool ok = !ferror(f);
+  fclose(f);
+  return ok;
+}
+double* dup_doubles(const std::vector<double>& v) { double* p = (double*)malloc(8 * (v.size() + 1)); if (p && !v.empty()) memcpy(p, v.data(), 8 * v.size()); return p; }
+
+// contact_net.load_keypoint_dir (openpose_utils.py:48-76)
+std::string load_openpose_dir(const std::string& dir, int num_joints, int& n_frames, std::vector<double>& data) {
+  DIR* d = opendir(dir.c_str());
+  if (!d) return dir + ": cannot open the directory";
+  std::vector<std::string> files;
+  while (dirent* en = readdir(d)) {
+    const std::string name = en->d_name;
+    if (name == "." || name == "..") continue;
+    const size_t dot = name.rfind('.');
+    if ((dot == std::string::npos ? name : name.substr(dot + 1)) == "json") files.push_back(name);      // f.split('.')[-1] == 'json'
+  }
+  closedir(d);
+  std::sort(files.begin(), files.end());
+  if (files.empty()) return dir + ": no .json result files";
+  for (const std::string& name : files) {
+    const std::string path = dir + "/" + name;
+    std::string text;
+    if (!read_file(path, text)) return path + ": cannot open";
+    chd_json::Value root;
+    const std::string err = chd_json::parse(text, root);
+    if (!err.empty()) return path + ": " + err;
+    const chd_json::Value* people = root.get("people");
+    if (!people || people->kind != chd_json::Value::Array) return path + ": no \"people\" array";
+    if (people->size() == 0) { data.insert(data.end(), (size_t)num_joints * 3, 0.0); continue; }
+    if (people->all_numbers) return path + ": people[0] is not an object";
+    if (!chd_json::numbers(people->items[0].get("pose_keypoints_2d"), data, (size_t)num_joints * 3))
+      return path + ": people[0].pose_keypoints_2d is not an array of " + std::to_string(num_joints * 3) + " numbers";
+  }
+  n_frames = (int)files.size();
+  return "";
+}
+
+// totalcap_io.load_totalcap_results (totalcap_utils.py:33-79)
+std::string load_totalcap(const std::string& path, chd_totalcap_clip& o) {
+  std::string text;
+  if (!read_file(path, text)) return path + ": cannot open";
+  chd_json::Value root;
+  const std::string err = chd_json::parse(text, root);
+  if (!err.empty()) return path + ": " + err;
+  const chd_json::Value* frames = root.get("totalcapResults");
+  if (!frames || frames->kind != chd_json::Value::Array) return path + ": no \"totalcapResults\" array";
+  std::vector<double> trans, j3, s3, sr, bc, fc;
+  int nj = -1, ns = -1, nb = -1, nf = -1;
+  if (frames->all_numbers) return path + ": \"totalcapResults\" is not an array of frames";
+  for (size_t k = 0; k < frames->items.size(); ++k) {
+    const chd_json::Value& fr = frames->items[k];
+    const std::string at = path + ": frame " + std::to_string(k) + ": ";
+    if (!chd_json::xyz(fr.get("trans"), trans)) return at + "\"trans\" is not {x, y, z}";
+    const chd_json::Value *joints = fr.get("joints"), *smpl = fr.get("SMPLJoints");
+    if (!joints || joints->kind != chd_json::Value::Array || joints->all_numbers || !smpl || smpl->kind != chd_json::Value::Array || smpl->all_numbers) return at + "\"joints\" / \"SMPLJoints\" missing";
+    if (nj < 0) { nj = (int)joints->items.size(); ns = (int)smpl->items.size(); }
+    if ((int)joints->items.size() != nj || (int)smpl->items.size() != ns) return at + "another number of joints than frame 0";
+    for (const chd_json::Value& j : joints->items) if (!chd_json::xyz(j.get("pos"), j3)) return at + "a joint without \"pos\": {x, y, z}";
+    for (const chd_json::Value& j : smpl->items) if (!chd_json::xyz(j.get("pos"), s3) || !chd_json::xyz(j.get("rot"), sr)) return at + "an SMPL joint without \"pos\" / \"rot\": {x, y, z}";
+    const size_t b0 = bc.size(), f0 = fc.size();
+    if (!chd_json::numbers(fr.get("bodyCoeffs"), bc) || !chd_json::numbers(fr.get("faceCoeffs"), fc)) return at + "\"bodyCoeffs\" / \"faceCoeffs\" are not arrays of numbers";
+    if (nb < 0) { nb = (int)(bc.size() - b0); nf = (int)(fc.size() - f0); }
+    if ((int)(bc.size() - b0) != nb || (int)(fc.size() - f0) != nf) return at + "another number of coefficients than frame 0";
+  }
+  o.n_frames = (int)frames->items.size(); o.n_joints = nj < 0 ? 0 : nj; o.n_smpl_joints = ns < 0 ? 0 : ns; o.n_body_coeffs = nb < 0 ? 0 : nb; o.n_face_coeffs = nf < 0 ? 0 : nf;
+  o.root_trans = dup_doubles(trans); o.joint3d = dup_doubles(j3); o.smpl_joint3d = dup_doubles(s3); o.smpl_joint_angles = dup_doubles(sr);
+  o.body_coeffs = dup_doubles(bc); o.face_coeffs = dup_doubles(fc);
+  return "";
+}
+
+template <class Body> int run_on_threads(int n, int n_threads, Body body) {
+  unsigned nt = n_threads > 0 ? (unsigned)n_threads : std::thread::hardware_concurrency();
+  if (nt == 0) nt = 4;
+  if (nt > 64) nt = 64;
+  if ((int)nt > n) nt = (unsigned)(n > 0 ? n : 1);
+  std::atomic<int> next{0}, failed{0};
+  auto loop = [&]() { for (;;) { const int i = next.fetch_add(1); if (i >= n) return; if (!body(i)) failed.fetch_add(1); } };
+  std::vector<std::thread> pool;
+  for (unsigned t = 1; t < nt; ++t) pool.emplace_back(loop);
+  loop();
+  for (auto& th : pool) th.join();
+  return failed.load();
+}
+}  // namespace
+
+extern "C" {
+
+int chd_openpose_load_dirs(int n, const char* const* dirs, int num_joints, int n_threads, chd_keypoint_clip* out) {
+  if (n < 0 || num_joints < 1 || (n > 0 && (!dirs || !out))) return -1;
+  for (int i = 0; i < n; ++i) memset(&out[i], 0, sizeof(chd_keypoint_clip));
+  return run_on_threads(n, n_threads, [&](int i) {
+    std::string err; std::vector<double> data; int nf = 0;
+    try { err = load_openpose_dir(dirs[i], num_joints, nf, data); } catch (const std::exception& e) { err = std::string(dirs[i]) + ": " + e.what(); }
+    if (!err.empty()) { out[i].error = dup_str(err); return false; }
+    out[i].n_frames = nf; out[i].data = dup_doubles(data);
+    return true;
+  });
+}
+void chd_openpose_free(int n, chd_keypoint_clip* clips) {
+  if (!clips) return;
+  for (int i = 0; i < n; ++i) { free(clips[i].data); free(clips[i].error); memset(&clips[i], 0, sizeof(chd_keypoint_clip)); }
+}
+
+int chd_totalcap_load_batch(int n, const char* const* paths, int n_threads, chd_totalcap_clip* out) {
+  if (n < 0 || (n > 0 && (!paths || !out))) return -1;
+  for (int i = 0; i < n; ++i) memset(&out[i], 0, sizeof(chd_totalcap_clip));
+  return run_on_threads(n, n_threads, [&](int i) {
+    std::string err;
+    try { err = load_totalcap(paths[i], out[i]); } catch (const std::exception& e) { err = std::string(paths[i]) + ": " + e.what(); }
+    if (!err.empty()) { out[i].error = dup_str(err); return false; }
+    return true;
+  });
+}
+void chd_totalcap_free(int n, chd_totalcap_clip* clips) {
+  if (!clips) return;
+  for (int i = 0; i < n; ++i) {
+    free(clips[i].root_trans); free(clips[i].joint3d); free(clips[i].smpl_joint3d); free(clips[i].smpl_joint_angles); free(clips[i].body_coeffs); free(clips[i].face_coeffs); free(clips[i].error);
+    memset(&clips[i], 0, sizeof(chd_totalcap_clip));
   }
 }
 

@@ -11,9 +11,10 @@ from . import skeleton_io as sk
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_CSRC, 'libchd_prepare.so')
-SOURCES = ['chd_prepare.hip', 'chd_prepare_kernels.hpp', 'chd_bvh.hpp']
-EXPORTS = ['chd_prep_version', 'chd_prep_frames', 'chd_prep_last_kernel_ms', 'chd_prep_last_error', 'chd_bvh_load_batch', 'chd_bvh_free']
-ABI_VERSION = 1
+SOURCES = ['chd_prepare.hip', 'chd_prepare_kernels.hpp', 'chd_bvh.hpp', 'chd_json.hpp']
+EXPORTS = ['chd_prep_version', 'chd_prep_frames', 'chd_prep_last_kernel_ms', 'chd_prep_last_error', 'chd_bvh_load_batch', 'chd_bvh_free',
+           'chd_openpose_load_dirs', 'chd_openpose_free', 'chd_totalcap_load_batch', 'chd_totalcap_free']
+ABI_VERSION = 2
 MAX_JOINTS, MAX_SEGMENTS, MAX_SEGMENT_JOINTS, OUT_STRIDE = 64, 32, 256, 28
 PD = C.POINTER(C.c_double)
 
@@ -58,6 +59,10 @@ def load_library():
         L.chd_prep_last_kernel_ms.restype = C.c_double
         L.chd_bvh_load_batch.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_int, C.POINTER(ChdBvhClip)]
         L.chd_bvh_free.argtypes = [C.c_int, C.POINTER(ChdBvhClip)]
+        L.chd_openpose_load_dirs.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.POINTER(ChdKeypointClip)]
+        L.chd_openpose_free.argtypes = [C.c_int, C.POINTER(ChdKeypointClip)]
+        L.chd_totalcap_load_batch.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_int, C.POINTER(ChdTotalcapClip)]
+        L.chd_totalcap_free.argtypes = [C.c_int, C.POINTER(ChdTotalcapClip)]
         _LIB = L
     return _LIB
 
@@ -105,6 +110,65 @@ def prep_frames(skel, rot, pos, device=0):
 
 def last_kernel_ms():
     return float(load_library().chd_prep_last_kernel_ms())
+
+
+class ChdKeypointClip(C.Structure):
+    _fields_ = [('n_frames', C.c_int), ('data', PD), ('error', C.c_void_p)]
+
+
+class ChdTotalcapClip(C.Structure):
+    _fields_ = [('n_frames', C.c_int), ('n_joints', C.c_int), ('n_smpl_joints', C.c_int), ('n_body_coeffs', C.c_int), ('n_face_coeffs', C.c_int),
+                ('root_trans', PD), ('joint3d', PD), ('smpl_joint3d', PD), ('smpl_joint_angles', PD), ('body_coeffs', PD), ('face_coeffs', PD), ('error', C.c_void_p)]
+
+
+def _arr(ptr, shape):
+    n = int(np.prod(shape))
+    return np.ctypeslib.as_array(ptr, shape=(max(n, 1),))[:n].reshape(shape).copy()
+
+
+def load_keypoint_dirs(dirs, num_joints=25, n_threads=0):
+    """`contact_net.load_keypoint_dir` for a list of OpenPose result directories, read natively on the host's cores -> [F x num_joints x 3].  A directory with a file that
+    is not what OpenPose writes raises ValueError naming the file."""
+    L = load_library()
+    n = len(dirs)
+    arr = (C.c_char_p * n)(*[os.fsencode(p) for p in dirs])
+    clips = (ChdKeypointClip * n)()
+    rc = L.chd_openpose_load_dirs(n, arr, int(num_joints), int(n_threads), clips)
+    try:
+        if rc < 0:
+            raise ValueError('chd_openpose_load_dirs: bad arguments')
+        out = []
+        for c in clips:
+            if c.error:
+                raise ValueError(C.string_at(c.error).decode())
+            out.append(_arr(c.data, (c.n_frames, num_joints, 3)))
+        return out
+    finally:
+        L.chd_openpose_free(n, clips)
+
+
+def load_totalcap_batch(paths, n_threads=0):
+    """`totalcap_io.load_totalcap_results` for a list of tracked_results.json files, read natively on the host's cores -> [TotalCapResults]."""
+    from .totalcap_io import TotalCapResults
+    L = load_library()
+    n = len(paths)
+    arr = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
+    clips = (ChdTotalcapClip * n)()
+    rc = L.chd_totalcap_load_batch(n, arr, int(n_threads), clips)
+    try:
+        if rc < 0:
+            raise ValueError('chd_totalcap_load_batch: bad arguments')
+        out = []
+        for c in clips:
+            if c.error:
+                raise ValueError(C.string_at(c.error).decode())
+            F = c.n_frames
+            out.append(TotalCapResults(root_trans=_arr(c.root_trans, (F, 3)), joint3d=_arr(c.joint3d, (F, c.n_joints, 3)), smpl_joint3d=_arr(c.smpl_joint3d, (F, c.n_smpl_joints, 3)),
+                                       smpl_joint_angles=_arr(c.smpl_joint_angles, (F, c.n_smpl_joints, 3)), body_coeffs=_arr(c.body_coeffs, (F, c.n_body_coeffs)),
+                                       face_coeffs=_arr(c.face_coeffs, (F, c.n_face_coeffs))))
+        return out
+    finally:
+        L.chd_totalcap_free(n, clips)
 
 
 def load_bvh_batch(paths, n_threads=0):

@@ -24,16 +24,17 @@ MTC_FOCAL_LENGTH = (2000.0, 2000.0)          # kinematic_optimizer.py:27-28: the
 MTC_PP = (1920 / 2, 1080 / 2)
 
 
-def load_clip(video_dir, skeleton, start=0, end=100, use_gt_floor=False):
-    """kinematic_optimizer.py:43-153 up to the call of optimize_trajectory -> the clip dict KinematicOptimizer.optimize takes."""
+def load_clip(video_dir, skeleton, start=0, end=100, use_gt_floor=False, keypoints=None, totalcap=None):
+    """kinematic_optimizer.py:43-153 up to the call of optimize_trajectory -> the clip dict KinematicOptimizer.optimize takes.
+    `keypoints` / `totalcap`: the two JSON inputs already read (optimize_videos reads them for all videos at once through the native readers)."""
     openpose_dir = os.path.join(video_dir, 'openpose_result')
     totalcap_path = os.path.join(video_dir, 'tracked_results.json')
     contacts_path = os.path.join(video_dir, 'foot_contacts.npy')
     for p, what in ((openpose_dir, 'openpose results'), (totalcap_path, 'total capture results'), (contacts_path, 'foot contact labels')):
         if not os.path.exists(p):
             raise FileNotFoundError('Could not find %s in %s' % (what, video_dir))
-    kp = load_keypoint_dir(openpose_dir)                                                  # F x 25 x 3
-    res = tc.load_totalcap_results(totalcap_path)
+    kp = keypoints if keypoints is not None else load_keypoint_dir(openpose_dir)         # F x 25 x 3
+    res = totalcap if totalcap is not None else tc.load_totalcap_results(totalcap_path)
     body25_root, body25_3d = tc.normalize_root_pos(res.root_trans, res.joint3d)
     _, smpl_3d = tc.normalize_root_pos(res.root_trans, res.smpl_joint3d, root_idx=tc.SMPL_ROOT_IDX)
     poses3d = tc.create_combined_model(body25_3d, smpl_3d)[start:end]
@@ -58,7 +59,14 @@ def optimize_videos(video_dirs, out_dirs, skel_path, start=0, ends=None, use_gt_
     """All videos in one batched solve.  Returns the per-video results of KinematicOptimizer.optimize."""
     skeleton, names, _ = sio.load_bvh(skel_path)
     ends = ends if ends is not None else [100] * len(video_dirs)
-    clips = [load_clip(d, skeleton, start, e, use_gt_floor) for d, e in zip(video_dirs, ends)]
+    for d in video_dirs:                                                                   # (the reference's messages, before anything is read)
+        for p, what in ((os.path.join(d, 'openpose_result'), 'openpose results'), (os.path.join(d, 'tracked_results.json'), 'total capture results')):
+            if not os.path.exists(p):
+                raise FileNotFoundError('Could not find %s in %s' % (what, d))
+    from . import prepare_capi                                                             # both JSON inputs of ALL videos on the host's cores (libchd_prepare.so)
+    kps = prepare_capi.load_keypoint_dirs([os.path.join(d, 'openpose_result') for d in video_dirs])
+    tcs = prepare_capi.load_totalcap_batch([os.path.join(d, 'tracked_results.json') for d in video_dirs])
+    clips = [load_clip(d, skeleton, start, e, use_gt_floor, kp, res) for d, e, kp, res in zip(video_dirs, ends, kps, tcs)]
     opt = optimizer if optimizer is not None else kopt.KinematicOptimizer(device=device, parents=skeleton.parents)
     results = opt.optimize(clips)
     for out, r in zip(out_dirs, results):

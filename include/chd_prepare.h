@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CHD_PREP_ABI_VERSION 1
+#define CHD_PREP_ABI_VERSION 2
 #define CHD_PREP_MAX_JOINTS 64
 #define CHD_PREP_MAX_SEGMENTS 32
 #define CHD_PREP_MAX_SEGMENT_JOINTS 256
@@ -64,6 +64,31 @@ typedef struct chd_bvh_clip {
 /* Parses n files on up to n_threads host threads (0 = all cores).  Returns the number of files that failed (their `error` is set); < 0 on bad arguments. */
 int chd_bvh_load_batch(int n, const char* const* paths, int n_threads, chd_bvh_clip* out /* n entries */);
 void chd_bvh_free(int n, chd_bvh_clip* clips);
+
+/* ---- the two JSON inputs in front of the kinematic optimisation and the contact network (ABI version 2; host code, csrc/chd_json.hpp) -----------------------------
+ * Reference readers: openpose_utils.py:48-76 (one result file per frame, people[0].pose_keypoints_2d; the contact network's data set and
+ * src/optimize/kinematic_optimizer.py:60-75 read the same directory) and totalcap_utils.py:33-79 (monocular total capture's tracked_results.json).  Both are
+ * read for ALL videos of a run on the host's cores.  A file that is not the JSON these formats use fails ITS clip with a message naming it. */
+typedef struct chd_keypoint_clip {
+  int n_frames;                         /* result files of the directory whose name ends in .json, in name order */
+  double* data;                         /* n_frames x num_joints x 3 (x, y, confidence); zeros for a frame without people */
+  char* error;
+} chd_keypoint_clip;
+int chd_openpose_load_dirs(int n, const char* const* dirs, int num_joints, int n_threads, chd_keypoint_clip* out /* n entries */);
+void chd_openpose_free(int n, chd_keypoint_clip* clips);
+
+typedef struct chd_totalcap_clip {
+  int n_frames, n_joints, n_smpl_joints, n_body_coeffs, n_face_coeffs;      /* 25, 22, 30, 200 in the reference's data */
+  double* root_trans;                   /* n_frames x 3 */
+  double* joint3d;                      /* n_frames x n_joints x 3 */
+  double* smpl_joint3d;                 /* n_frames x n_smpl_joints x 3 */
+  double* smpl_joint_angles;            /* n_frames x n_smpl_joints x 3 (angle-axis) */
+  double* body_coeffs;                  /* n_frames x n_body_coeffs */
+  double* face_coeffs;                  /* n_frames x n_face_coeffs */
+  char* error;
+} chd_totalcap_clip;
+int chd_totalcap_load_batch(int n, const char* const* paths, int n_threads, chd_totalcap_clip* out /* n entries */);
+void chd_totalcap_free(int n, chd_totalcap_clip* clips);
 
 #ifdef __cplusplus
 }
