@@ -53,8 +53,11 @@ def run(n_videos=32, frames=60, keep=None):
     torch.save(cn.randomize_batchnorm_stats(cn.OpenPoseModel(), seed=0).state_dict(), weights)
     t_make = time.perf_counter() - t0
     stages = {}
-    if torch.cuda.is_available():                  # (context creation and the first library GEMM are the process's, not the stage's: 1.3 s of the 1.4 s this stage showed for 64 x 100)
-        a = torch.randn(64, 64, device='cuda'); (a @ a).sum().item()
+    if torch.cuda.is_available():                  # (context creation and the GEMM libraries' first use are the process's, not the stage's: 0.2-1.3 s of what this stage showed when it
+        from chd_amd.contact_net import synthetic_keypoints, detect_contacts_device      #  was the first GPU work of the process; inside bench.py the contact-net metric has run before)
+        warm = cn.OpenPoseModel()
+        detect_contacts_device([synthetic_keypoints(s, F=frames) for s in range(2)], warm, torch.device('cuda'))
+        torch.cuda.synchronize()
     t = time.perf_counter()
     rc0 = run_detect_contacts.main(['--data', root, '--weights', weights, '--device-ops'])
     torch.cuda.synchronize()
