@@ -29,6 +29,8 @@ def work(job):
     if case[0] == 'dir':
         from chd_amd.io_formats import read_inputs
         seq = read_inputs(case[1], case[2]); key = os.path.basename(case[1].rstrip('/'))
+        if key.startswith('phys_optim_in'):
+            key = os.path.basename(os.path.dirname(case[1].rstrip('/')))
     else:
         seq = G.make_case(*case[1:]); key = G.case_key(*case[1:])
     e = emu.EmuProblem(seq, default_config(max_iter=caps))
