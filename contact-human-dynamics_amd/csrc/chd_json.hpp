@@ -1,8 +1,9 @@
 // chd_json.hpp -- a small JSON reader (host) for the two input formats in front of the kinematic optimisation: OpenPose's per-frame result files
 // (openpose_utils.py:48-76 reads people[0].pose_keypoints_2d) and monocular total capture's tracked_results.json (totalcap_utils.py:33-79).
 //
-// Written from RFC 8259: objects, arrays, strings (escapes are skipped over, not decoded: no value read here is a string), numbers through std::from_chars / strtod (correctly rounded,
-// like Python's float), true / false / null.  Strict: anything else -- trailing commas, NaN, a second top-level value -- is an error naming the byte offset; the
+// Written from RFC 8259: objects, arrays, strings (escapes are VALIDATED -- the nine escape characters, four hexadecimal digits after \u, well-formed UTF-8 -- but not decoded:
+// no value read here is a string), numbers through std::from_chars / strtod (correctly rounded, like Python's float), true / false / null, and -- as Python's json module does
+// beyond the RFC -- the literals NaN, Infinity and -Infinity.  Strict otherwise: trailing commas, a second top-level value, duplicate keys are errors naming the byte offset; the
 // caller reports it with the file name and fails that file only.  The Python mirrors (contact_net.load_keypoint_dir, totalcap_io.load_totalcap_results) use the json
 // module; tests/test_ingest_native.py holds the two together, value for value.
 #pragma once
@@ -45,8 +46,27 @@ struct Parser {
     const char* s = p;
     bool escaped = false;
     while (p < e && *p != '"') {
-      if ((unsigned char)*p < 0x20) return fail("control character in a string");
-      if (*p == '\\') { escaped = true; ++p; if (p >= e) break; if (*p == 'u') { if (e - p < 5) return fail("truncated \\u escape"); p += 4; } }
+      const unsigned char ch = (unsigned char)*p;
+      if (ch < 0x20) return fail("control character in a string");
+      if (ch == '\\') {
+        escaped = true; ++p;
+        if (p >= e) break;
+        if (*p == 'u') {
+          if (e - p < 5) return fail("truncated \\u escape");
+          for (int k = 1; k <= 4; ++k) { const char h = p[k]; if (!((h >= '0' && h <= '9') || (h >= 'a' && h <= 'f') || (h >= 'A' && h <= 'F'))) return fail("\\u escape needs four hexadecimal digits"); }
+          p += 4;
+        } else if (!strchr("\"\\/bfnrt", *p)) return fail("invalid escape in a string");
+        ++p;
+        continue;
+      }
+      if (ch >= 0x80) {          // UTF-8, as Python's text-mode reader demands it (well-formed sequences only: no stray continuation bytes, overlong forms, surrogates, or code points above U+10FFFF)
+        int n = ch >= 0xF0 ? 3 : ch >= 0xE0 ? 2 : 1;
+        if (ch < 0xC2 || ch > 0xF4 || e - p <= n) return fail("invalid UTF-8 in a string");
+        for (int k = 1; k <= n; ++k) if (((unsigned char)p[k] & 0xC0) != 0x80) return fail("invalid UTF-8 in a string");
+        const unsigned char c1 = (unsigned char)p[1];
+        if ((ch == 0xE0 && c1 < 0xA0) || (ch == 0xED && c1 > 0x9F) || (ch == 0xF0 && c1 < 0x90) || (ch == 0xF4 && c1 > 0x8F)) return fail("invalid UTF-8 in a string");
+        p += n;
+      }
       ++p;
     }
     if (p >= e) return fail("unterminated string");
@@ -57,6 +77,10 @@ struct Parser {
   bool number(double* out) {
     // the grammar first (strtod alone would take "0x10", "inf", ".5"), then the conversion
     const char* s = p;
+    // the three literals Python's json module accepts beside the RFC's grammar (trackers occasionally emit them): the mirrors read them, so does this reader
+    if (e - p >= 3 && !memcmp(p, "NaN", 3)) { p += 3; *out = __builtin_nan(""); return true; }
+    if (e - p >= 8 && !memcmp(p, "Infinity", 8)) { p += 8; *out = __builtin_inf(); return true; }
+    if (e - p >= 9 && !memcmp(p, "-Infinity", 9)) { p += 9; *out = -__builtin_inf(); return true; }
     if (p < e && *p == '-') ++p;
     if (p >= e) return fail("truncated number");
     if (*p == '0') ++p;
@@ -111,7 +135,7 @@ struct Parser {
       v.all_numbers = true;
       for (;;) {
         ws();
-        if (v.all_numbers && p < e && (*p == '-' || (*p >= '0' && *p <= '9'))) {
+        if (v.all_numbers && p < e && (*p == '-' || (*p >= '0' && *p <= '9') || *p == 'N' || *p == 'I')) {
           double x;
           if (!number(&x)) return false;
           v.nums.push_back(x);

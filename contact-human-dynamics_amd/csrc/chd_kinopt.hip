@@ -15,6 +15,7 @@ using namespace chd_kin;
 namespace {
 thread_local std::string g_err;
 thread_local double g_kernel_ms = 0.0;
+thread_local int g_retried = 0;                 // the last call on this thread fell back to one workgroup per clip (chd_kin_last_call_retried)
 int fail(const std::string& what, hipError_t e = hipSuccess) {
   g_err = e == hipSuccess ? what : what + ": " + hipGetErrorString(e);
   return 1;
@@ -68,8 +69,35 @@ const char* chd_kin_version(void) { return "chd_kinopt 0.1 (gfx950)"; }
 void chd_kin_config_default(chd_kin_config* cfg) { config_default(cfg); }
 const char* chd_kin_last_error(void) { return g_err.c_str(); }
 double chd_kin_last_kernel_ms(void) { return g_kernel_ms; }
+int chd_kin_last_call_retried(void) { return g_retried; }
 
+static int solve_batch_once(const chd_kin_config* cfg, int device, int B, chd_kin_seq* in, bool* not_resident);
+
+// The clusters' workgroups wait on each other, so a launch needs all of them resident at once; the grid is sized by the occupancy the runtime reports, which
+// holds on an exclusive device.  When something else holds compute units (a second process or rank on the same GPU, a compute-unit mask, a long co-tenant
+// kernel) a cluster's bounded wait (5 s) ends the launch with an error flag.  The batch is then solved ONCE MORE with one workgroup per clip (frames per
+// workgroup = the longest clip: the slices live in device memory and the synchronisation never leaves the compute unit -- round 4's form, ~4 x slower, no
+// co-residency assumption), from the caller's unchanged start points; chd_kin_last_call_retried() tells.  reserved[0] = 1 turns the retry off (the error is
+// returned: tests, and callers who would rather fail fast).  The device should be exclusive to the process for the cluster form to pay.
 int chd_kin_solve_batch(const chd_kin_config* cfg, int device, int B, chd_kin_seq* in) {
+  g_retried = 0;
+  bool not_resident = false;
+  const int rc = solve_batch_once(cfg, device, B, in, &not_resident);
+  if (rc == 0 || !not_resident || !cfg || cfg->reserved[0] == 1) return rc;
+  chd_kin_config one = *cfg;
+  int fmax = 2;
+  for (int b = 0; b < B; ++b) fmax = in[b].n_frames > fmax ? in[b].n_frames : fmax;
+  one.reserved[2] = fmax;                       // one workgroup per clip
+  one.reserved[3] = 0;
+  const std::string first = g_err;
+  const int rc2 = solve_batch_once(&one, device, B, in, &not_resident);
+  if (rc2 != 0) { g_err = first + "; the retry with one workgroup per clip failed too: " + g_err; return rc2; }
+  g_retried = 1;
+  return 0;
+}
+
+static int solve_batch_once(const chd_kin_config* cfg, int device, int B, chd_kin_seq* in, bool* not_resident) {
+  *not_resident = false;
   if (!cfg || !in || B < 1) return fail("bad arguments");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail("no HIP device (this library has no CPU path)");
@@ -79,10 +107,10 @@ int chd_kin_solve_batch(const chd_kin_config* cfg, int device, int B, chd_kin_se
   int lds_max = 0, n_cu = 0;
   if ((e = hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device)) != hipSuccess) return fail("hipDeviceGetAttribute", e);
   if ((e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return fail("hipDeviceGetAttribute", e);
-  {   // LDS doubles per workgroup (default 19 968 = 156 KB, or reserved[1]), checked against the device like an explicit value: a device / partition mode with
+  {   // LDS doubles per workgroup (default 19 760 = 154 KB, or reserved[1]), checked against the device like an explicit value: a device / partition mode with
       // less LDS fails here with a message, not in the launch
     const long long want = cfg->reserved[1] > 0 ? cfg->reserved[1] : (long long)KIN_LDS_DOUBLES_DEFAULT;
-    if (want < HALO_V + KC_HALO || want * 8 + 4608 > lds_max) return fail(cfg->reserved[1] > 0 ? "reserved[1] (LDS doubles per workgroup) out of range: 598 .. device limit - 128" : "the device offers less than the 157 KB of LDS per workgroup the default slices need: set reserved[1] (LDS doubles per workgroup, >= 598)");
+    if (want < HALO_V + KC_HALO || want * 8 + 4608 > lds_max) return fail(cfg->reserved[1] > 0 ? "reserved[1] (LDS doubles per workgroup) out of range: 598 .. device limit - 128" : "the device offers less than the 159 KB of LDS per workgroup the default slices need: set reserved[1] (LDS doubles per workgroup, >= 598)");
   }
   KinBatch bt;
   if (!bt.build(cfg, B, in)) return fail(bt.err);
@@ -171,7 +199,7 @@ int chd_kin_solve_batch(const chd_kin_config* cfg, int device, int B, chd_kin_se
   float ms = 0.0f;
   KIN_TRY(hipEventElapsedTime(&ms, ev0, ev1), "hipEventElapsedTime");
 #undef KIN_TRY
-  if (gave_up) { release(); return fail("a cluster of workgroups waited too long (5 s) for a member: the launch was not fully resident (another process on the device, or a partition with fewer compute units than reported?)"); }
+  if (gave_up) { release(); *not_resident = true; return fail("a cluster of workgroups waited too long (5 s) for a member: the launch was not fully resident (another process on the device, or a partition with fewer compute units than reported?)"); }
   bt.scatter(fin.data(), stats.data(), in);
 #ifdef KIN_PROFILE
   {

@@ -63,6 +63,7 @@ struct TraceRange { explicit TraceRange(const std::string&) {} };
 static_assert(sizeof(SeqDesc) % 8 == 0, "SeqDesc is copied word by word");
 static_assert(sizeof(SeqDesc) + sizeof(Ctx) + 64 <= 4096, "static LDS of the solver kernel must fit the 4 KB left beside the dynamic part");
 
+enum { CHD_SLOT_WAIT_SENTINEL = 1 << 28 };      // added to a launch's queue counter by a workgroup that gave up waiting for a workspace slot (launch_drained reports it)
 #ifndef CHD_HOST_EMU
 // Workspace slots.  A resident workgroup needs a workspace (~35 MB at 90 frames) only while it is resident, and at most `n_slots` workgroups are (one per
 // compute unit: a workgroup needs the whole LDS) -- however many launches are in flight.  So the handle owns ONE set of n_slots workspaces, and a workgroup
@@ -71,16 +72,21 @@ static_assert(sizeof(SeqDesc) + sizeof(Ctx) + 64 <= 4096, "static LDS of the sol
 // clears, the acquire pairs with it.  (Until round 4 a launch indexed a pool of its own by blockIdx: four pools, four launches in flight, and a pool could not
 // be reused before the last straggler of its previous launch had finished.)
 __device__ inline int claim_slot(int* slot_busy, int n_slots) {
-  // Spins without a bound: a slot holder always makes progress (it never waits for anything a waiting workgroup owns), so a free slot turns up as soon as one
-  // launch's queue is drained.  (Until round 5 the loop gave up after 4096 sweeps and the workgroup left WITHOUT draining its queue: with more resident
-  // workgroups than slots -- max_workgroups below the compute-unit count, small lds_kilobytes, several launches in flight -- sequences were never solved and
-  // their zeroed result slots read as "converged".  The host now also checks every launch's queue counter: launch_drained.)
+  // A slot holder always makes progress (it never waits for anything a waiting workgroup owns), so a free slot turns up as soon as one launch's queue is
+  // drained: the wait is bounded only against a slot flag that was LEFT SET -- a faulted or aborted earlier launch on the same handle -- which would otherwise
+  // hang the device: after ~10 minutes of wall clock (100 MHz counter; far beyond any launch of this library) the workgroup gives up, returns -1 and the
+  // kernel marks the launch's queue counter so that the host fails the call (launch_drained).  (Until round 5 the loop gave up after 4096 sweeps and the
+  // workgroup left WITHOUT a trace: sequences were never solved and their zeroed result slots read as "converged".)
   int s = (int)(blockIdx.x % (unsigned)n_slots);
+  const long long t0 = (long long)wall_clock64();
   for (unsigned sweep = 0;; ++sweep) {
     int expected = 0;
     if (__hip_atomic_compare_exchange_strong(&slot_busy[s], &expected, 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return s;
     s = s + 1 == n_slots ? 0 : s + 1;
-    if ((sweep & 63u) == 63u) __builtin_amdgcn_s_sleep(64);
+    if ((sweep & 63u) == 63u) {
+      __builtin_amdgcn_s_sleep(64);
+      if ((long long)wall_clock64() - t0 > 600LL * 100000000LL) return -1;
+    }
   }
 }
 // (returns false when the queue is empty.  Not a pointer: the descriptor sits at LDS address 0, which is what a null
@@ -115,6 +121,10 @@ __global__ __launch_bounds__(CHD_MAX_THREADS) void chd_solve_kernel(const SeqDes
   if (threadIdx.x == 0) s_slot = claim_slot(slot_busy, n_slots);
   __syncthreads();
   const int slot = s_slot;
+  if (slot < 0) {                                   // no workspace: nothing can be solved here; the host sees the mark and fails the call
+    if (threadIdx.x == 0) atomicAdd(counter, (int)CHD_SLOT_WAIT_SENTINEL);
+    return;
+  }
   for (;;) {
     if (!take_sequence(&s_desc, &s_item, descs, order, n_items, counter, wd_pool, wd_stride, wi_pool, wi_stride, slot)) break;
     run_sequence((QP)&s_desc, *(LCtx*)&s_ctx, (LdsD*)lds, lds_doubles, tol, stall_window, stage_first, stage_last);
@@ -256,11 +266,23 @@ static int fail(chd_handle* h, const std::string& msg) { if (tl_err_sink) *tl_er
 
 // run fn(i) for i in [0, n) on the host's cores (text parsing / formatting of thousands of directories would otherwise take
 // as long as the solve itself: ~1 ms per file set)
+// Host threads one process may use: at most 32, and -- one process per GPU on a shared host -- the host's hardware threads divided by the ranks the launcher
+// started on it (LOCAL_WORLD_SIZE: set by torch.distributed.run and by bench.py's own launcher; 8 ranks x 32 builder threads would otherwise oversubscribe a
+// 128-thread host).  CHD_HOST_THREADS overrides.
+static unsigned host_thread_cap() {
+  if (const char* e = std::getenv("CHD_HOST_THREADS")) { const int v = std::atoi(e); if (v > 0) return (unsigned)v; }
+  unsigned hc = std::thread::hardware_concurrency();
+  if (hc == 0) hc = 4;
+  int lw = 1;
+  if (const char* e = std::getenv("LOCAL_WORLD_SIZE")) { lw = std::atoi(e); if (lw < 1) lw = 1; }
+  unsigned nt = hc / (unsigned)lw;
+  if (nt < 2) nt = 2;
+  if (nt > 32) nt = 32;
+  return nt;
+}
 template <class F>
 static void host_parallel_for(int n, F fn) {
-  unsigned nt = std::thread::hardware_concurrency();
-  if (nt == 0) nt = 4;
-  if (nt > 32) nt = 32;
+  unsigned nt = host_thread_cap();
   if ((int)nt > n) nt = (unsigned)n;
   if (nt <= 1) { for (int i = 0; i < n; ++i) fn(i); return; }
   std::vector<std::thread> pool;
@@ -270,9 +292,7 @@ static void host_parallel_for(int n, F fn) {
 
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static unsigned host_threads(int n) {
-  unsigned nt = std::thread::hardware_concurrency();
-  if (nt == 0) nt = 4;
-  if (nt > 32) nt = 32;
+  unsigned nt = host_thread_cap();
   if ((int)nt > n) nt = (unsigned)(n > 0 ? n : 1);
   return nt;
 }
@@ -524,6 +544,8 @@ static int launch_drained(chd_handle* h, chd_batch* b, size_t n_items) {
   int cnt = -1;
   HIP_TRY(h, copy_d2h(h, b, &cnt, b->d_counter, sizeof(int)));
   const int grid = (int)std::min<size_t>(n_items, (size_t)h->n_wg);
+  if (cnt >= (int)CHD_SLOT_WAIT_SENTINEL)
+    return fail(h, "a workgroup of the solver launch waited 10 minutes for a workspace slot: a slot flag was left set by a faulted or aborted earlier launch on this handle -- destroy the handle and create a new one");
   if (cnt != (int)n_items + grid)
     return fail(h, "solver launch left its queue undrained: counter " + std::to_string(cnt) + ", expected " + std::to_string((int)n_items + grid) + " (" + std::to_string(n_items) + " sequences, " + std::to_string(grid) + " workgroups)");
   return 0;

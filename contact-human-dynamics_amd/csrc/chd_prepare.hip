@@ -57,7 +57,9 @@ int chd_prep_frames(const chd_prep_skeleton* skel, int device, long long n, cons
   const int J = skel->n_joints;
   if (J < 1 || J > CHD_PREP_MAX_JOINTS || skel->n_joints_body < 1 || skel->n_joints_body > J || skel->n_segments < 1 || skel->n_segments > CHD_PREP_MAX_SEGMENTS ||
       skel->seg_first[skel->n_segments] > CHD_PREP_MAX_SEGMENT_JOINTS) { g_err = "chd_prep_frames: skeleton tables out of range"; return -1; }
-  for (int j = 0; j < J; ++j) if (skel->parents[j] >= j) { g_err = "chd_prep_frames: joints must follow their parents"; return -1; }
+  if (skel->parents[0] != -1) { g_err = "chd_prep_frames: parents[0] must be -1 (the root)"; return -1; }
+  for (int j = 1; j < J; ++j) if (skel->parents[j] >= j || skel->parents[j] < 0) { g_err = "chd_prep_frames: joints must follow their parents (0 <= parents[j] < j)"; return -1; }
+  if (skel->seg_first[0] != 0) { g_err = "chd_prep_frames: seg_first[0] must be 0"; return -1; }
   for (int s = 0; s < skel->n_segments; ++s) {
     if (skel->seg_first[s + 1] <= skel->seg_first[s]) { g_err = "chd_prep_frames: empty segment"; return -1; }
     for (int k = skel->seg_first[s]; k < skel->seg_first[s + 1]; ++k) if (skel->seg_joint[k] < 0 || skel->seg_joint[k] >= skel->n_joints_body) { g_err = "chd_prep_frames: segment joint out of range"; return -1; }
@@ -130,10 +132,21 @@ int chd_bvh_load_batch(int n, const char* const* paths, int n_threads, chd_bvh_c
       std::string names;
       for (size_t k = 0; k < c.names.size(); ++k) { if (k) names += '\n'; names += c.names[k]; }
       o.names = dup_str(names);
-      o.parents = (int*)malloc(sizeof(int) * c.parents.size()); memcpy(o.parents, c.parents.data(), sizeof(int) * c.parents.size());
-      o.offsets = (double*)malloc(8 * c.offsets.size()); memcpy(o.offsets, c.offsets.data(), 8 * c.offsets.size());
-      o.positions = (double*)malloc(8 * (c.positions.size() + 1)); memcpy(o.positions, c.positions.data(), 8 * c.positions.size());
-      o.rotations = (double*)malloc(8 * (c.rotations.size() + 1)); memcpy(o.rotations, c.rotations.data(), 8 * c.rotations.size());
+      o.parents = (int*)malloc(sizeof(int) * (c.parents.size() + 1));
+      o.offsets = (double*)malloc(8 * (c.offsets.size() + 1));
+      o.positions = (double*)malloc(8 * (c.positions.size() + 1));
+      o.rotations = (double*)malloc(8 * (c.rotations.size() + 1));
+      if (!o.names || !o.parents || !o.offsets || !o.positions || !o.rotations) {      // out of memory: this clip fails on its own, with a message
+        free(o.names); free(o.parents); free(o.offsets); free(o.positions); free(o.rotations);
+        memset(&o, 0, sizeof(chd_bvh_clip));
+        o.error = dup_str(std::string(paths[i]) + ": out of memory");
+        failed.fetch_add(1);
+        continue;
+      }
+      memcpy(o.parents, c.parents.data(), sizeof(int) * c.parents.size());
+      memcpy(o.offsets, c.offsets.data(), 8 * c.offsets.size());
+      memcpy(o.positions, c.positions.data(), 8 * c.positions.size());
+      memcpy(o.rotations, c.rotations.data(), 8 * c.rotations.size());
     }
   };
   std::vector<std::thread> pool;

@@ -34,7 +34,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.environ.get('CHD_KINOPT_LIB') or os.path.join(_CSRC, 'libchd_kinopt.so')      # (override: kernel experiments with variant builds)
 SOURCES = ['chd_kinopt.hip', 'chd_kinopt_kernels.hpp', 'chd_kinopt_host.hpp']
-EXPORTS = ['chd_kin_version', 'chd_kin_config_default', 'chd_kin_solve_batch', 'chd_kin_last_error', 'chd_kin_last_kernel_ms']
+EXPORTS = ['chd_kin_version', 'chd_kin_config_default', 'chd_kin_solve_batch', 'chd_kin_last_error', 'chd_kin_last_kernel_ms', 'chd_kin_last_call_retried']
 
 # ---- SkeletonDefinitions.py:64-137 (combined skeleton: body-25 + three spine joints) --------------------------------------------
 ROOT_IDX = 8                                            # COMBINED_ROOT_IDX (data order)
@@ -95,6 +95,10 @@ class KinSolver:
 
     def last_kernel_ms(self):
         return float(self.lib.chd_kin_last_kernel_ms())
+
+    def last_call_retried(self):
+        """True when the last solve() on this thread found its launch not fully resident and fell back to one workgroup per clip (include/chd_kinopt.h)"""
+        return bool(self.lib.chd_kin_last_call_retried())
 
 
 # ---- host steps ------------------------------------------------------------------------------------------------------------------
@@ -315,6 +319,7 @@ class KinematicOptimizer:
         chunk.  The least-squares launches of the threads take turns on the device (a launch's workgroups wait on each other: chd_kinopt.hip lets one run at
         a time), each of them fills it: a 100-frame clip is a cluster of 8 workgroups, 32 clusters are resident and draw clips from the launch's queue.  More
         than two threads do not help (measured: every launch has a tail).  A clip's result does not depend on the chunk it is in."""
+        self.timings['chunks'] = []                # (the marks of THIS call's chunks: a long-lived optimizer must not accumulate them)
         if workers >= 2 and 128 < len(clips) <= chunk:
             chunk = (len(clips) + 1) // 2          # two halves, so that one half's host steps run under the other half's kernels
         if len(clips) <= chunk or workers < 2:

@@ -30,7 +30,7 @@ typedef struct chd_kin_config {
   int reserved[4];         /* tuning knobs, 0 = default: [1] doubles of LDS per workgroup (default 19 760 = 154 KB: slices of up to 13 frames stay in LDS),
                               [2] frames per workgroup (default: what the LDS block holds; smaller = more workgroups per clip, larger = slices that live in
                               device memory), [3] = 0x7e57: test hook (one workgroup of the first cluster never shows up: the call must come back
-                              with an error after the waiting limit, not hang), [0] unused.  A clip of F frames is solved by a cluster of ceil(F / frames-per-workgroup) workgroups (at most
+                              with an error after the waiting limit, not hang), [0] = 1: no retry with one workgroup per clip when a launch turns out not to be fully resident (below).  A clip of F frames is solved by a cluster of ceil(F / frames-per-workgroup) workgroups (at most
                               16, never slices of fewer than two frames).  Results are bitwise reproducible for fixed values and independent of the batch a clip is in. */
 } chd_kin_config;
 
@@ -66,6 +66,12 @@ const char* chd_kin_last_error(void);
 
 /* Device time (HIP events around the launch) of the last successful call on this thread, in milliseconds. */
 double chd_kin_last_kernel_ms(void);
+
+/* The workgroups of a cluster wait on each other: the launch assumes they are all resident, which holds on a device that is exclusive to the process.  When a
+ * cluster's bounded wait (5 s) expires -- another process / rank on the same GPU, a compute-unit mask, a long co-tenant kernel -- chd_kin_solve_batch solves the
+ * batch once more with ONE workgroup per clip (slices in device memory, no wait across compute units; slower, results equal to rounding) instead of failing,
+ * unless cfg->reserved[0] == 1.  1 if the last call on this thread took that path. */
+int chd_kin_last_call_retried(void);
 
 #ifdef __cplusplus
 }

@@ -137,3 +137,44 @@ def test_bench_refuses_a_world_that_is_not_gpus(monkeypatch):
     monkeypatch.setenv('WORLD_SIZE', '2'); monkeypatch.setenv('RANK', '0')
     with pytest.raises(SystemExit):
         bench.main(['--gpus', '4', '--steps', '1', '--batch', '2', '--frames', '24'], solver_factory=_EmuSolver)
+
+
+def test_bench_as_eight_ranks_from_a_plain_shell(capfd, monkeypatch):
+    """The driver's largest configuration without hardware: `bench.main(['--gpus', '8', ...])` starts EIGHT gloo ranks itself.  One JSON line,
+    n_gpus 8, the weak-scaling aggregate covers 8 x batch sequences, and the strong-scaling leg's LPT shards cover its fixed total exactly once (16 sequences: two
+    per rank)."""
+    sys.path.insert(0, os.path.join(HERE, 'host_emu'))
+    import emu
+    emu.build()
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'LOCAL_WORLD_SIZE'):
+        monkeypatch.delenv(k, raising=False)
+    sys.path.insert(0, ROOT)
+    import bench
+    capfd.readouterr()
+    bench.main(['--gpus', '8', '--steps', '1', '--warmup', '0', '--batch', '1', '--frames', '24', '--no-cpu-baseline', '--no-side-metrics', '--strong-total', '16'],
+               solver_factory=_EmuSolver)
+    out = capfd.readouterr().out
+    lines = [ln for ln in out.splitlines() if ln.strip().startswith('{')]
+    assert len(lines) == 1, out
+    o = json.loads(lines[0])
+    assert o['n_gpus'] == 8 and o['scaling'] == 'weak' and o['roofline']['peak'] == 8000.0 * 8
+    assert abs(o['value'] * o['ms_per_step'] * 1e-3 - 8.0) < 1e-6          # batch 1, one step, per rank: 8 sequences in the timed region
+    st = o['strong_scaling']
+    assert st['total_sequences'] == 16 and st['sequences_rank0'] == 2 and st['n_gpus'] == 8
+    assert abs(st['value'] * st['seconds'] - 16.0) < 1e-9
+    assert o['strong_scaling_value'] == st['value']                       # (top-level copy for parsers that keep first-level numbers)
+
+
+def test_rank_local_workloads_are_disjoint_and_shards_cover_the_total_once():
+    """What makes the 8-rank numbers meaningful: rank r's weak-scaling seeds are r*K*128 .. (no sequence is solved twice), and `sharding.lpt_assign` of the 4 000
+    strong-scaling sequences over 8 ranks is a partition (every index exactly once, loads within one sequence of each other for equal lengths)."""
+    import chd_amd  # noqa: F401
+    from chd_amd.sharding import lpt_assign
+    K, B, W = 20, 128, 8
+    seeds = [set(range(r * K * B, (r + 1) * K * B)) for r in range(W)]
+    assert sum(len(s) for s in seeds) == len(set().union(*seeds)) == W * K * B
+    shards = lpt_assign([90] * 4000, W)
+    flat = sorted(i for sh in shards for i in sh)
+    assert flat == list(range(4000)) and max(len(sh) for sh in shards) - min(len(sh) for sh in shards) <= 1
+    mixed = lpt_assign([60, 120] * 999 + [600, 90], W)
+    assert sorted(i for sh in mixed for i in sh) == list(range(2000))

@@ -72,7 +72,8 @@ def test_what_is_not_the_format_fails_its_clip_with_the_files_name(videos, tmp_p
     good = os.path.join(videos[0], 'openpose_result')
     bad = tmp_path / 'openpose_result'
     bad.mkdir()
-    cases = {'trailing comma': '{"people":[{"pose_keypoints_2d":[1,2,3,]}]}', 'NaN': '{"people":[{"pose_keypoints_2d":[NaN]}]}', 'two values': '{"people":[]} {}',
+    cases = {'trailing comma': '{"people":[{"pose_keypoints_2d":[1,2,3,]}]}', 'bad literal': '{"people":[{"pose_keypoints_2d":[nan]}]}', 'two values': '{"people":[]} {}',
+             'unknown escape': '{"note":"a \\q b","people":[]}', 'short unicode escape': '{"note":"\\u12G4","people":[]}',
              'wrong length': '{"people":[{"pose_keypoints_2d":[1,2,3]}]}', 'no people': '{"persons":[]}', 'leading dot': '{"people":[{"pose_keypoints_2d":[.5]}]}',
              'duplicate key': '{"people":[],"people":[]}', 'truncated': '{"people":[{"pose_keypoints_2d":[1,2'}
     for what, text in cases.items():
@@ -81,7 +82,7 @@ def test_what_is_not_the_format_fails_its_clip_with_the_files_name(videos, tmp_p
         (bad / 'frame_0.json').write_text(text)
         with pytest.raises(ValueError, match='frame_0.json'):
             pc.load_keypoint_dirs([good, str(bad)])
-        with pytest.raises((ValueError, KeyError, json.JSONDecodeError)) if what not in ('NaN', 'duplicate key', 'wrong length') else _accepts():      # the Python mirror: stricter here only where json is laxer
+        with pytest.raises((ValueError, KeyError, json.JSONDecodeError)) if what not in ('duplicate key', 'wrong length') else _accepts():      # the Python mirror: stricter here only where json is laxer
             cn.load_keypoint_dir(str(bad))
     with pytest.raises(ValueError, match='no .json result files'):
         pc.load_keypoint_dirs([str(tmp_path)])
@@ -91,6 +92,24 @@ def test_what_is_not_the_format_fails_its_clip_with_the_files_name(videos, tmp_p
         pc.load_totalcap_batch([str(p)])
     with pytest.raises(ValueError, match='cannot open'):
         pc.load_totalcap_batch([str(tmp_path / 'absent.json')])
+
+
+def test_nan_and_infinity_literals_are_read_like_the_json_module_reads_them(tmp_path):
+    """Round 6 (advisor): Python's json module accepts NaN / Infinity / -Infinity, and trackers occasionally write them; the native reader used to fail the whole
+    run on such a file while the Python mirror went on.  Now both give the same arrays.  Invalid UTF-8 inside a string fails in both."""
+    d = tmp_path / 'openpose_result'
+    d.mkdir()
+    body = ['NaN', 'Infinity', '-Infinity', '1.5', '-2'] * 15
+    (d / 'f_0_keypoints.json').write_text('{"people":[{"pose_keypoints_2d":[' + ','.join(body) + ']}]}')
+    a = pc.load_keypoint_dirs([str(d)])[0]
+    b = cn.load_keypoint_dir(str(d))
+    assert a.shape == b.shape == (1, 25, 3)
+    assert np.array_equal(a, b, equal_nan=True) and np.isnan(a).sum() == 15 and np.isposinf(a).sum() == 15 and np.isneginf(a).sum() == 15
+    (d / 'f_0_keypoints.json').write_bytes(b'{"note":"\xff\xfe","people":[]}')
+    with pytest.raises(ValueError, match='UTF-8'):
+        pc.load_keypoint_dirs([str(d)])
+    with pytest.raises((ValueError, UnicodeDecodeError)):
+        cn.load_keypoint_dir(str(d))
 
 
 class _accepts:

@@ -120,9 +120,19 @@ def test_a_missing_workgroup_is_an_error_not_a_hang(gold):
     test hook `reserved[3] = 0x7e57`, which makes the last workgroup of the first cluster return at once): the launch winds down, the call reports it, and
     the next call on the same device works."""
     p = problem(gold, 1, 1)[0]
-    bad = kopt.KinSolver(device=0, lsmr_maxiter=3); bad.cfg.reserved[2] = 4; bad.cfg.reserved[3] = 0x7e57
+    bad = kopt.KinSolver(device=0, lsmr_maxiter=3); bad.cfg.reserved[2] = 4; bad.cfg.reserved[3] = 0x7e57; bad.cfg.reserved[0] = 1      # (no retry: the error itself)
     with pytest.raises(RuntimeError, match='waited too long'):
         bad.solve([p, p, p])
+    # default behaviour (round 6, advisor): the batch is solved once more with one workgroup per clip instead of failing -- same results to rounding as a
+    # call that asked for one workgroup per clip in the first place
+    retry = kopt.KinSolver(device=0, lsmr_maxiter=3); retry.cfg.reserved[2] = 4; retry.cfg.reserved[3] = 0x7e57
+    rr = retry.solve([p, p, p])
+    assert retry.last_call_retried()
+    one = kopt.KinSolver(device=0, lsmr_maxiter=3); one.cfg.reserved[2] = int(np.asarray(p['pose3d']).shape[0])      # one workgroup per clip, asked for
+    r1 = one.solve([p])[0]
+    assert not one.last_call_retried()
+    for r in rr:
+        assert np.array_equal(r['x'], r1['x']) and r['cost'] == r1['cost']
     good = kopt.KinSolver(device=0, lsmr_maxiter=3); good.cfg.reserved[2] = 4
     r = good.solve([p])[0]
     assert r['nfev'] >= 1 and np.isfinite(r['cost'])

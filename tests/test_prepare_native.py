@@ -143,3 +143,8 @@ def test_skeleton_tables_are_validated(gold, tmp_path, character):
     bad = pc.ChdPrepSkeleton.from_buffer_copy(s); bad.parents[3] = 7                       # a joint in front of its parent
     rc = L.chd_prep_frames(C.byref(bad), 0, 1, anim.rotations[:1].ctypes.data_as(pc.PD), anim.positions[:1].ctypes.data_as(pc.PD), out.ctypes.data_as(pc.PD))
     assert rc != 0 and b'parents' in L.chd_prep_last_error()
+    # round 6 (advisor): every index the kernel follows is checked before the launch -- a negative segment start, a parent below -1, a root with a parent
+    for edit, word in ((lambda b: b.seg_first.__setitem__(0, -2), b'seg_first'), (lambda b: b.parents.__setitem__(5, -3), b'parents'), (lambda b: b.parents.__setitem__(0, 2), b'parents[0]')):
+        bad = pc.ChdPrepSkeleton.from_buffer_copy(s); edit(bad)
+        rc = L.chd_prep_frames(C.byref(bad), 0, 1, anim.rotations[:1].ctypes.data_as(pc.PD), anim.positions[:1].ctypes.data_as(pc.PD), out.ctypes.data_as(pc.PD))
+        assert rc != 0 and word in L.chd_prep_last_error(), L.chd_prep_last_error()

@@ -111,7 +111,7 @@ def test_driver_outputs_do_not_depend_on_the_number_of_ranks(tmp_path):
     emu.build()
     roots = {}
     ctx = mp.get_context('spawn')
-    for world in (1, 2):
+    for world in (1, 2, 8):          # (8: the driver's largest configuration -- one directory per rank here)
         root = str(tmp_path / ('w%d' % world)); os.makedirs(root)
         _make_tree(root)
         roots[world] = root
@@ -127,7 +127,9 @@ def test_driver_outputs_do_not_depend_on_the_number_of_ranks(tmp_path):
         assert all(g[1] == 0 for g in got) and got[0][2] == 8.0           # every rank succeeded; the shards cover all 8 directories
     names = ['sol_out_durations.txt', 'sol_out_dynamics.txt', 'sol_out_no_dynamics.txt', 'success_log.txt']
     for i in range(8):
-        a = os.path.join(roots[1], 'video_%02d' % i, 'phys_optim_out_ybot'); b = os.path.join(roots[2], 'video_%02d' % i, 'phys_optim_out_ybot')
-        assert sorted(os.listdir(a)) == names and sorted(os.listdir(b)) == names
-        for n in names:
-            assert open(os.path.join(a, n), 'rb').read() == open(os.path.join(b, n), 'rb').read(), (i, n)
+        a = os.path.join(roots[1], 'video_%02d' % i, 'phys_optim_out_ybot')
+        for world in (2, 8):
+            b = os.path.join(roots[world], 'video_%02d' % i, 'phys_optim_out_ybot')
+            assert sorted(os.listdir(a)) == names and sorted(os.listdir(b)) == names          # every directory written exactly once, by whichever rank owns it
+            for n in names:
+                assert open(os.path.join(a, n), 'rb').read() == open(os.path.join(b, n), 'rb').read(), (world, i, n)
