@@ -101,6 +101,21 @@ def check_forces(seeds, snaps_per_seq, dyn):
             got = np.asarray(snaps[k]['ee_force'] if isinstance(snaps[k], dict) else snaps[k].ee_force)
             dist[i, k] = rel_l2(got, ref) if got.shape == ref.shape and np.linalg.norm(ref) > 0 else 0.0
     assert np.all(dist <= made * 1.05 + 0.02), 'forces further from the converged solution than when the fixture was made: %s' % np.round(dist - made, 3).max(axis=0)
+    # ... and a BAR, not only that ratchet (round 6), on what the dynamics rows do determine -- the NET force of the four contact points: (i) it is consistent with the returned
+    # motion (the dynamics residual above: sum f = m (a + g), moments likewise, to 1e-4), and (ii) its distance to the converged solve's is bounded: at the reference's tol 1e-3 the
+    # force splines are NOT converged (32 bench seeds: 0.55 / 0.68 in the median at the two dynamics snapshots, 0.98 at most -- the centre of mass's second derivative moves that
+    # much while its position moves 6e-3; two CONVERGED independent solvers still differ by 3e-2: tests/test_cross_solver.py), so the bar is "no further than the start guess is":
+    # median <= 0.80, no sequence above 1.05.  A caller who needs converged forces pays for tol 1e-6 (bench: value_at_tol_1e-6).
+    net = np.zeros_like(dist)
+    for i, (seed, snaps) in enumerate(zip(seeds, snaps_per_seq)):
+        for k in (1, 2):
+            ref = g['s%d_snap%d_ee_force' % (seed, k)]
+            got = np.asarray(snaps[k]['ee_force'] if isinstance(snaps[k], dict) else snaps[k].ee_force)
+            if got.shape == ref.shape and np.linalg.norm(ref) > 0:
+                net[i, k] = rel_l2(got.sum(axis=0), ref.sum(axis=0))
+    assert np.all(net <= 1.05), 'net ground reaction force further than 1.05 from the converged solve: %s' % np.round(net.max(axis=0), 3)
+    if len(seeds) >= 16:
+        assert np.all(np.median(net, axis=0) <= 0.80), 'net ground reaction force, median distance to the converged solve: %s' % np.round(np.median(net, axis=0), 3)
     return dist
 
 
