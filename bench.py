@@ -572,11 +572,12 @@ def main(argv=None, solver_factory=None):
             v, st2 = timed_solve(seqs[:500])
             side['value_500_sequences_in_one_call'] = v
             # what solver-INDEPENDENT positions cost (tests/golden/cross_solver_golden.json: centre of mass / angles / feet of two converged solvers agree to 1e-5, at the
-            # reference's tol 1e-3 they depend on the iterates): the first 512 sequences with every stage run to tol 1e-6 -- NOT the reference's setting, never `value`
-            n6 = min(512, len(seqs))
+            # reference's tol 1e-3 they depend on the iterates): the first 128 sequences with every stage run to tol 1e-6 -- NOT the reference's setting, never `value`
+            n6 = min(128, len(seqs))
             v, st2 = timed_solve(seqs[:n6], tol=1e-6)
             side['value_at_tol_1e-6'] = v
-            side['at_tol_1e-6'] = {'sequences': n6, 'ipm_iterations_per_sequence': st2['total_iters'] / max(1, n6), 'fallbacks': st2['n_fallback'],
+            side['at_tol_1e-6'] = {'sequences': n6, 'seconds': n6 / v, 'ipm_iterations_per_sequence': st2['total_iters'] / max(1, n6), 'fallbacks': st2['n_fallback'], 'slowest_sequence_ms': st2['max_seq_ms'],
+                                   'mean_sequence_ms': st2['phase_ms'][5] / max(1, n6),
                                    'note': 'every stage to tol 1e-6 instead of the reference\'s 1e-3 (phys_optim.cpp:578); one call, inputs resident'}
             side['kernel_busy_fraction_500_sequences'] = st2['phase_ms'][5] / max(1e-9, st2['n_workgroups'] * (st2['kernel_ms'][0] + st2['kernel_ms'][1]))
             # BASELINE configs[4]: one 600-frame sequence on a 10-degree floor, alone in a launch
