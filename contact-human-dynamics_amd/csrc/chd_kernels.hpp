@@ -1345,17 +1345,31 @@ CHD_DEV void kfactor_band(LCtx& c, const GI* sign, LdsD* dv, LdsD* DL, LdsD* dv2
 #endif
     }
 #ifndef CHD_HOST_EMU
+#ifdef CHD_B_TIMING
+    const long long tb0_ = CHD_CLOCK();
+#endif
     if (more && threadIdx.x < 64) lookahead_wave<NB>(c, sign, dv, PT, ldp, P.pr - NB, P.nbelow, c0 + P.jb, P.act, nact, dv2, DL2, c0n, Nb - c0n < NB ? Nb - c0n : NB);
     else
 #endif
     trailing_phase<NB>(c, sign, dv, PT, ldp, P.pr - NB, P.nbelow, c0 + P.jb, P.act, nact, more, dv2, DL2, c0n, Nb - c0n < NB ? Nb - c0n : NB);
     TACC(c, 11, CHD_CLOCK() - tp_); tp_ = CHD_CLOCK();
+#if defined(CHD_B_TIMING) && !defined(CHD_HOST_EMU)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long tb1_ = CHD_CLOCK();
+#endif
     // the panel's own columns go out last: nothing reads them before the barrier, and ahead of the update they would only stand
     // between its loads and the memory (the vector-memory counter retires in order)
 #ifdef CHD_HOST_EMU
     panel_store<NB>(c, P, nact, 0);
 #else
     panel_store<NB>(c, P, nact, more ? 64 : 0);
+#endif
+#if defined(CHD_B_TIMING) && !defined(CHD_HOST_EMU)
+    const long long tb2_ = CHD_CLOCK();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long tb3_ = CHD_CLOCK();
+    if (threadIdx.x == 64) { c.tacc[16] += tb1_ - tb0_; c.tacc[17] += tb2_ - tb1_; c.tacc[18] += tb3_ - tb2_; }       // second wavefront: list + tiles (drained), panel store issue, its drain
+    if (threadIdx.x == 448) { c.tacc[19] += tb1_ - tb0_; c.tacc[20] += tb3_ - tb1_; }                                    // last wavefront: tiles (drained), store + drain
 #endif
     CHD_SYNC();
     TACC(c, 10, CHD_CLOCK() - tp_);
