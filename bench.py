@@ -306,7 +306,11 @@ def contact_net_rate(device, n_videos=128, frames=FRAMES, reps=20):
            'unit': 'frames/s', 'videos': n_videos, 'frames': frames,
            'roofline': {'bound': 'hbm', 'achieved': abytes / t_fwd / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': abytes / t_fwd / 1e9 / HBM_PEAK_GBS,
                         'algorithmic_bytes_per_forward': abytes, 'weight_bytes': wbytes, 'flops_per_forward': 2 * 0.954e6 * int(x.shape[0]),
-                        'note': 'forward pass of all windows of all videos (library GEMMs of PyTorch-ROCm); 5 small layers: launch-latency bound at this size'},
+                        'note': 'forward pass of all windows of all videos (library GEMMs of PyTorch-ROCm) against the HBM peak; the binding roofline of this size is the fp32 matrix core: roofline_mfma'},
+           # 0.954 MMAC per window in exact fp32 (gfx950 has no TF32): at 10 496 windows the five GEMMs are bound by the fp32 matrix rate, not by bytes or launches
+           # (replayed as one HIP graph the forward is no faster: fps_hip_graph)
+           'roofline_mfma': {'bound': 'mfma', 'achieved': 2 * 0.954e6 * int(x.shape[0]) / t_fwd / 1e12, 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': 2 * 0.954e6 * int(x.shape[0]) / t_fwd / 1e12 / 157.3,
+                             'note': 'fp32 in / fp32 accumulate; peak = dense fp32 MFMA of MI355X_MICROARCH.md'},
            'windows': int(x.shape[0]), 'dtype': 'f32', 'device': str(device),
            'note': 'fps: forward pass, windows resident on the device; fps_end_to_end: NumPy pre-processing + upload + forward + vote merge; '
                    'fps_end_to_end_device_ops: the same with gap interpolation, windowing and vote merge as tensor ops on the device'}
