@@ -1,6 +1,7 @@
 """Globalisation / damping studies on the CPU (round 6): runs the host emulation of the kernel source with the study switches of chd_kernels.hpp set through the
 environment (CHD_GLOB_FILTER, CHD_FILTER_MAXBT, CHD_L1_FLOOR, ...) on
   * the lockstep fixture's 200 sequences (+ the four pipeline clips it holds),
+  * W: 256 fresh walks (seeds 3000..3255) -- the fixture's 36 hard seeds are the PREVIOUS rules' stragglers and flatter any change,
   * the bench workload's known stragglers (seeds 1688, 88: 199 / 231 iterations in the duration stage),
   * physics input directories the repo's own upstream stages produced (tools/gpu_r06_start.sh: 192 clips x 100 frames = sets A, B, C of 64),
 and prints ONE summary row per set: what VERDICT r05 next-1 asks a rule to be judged by (total, max, stage-3 p99, clips above 800 / at the cap, failed stages).
@@ -39,7 +40,7 @@ if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('env', nargs='*', help='KEY=VALUE study switches')
     ap.add_argument('--name', default='study')
-    ap.add_argument('--sets', nargs='*', default=['fixture', 'stragglers', 'A', 'B', 'C'])
+    ap.add_argument('--sets', nargs='*', default=['fixture', 'W', 'stragglers', 'A', 'B', 'C'])
     ap.add_argument('--clips', default='/tmp/pipe192')
     ap.add_argument('--workers', type=int, default=8)
     ap.add_argument('--out', default='/tmp/glob_study')
@@ -54,6 +55,8 @@ if __name__ == '__main__':
         sets['fixture'] = [('seed',) + c for c in G.FLAT + G.TILTED + G.HARD + G.PIPE]
     if 'small' in a.sets:
         sets['small'] = [('seed',) + c for c in G.FLAT[:16] + G.TILTED[:8] + G.HARD[:12] + G.PIPE]
+    if 'W' in a.sets:          # 256 FRESH walks (seeds outside every fixture): what the fixture's hand-picked hard seeds cannot tell (profiles/r06_globalisation_study.md, ratio rule)
+        sets['W'] = [('seed', 3000 + i, 90, 0.0) for i in range(256)]
     if 'stragglers' in a.sets:
         sets['stragglers'] = [('seed', 1688, 90, 0.0), ('seed', 88, 90, 0.0)]
     for name, lo in (('A', 0), ('B', 64), ('C', 128)):
