@@ -594,6 +594,14 @@ def main(argv=None, solver_factory=None):
             side['long_600_frames'] = {'upload_seconds_incl_table_build': t_up, 'kernel_ms': st3['kernel_ms'][0] + st3['kernel_ms'][1], 'iterations': st3['total_iters'],
                                        'kkt_dim': r3.sizes['kkt_dim'], 'halfband': r3.sizes['halfband'], 'border': r3.sizes['border'], 'stage_status': list(r3.stage_status),
                                        'time_share': {k: st3['phase_ms'][i] / max(1e-9, st3['phase_ms'][5]) for k, i in (('evaluation_full', 0), ('evaluation_values', 1), ('factorisation', 2), ('substitution', 3), ('kkt_matvec', 4))}}
+            # chd_config.damping_rule = 1 (round 6, off by default: it costs a launch of thousands of walks 7 %): what it buys where few or long sequences share a call
+            v, st2 = timed_solve(seqs[:500], damping_rule=1)
+            s4 = PhysOptim(device=local, config=default_config(damping_rule=1))
+            b4 = s4.upload([long_seq]); st4 = b4.solve(); b4.free(); s4.close()
+            side['damping_rule_1'] = {'value_500_sequences_in_one_call': v, 'ipm_iterations_per_sequence_500': st2['total_iters'] / 500.0,
+                                      'long_600_frames_kernel_ms': st4['kernel_ms'][0] + st4['kernel_ms'][1], 'long_600_frames_iterations': st4['total_iters'],
+                                      'note': 'chd_config.damping_rule = 1: the damping also grows after an ACCEPTED step that delivered < 1/4 of the predicted merit reduction; NOT the configuration of '
+                                              '`value` (2 560 walks in one launch lose 7 % with it: profiles/r06_globalisation_study.md)'}
         except Exception as exc:
             side['side_run_error'] = '%s: %s' % (type(exc).__name__, exc)
 

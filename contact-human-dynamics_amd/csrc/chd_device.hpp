@@ -100,6 +100,7 @@ struct SeqDesc {
 
   int F, cap;         // data frames, snapshot capacity
   double dt, T, mass, leg_len, heel_len, heel_dist;
+  double ratio_low;                    // chd_config.damping_rule = 1: an accepted step that delivers less than this fraction of the predicted merit reduction raises the damping (0 = rule off; solve_stage)
   double normal[3], point[3], gdir[3], hx, hy, bn[3], bt1[3], bt2[3];
   SplineDesc sp[N_SPLINES];
   int n_phase[N_EE], phase_off[N_EE], start_contact[N_EE];

@@ -3178,6 +3178,7 @@ CHD_NOINLINE CHD_DEV void solve_stage(LCtx& c, StageResult& res) {
     cn = block_sum(c, cn);
 
     bool ok = false, used_soc = false;
+    double ratio_num = 0.0, ratio_den = 0.0;      // actual and predicted reduction of the merit function by the accepted step (chd_config.damping_rule = 1, below)
 #ifdef CHD_HOST_EMU
     double trace_dphi = 0.0;      // (CHD_EMU_TRACE: the directional derivative of the merit function the accepted step was judged with)
 #endif
@@ -3268,7 +3269,7 @@ CHD_NOINLINE CHD_DEV void solve_stage(LCtx& c, StageResult& res) {
         PAR_FOR(i, m) cnt_ += fabs(rt[i]);
         cnt_ = block_sum(c, cnt_);
         const double phit = ft + barrier_val(c, st, mu) + nu * cnt_;
-        if (phit <= phi0 + 1e-4 * alpha * Dphi + 1e-12 * fabs(phi0)) { ok = true; break; }
+        if (phit <= phi0 + 1e-4 * alpha * Dphi + 1e-12 * fabs(phi0)) { ok = true; ratio_num = phi0 - phit; ratio_den = -(alpha * Dphi + 0.5 * alpha * alpha * fmax(dHd, 0.0)); break; }
         if (nls == 0 && cnt_ > 1e-12) {
           // second-order correction: same factorisation, constraint residual of the trial point
           PAR_FOR(j, n) rhs2[pos_var[j]] = 0.0;
@@ -3297,7 +3298,7 @@ CHD_NOINLINE CHD_DEV void solve_stage(LCtx& c, StageResult& res) {
             PAR_FOR(i, m) cns += fabs(rt[i]);
             cns = block_sum(c, cns);
             const double phis = fs + barrier_val(c, ss2, mu) + nu * cns;
-            if (phis <= phi0 + 1e-4 * alpha * Dphi + 1e-12 * fabs(phi0)) { ok = true; used_soc = true; break; }
+            if (phis <= phi0 + 1e-4 * alpha * Dphi + 1e-12 * fabs(phi0)) { ok = true; used_soc = true; ratio_num = phi0 - phis; ratio_den = -(alpha * Dphi + 0.5 * alpha * alpha * fmax(dHd, 0.0)); break; }
           }
         }
         alpha *= 0.5; ++nls;
@@ -3315,8 +3316,12 @@ CHD_NOINLINE CHD_DEV void solve_stage(LCtx& c, StageResult& res) {
     // model -- so that it settles where the exact model just passes the pivot test, as IPOPT's inertia correction does, instead of staying at a level where
     // every iteration pays a failed factorisation and takes a Gauss-Newton step (the two-cycles of the kinematic optimisation's clips: 1 700 iterations in
     // stage 2.1 with the dual infeasibility alternating between 0.024 and 0.031; profiles/r04_curvature_study.md 6)
-    if (attempt == 0 && nls == 0) dw = fmax(CHD_DELTA_W_MIN, dw / 2.0);
-    else if (nls >= 1) dw *= 4.0;
+    // chd_config.damping_rule = 1 (round 6; off by default): the damping also grows, like after a backtrack, when the ACCEPTED step delivered less than a quarter of the reduction
+    // the quadratic model of the merit function promised (Levenberg-Marquardt's ratio test; a model that predicts no reduction counts as ratio 0).  With the rule off only rejections
+    // move the damping up.  Few or long sequences per call gain from it, a launch of thousands of walks loses 7 %: include/chd_phys.h, profiles/r06_globalisation_study.md.
+    const bool poor_ratio = q->ratio_low > 0.0 && !(ratio_num >= q->ratio_low * ratio_den);
+    if (nls >= 1 || poor_ratio) dw *= 4.0;
+    else if (attempt == 0) dw = fmax(CHD_DELTA_W_MIN, dw / 2.0);
     else if (second_used) dw *= CHD_DW_GROW_SECOND;
     PAR_FOR(j, n) x[j] = used_soc ? xs[j] : x[j] + alpha * dx[j];
     PAR_FOR(i, m) {

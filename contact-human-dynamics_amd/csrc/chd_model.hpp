@@ -93,6 +93,7 @@ class SeqModel {
     const int F = in.F;
     if (F < 8) throw std::runtime_error("sequence too short (need at least 8 frames)");
     d.F = F; d.cap = F + 4; d.dt = in.dt;
+    d.ratio_low = cfg.damping_rule == 1 ? 0.25 : 0.0;
     d.mass = in.mass; d.leg_len = in.leg_len; d.heel_len = in.heel_len; d.heel_dist = in.heel_dist;
     // NLP ee order 0 L-toe, 1 R-toe, 2 L-heel, 3 R-heel <- file slots 0, 2, 1, 3 (phys_optim.cpp:505-513)
     const int slot[4] = {0, 2, 1, 3};

@@ -897,7 +897,8 @@ void chd_config_default(chd_config* c) {
   c->lds_kilobytes = 0;
   c->factorisation = 0;
   c->pipeline_chunk = 0;
-  for (int i = 0; i < 2; ++i) c->reserved[i] = 0;
+  c->damping_rule = 0;
+  c->reserved[0] = 0;
 }
 
 int chd_phys_create(const chd_config* cfg, int device_id, chd_handle** out) {

@@ -12,7 +12,7 @@ class ChdConfig(C.Structure):
     _fields_ = [('w_com_lin', C.c_double), ('w_com_ang', C.c_double), ('w_ee', C.c_double),
                 ('w_smooth', C.c_double), ('w_dur', C.c_double), ('max_iter', C.c_int * N_STAGES),
                 ('tol', C.c_double), ('threads_per_sequence', C.c_int), ('stall_window', C.c_int), ('max_workgroups', C.c_int),
-                ('lds_kilobytes', C.c_int), ('factorisation', C.c_int), ('pipeline_chunk', C.c_int), ('reserved', C.c_int * 2)]
+                ('lds_kilobytes', C.c_int), ('factorisation', C.c_int), ('pipeline_chunk', C.c_int), ('damping_rule', C.c_int), ('reserved', C.c_int * 1)]
 
 
 class ChdSeqIn(C.Structure):

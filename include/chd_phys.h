@@ -56,7 +56,12 @@ typedef struct chd_config {
                                  * tables of chunk k + 1 (and reads / writes the files of its neighbours) while the device solves chunk k, and up to
                                  * four chunks' launches share the device.  0 = automatic (a first chunk of 256, the rest in three equal chunks of 256 .. 4 096); < 0 = one chunk: set-up,
                                  * solve and fetch in turn, as rounds 1-3 did */
-  int reserved[2];
+  int damping_rule;             /* 0 (default): the shipped rule -- the Levenberg damping is halved after a clean step, x 4 after a backtrack, x 1.5 after a second-model iteration.
+                                 * 1: additionally x 4 after an ACCEPTED step that delivered less than a quarter of the merit reduction its quadratic model promised
+                                 * (Levenberg-Marquardt's ratio test).  Measured on the MI355X (profiles/r06_globalisation_study.md): FEW or LONG sequences per call gain -- 500 walks in
+                                 * one call 437 -> 602 sequences/s, one 600-frame sequence 5.6 -> 4.2 s, the pipeline's clips 21 -> 26 videos/s -- a launch of thousands of 90-frame walks
+                                 * loses 7 % (2.4 % more iterations, a longer tail).  (Was reserved[0], always 0: layout and ABI version unchanged.) */
+  int reserved[1];
 } chd_config;
 
 /* One sequence = the content of phys_optim_in_<char>/{skel,motion,terrain,contact}_info.txt

@@ -40,6 +40,7 @@ struct IpmOptions {
   double mu_init_warm = 1e-3;   // warm-started stages
   double delta_w0 = 1e-4, delta_w_min = 1e-9, delta_c = 1e-9, delta_w_max = 1e8;
   double dw_grow_second = 1.5;      // growth of the damping after an iteration that needed the second model (CHD_DW_GROW_SECOND)
+  double ratio_low = 0.0;           // > 0 (0.25 = chd_config.damping_rule 1): an ACCEPTED step below this actual / predicted merit reduction raises the damping too
   double constr_viol_tol = 1e-4;   // IPOPT default (unscaled)
   int max_backtrack = 3;
   bool use_soc = true;
@@ -430,6 +431,7 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
     res.bandwidth = std::max(res.bandwidth, w);
 
     bool ok = false, used_soc = false; double alpha = 0, a_du = 1.0; int nls = 0, attempt = 0;
+    double ratio_num = 0.0, ratio_den = 0.0;      // actual / predicted reduction of the merit function by the accepted step (IpmOptions::ratio_low)
     // Second model of an iteration: when an attempt with the exact blocks (heel-distance curvature, node x duration block) fails and the exact duration-duration block fails -- wrong inertia, or the line
     // search runs out of backtracks -- the Hessian is rebuilt ONCE without them (plain Gauss-Newton, positive semi-definite by construction) and the attempt is repeated
     // with the same damping; only if that fails too does the damping grow.  (Rounds 2-3 kept max(lam, 0) of the heel-distance block instead; near-redundant
@@ -614,7 +616,7 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
         double cnt = 0; for (int i = 0; i < m; ++i) cnt += std::fabs(rt[i]);
         double phit = ft + barrier(st, mu) + nu * cnt;
         if (opt.verbose) std::printf("   ls a=%.3e f %.6e->%.6e bar %.6e->%.6e cn %.6e->%.6e Dphi %.3e gdx %.3e dbar %.3e dHd %.3e a_pr %.3e\n", alpha, f, ft, barrier(s, mu), barrier(st, mu), cn, cnt, Dphi, gdx, dbar, dHd, a_pr);
-        if (phit <= phi0 + 1e-4 * alpha * Dphi + 1e-12 * std::fabs(phi0)) { ok = true; break; }
+        if (phit <= phi0 + 1e-4 * alpha * Dphi + 1e-12 * std::fabs(phi0)) { ok = true; ratio_num = phi0 - phit; ratio_den = -(alpha * Dphi + 0.5 * alpha * alpha * std::fmax(dHd, 0.0)); break; }
         if (nls == 0 && opt.use_soc && cnt > cn_floor) {
           // second-order correction (IPOPT sec. 2.4): same factorisation, rhs = constraint
           // residual at the trial point; avoids the Maratos effect of the l1 merit function.
@@ -638,7 +640,7 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
             resid(ct, ss2, rt);
             double cns = 0; for (int i = 0; i < m; ++i) cns += std::fabs(rt[i]);
             double phis = fs + barrier(ss2, mu) + nu * cns;
-            if (phis <= phi0 + 1e-4 * alpha * Dphi + 1e-12 * std::fabs(phi0)) { ok = true; used_soc = true; break; }
+            if (phis <= phi0 + 1e-4 * alpha * Dphi + 1e-12 * std::fabs(phi0)) { ok = true; used_soc = true; ratio_num = phi0 - phis; ratio_den = -(alpha * Dphi + 0.5 * alpha * alpha * std::fmax(dHd, 0.0)); break; }
           }
         }
         alpha *= 0.5; ++nls;
@@ -651,8 +653,11 @@ inline IpmResult ipm_solve(Problem& P, const IpmOptions& opt) {
     if (!ok) { status = -2; P.set_x(x.data()); break; }
     // the damping follows the exact model: halved after a clean first-model step, raised by half when the iteration had to fall back to the second model
     // (chd_kernels.hpp solve_stage has the same rule and the reason)
-    if (attempt == 0 && nls == 0) dw = std::max(opt.delta_w_min, dw / 2.0);
-    else if (nls >= 1) dw *= 4.0;
+    // ... and, with chd_config.damping_rule = 1 (ratio_low = 0.25; off by default), raised like after a backtrack when the accepted step delivered less than that fraction of the
+    // reduction the quadratic model of the merit function promised (the filter mode leaves both sides at zero: no effect there)
+    const bool poor_ratio = opt.ratio_low > 0.0 && !(ratio_num >= opt.ratio_low * ratio_den);
+    if (nls >= 1 || poor_ratio) dw *= 4.0;
+    else if (attempt == 0) dw = std::max(opt.delta_w_min, dw / 2.0);
     else if (second_used) dw *= opt.dw_grow_second;
     last_alpha = alpha; last_nls = nls; last_att = attempt; last_soc = used_soc;
     if (opt.lbfgs) lb_xold = x;

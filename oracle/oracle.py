@@ -61,6 +61,7 @@ def lib():
         L.orc_set_durations.argtypes = [C.c_void_p, PD]
         L.orc_n_phases.argtypes = [C.c_void_p, C.c_int]
         L.orc_set_study_mask.argtypes = [C.c_int, C.c_double]
+        L.orc_set_ratio_low.argtypes = [C.c_double]
         if os.environ.get('ORC_STUDY_MASK'):          # study runs only (tests/tools): 0 = the shipped algorithm
             L.orc_set_study_mask(int(os.environ['ORC_STUDY_MASK']), float(os.environ.get('ORC_CLIP_CAP', '0')))
         _LIB = L

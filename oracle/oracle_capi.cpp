@@ -9,6 +9,8 @@ using namespace orc;
 static int g_verbose = 0, g_inertia_retry = 1, g_stall_window = 0, g_lbfgs = 0, g_study_mask = 0;
 extern "C" {
 void orc_set_verbose(int v) { g_verbose = v; }
+static double g_ratio_low = 0.0;
+void orc_set_ratio_low(double v) { g_ratio_low = v; }      // chd_config.damping_rule = 1 <-> 0.25 (IpmOptions::ratio_low)
 void orc_set_inertia_retry(int v) { g_inertia_retry = v; }
 void orc_set_stall_window(int v) { g_stall_window = v; }
 static double g_clip_cap = 1e300;
@@ -140,6 +142,7 @@ int orc_solve_stage(void* h, int stage, int max_iter, double* stats /*8*/) {
   opt.max_iter = max_iter > 0 ? max_iter : p->cfg.max_iter[stage];
   opt.ref_tol = p->cfg.tol;
   opt.verbose = g_verbose != 0;
+  opt.ratio_low = g_ratio_low;
   opt.inertia_retry = g_inertia_retry != 0;
   opt.stall_window = g_stall_window;
   opt.lbfgs = g_lbfgs != 0;

@@ -60,6 +60,38 @@ def test_solve_matches_oracle(solver, oracle_lib, seed, F):
         assert r.stage_status[stg] == ostats[stg][0]
 
 
+def test_damping_rule_1_on_gpu_in_lockstep_with_the_emulation_of_the_kernel_source():
+    """chd_config.damping_rule = 1 through the C ABI on the MI355X against the host emulation of the same source (itself held to the oracle's ratio_low = 0.25 by
+    tests/test_host_emu.py): identical stage statuses and iteration counts, snapshots to 1e-9 -- on walks incl. the bench straggler 1688, whose duration stage the rule changes."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'host_emu'))
+    import emu
+    from chd_amd.phys_optim import PhysOptim, default_config
+    emu.build()
+    caps = [7000, 7000, 7000, 2500, 2000, 7000]
+    seqs = [make_walk(seed=s, F=F, randomize=True) for s, F in ((9, 90), (1688, 90), (2, 40), (31, 60))]
+    s = PhysOptim(device=0, config=default_config(max_iter=caps, damping_rule=1))
+    res, _ = s.solve(seqs)
+    s.close()
+    d = PhysOptim(device=0, config=default_config(max_iter=caps))
+    res0, _ = d.solve(seqs[1:2])
+    d.close()
+    assert list(res0[0].stage_iters) != list(res[1].stage_iters)          # (not a no-op on the straggler)
+    for seq, r in zip(seqs, res):
+        e = emu.EmuProblem(seq, default_config(max_iter=caps, damping_rule=1))
+        e.solve(0, 4)
+        st, sn = e.results()
+        n_st = 5
+        if int(st[4][0]) != 0:
+            assert e.rebuild_fallback() == 1
+            e.solve(5, 5); st, sn = e.results(); n_st = 6
+        assert [(int(st[k][0]), int(st[k][1])) for k in range(n_st)] == [(int(r.stage_status[k]), int(r.stage_iters[k])) for k in range(n_st)]
+        for k in range(3):
+            err = snapshot_errors(r.snapshots[k], sn[k])
+            assert err['contact_mismatch'] == 0 and max(err['base_lin'], err['base_ang_deg'], err['ee_pos'], err['ee_force']) < 1e-9, err
+
+
 def test_solve_matches_golden_vectors(solver):
     """The committed oracle outputs (tests/golden/phys_golden.npz, made by tests/golden/make_phys_golden.py): the HIP
     path reproduces the three snapshots of every case to 1e-3 relative L2 (measured: ~1e-12), contact flags bit-exact,
