@@ -11,7 +11,13 @@ timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver.j
 cd /tmp && export TMPDIR=/tmp
 P="python $R/bench.py --gen-workers 8 --no-cpu-baseline --no-side-metrics --strong-total 0"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $P --steps 20 --warmup 5 > $OUT/trace_bench.json 2> $OUT/trace.err; head -3 $OUT/trace/trace_kernel_stats.csv
-timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- $P --steps 1 --warmup 0 > $OUT/fetch_bench.json 2> $OUT/fetch.err
+sleep 5
+# (the first counter pass after the trace run has twice been ended by a stray SIGTERM within its first second: it is repeated until its output exists)
+for try in 1 2 3; do
+  timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- $P --steps 1 --warmup 0 > $OUT/fetch_bench.json 2> $OUT/fetch.err
+  if find $OUT/pmc_fetch -name "*counter_collection.csv" 2>/dev/null | grep -q .; then break; fi
+  sleep 5
+done
 timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o write -- $P --steps 1 --warmup 0 > $OUT/write_bench.json 2> $OUT/write.err
 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAVE_CYCLES --output-format csv -d $OUT/pmc_mfma -o mfma -- $P --steps 2 --warmup 0 > $OUT/mfma_bench.json 2> $OUT/mfma.err
 timeout 400 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM --output-format csv -d $OUT/pmc_sq -o sq -- $P --steps 2 --warmup 0 > $OUT/sq_bench.json 2> $OUT/sq.err
