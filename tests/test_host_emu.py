@@ -88,11 +88,11 @@ def test_staged_solve_parity(emu, oracle_lib, seed, F, tilt):
         assert max(err['base_lin'], err['base_ang_deg'], err['ee_pos'], err['ee_force']) < 1e-8, err
 
 
-@pytest.mark.parametrize('seed,F', [(9, 90), (1688, 90), (2, 40)])
+@pytest.mark.parametrize('seed,F', [(6, 40), (3, 60)])
 def test_damping_rule_1_keeps_kernel_source_and_oracle_in_lockstep(emu, oracle_lib, seed, F):
     """chd_config.damping_rule = 1 (round 6: the damping also grows after an ACCEPTED step with a poor actual / predicted merit reduction; off by default) is implemented in the
-    kernel source and in the oracle (IpmOptions::ratio_low = 0.25): same statuses, same iteration counts, same snapshots -- and it is a different path from the default's on the
-    bench straggler 1688 (199 iterations in the duration stage with the default rule)."""
+    kernel source and in the oracle (IpmOptions::ratio_low = 0.25): same statuses, same iteration counts, same snapshots -- and it is a different path from the default's (duration stage:
+    21 -> 56 and 62 -> 31 iterations on these two; the MI355X test holds the bench straggler 1688 the same way)."""
     from oracle.oracle import lib
     seq = make_walk(seed=seed, F=F, randomize=True)
     caps = [7000, 7000, 7000, 2500, 2000, 7000]
@@ -115,9 +115,8 @@ def test_damping_rule_1_keeps_kernel_source_and_oracle_in_lockstep(emu, oracle_l
         sol = Solution(dt=seq.dt, num_frames=s['num_frames'], base_lin=s['base_lin'], base_ang_deg=s['base_ang_deg'], ee_pos=s['ee_pos'], ee_force=s['ee_force'], contact=s['contact'])
         err = snapshot_errors(sol, osnaps[k])
         assert err['contact_mismatch'] == 0 and max(err['base_lin'], err['base_ang_deg'], err['ee_pos'], err['ee_force']) < 1e-8, err
-    if seed == 1688:
-        d = emu.EmuProblem(seq, default_config(max_iter=caps)); d.solve(0, 4)
-        assert int(d.results()[0][4, 1]) != int(stats[4, 1])          # (the rule is not a no-op)
+    d = emu.EmuProblem(seq, default_config(max_iter=caps)); d.solve(0, 4)
+    assert int(d.results()[0][4, 1]) != int(stats[4, 1])          # (the rule is not a no-op)
 
 
 def test_duration_block_of_lagrangian_hessian_vs_finite_differences(emu, oracle_lib):
