@@ -128,6 +128,7 @@ struct SeqDesc {
   int o_flags, o_first, o_sign;
   int o_envw;           // working copy of the stage's envelope (2 ints per KKT position): widened when an entry lands outside it
   int o_rcntw;          // working copy of StageDesc::o_rcnt
+  int o_side_v, o_side_pq, side_cap;   // the Gauss-Newton values of the KKT entries that the exact blocks of an evaluation changed (chd_kernels.hpp model_switch): side_cap doubles in wd, 2 side_cap ints in wi
   int o_csr_rp, o_csr_col, o_csr_row, csr_cap;      // the marked entries of the unfactored matrix as a row-sorted list (chd_kernels.hpp "KKT storage"): N + 1 row starts, csr_cap (column, row) pairs
   StageDesc st[N_STAGES];
 };

@@ -149,6 +149,8 @@ struct Ctx {
   GI* csr_rp; GI* csr_col; GI* csr_row;      // the marked entries as a row-sorted list, rebuilt from the masks when an evaluation has added bits
   int csr_nnz, csr_cap;
   int pm_dirty;                   // an entry was marked since the list was built (any thread sets it; read after a barrier)
+  int side_n;                     // entries of the side list (below) filled by the last evaluation with exact blocks; any thread increments it
+  int side_ok;                    // 1: the side list describes the difference between the K0 that is stored now (first model) and the second model of the same point
   const GI* pos_var; const GI* pos_row;
   GI* env;              // [2p] first, [2p+1] last band position coupled to p (envelope): the stage's working copy
   GI* rcnt;             // [k]: the border rows [0, rcnt[k]) are the ones that can reach band column k (working copy)
@@ -637,6 +639,35 @@ CHD_DEV void kadd_batch(LCtx& c, const int* p, const int* qq, const double* val)
   for (int i = 0; i < N; ++i) { oa[i] = *(sl[i].a ? sl[i].a : c.K0b); ob[i] = *(sl[i].b ? sl[i].b : c.K0b); }
 #pragma unroll
   for (int i = 0; i < N; ++i) { if (sl[i].a) K0_ADD(c, sl[i].a, oa[i], val[i]); if (sl[i].b) K0_ADD(c, sl[i].b, ob[i], val[i]); }
+}
+// ---- The second model without a second evaluation (round 6).  The exact blocks of the Lagrangian Hessian enter K0 in eval_cost_grad_hess only, added to (or beside) the
+// Gauss-Newton value of an entry by the ONE thread that owns it.  That thread also knows what the entry holds in the second model of the same point -- the Gauss-Newton
+// value alone, bit for bit what a fresh evaluation with c.second_model = 1 computes, or nothing (-0.0, the cleared marker) -- and leaves it in a side list when the two differ.
+// When the first model's factorisation meets a pivot of the wrong sign (17 % of the iterations), model_switch writes those values over the entries instead of evaluating
+// splines, rows and costs again (0.9 ms each): c, g and f do not depend on the model.  An entry whose first-model value cancelled to zero exactly was never stored and
+// cannot be switched: the evaluation then clears side_ok and the second model is evaluated the old way.
+#ifdef CHD_HOST_EMU
+CHD_DEV int side_take(LCtx& c) { return c.side_n++; }
+#else
+CHD_DEV int side_take(LCtx& c) { return __hip_atomic_fetch_add(&c.side_n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#endif
+CHD_DEV void side_put(LCtx& c, const int p, const int qq, const double gn) {
+  const int k = side_take(c);
+  if (k < c.q->side_cap) {
+    GI* pq = c.q->wi + c.q->o_side_pq;
+    pq[2 * k] = p; pq[2 * k + 1] = qq; c.q->wd[c.q->o_side_v + k] = gn;
+  }
+}
+CHD_DEV double side_gn(const double v) { return v != 0.0 ? v : -0.0; }      // what K0_ADD leaves in a cleared entry when it is handed v
+CHD_DEV void model_switch(LCtx& c) {
+  const GI* pq = c.q->wi + c.q->o_side_pq;
+  const GD* sv = c.q->wd + c.q->o_side_v;
+  PAR_FOR(e, c.side_n) {
+    const KSlot sl = kslot(c, pq[2 * e], pq[2 * e + 1]);
+    if (sl.a) *sl.a = sv[e];
+    if (sl.b) *sl.b = sv[e];
+  }
+  CHD_SYNC();
 }
 CHD_DEV double kget(const LCtx& c, int p, int qq) {
   if (p < c.Nb && qq < c.Nb) {
@@ -2677,6 +2708,11 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(LCtx& c, GD* g, const GD* lam) {
           pp[dim] = on ? c.pos_var[sp.var_off + v1] : -1; qv[dim] = on ? c.pos_var[sp.var_off + v2] : 0; vv[dim] = c.sf * acc + acch;
         }
         kadd_batch<3>(c, pp, qv, vv);      // the three dimensions are three different entries
+        if (acch != 0.0) {                 // the second model's entry: the Gauss-Newton sum alone (model_switch)
+          const double gn = acc != 0.0 ? side_gn(c.sf * acc) : -0.0;
+#pragma unroll
+          for (int dim = 0; dim < 3; ++dim) if (pp[dim] >= 0) { if (vv[dim] != 0.0) side_put(c, pp[dim], qv[dim], gn); else c.side_ok = 0; }
+        }
       }
     }
     EVT(c, 16);
@@ -2761,6 +2797,8 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(LCtx& c, GD* g, const GD* lam) {
         pp[dim] = on ? c.pos_var[sa.var_off + v1] : -1; qv[dim] = on ? c.pos_var[sb.var_off + v2] : 0; vv[dim] = acc;
       }
       kadd_batch<3>(c, pp, qv, vv);
+#pragma unroll
+      for (int dim = 0; dim < 3; ++dim) if (pp[dim] >= 0) side_put(c, pp[dim], qv[dim], -0.0);      // (the second model has no toe x heel block)
     }
   }
   EVT(c, 18);
@@ -2805,7 +2843,7 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(LCtx& c, GD* g, const GD* lam) {
           if (k > ca || l > cb) continue;
           acc += x2[2 + (k == ca ? 2 : 0) + (l == cb ? 1 : 0)];
         }
-        if (acc != 0.0) kadd(c, c.pos_var[S->dur_off[pr_] + k], c.pos_var[S->dur_off[pr_ + 2] + l], acc);
+        if (acc != 0.0) { kadd(c, c.pos_var[S->dur_off[pr_] + k], c.pos_var[S->dur_off[pr_ + 2] + l], acc); side_put(c, c.pos_var[S->dur_off[pr_] + k], c.pos_var[S->dur_off[pr_ + 2] + l], -0.0); }
       }
     }
   }
@@ -2852,12 +2890,14 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(LCtx& c, GD* g, const GD* lam) {
       }
       hacc = group_sum(hacc); gacc = group_sum(gacc); h2 = group_sum(h2);
       if (lane_ != 0) continue;
+      double hgn = hacc;                  // the second model's sum: without the exact terms
       hacc += h2 / c.sf;
       if (k2 == k && S->w_dur >= 0) {     // DurationCost (duration_cost.cpp:25-50): 1/2 w (T0 - T)^2
-        hacc += S->w_dur;
+        hacc += S->w_dur; hgn += S->w_dur;
         gacc += S->w_dur * (q->wd[q->o_phase_dur + q->phase_off[e] + k] - q->cd[q->o_phase_dur0 + q->phase_off[e] + k]);
       }
       kadd(c, Pk, c.pos_var[S->dur_off[e] + k2], c.sf * hacc);
+      if (h2 != 0.0) { if (c.sf * hacc != 0.0) side_put(c, Pk, c.pos_var[S->dur_off[e] + k2], side_gn(c.sf * hgn)); else c.side_ok = 0; }
       if (k2 == k) g[S->dur_off[e] + k] = c.sf * gacc;
     }
     // ---- (T_k, node variable) entries: one thread per node variable.  Gauss-Newton part (cost terms of the ee-motion splines): the thread gathers the
@@ -2960,6 +3000,13 @@ CHD_NOINLINE CHD_DEV void eval_cost_grad_hess(LCtx& c, GD* g, const GD* lam) {
               pp[kk] = on ? c.pos_var[S->dur_off[te] + k0 + kk] : -1; qv[kk] = Pv;
             }
             kadd_batch<8>(c, pp, qv, vv);
+            if (DX) {
+#pragma unroll
+              for (int kk = 0; kk < 8; ++kk)
+                if (k0 + kk < nv && hx[kk] != 0.0) {      // the exact part changed this entry: the second model holds the cost's Gauss-Newton term alone (own end-effector) or nothing
+                  if (vv[kk] != 0.0) side_put(c, pp[kk], Pv, own_cost ? side_gn(c.sf * hk[kk]) : -0.0); else c.side_ok = 0;
+                }
+            }
           }
         }
       }
@@ -2979,6 +3026,7 @@ CHD_DEV double eval_nlp(LCtx& c, const GD* x, int mode, GD* c_out, GD* g, const 
   state_from_x(c, x);
   if (mode == EV_FULL) {
     kzero(c);
+    if (CHD_TID == 0) { c.side_n = 0; c.side_ok = (lam != nullptr && !c.second_model) ? 1 : 0; }      // (ordered before the entry tasks by the barriers of the cache fill below)
     if (c.S->opt_dur && lam) {
       PAR_FOR(i, 4 * c.q->d2_slots * D2_STRIDE) c.q->wd[c.q->o_d2tab + i] = 0.0;
       PAR_FOR(i, 2 * c.q->n_trom * X2_STRIDE) c.q->wd[c.q->o_x2tab + i] = 0.0;
@@ -2995,6 +3043,7 @@ CHD_DEV double eval_nlp(LCtx& c, const GD* x, int mode, GD* c_out, GD* g, const 
     eval_cost_grad_hess(c, g, lam);
     c.err = block_max(c, (double)c.err) > 0.5 ? 1 : 0;     // a band overflow seen by any thread
     if (c.pm_dirty) csr_rebuild(c);                        // (uniform: the flag is read behind the reduction's barriers) the evaluation wrote entries the readers' list does not hold yet
+    if (CHD_TID == 0 && c.side_n > c.q->side_cap) c.side_ok = 0;      // (the side list overflowed: the second model of this point is evaluated)
     TACC(c, 23, CHD_CLOCK() - te_);
   }
   CHD_SYNC();
@@ -3038,6 +3087,19 @@ CHD_DEV void residual(LCtx& c, const GD* cc, const GD* ss, GD* r) {
   CHD_SYNC();
 }
 
+#ifdef CHD_HOST_EMU
+// CHD_EMU_SWITCH_CHECK=1 (tests): after model_switch the second model is ALSO evaluated the old way, and every listed entry must hold the same bits
+#define CHD_SWITCH_CHECK_OFF && !std::getenv("CHD_EMU_SWITCH_OFF")
+#define CHD_SWITCH_SELF_CHECK() do { if (std::getenv("CHD_EMU_SWITCH_CHECK")) { \
+    std::vector<unsigned long long> sw_(c.csr_nnz); for (int e_ = 0; e_ < c.csr_nnz; ++e_) sw_[e_] = dbits(*k0_at(c, c.csr_row[e_], c.csr_col[e_])); \
+    const int nn_ = c.csr_nnz, ns_ = c.side_n; c.second_model = 1; const double f2_ = eval_nlp(c, x, EV_FULL, cc, g, lam); c.second_model = 0; \
+    long long bad_ = nn_ != c.csr_nnz; for (int e_ = 0; e_ < c.csr_nnz && e_ < nn_; ++e_) if (sw_[e_] != dbits(*k0_at(c, c.csr_row[e_], c.csr_col[e_]))) ++bad_; \
+    if (bad_ || dbits(f2_) != dbits(f)) { std::fprintf(stderr, "MODEL SWITCH MISMATCH stage %d it %d: %lld entries (f %.17g vs %.17g)\n", S->stage, it, bad_, f, f2_); c.err = 3; } \
+    else if (std::getenv("CHD_EMU_SWITCH_CHECK")[0] == '2') std::fprintf(stderr, "model switch ok: stage %d it %d, %d entries of %d switched\n", S->stage, it, ns_, nn_); } } while (0)
+#else
+#define CHD_SWITCH_CHECK_OFF
+#define CHD_SWITCH_SELF_CHECK() ((void)0)
+#endif
 CHD_NOINLINE CHD_DEV void solve_stage(LCtx& c, StageResult& res) {
   QP q = c.q; SDP S = c.S;
   const int n = c.n, m = c.m, N = c.N;
@@ -3195,6 +3257,14 @@ CHD_NOINLINE CHD_DEV void solve_stage(LCtx& c, StageResult& res) {
     auto second_model = [&]() -> bool {
       if (second_used || it == 0) return false;          // (the first model of a stage has no curvature terms)
       second_used = true;
+      CHD_SYNC();
+      if (c.side_ok CHD_SWITCH_CHECK_OFF) {          // K0 <- the second model of this point from the side list of the evaluation that built the first (same c, g, f)
+        model_switch(c);
+        if (CHD_TID == 0) c.side_ok = 0;
+        CHD_SYNC();
+        CHD_SWITCH_SELF_CHECK();
+        return true;
+      }
       if (CHD_TID == 0) c.second_model = 1;
       CHD_SYNC();
       f = eval_nlp(c, x, EV_FULL, cc, g, lam);
@@ -3387,7 +3457,7 @@ CHD_DEV void bind_stage(LCtx& c, QP q, int stage) {
     c.W2 = 2 * c.w + 1; c.LD = c.N;
     c.MW = (c.W2 + 63) >> 6; c.LW = (c.LD + 63) >> 6; c.CW = (c.bc + 63) >> 6;
     c.pmb = (GU*)(q->wd + q->o_pmb); c.pmx = (GU*)(q->wd + q->o_pmx); c.pmt = (GU*)(q->wd + q->o_pmt);
-    c.csr_rp = q->wi + q->o_csr_rp; c.csr_col = q->wi + q->o_csr_col; c.csr_row = q->wi + q->o_csr_row; c.csr_cap = q->csr_cap; c.csr_nnz = 0; c.pm_dirty = 0;
+    c.csr_rp = q->wi + q->o_csr_rp; c.csr_col = q->wi + q->o_csr_col; c.csr_row = q->wi + q->o_csr_row; c.csr_cap = q->csr_cap; c.csr_nnz = 0; c.pm_dirty = 0; c.side_n = 0; c.side_ok = 0;
     c.K0b = q->wd + q->o_K0b; c.K0x = q->wd + q->o_K0x; c.Kfb = q->wd + q->o_Kfb; c.Kfx = q->wd + q->o_Kfx;
     c.pos_var = q->ci + c.S->o_pos_var; c.pos_row = q->ci + c.S->o_pos_row; c.env = q->wi + q->o_envw; c.rcnt = q->wi + q->o_rcntw;
     c.sf = 1.0; c.err = 0; c.n_bad_pivots = 0; c.second_model = 0;

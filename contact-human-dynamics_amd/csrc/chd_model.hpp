@@ -780,6 +780,8 @@ class SeqModel {
     d.o_x2tab = take(2LL * d.n_trom * X2_STRIDE);
     d.o_rcache = take(4LL * d.n_trom * RC_STRIDE);
     d.o_xtab = take(4LL * (4LL * d.n_tdyn + 5LL * d.n_trom) * XR_STRIDE);      // node x duration records (chd_device.hpp: XB_*)
+    d.side_cap = 24 * d.max_n + 4096;
+    d.o_side_v = take(d.side_cap);
     const long long Nb_cap = N_cap, W2 = 2LL * w_cap + 1, LD = N_cap;
     d.o_pmb = take(Nb_cap * ((W2 + 63) / 64)); d.o_pmx = take((long long)bc_cap * ((LD + 63) / 64)); d.o_pmt = take(Nb_cap * ((bc_cap + 63) / 64));
     d.sz_K0b = Nb_cap * W2; d.sz_K0x = (long long)bc_cap * LD;
@@ -798,6 +800,7 @@ class SeqModel {
     d.o_envw = take_i(2LL * d.max_N);
     d.o_rcntw = take_i(d.max_N);
     d.csr_cap = (int)std::min<long long>(48LL * N_cap + (long long)bc_cap * N_cap, 1LL << 28);      // band rows ~14 entries each; the border up to half dense, listed in both orientations
+    d.o_side_pq = take_i(2LL * d.side_cap);
     d.o_csr_rp = take_i(d.max_N + 2); d.o_csr_col = take_i(d.csr_cap); d.o_csr_row = take_i(d.csr_cap);
     wi_size = oi;
   }

@@ -272,3 +272,27 @@ print('RESULT', int(same), '%%.3e' %% worst, [int(stats[st, 1]) for st in range(
         out[variant] = line[0].split()
     assert out[''][1] == '1' and float(out[''][2]) < 1e-8, out                           # lockstep (default build)
     assert out['noinertia'][1] == '0' and float(out['noinertia'][2]) > 1e-3, out          # what the retry fixes
+
+
+def test_model_switch_equals_a_second_evaluation_bit_for_bit(emu, monkeypatch, capfd):
+    """Round 6: when the first model's factorisation fails, K0 becomes the second model by writing a side list of Gauss-Newton values over the entries the exact blocks changed
+    (chd_kernels.hpp model_switch) instead of a second evaluation.  With CHD_EMU_SWITCH_CHECK the emulation evaluates the second model the old way as well after every switch and
+    compares every listed entry and the objective bit for bit (a difference sets the error flag and prints a line); CHD_EMU_SWITCH_OFF takes the old path throughout: same iterates."""
+    caps = [7000, 7000, 7000, 2500, 2000, 7000]
+    out = {}
+    for mode in ('check', 'off'):
+        monkeypatch.delenv('CHD_EMU_SWITCH_CHECK', raising=False); monkeypatch.delenv('CHD_EMU_SWITCH_OFF', raising=False)
+        monkeypatch.setenv('CHD_EMU_SWITCH_CHECK' if mode == 'check' else 'CHD_EMU_SWITCH_OFF', '2' if mode == 'check' else '1')
+        rows = []
+        for seed, F in ((3, 60), (8, 60), (1, 40)):
+            e = emu.EmuProblem(make_walk(seed=seed, F=F, randomize=True), default_config(max_iter=caps))
+            e.solve(0, 4)
+            st, sn = e.results()
+            rows.append(([(int(st[k][0]), int(st[k][1])) for k in range(5)], [np.asarray(sn[k]['ee_force']).copy() for k in range(3)]))
+        out[mode] = rows
+        err = capfd.readouterr().err
+        assert 'MISMATCH' not in err
+        if mode == 'check':
+            assert err.count('model switch ok') >= 5          # (the path is exercised: stages with fixed durations and the duration stage)
+    for a, b in zip(out['check'], out['off']):
+        assert a[0] == b[0] and all(np.array_equal(x, y) for x, y in zip(a[1], b[1]))
